@@ -1,0 +1,177 @@
+/* lsx.h -- C ABI of the MALI formal-solution engine ("lsx").
+ *
+ * This is the drop-in boundary for Lightspinner's hot path.  The reference has no
+ * FFI layer: its boundary is the Python class API of rh_method.Context
+ *   Context.__init__                     /root/reference/rh_method.py:531-563
+ *   Context.formal_sol_gamma_matrices    /root/reference/rh_method.py:565-708
+ *   Context.stat_equil                   /root/reference/rh_method.py:710-745
+ * and, one level down, formal_solver.piecewise_linear_1d
+ *                                        /root/reference/formal_solver.py:144-212.
+ * The entry points below are what a ctypes binding for exactly those four call
+ * sites needs (see INTEGRATION.md for the reference-side stub).  Plain pointers and
+ * sizes only; all floating point is IEEE float64; all arrays are C-contiguous with
+ * the index order written in brackets (last index fastest).
+ *
+ * Two shared libraries export this identical ABI:
+ *   lightspinner_amd/csrc/liblsx_hip.so   the product: HIP kernels for gfx950
+ *   oracle/liblsx_oracle.so               TEST INFRASTRUCTURE ONLY: scalar C
+ *                                         restatement of the reference (checker and
+ *                                         timed CPU baseline, never the product path)
+ *
+ * Return value of every int function: 0 = ok, otherwise an LSX_E* code;
+ * lsx_last_error() then returns a human-readable message (thread-local).
+ * A context owns one device + one stream; contexts are independent; a single
+ * context is not thread-safe (same as the reference, rh_method.py:432-436).
+ */
+#ifndef LSX_H
+#define LSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSX_ABI_VERSION 1
+
+enum {
+    LSX_OK = 0,
+    LSX_EINVAL = 1,      /* bad argument / inconsistent descriptor                  */
+    LSX_EDEVICE = 2,     /* HIP runtime error (message carries hipGetErrorString)    */
+    LSX_ESINGULAR = 3,   /* singular statistical-equilibrium system (cf. LinAlgError,
+                            rh_method.py:739); populations of that (col,k) untouched */
+    LSX_ENONFINITE = 4,  /* reserved                                                 */
+    LSX_EUNSUPPORTED = 5 /* valid request this build cannot run (e.g. Nrays > 8)     */
+};
+
+/* One radiative transition as rh_method.ComputationalTransition sees it
+ * (rh_method.py:93-131).  Order of the table = order of
+ * [atom.trans for atom in ctx.activeAtoms]: atoms by ascending atomic weight
+ * (atomic_set.py:269-273), within an atom lines first then continua
+ * (rh_method.py:399-405). */
+typedef struct lsx_transition {
+    int32_t atom;      /* index into the active-atom list                             */
+    int32_t is_line;   /* 1 = bound-bound (VoigtLine), 0 = bound-free continuum       */
+    int32_t i, j;      /* lower / upper level index inside the atom                   */
+    int32_t Nblue;     /* index of the transition's bluest point in the global grid   */
+    int32_t Nlambda;   /* number of points of its local grid (a slice of the global)  */
+    double Aji, Bji, Bij, lambda0; /* lines only (lambda0 in nm), 0 for continua      */
+} lsx_transition;
+
+/* Column-independent problem description (what Context.__init__ derives from
+ * spect / the atomic models). */
+typedef struct lsx_problem {
+    int32_t abi_version;        /* = LSX_ABI_VERSION                                   */
+    int32_t Nspace, Nrays, Nspect, Natoms, Ntrans;
+    const int32_t* Nlevel;      /* [Natoms]                                            */
+    const double* wavelength;   /* [Nspect] nm, ascending (spect.wavelength)           */
+    const double* muz;          /* [Nrays]  (atmos.muz)                                */
+    const double* wmu;          /* [Nrays]  (atmos.wmu)                                */
+    const lsx_transition* trans;/* [Ntrans]                                            */
+    const uint8_t* active;      /* [Ntrans][Nspect] t.active (rh_method.py:124-127)    */
+    const double* alpha;        /* continuum cross-sections, concatenated over the
+                                   continua in table order, Nlambda entries each       */
+    int32_t sca_per_lambda;     /* 0: bg_sca is [Nspace] per column (Thomson only, as
+                                   background.py:45-47 produces); 1: [Nspect][Nspace]  */
+    int32_t phi_compact;        /* 0: phi is [Nl][Nrays][2][Nspace] per line as
+                                   rh_method.py:224; 1: phi is [Nl][Nspace] (valid when
+                                   vlos == 0 so the profile is ray independent)        */
+} lsx_problem;
+
+/* Per-column hot-path inputs for `ncol` consecutive columns; every pointer has a
+ * leading [ncol] index.  NLtot = sum Nlevel, NL2tot = sum Nlevel^2,
+ * Nlines = number of line transitions, SNl = sum of Nlambda over lines
+ * (both in table order). */
+typedef struct lsx_columns {
+    const double* height;       /* [ncol][Nspace] m            atmos.height            */
+    const double* temperature;  /* [ncol][Nspace] K            atmos.temperature       */
+    const double* nStar;        /* [ncol][NLtot][Nspace]       atom.nStar, atoms concatenated */
+    const double* nTotal;       /* [ncol][Natoms][Nspace]      atom.nTotal             */
+    const double* n;            /* [ncol][NLtot][Nspace]       initial atom.n (warm start,
+                                                               rh_method.py:412-416)   */
+    const double* C;            /* [ncol][NL2tot][Nspace]      atom.C[to][from][k] after
+                                                               compute_collisions incl. the
+                                                               clamp (rh_method.py:474-487) */
+    const double* bg_chi;       /* [ncol][Nspect][Nspace]      background.chi          */
+    const double* bg_eta;       /* [ncol][Nspect][Nspace]      background.eta          */
+    const double* bg_sca;       /* [ncol][Nspace] or [ncol][Nspect][Nspace]            */
+    const double* phi;          /* [ncol][SNl][Nrays][2][Nspace] or [ncol][SNl][Nspace] */
+    const double* wphi;         /* [ncol][Nlines][Nspace]      t.wphi                  */
+} lsx_columns;
+
+typedef struct lsx_ctx lsx_ctx;
+
+/* What lsx_get / lsx_set address.  Shapes per column (leading [ncol] implied): */
+enum {
+    LSX_I = 0,         /* [Nspect][Nrays]   ctx.I  (emergent, rh_method.py:638)       */
+    LSX_J = 1,         /* [Nspect][Nspace]  ctx.J                                     */
+    LSX_N = 2,         /* [NLtot][Nspace]   atom.n                                    */
+    LSX_GAMMA = 3,     /* [NL2tot][Nspace]  atom.Gamma[i][j][k], atoms concatenated   */
+    LSX_DJ_COL = 4,    /* [1]  per-column max|1-Jdag/J| of the last FS call           */
+    LSX_DPOPS_COL = 5, /* [1]  per-column max rel. population change of the last SE   */
+    LSX_NSTAR = 6,     /* [NLtot][Nspace]                                             */
+    LSX_C = 7,         /* [NL2tot][Nspace]                                            */
+    LSX_RIJ = 8,       /* [Ntrans][Nspace]  t.Rij, accumulated over calls exactly as the
+                          reference does (rh_method.py:691; never zeroed, quirk kept)    */
+    LSX_RJI = 9        /* [Ntrans][Nspace]  t.Rji (rh_method.py:692, uses Vij: quirk kept) */
+};
+
+/* Create a context for `ncol` columns on HIP device `device` (ignored by the
+ * oracle).  `stream` is a hipStream_t to launch on (e.g. torch's current stream),
+ * or NULL for a stream owned by the context. */
+int lsx_create(const lsx_problem* desc, int32_t ncol, int32_t device, void* stream,
+               lsx_ctx** out);
+void lsx_destroy(lsx_ctx* ctx);
+
+/* Upload (copy) inputs for columns [col0, col0+ncol).  J is reset to 0 for those
+ * columns (rh_method.py:562).  Host pointers. */
+int lsx_set_columns(lsx_ctx* ctx, int32_t col0, int32_t ncol, const lsx_columns* cols);
+
+/* One Context.formal_sol_gamma_matrices() over all columns.  *dJ_max receives the
+ * maximum over columns of the reference's return value (rh_method.py:705-708). */
+int lsx_formal_sol_gamma(lsx_ctx* ctx, double* dJ_max);
+
+/* One Context.stat_equil() over all columns; *dPops_max = max over columns
+ * (rh_method.py:741-745).  Updates the populations held by the context. */
+int lsx_stat_equil(lsx_ctx* ctx, double* dPops_max);
+
+/* Asynchronous forms: enqueue only; lsx_sync waits and returns both maxima of the
+ * most recent calls (either pointer may be NULL). */
+int lsx_formal_sol_gamma_async(lsx_ctx* ctx);
+int lsx_stat_equil_async(lsx_ctx* ctx);
+int lsx_sync(lsx_ctx* ctx, double* dJ_max, double* dPops_max);
+
+/* Copy results for columns [col0, col0+ncol) to host memory (reference layouts). */
+int lsx_get(lsx_ctx* ctx, int32_t what, int32_t col0, int32_t ncol, double* dst,
+            size_t nbytes);
+/* Overwrite LSX_N (warm start, response_fn.py:33) or LSX_J for a column range. */
+int lsx_set(lsx_ctx* ctx, int32_t what, int32_t col0, int32_t ncol, const double* src,
+            size_t nbytes);
+
+/* formal_solver.piecewise_linear_1d for `nray` independent rays sharing one depth
+ * grid (formal_solver.py:144-212).  chi, S: [nray][Nspace]; mu, wav: [nray];
+ * to_obs: [nray] (1 = up-going/toFrom True); temperature: [Nspace] (only the last
+ * two entries are used, formal_solver.py:206).  Out: I, PsiStar [nray][Nspace]. */
+int lsx_piecewise_linear_1d(int32_t device, int32_t nray, int32_t Nspace,
+                            const double* height, const double* temperature,
+                            const double* mu, const int32_t* to_obs, const double* wav,
+                            const double* chi, const double* S, double* I, double* PsiStar);
+
+/* Measurement hooks (bench.py): time `reps` back-to-back FS calls with device events
+ * on the context's stream.  ms_total = whole FS call (all kernels), ms_sweep = the
+ * dominant sweep kernel(s) alone, both averaged per call. */
+int lsx_time_formal_sol(lsx_ctx* ctx, int32_t warmup, int32_t reps, double* ms_total,
+                        double* ms_sweep);
+
+/* Introspection */
+const char* lsx_last_error(void);
+const char* lsx_backend_name(void);    /* "hip-gfx950" or "oracle-c"                   */
+int32_t lsx_abi_version(void);
+/* Algorithmic bytes one FS call moves per column (SURVEY 8d formula) */
+double lsx_algorithmic_bytes_per_column(const lsx_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSX_H */

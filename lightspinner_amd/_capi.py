@@ -1,0 +1,163 @@
+"""ctypes binding of the lsx C ABI (include/lsx.h).
+
+The product loads exactly one library: lightspinner_amd/csrc/liblsx_hip.so (HIP
+kernels for gfx950).  There is no CPU fallback: if that library is missing or does
+not load, `load_hip_library()` raises.  `LsxLibrary(path)` is generic over the path
+only so that tests can bind the oracle (same ABI) as a checker.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ABI_VERSION = 1
+
+# item selectors (include/lsx.h)
+LSX_I, LSX_J, LSX_N, LSX_GAMMA, LSX_DJ_COL, LSX_DPOPS_COL, LSX_NSTAR, LSX_C, LSX_RIJ, LSX_RJI = range(10)
+
+ERRORS = {1: 'LSX_EINVAL', 2: 'LSX_EDEVICE', 3: 'LSX_ESINGULAR', 4: 'LSX_ENONFINITE', 5: 'LSX_EUNSUPPORTED'}
+
+_dp = C.POINTER(C.c_double)
+
+
+class LsxTransition(C.Structure):
+    _fields_ = [('atom', C.c_int32), ('is_line', C.c_int32), ('i', C.c_int32), ('j', C.c_int32),
+                ('Nblue', C.c_int32), ('Nlambda', C.c_int32),
+                ('Aji', C.c_double), ('Bji', C.c_double), ('Bij', C.c_double), ('lambda0', C.c_double)]
+
+
+class LsxProblem(C.Structure):
+    _fields_ = [('abi_version', C.c_int32),
+                ('Nspace', C.c_int32), ('Nrays', C.c_int32), ('Nspect', C.c_int32),
+                ('Natoms', C.c_int32), ('Ntrans', C.c_int32),
+                ('Nlevel', C.POINTER(C.c_int32)),
+                ('wavelength', _dp), ('muz', _dp), ('wmu', _dp),
+                ('trans', C.POINTER(LsxTransition)),
+                ('active', C.POINTER(C.c_uint8)),
+                ('alpha', _dp),
+                ('sca_per_lambda', C.c_int32), ('phi_compact', C.c_int32)]
+
+
+class LsxColumns(C.Structure):
+    _fields_ = [(k, _dp) for k in ('height', 'temperature', 'nStar', 'nTotal', 'n', 'C',
+                                   'bg_chi', 'bg_eta', 'bg_sca', 'phi', 'wphi')]
+
+
+# every symbol include/lsx.h declares
+REQUIRED_SYMBOLS = (
+    'lsx_create', 'lsx_destroy', 'lsx_set_columns', 'lsx_formal_sol_gamma', 'lsx_stat_equil',
+    'lsx_formal_sol_gamma_async', 'lsx_stat_equil_async', 'lsx_sync', 'lsx_get', 'lsx_set',
+    'lsx_piecewise_linear_1d', 'lsx_time_formal_sol', 'lsx_last_error', 'lsx_backend_name',
+    'lsx_abi_version', 'lsx_algorithmic_bytes_per_column',
+)
+
+
+class LsxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('%s: %s' % (ERRORS.get(code, 'error %d' % code), msg))
+        self.code = code
+
+
+class LsxSingularError(LsxError, np.linalg.LinAlgError):
+    """Singular statistical-equilibrium system; the reference raises
+    numpy.linalg.LinAlgError from scipy.linalg.solve here (rh_method.py:739)."""
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError('expected shape %s, got %s' % (tuple(shape), a.shape))
+    return a
+
+
+class LsxLibrary:
+    """A loaded library exporting the lsx ABI."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.path = path
+        self.dll = C.CDLL(path, mode=getattr(os, 'RTLD_LOCAL', 0) | getattr(os, 'RTLD_NOW', 2))
+        missing = [s for s in REQUIRED_SYMBOLS if not hasattr(self.dll, s)]
+        if missing:
+            raise ImportError('%s does not export: %s' % (path, ', '.join(missing)))
+        d = self.dll
+        d.lsx_abi_version.restype = C.c_int32
+        if d.lsx_abi_version() != ABI_VERSION:
+            raise ImportError('%s: ABI version %d, expected %d' % (path, d.lsx_abi_version(), ABI_VERSION))
+        d.lsx_last_error.restype = C.c_char_p
+        d.lsx_backend_name.restype = C.c_char_p
+        d.lsx_create.argtypes = [C.POINTER(LsxProblem), C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
+        d.lsx_destroy.argtypes = [C.c_void_p]
+        d.lsx_destroy.restype = None
+        d.lsx_set_columns.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(LsxColumns)]
+        d.lsx_formal_sol_gamma.argtypes = [C.c_void_p, _dp]
+        d.lsx_stat_equil.argtypes = [C.c_void_p, _dp]
+        d.lsx_formal_sol_gamma_async.argtypes = [C.c_void_p]
+        d.lsx_stat_equil_async.argtypes = [C.c_void_p]
+        d.lsx_sync.argtypes = [C.c_void_p, _dp, _dp]
+        d.lsx_get.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp, C.c_size_t]
+        d.lsx_set.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp, C.c_size_t]
+        d.lsx_piecewise_linear_1d.argtypes = [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp,
+                                              C.POINTER(C.c_int32), _dp, _dp, _dp, _dp, _dp]
+        d.lsx_time_formal_sol.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp]
+        d.lsx_algorithmic_bytes_per_column.argtypes = [C.c_void_p]
+        d.lsx_algorithmic_bytes_per_column.restype = C.c_double
+
+    @property
+    def backend(self):
+        return self.dll.lsx_backend_name().decode()
+
+    def check(self, rc):
+        if rc != 0:
+            msg = self.dll.lsx_last_error().decode(errors='replace')
+            if rc == 3:
+                raise LsxSingularError(rc, msg)
+            raise LsxError(rc, msg)
+
+    def piecewise_linear_1d(self, height, temperature, mu, to_obs, wav, chi, S, device=0):
+        """Batched formal_solver.piecewise_linear_1d (formal_solver.py:144-212)."""
+        chi = f64(chi)
+        S = f64(S, chi.shape)
+        if chi.ndim != 2:
+            raise ValueError('chi, S must be [nray, Nspace]')
+        nray, ns = chi.shape
+        height = f64(height, (ns,))
+        temperature = f64(temperature, (ns,))
+        mu = f64(mu, (nray,))
+        wav = f64(wav, (nray,))
+        to_obs = np.ascontiguousarray(to_obs, dtype=np.int32)
+        if to_obs.shape != (nray,):
+            raise ValueError('to_obs must be [nray]')
+        I = np.empty_like(chi)
+        Psi = np.empty_like(chi)
+        self.check(self.dll.lsx_piecewise_linear_1d(device, nray, ns, _ptr(height), _ptr(temperature), _ptr(mu),
+                                                    to_obs.ctypes.data_as(C.POINTER(C.c_int32)), _ptr(wav),
+                                                    _ptr(chi), _ptr(S), _ptr(I), _ptr(Psi)))
+        return I, Psi
+
+
+_HIP_LIB = None
+
+
+def hip_library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'liblsx_hip.so')
+
+
+def load_hip_library():
+    """Load the HIP backend or fail loudly -- the product has no other backend."""
+    global _HIP_LIB
+    if _HIP_LIB is None:
+        path = hip_library_path()
+        if not os.path.exists(path):
+            raise ImportError(
+                'lightspinner_amd: HIP extension %s not built (run `python -c "import __graft_entry__ as g; '
+                'g.build()"` or `make -C lightspinner_amd/csrc`). There is no CPU fallback.' % path)
+        _HIP_LIB = LsxLibrary(path)
+        if not _HIP_LIB.backend.startswith('hip'):
+            raise ImportError('%s is not the HIP backend (%s)' % (path, _HIP_LIB.backend))
+    return _HIP_LIB

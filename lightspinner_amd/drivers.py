@@ -1,0 +1,56 @@
+"""Driver loops of the reference, over an Engine / Context with many columns.
+
+D1  test.py:20-29 / response_fn.py:11-21  -- MALI iteration to convergence
+D2  response_fn.py:23-67                  -- brute-force temperature response function
+"""
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional
+
+import numpy as np
+
+
+@dataclass
+class MaliHistory:
+    dJ: List[float] = field(default_factory=list)
+    dPops: List[float] = field(default_factory=list)   # nan while only J is iterated
+    converged: bool = False
+
+    @property
+    def n_iter(self):
+        return len(self.dJ)
+
+
+def iterate_mali(ctx, dJ_tol=2e-3, dPops_tol=1e-3, n_lambda_only=3, max_iter=500,
+                 reduce_max: Optional[Callable[[float, float], tuple]] = None, log=None) -> MaliHistory:
+    """`while dJ > 2e-3 or dPops > 1e-3` loop of test.py:20-29 with the reference's
+    defaults: the first 3 iterations update J only (`if i > 3`, test.py:27).
+
+    ctx needs formal_sol_gamma_matrices() and stat_equil() (Context, BatchContext or
+    an Engine adapter).  reduce_max((dJ, dPops)) -> (dJ, dPops) is the hook where the
+    multi-GPU driver takes the max over ranks (parallel.allreduce_max)."""
+    h = MaliHistory()
+    dJ, dPops, i = 1.0, 1.0, 0
+    while dJ > dJ_tol or dPops > dPops_tol:
+        i += 1
+        dJ = ctx.formal_sol_gamma_matrices()
+        if i > n_lambda_only:
+            dPops = ctx.stat_equil()
+        if reduce_max is not None:
+            dJ, dPops = reduce_max(dJ, dPops)
+        h.dJ.append(dJ)
+        h.dPops.append(dPops if i > n_lambda_only else float('nan'))
+        if log:
+            log('Iteration %.3d: dJ: %.2e, dPops: %s' % (i, dJ, 'Just iterating Jbar' if i <= n_lambda_only else '%.2e' % dPops))
+        if i >= max_iter or not (np.isfinite(dJ) and np.isfinite(dPops)):
+            break
+    h.converged = (dJ <= dJ_tol and dPops <= dPops_tol)
+    return h
+
+
+def response_function(I_plus, I_minus, I_base, mu_index=-1):
+    """response_fn.py:59-67: rf[la, k] = (I+[la, mu] - I-[la, mu]) / I_base[la, mu].
+    I_plus / I_minus: [Nspace][Nspect][Nrays] (one converged run per perturbed depth),
+    I_base: [Nspect][Nrays]."""
+    Ip = np.asarray(I_plus)[:, :, mu_index].T      # [Nspect][Nspace]
+    Im = np.asarray(I_minus)[:, :, mu_index].T
+    return (Ip - Im) / np.asarray(I_base)[:, mu_index][:, None]

@@ -1,0 +1,253 @@
+"""Flat, column-batched description of the hot-path inputs and the Engine that
+feeds them through the lsx C ABI.
+
+`Problem`      -- what is common to every column: grids, quadrature, transition table
+                  (what rh_method.Context.__init__ derives from `spect`, rh_method.py:531-563)
+`ColumnBlock`  -- per-column arrays with a leading [ncol] index, in the reference's
+                  own layouts (rh_method.py:387-423 and 93-131)
+`Engine`       -- owns one lsx_ctx (one device, one stream)
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from . import _capi
+from ._capi import f64, _ptr
+
+
+@dataclass
+class Transition:
+    atom: int
+    is_line: bool
+    i: int
+    j: int
+    Nblue: int
+    Nlambda: int
+    Aji: float = 0.0
+    Bji: float = 0.0
+    Bij: float = 0.0
+    lambda0: float = 0.0
+    alpha: Optional[np.ndarray] = None  # continua: [Nlambda]
+
+
+@dataclass
+class Problem:
+    Nspace: int
+    wavelength: np.ndarray          # [Nspect] nm
+    muz: np.ndarray                 # [Nrays]
+    wmu: np.ndarray                 # [Nrays]
+    Nlevel: List[int]               # per active atom
+    trans: List[Transition]         # ordered as [t for atom in activeAtoms for t in atom.trans]
+    active: np.ndarray              # bool [Ntrans][Nspect]
+    sca_per_lambda: bool = False
+    phi_compact: bool = False
+    atom_names: List[str] = field(default_factory=list)
+
+    def __post_init__(self):
+        self.wavelength = f64(self.wavelength)
+        self.muz = f64(self.muz)
+        self.wmu = f64(self.wmu)
+        self.Nlevel = [int(x) for x in self.Nlevel]
+        self.active = np.ascontiguousarray(self.active, dtype=np.uint8).reshape(len(self.trans), self.Nspect)
+        if self.muz.shape != self.wmu.shape:
+            raise ValueError('muz and wmu must have the same shape')
+
+    @property
+    def Nspect(self): return int(self.wavelength.shape[0])
+    @property
+    def Nrays(self): return int(self.muz.shape[0])
+    @property
+    def Natoms(self): return len(self.Nlevel)
+    @property
+    def Ntrans(self): return len(self.trans)
+    @property
+    def NLtot(self): return int(sum(self.Nlevel))
+    @property
+    def NL2tot(self): return int(sum(n * n for n in self.Nlevel))
+    @property
+    def lines(self): return [t for t in self.trans if t.is_line]
+    @property
+    def Nlines(self): return len(self.lines)
+    @property
+    def SNl(self): return int(sum(t.Nlambda for t in self.lines))
+    @property
+    def lev_off(self): return np.concatenate([[0], np.cumsum(self.Nlevel)[:-1]]).astype(int)
+    @property
+    def lev2_off(self): return np.concatenate([[0], np.cumsum([n * n for n in self.Nlevel])[:-1]]).astype(int)
+
+    def phi_shape(self):
+        if self.phi_compact:
+            return (self.SNl, self.Nspace)
+        return (self.SNl, self.Nrays, 2, self.Nspace)
+
+    def sca_shape(self):
+        return (self.Nspect, self.Nspace) if self.sca_per_lambda else (self.Nspace,)
+
+    def work_units_per_column(self):
+        """depth-points x wavelengths x rays (both directions) per FS call."""
+        return self.Nspect * self.Nrays * 2 * self.Nspace
+
+    def to_c(self):
+        """-> (LsxProblem, keepalive list)"""
+        keep = []
+        tarr = (_capi.LsxTransition * max(1, self.Ntrans))()
+        alphas = []
+        for k, t in enumerate(self.trans):
+            tarr[k] = _capi.LsxTransition(t.atom, 1 if t.is_line else 0, t.i, t.j, t.Nblue, t.Nlambda,
+                                          t.Aji, t.Bji, t.Bij, t.lambda0)
+            if not t.is_line:
+                a = f64(t.alpha, (t.Nlambda,))
+                alphas.append(a)
+        alpha = np.concatenate(alphas) if alphas else np.zeros(1)
+        alpha = f64(alpha)
+        nlevel = np.ascontiguousarray(self.Nlevel, dtype=np.int32)
+        p = _capi.LsxProblem()
+        p.abi_version = _capi.ABI_VERSION
+        p.Nspace, p.Nrays, p.Nspect = self.Nspace, self.Nrays, self.Nspect
+        p.Natoms, p.Ntrans = self.Natoms, self.Ntrans
+        p.Nlevel = nlevel.ctypes.data_as(C.POINTER(C.c_int32))
+        p.wavelength = _ptr(self.wavelength)
+        p.muz = _ptr(self.muz)
+        p.wmu = _ptr(self.wmu)
+        p.trans = tarr
+        p.active = self.active.ctypes.data_as(C.POINTER(C.c_uint8))
+        p.alpha = _ptr(alpha)
+        p.sca_per_lambda = 1 if self.sca_per_lambda else 0
+        p.phi_compact = 1 if self.phi_compact else 0
+        keep += [tarr, alpha, nlevel]
+        return p, keep
+
+
+_COLUMN_FIELDS = ('height', 'temperature', 'nStar', 'nTotal', 'n', 'C', 'bg_chi', 'bg_eta', 'bg_sca', 'phi', 'wphi')
+
+
+@dataclass
+class ColumnBlock:
+    """Per-column inputs, leading index = column (include/lsx.h: lsx_columns)."""
+    height: np.ndarray
+    temperature: np.ndarray
+    nStar: np.ndarray
+    nTotal: np.ndarray
+    n: np.ndarray
+    C: np.ndarray
+    bg_chi: np.ndarray
+    bg_eta: np.ndarray
+    bg_sca: np.ndarray
+    phi: np.ndarray
+    wphi: np.ndarray
+
+    @property
+    def ncol(self):
+        return int(self.height.shape[0])
+
+    def validate(self, p: Problem):
+        nc, Ns = self.ncol, p.Nspace
+        shapes = dict(height=(nc, Ns), temperature=(nc, Ns), nStar=(nc, p.NLtot, Ns), nTotal=(nc, p.Natoms, Ns),
+                      n=(nc, p.NLtot, Ns), C=(nc, p.NL2tot, Ns), bg_chi=(nc, p.Nspect, Ns),
+                      bg_eta=(nc, p.Nspect, Ns), bg_sca=(nc,) + p.sca_shape(), phi=(nc,) + p.phi_shape(),
+                      wphi=(nc, p.Nlines, Ns))
+        for k in _COLUMN_FIELDS:
+            setattr(self, k, f64(getattr(self, k), shapes[k]))
+        return self
+
+    def slice(self, c0, c1):
+        return ColumnBlock(**{k: getattr(self, k)[c0:c1] for k in _COLUMN_FIELDS})
+
+    def to_c(self):
+        s = _capi.LsxColumns()
+        for k in _COLUMN_FIELDS:
+            setattr(s, k, _ptr(getattr(self, k)))
+        return s
+
+    @staticmethod
+    def concatenate(blocks):
+        return ColumnBlock(**{k: np.concatenate([getattr(b, k) for b in blocks]) for k in _COLUMN_FIELDS})
+
+
+class Engine:
+    """One lsx_ctx.  `lib=None` binds the HIP backend (and raises if it is not built)."""
+
+    def __init__(self, problem: Problem, ncol: int, device: int = 0, stream: Optional[int] = None, lib=None):
+        self.lib = lib if lib is not None else _capi.load_hip_library()
+        self.problem = problem
+        self.ncol = int(ncol)
+        self._h = C.c_void_p()
+        cprob, self._keep = problem.to_c()
+        self.lib.check(self.lib.dll.lsx_create(C.byref(cprob), self.ncol, int(device),
+                                               C.c_void_p(stream) if stream else None, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self.lib.dll.lsx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- data in --------------------------------------------------------------
+    def set_columns(self, col0: int, block: ColumnBlock):
+        block.validate(self.problem)
+        cs = block.to_c()
+        self.lib.check(self.lib.dll.lsx_set_columns(self._h, int(col0), block.ncol, C.byref(cs)))
+
+    def set(self, what, arr, col0=0):
+        arr = f64(arr)
+        ncol = arr.shape[0]
+        self.lib.check(self.lib.dll.lsx_set(self._h, what, int(col0), ncol, _ptr(arr), arr.nbytes))
+
+    # -- hot path -------------------------------------------------------------
+    def formal_sol_gamma(self) -> float:
+        v = C.c_double()
+        self.lib.check(self.lib.dll.lsx_formal_sol_gamma(self._h, C.byref(v)))
+        return v.value
+
+    def stat_equil(self) -> float:
+        v = C.c_double()
+        self.lib.check(self.lib.dll.lsx_stat_equil(self._h, C.byref(v)))
+        return v.value
+
+    def formal_sol_gamma_async(self):
+        self.lib.check(self.lib.dll.lsx_formal_sol_gamma_async(self._h))
+
+    def stat_equil_async(self):
+        self.lib.check(self.lib.dll.lsx_stat_equil_async(self._h))
+
+    def sync(self):
+        a, b = C.c_double(), C.c_double()
+        self.lib.check(self.lib.dll.lsx_sync(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def time_formal_sol(self, warmup, reps):
+        a, b = C.c_double(), C.c_double()
+        self.lib.check(self.lib.dll.lsx_time_formal_sol(self._h, int(warmup), int(reps), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def algorithmic_bytes_per_column(self) -> float:
+        return float(self.lib.dll.lsx_algorithmic_bytes_per_column(self._h))
+
+    # -- data out -------------------------------------------------------------
+    def _shape(self, what):
+        p = self.problem
+        return {_capi.LSX_I: (p.Nspect, p.Nrays), _capi.LSX_J: (p.Nspect, p.Nspace),
+                _capi.LSX_N: (p.NLtot, p.Nspace), _capi.LSX_GAMMA: (p.NL2tot, p.Nspace),
+                _capi.LSX_DJ_COL: (), _capi.LSX_DPOPS_COL: (), _capi.LSX_NSTAR: (p.NLtot, p.Nspace),
+                _capi.LSX_C: (p.NL2tot, p.Nspace), _capi.LSX_RIJ: (p.Ntrans, p.Nspace),
+                _capi.LSX_RJI: (p.Ntrans, p.Nspace)}[what]
+
+    def get(self, what, col0=0, ncol=None):
+        ncol = self.ncol - col0 if ncol is None else ncol
+        out = np.empty((ncol,) + self._shape(what), dtype=np.float64)
+        self.lib.check(self.lib.dll.lsx_get(self._h, what, int(col0), int(ncol), _ptr(out), out.nbytes))
+        return out
+
+    def gamma_of_atom(self, G, a):
+        """view [ncol][Nl][Nl][Nspace] of atom a inside an LSX_GAMMA array"""
+        p = self.problem
+        nl = p.Nlevel[a]
+        o = p.lev2_off[a]
+        return G[:, o:o + nl * nl, :].reshape(G.shape[0], nl, nl, p.Nspace)

@@ -1,0 +1,682 @@
+/* lsx_oracle.c -- TEST INFRASTRUCTURE, NOT THE PRODUCT.
+ *
+ * Scalar C restatement of Lightspinner's MALI hot path behind the lsx C ABI
+ * (include/lsx.h).  It exists to (1) check the HIP kernels, (2) be the timed CPU
+ * baseline in bench.py.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it; lightspinner_amd/ never does.
+ *
+ * Parity is PINNED: tests/test_oracle_golden.py checks this file against golden
+ * vectors produced by importing the unmodified reference (tests/golden/make_golden.py).
+ *
+ * Every function cites the reference lines it restates; the floating-point
+ * operation ORDER of the reference's numpy expressions is kept (build with
+ * -ffp-contract=off) so results agree to a few ulp.
+ *
+ * Reference: /root/reference/formal_solver.py, rh_method.py, utils.py, constants.py
+ */
+#include "../include/lsx.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* constants.py:1-27 (values reproduced bit for bit) */
+static const double CLight = 2.99792458E+08;
+static const double HPlanck = 6.6260755E-34;
+static const double KBoltzmann = 1.380658E-23;
+static const double NM_TO_M = 1.0E-09;
+#define HC (HPlanck * CLight)
+
+static __thread char g_err[512];
+static int fail(int code, const char* msg)
+{
+    snprintf(g_err, sizeof g_err, "%s", msg);
+    return code;
+}
+const char* lsx_last_error(void) { return g_err; }
+const char* lsx_backend_name(void) { return "oracle-c"; }
+int32_t lsx_abi_version(void) { return LSX_ABI_VERSION; }
+
+struct lsx_ctx {
+    int Nspace, Nrays, Nspect, Natoms, Ntrans, ncol;
+    int NLtot, NL2tot, Nlines, SNl, SNc;
+    int sca_per_lambda, phi_compact;
+    int* Nlevel;
+    int* lev_off;  /* [Natoms] offset into NLtot   */
+    int* lev2_off; /* [Natoms] offset into NL2tot  */
+    double *wavelength, *muz, *wmu;
+    lsx_transition* trans;
+    uint8_t* active;
+    double* alpha;
+    int* alpha_off; /* [Ntrans] offset into alpha (continua)          */
+    int* phi_off;   /* [Ntrans] offset (in lambda points) into SNl    */
+    int* line_idx;  /* [Ntrans] index among lines                      */
+    /* per column, reference layouts */
+    double *height, *temperature, *nStar, *nTotal, *n, *C, *bg_chi, *bg_eta, *bg_sca, *phi, *wphi;
+    double *J, *I, *Gamma, *Rij, *Rji, *dJcol, *dPcol;
+    int nthreads;
+    double last_dJ, last_dP;
+};
+
+static size_t phi_per_col(const lsx_ctx* c)
+{
+    return (size_t)c->SNl * (c->phi_compact ? 1 : (size_t)c->Nrays * 2) * c->Nspace;
+}
+static size_t sca_per_col(const lsx_ctx* c)
+{
+    return (size_t)(c->sca_per_lambda ? c->Nspect : 1) * c->Nspace;
+}
+
+int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream, lsx_ctx** out)
+{
+    (void)device;
+    (void)stream;
+    if (!d || !out || ncol < 1) return fail(LSX_EINVAL, "lsx_create: null argument or ncol < 1");
+    if (d->abi_version != LSX_ABI_VERSION) return fail(LSX_EINVAL, "lsx_create: ABI version mismatch");
+    if (d->Nspace < 3) return fail(LSX_EINVAL, "lsx_create: Nspace must be >= 3 (formal_solver.py:120-139)");
+    if (d->Nrays < 1 || d->Nspect < 1 || d->Natoms < 1 || d->Ntrans < 0)
+        return fail(LSX_EINVAL, "lsx_create: bad dimensions");
+    lsx_ctx* c = (lsx_ctx*)calloc(1, sizeof *c);
+    c->Nspace = d->Nspace; c->Nrays = d->Nrays; c->Nspect = d->Nspect;
+    c->Natoms = d->Natoms; c->Ntrans = d->Ntrans; c->ncol = ncol;
+    c->sca_per_lambda = d->sca_per_lambda; c->phi_compact = d->phi_compact;
+    c->Nlevel = (int*)malloc(sizeof(int) * c->Natoms);
+    c->lev_off = (int*)malloc(sizeof(int) * c->Natoms);
+    c->lev2_off = (int*)malloc(sizeof(int) * c->Natoms);
+    for (int a = 0; a < c->Natoms; ++a) {
+        c->Nlevel[a] = d->Nlevel[a];
+        c->lev_off[a] = c->NLtot; c->lev2_off[a] = c->NL2tot;
+        c->NLtot += d->Nlevel[a]; c->NL2tot += d->Nlevel[a] * d->Nlevel[a];
+    }
+#define DUP(dst, src, cnt, T) do { dst = (T*)malloc(sizeof(T) * (size_t)(cnt)); memcpy(dst, src, sizeof(T) * (size_t)(cnt)); } while (0)
+    DUP(c->wavelength, d->wavelength, c->Nspect, double);
+    DUP(c->muz, d->muz, c->Nrays, double);
+    DUP(c->wmu, d->wmu, c->Nrays, double);
+    DUP(c->trans, d->trans, c->Ntrans > 0 ? c->Ntrans : 1, lsx_transition);
+    DUP(c->active, d->active, (size_t)(c->Ntrans > 0 ? c->Ntrans : 1) * c->Nspect, uint8_t);
+    c->alpha_off = (int*)calloc(c->Ntrans + 1, sizeof(int));
+    c->phi_off = (int*)calloc(c->Ntrans + 1, sizeof(int));
+    c->line_idx = (int*)calloc(c->Ntrans + 1, sizeof(int));
+    for (int t = 0; t < c->Ntrans; ++t) {
+        const lsx_transition* tr = &c->trans[t];
+        if (tr->atom < 0 || tr->atom >= c->Natoms || tr->i < 0 || tr->j >= c->Nlevel[tr->atom] || tr->i >= tr->j ||
+            tr->Nblue < 0 || tr->Nlambda < 2 || tr->Nblue + tr->Nlambda > c->Nspect) {
+            lsx_destroy(c);
+            return fail(LSX_EINVAL, "lsx_create: inconsistent transition table entry");
+        }
+        if (tr->is_line) { c->phi_off[t] = c->SNl; c->line_idx[t] = c->Nlines; c->SNl += tr->Nlambda; c->Nlines++; }
+        else { c->alpha_off[t] = c->SNc; c->SNc += tr->Nlambda; }
+    }
+    DUP(c->alpha, d->alpha, c->SNc > 0 ? c->SNc : 1, double);
+#undef DUP
+    size_t nc = (size_t)ncol, Ns = (size_t)c->Nspace;
+    c->height = (double*)calloc(nc * Ns, 8); c->temperature = (double*)calloc(nc * Ns, 8);
+    c->nStar = (double*)calloc(nc * c->NLtot * Ns, 8); c->n = (double*)calloc(nc * c->NLtot * Ns, 8);
+    c->nTotal = (double*)calloc(nc * c->Natoms * Ns, 8);
+    c->C = (double*)calloc(nc * c->NL2tot * Ns, 8); c->Gamma = (double*)calloc(nc * c->NL2tot * Ns, 8);
+    c->bg_chi = (double*)calloc(nc * c->Nspect * Ns, 8); c->bg_eta = (double*)calloc(nc * c->Nspect * Ns, 8);
+    c->bg_sca = (double*)calloc(nc * sca_per_col(c), 8);
+    c->phi = (double*)calloc(nc * (phi_per_col(c) ? phi_per_col(c) : 1), 8);
+    c->wphi = (double*)calloc(nc * (c->Nlines ? c->Nlines : 1) * Ns, 8);
+    c->J = (double*)calloc(nc * c->Nspect * Ns, 8); c->I = (double*)calloc(nc * c->Nspect * c->Nrays, 8);
+    c->Rij = (double*)calloc(nc * (c->Ntrans ? c->Ntrans : 1) * Ns, 8);
+    c->Rji = (double*)calloc(nc * (c->Ntrans ? c->Ntrans : 1) * Ns, 8);
+    c->dJcol = (double*)calloc(nc, 8); c->dPcol = (double*)calloc(nc, 8);
+    c->nthreads = 1;
+    *out = c;
+    return LSX_OK;
+}
+
+void lsx_destroy(lsx_ctx* c)
+{
+    if (!c) return;
+    free(c->Nlevel); free(c->lev_off); free(c->lev2_off); free(c->wavelength); free(c->muz); free(c->wmu);
+    free(c->trans); free(c->active); free(c->alpha); free(c->alpha_off); free(c->phi_off); free(c->line_idx);
+    free(c->height); free(c->temperature); free(c->nStar); free(c->nTotal); free(c->n); free(c->C);
+    free(c->bg_chi); free(c->bg_eta); free(c->bg_sca); free(c->phi); free(c->wphi);
+    free(c->J); free(c->I); free(c->Gamma); free(c->Rij); free(c->Rji); free(c->dJcol); free(c->dPcol);
+    free(c);
+}
+
+/* oracle-only knob: number of OpenMP threads used over columns (default 1) */
+int lsx_oracle_set_threads(lsx_ctx* c, int32_t n)
+{
+    if (!c || n < 1) return fail(LSX_EINVAL, "lsx_oracle_set_threads: bad argument");
+    c->nthreads = n;
+    return LSX_OK;
+}
+
+int lsx_set_columns(lsx_ctx* c, int32_t col0, int32_t ncol, const lsx_columns* s)
+{
+    if (!c || !s || col0 < 0 || ncol < 1 || col0 + ncol > c->ncol) return fail(LSX_EINVAL, "lsx_set_columns: bad range");
+    size_t Ns = c->Nspace, o = (size_t)col0, n = (size_t)ncol;
+#define CP(dst, src, per) do { if (!(src)) return fail(LSX_EINVAL, "lsx_set_columns: null " #src); memcpy(dst + o * (per), src, n * (per) * 8); } while (0)
+    CP(c->height, s->height, Ns); CP(c->temperature, s->temperature, Ns);
+    CP(c->nStar, s->nStar, c->NLtot * Ns); CP(c->nTotal, s->nTotal, c->Natoms * Ns); CP(c->n, s->n, c->NLtot * Ns);
+    CP(c->C, s->C, c->NL2tot * Ns); CP(c->bg_chi, s->bg_chi, c->Nspect * Ns); CP(c->bg_eta, s->bg_eta, c->Nspect * Ns);
+    CP(c->bg_sca, s->bg_sca, sca_per_col(c));
+    if (c->Nlines) { CP(c->phi, s->phi, phi_per_col(c)); CP(c->wphi, s->wphi, c->Nlines * Ns); }
+#undef CP
+    memset(c->J + o * c->Nspect * Ns, 0, n * c->Nspect * Ns * 8);   /* rh_method.py:562 */
+    memset(c->I + o * c->Nspect * c->Nrays, 0, n * c->Nspect * c->Nrays * 8);
+    memset(c->Rij + o * c->Ntrans * Ns, 0, n * c->Ntrans * Ns * 8);  /* rh_method.py:130-131 */
+    memset(c->Rji + o * c->Ntrans * Ns, 0, n * c->Ntrans * Ns * 8);
+    return LSX_OK;
+}
+
+/* ---- formal_solver.py:14-44 ------------------------------------------------ */
+static inline void w2(double dtau, double* w)
+{
+    if (dtau < 5e-4) {
+        w[0] = dtau * (1.0 - 0.5 * dtau);
+        w[1] = (dtau * dtau) * (0.5 - dtau / 3.0);
+    } else if (dtau > 50.0) {
+        w[0] = 1.0;
+        w[1] = 1.0;
+    } else {
+        double expdt = exp(-dtau);
+        w[0] = 1.0 - expdt;
+        w[1] = w[0] - dtau * expdt;
+    }
+}
+
+/* ---- formal_solver.py:46-142 ----------------------------------------------- */
+static void piecewise_1d_impl(double muz, int toFrom, double Istart, int Nspace, const double* z,
+                              const double* chi, const double* S, double* I, double* PsiStar)
+{
+    double zmu = 1.0 / muz;
+    int dk, kStart, kEnd;
+    if (toFrom) { dk = -1; kStart = Nspace - 1; kEnd = 0; }
+    else { dk = 1; kStart = 0; kEnd = Nspace - 1; }
+    double dtau_uw = 0.5 * (chi[kStart] + chi[kStart + dk]) * zmu * fabs(z[kStart] - z[kStart + dk]);
+    double dS_uw = (S[kStart] - S[kStart + dk]) / dtau_uw;
+    double Iupw = Istart;
+    I[kStart] = Iupw;
+    PsiStar[kStart] = 0.0; /* LambdaStar, divided by chi below */
+    double w[2] = {0.0, 0.0};
+    int k = kStart; /* the reference's loop variable survives the loop (line 138) */
+    for (k = kStart + dk; k != kEnd; k += dk) {
+        w2(dtau_uw, w);
+        I[k] = Iupw * (1.0 - w[0]) + w[0] * S[k] + w[1] * dS_uw;
+        PsiStar[k] = w[0] - w[1] / dtau_uw;
+        double dtau_dw = 0.5 * (chi[k] + chi[k + dk]) * zmu * fabs(z[k] - z[k + dk]);
+        double dS_dw = (S[k] - S[k + dk]) / dtau_dw;
+        Iupw = I[k];
+        dS_uw = dS_dw;
+        dtau_uw = dtau_dw;
+    }
+    /* formal_solver.py:138-139: stale w and S[k] with k = kEnd - dk (reference quirk, kept) */
+    int klast = kEnd - dk;
+    I[kEnd] = (1.0 - w[0]) * Iupw + w[0] * S[klast] + w[1] * dS_uw;
+    PsiStar[kEnd] = w[0] - w[1] / dtau_uw;
+    for (int q = 0; q < Nspace; ++q) PsiStar[q] = PsiStar[q] / chi[q];
+}
+
+/* ---- utils.py:17-22 -------------------------------------------------------- */
+static inline double planck(double temp, double wav)
+{
+    double hc_Tkla = HC / (KBoltzmann * NM_TO_M * wav) / temp;
+    double twohnu3_c2 = (2.0 * HC) / pow(NM_TO_M * wav, 3.0);
+    return twohnu3_c2 / (exp(hc_Tkla) - 1.0);
+}
+
+/* ---- formal_solver.py:144-212 ---------------------------------------------- */
+static void piecewise_linear_1d(int Nspace, const double* z, const double* temperature, double muz, int toFrom,
+                                double wav, const double* chi, const double* S, double* I, double* PsiStar)
+{
+    double zmu = 1.0 / muz;
+    double Iupw;
+    if (toFrom) {
+        int kStart = Nspace - 1, dk = -1;
+        double dtau_uw = zmu * (chi[kStart] + chi[kStart + dk]) * 0.5 * fabs(z[kStart] - z[kStart + dk]);
+        double B0 = planck(temperature[Nspace - 2], wav);
+        double B1 = planck(temperature[Nspace - 1], wav);
+        Iupw = B1 - (B0 - B1) / dtau_uw;
+    } else {
+        Iupw = 0.0;
+    }
+    piecewise_1d_impl(muz, toFrom, Iupw, Nspace, z, chi, S, I, PsiStar);
+}
+
+int lsx_piecewise_linear_1d(int32_t device, int32_t nray, int32_t Nspace, const double* height,
+                            const double* temperature, const double* mu, const int32_t* to_obs, const double* wav,
+                            const double* chi, const double* S, double* I, double* PsiStar)
+{
+    (void)device;
+    if (nray < 0 || Nspace < 3) return fail(LSX_EINVAL, "lsx_piecewise_linear_1d: need Nspace >= 3");
+    for (int r = 0; r < nray; ++r)
+        piecewise_linear_1d(Nspace, height, temperature, mu[r], to_obs[r], wav[r], chi + (size_t)r * Nspace,
+                            S + (size_t)r * Nspace, I + (size_t)r * Nspace, PsiStar + (size_t)r * Nspace);
+    return LSX_OK;
+}
+
+/* oracle-only helpers exposed for unit tests against the golden vectors */
+void lsx_oracle_w2(double dtau, double* w) { w2(dtau, w); }
+void lsx_oracle_piecewise_1d_impl(double muz, int32_t toFrom, double Istart, int32_t Nspace, const double* z,
+                                  const double* chi, const double* S, double* I, double* PsiStar)
+{
+    piecewise_1d_impl(muz, toFrom, Istart, Nspace, z, chi, S, I, PsiStar);
+}
+double lsx_oracle_planck(double temp, double wav) { return planck(temp, wav); }
+
+/* ---- rh_method.py:157-196 (single index form) ------------------------------- */
+static double wlambda(const lsx_ctx* c, const lsx_transition* t, int lt)
+{
+    const double* wl = c->wavelength + t->Nblue; /* local grid == global slice (atomic_set.py:412-424) */
+    double dopplerWidth = t->is_line ? CLight / t->lambda0 : 1.0;
+    int N = t->Nlambda;
+    if (lt == 0) return 0.5 * (wl[1] - wl[0]) * dopplerWidth;
+    if (lt == N - 1) return 0.5 * (wl[N - 1] - wl[N - 2]) * dopplerWidth;
+    return 0.5 * (wl[lt + 1] - wl[lt - 1]) * dopplerWidth;
+}
+
+/* ---- rh_method.py:565-708 for one column ------------------------------------ */
+static void formal_sol_gamma_column(lsx_ctx* c, int col, double* scratch)
+{
+    const int Ns = c->Nspace, Nrays = c->Nrays, Nspect = c->Nspect;
+    const double* z = c->height + (size_t)col * Ns;
+    const double* T = c->temperature + (size_t)col * Ns;
+    const double* n = c->n + (size_t)col * c->NLtot * Ns;
+    const double* nStar = c->nStar + (size_t)col * c->NLtot * Ns;
+    double* Gamma = c->Gamma + (size_t)col * c->NL2tot * Ns;
+    const double* Cm = c->C + (size_t)col * c->NL2tot * Ns;
+    const double* bchi = c->bg_chi + (size_t)col * Nspect * Ns;
+    const double* beta = c->bg_eta + (size_t)col * Nspect * Ns;
+    const double* bsca = c->bg_sca + (size_t)col * sca_per_col(c);
+    const double* phi = c->phi + (size_t)col * phi_per_col(c);
+    const double* wphi = c->wphi + (size_t)col * c->Nlines * Ns;
+    double* J = c->J + (size_t)col * Nspect * Ns;
+    double* Iout = c->I + (size_t)col * Nspect * Nrays;
+    double* Rij = c->Rij + (size_t)col * c->Ntrans * Ns;
+    double* Rji = c->Rji + (size_t)col * c->Ntrans * Ns;
+
+    /* scratch carve-up */
+    double* JDag = scratch;                        scratch += (size_t)Nspect * Ns;
+    double* gij = scratch;                         scratch += (size_t)c->Ntrans * Ns;
+    double* wla = scratch;                         scratch += (size_t)c->Ntrans * Ns;
+    double* aeta = scratch;                        scratch += (size_t)c->Natoms * Ns;
+    double* aU = scratch;                          scratch += (size_t)c->NLtot * Ns;
+    double* achi = scratch;                        scratch += (size_t)c->NLtot * Ns;
+    double* chiTot = scratch;                      scratch += Ns;
+    double* etaTot = scratch;                      scratch += Ns;
+    double* S = scratch;                           scratch += Ns;
+    double* I = scratch;                           scratch += Ns;
+    double* Psi = scratch;                         scratch += Ns;
+    double* Vij = scratch;                         scratch += Ns;
+    double* Vji = scratch;                         scratch += Ns;
+    double* Uji = scratch;                         scratch += Ns;
+    double* Ieff = scratch;                        scratch += Ns;
+
+    /* :587-590  Gamma = 0 + C */
+    for (size_t q = 0; q < (size_t)c->NL2tot * Ns; ++q) Gamma[q] = 0.0 + Cm[q];
+    /* :592-593 */
+    memcpy(JDag, J, (size_t)Nspect * Ns * 8);
+    memset(J, 0, (size_t)Nspect * Ns * 8);
+
+    const double hc_k = HC / (KBoltzmann * NM_TO_M);
+    const double hc_4pi = 0.25 * HC / M_PI;
+
+    for (int la = 0; la < Nspect; ++la) {
+        const double wav = c->wavelength[la];
+        /* setup_wavelength, :425-455 */
+        memset(gij, 0, (size_t)c->Ntrans * Ns * 8);
+        memset(wla, 0, (size_t)c->Ntrans * Ns * 8);
+        for (int kr = 0; kr < c->Ntrans; ++kr) {
+            const lsx_transition* t = &c->trans[kr];
+            if (!c->active[(size_t)kr * Nspect + la]) continue;
+            int lt = la - t->Nblue;
+            double wl = wlambda(c, t, lt);
+            if (t->is_line) {
+                const double* wp = wphi + (size_t)c->line_idx[kr] * Ns;
+                for (int k = 0; k < Ns; ++k) {
+                    gij[kr * Ns + k] = t->Bji / t->Bij;
+                    wla[kr * Ns + k] = wl * wp[k] / HC;
+                }
+            } else {
+                const double* nsi = nStar + (size_t)(c->lev_off[t->atom] + t->i) * Ns;
+                const double* nsj = nStar + (size_t)(c->lev_off[t->atom] + t->j) * Ns;
+                for (int k = 0; k < Ns; ++k) {
+                    gij[kr * Ns + k] = nsi[k] / nsj[k] * exp(-hc_k / wav / T[k]);
+                    wla[kr * Ns + k] = wl / wav / HPlanck;
+                }
+            }
+        }
+        for (int mu = 0; mu < Nrays; ++mu) {
+            for (int toFrom = 0; toFrom < 2; ++toFrom) {
+                memset(chiTot, 0, Ns * 8);
+                memset(etaTot, 0, Ns * 8);
+                memset(aeta, 0, (size_t)c->Natoms * Ns * 8);
+                memset(aU, 0, (size_t)c->NLtot * Ns * 8);
+                memset(achi, 0, (size_t)c->NLtot * Ns * 8);
+                for (int kr = 0; kr < c->Ntrans; ++kr) {
+                    const lsx_transition* t = &c->trans[kr];
+                    if (!c->active[(size_t)kr * Nspect + la]) continue;
+                    int lt = la - t->Nblue;
+                    const double* ni = n + (size_t)(c->lev_off[t->atom] + t->i) * Ns;
+                    const double* nj = n + (size_t)(c->lev_off[t->atom] + t->j) * Ns;
+                    double* chi_i = achi + (size_t)(c->lev_off[t->atom] + t->i) * Ns;
+                    double* chi_j = achi + (size_t)(c->lev_off[t->atom] + t->j) * Ns;
+                    double* U_j = aU + (size_t)(c->lev_off[t->atom] + t->j) * Ns;
+                    double* eta_a = aeta + (size_t)t->atom * Ns;
+                    /* uv(), :245-288 */
+                    if (t->is_line) {
+                        const double* ph = c->phi_compact
+                            ? phi + ((size_t)c->phi_off[kr] + lt) * Ns
+                            : phi + ((((size_t)c->phi_off[kr] + lt) * Nrays + mu) * 2 + toFrom) * Ns;
+                        double AB = t->Aji / t->Bji;
+                        double hB = hc_4pi * t->Bij;
+                        for (int k = 0; k < Ns; ++k) {
+                            Vij[k] = hB * ph[k];
+                            Vji[k] = gij[kr * Ns + k] * Vij[k];
+                            Uji[k] = AB * Vji[k];
+                        }
+                    } else {
+                        double al = c->alpha[c->alpha_off[kr] + lt];
+                        double f = 2.0 * HC / pow(NM_TO_M * wav, 3.0);
+                        for (int k = 0; k < Ns; ++k) {
+                            Vij[k] = al;
+                            Vji[k] = gij[kr * Ns + k] * Vij[k];
+                            Uji[k] = f * Vji[k];
+                        }
+                    }
+                    for (int k = 0; k < Ns; ++k) { /* :613-627 */
+                        double chi = ni[k] * Vij[k] - nj[k] * Vji[k];
+                        double eta = nj[k] * Uji[k];
+                        chi_i[k] += chi;
+                        chi_j[k] -= chi;
+                        U_j[k] += Uji[k];
+                        chiTot[k] += chi;
+                        etaTot[k] += eta;
+                        eta_a[k] += eta;
+                    }
+                }
+                const double* sca = bsca + (c->sca_per_lambda ? (size_t)la * Ns : 0);
+                for (int k = 0; k < Ns; ++k) { /* :630-632 */
+                    chiTot[k] += bchi[(size_t)la * Ns + k];
+                    S[k] = (etaTot[k] + beta[(size_t)la * Ns + k] + sca[k] * JDag[(size_t)la * Ns + k]) / chiTot[k];
+                }
+                piecewise_linear_1d(Ns, z, T, c->muz[mu], toFrom, wav, chiTot, S, I, Psi); /* :635 */
+                Iout[(size_t)la * Nrays + mu] = I[0];                                    /* :638 */
+                double hw = 0.5 * c->wmu[mu];
+                for (int k = 0; k < Ns; ++k) J[(size_t)la * Ns + k] += hw * I[k];        /* :640 */
+
+                for (int a = 0; a < c->Natoms; ++a) { /* :643-692 */
+                    for (int k = 0; k < Ns; ++k) Ieff[k] = I[k] - Psi[k] * aeta[(size_t)a * Ns + k];
+                    for (int kr = 0; kr < c->Ntrans; ++kr) {
+                        const lsx_transition* t = &c->trans[kr];
+                        if (t->atom != a || !c->active[(size_t)kr * Nspect + la]) continue;
+                        int lt = la - t->Nblue;
+                        if (t->is_line) {
+                            const double* ph = c->phi_compact
+                                ? phi + ((size_t)c->phi_off[kr] + lt) * Ns
+                                : phi + ((((size_t)c->phi_off[kr] + lt) * Nrays + mu) * 2 + toFrom) * Ns;
+                            double AB = t->Aji / t->Bji;
+                            double hB = hc_4pi * t->Bij;
+                            for (int k = 0; k < Ns; ++k) {
+                                Vij[k] = hB * ph[k];
+                                Vji[k] = gij[kr * Ns + k] * Vij[k];
+                                Uji[k] = AB * Vji[k];
+                            }
+                        } else {
+                            double al = c->alpha[c->alpha_off[kr] + lt];
+                            double f = 2.0 * HC / pow(NM_TO_M * wav, 3.0);
+                            for (int k = 0; k < Ns; ++k) {
+                                Vij[k] = al;
+                                Vji[k] = gij[kr * Ns + k] * Vij[k];
+                                Uji[k] = f * Vji[k];
+                            }
+                        }
+                        const int Nl = c->Nlevel[a];
+                        double* G = Gamma + (size_t)c->lev2_off[a] * Ns;
+                        double* Gij = G + ((size_t)t->i * Nl + t->j) * Ns;
+                        double* Gji = G + ((size_t)t->j * Nl + t->i) * Ns;
+                        const double* chi_i = achi + (size_t)(c->lev_off[a] + t->i) * Ns;
+                        const double* chi_j = achi + (size_t)(c->lev_off[a] + t->j) * Ns;
+                        const double* U_i = aU + (size_t)(c->lev_off[a] + t->i) * Ns;
+                        const double* U_j = aU + (size_t)(c->lev_off[a] + t->j) * Ns;
+                        for (int k = 0; k < Ns; ++k) {
+                            double wlamu = wla[kr * Ns + k] * hw * 4 * M_PI;
+                            double integrand = (Uji[k] + Vji[k] * Ieff[k]) - (chi_i[k] * Psi[k] * U_j[k]);
+                            Gij[k] += integrand * wlamu;
+                            integrand = (Vij[k] * Ieff[k]) - (chi_j[k] * Psi[k] * U_i[k]);
+                            Gji[k] += integrand * wlamu;
+                            /* :691-692 (quirk kept: Vij in Rji, never zeroed between calls) */
+                            Rij[(size_t)kr * Ns + k] += I[k] * Vij[k] * wlamu;
+                            Rji[(size_t)kr * Ns + k] += (Uji[k] + I[k] * Vij[k]) * wlamu;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    /* :698-703 diagonal */
+    for (int a = 0; a < c->Natoms; ++a) {
+        const int Nl = c->Nlevel[a];
+        double* G = Gamma + (size_t)c->lev2_off[a] * Ns;
+        for (int k = 0; k < Ns; ++k) {
+            for (int i = 0; i < Nl; ++i) G[((size_t)i * Nl + i) * Ns + k] = 0.0;
+            for (int i = 0; i < Nl; ++i) {
+                double s = 0.0;
+                for (int l = 0; l < Nl; ++l) s += G[((size_t)l * Nl + i) * Ns + k];
+                G[((size_t)i * Nl + i) * Ns + k] = -s;
+            }
+        }
+    }
+    /* :705-706 */
+    double dJ = 0.0;
+    int nan = 0;
+    for (size_t q = 0; q < (size_t)Nspect * Ns; ++q) {
+        double v = fabs(1.0 - JDag[q] / J[q]);
+        if (v != v) nan = 1;
+        else if (v > dJ) dJ = v;
+    }
+    c->dJcol[col] = nan ? NAN : dJ;
+}
+
+static size_t fs_scratch_doubles(const lsx_ctx* c)
+{
+    size_t Ns = c->Nspace;
+    return (size_t)c->Nspect * Ns + 2 * (size_t)c->Ntrans * Ns + (size_t)c->Natoms * Ns + 2 * (size_t)c->NLtot * Ns + 9 * Ns;
+}
+
+static double colmax(const double* v, int n)
+{
+    double m = 0.0;
+    for (int i = 0; i < n; ++i) {
+        if (v[i] != v[i]) return NAN;
+        if (v[i] > m) m = v[i];
+    }
+    return m;
+}
+
+int lsx_formal_sol_gamma_async(lsx_ctx* c)
+{
+    if (!c) return fail(LSX_EINVAL, "null ctx");
+    size_t nd = fs_scratch_doubles(c);
+#ifdef _OPENMP
+#pragma omp parallel num_threads(c->nthreads)
+#endif
+    {
+        double* scratch = (double*)malloc(nd * 8);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int col = 0; col < c->ncol; ++col) formal_sol_gamma_column(c, col, scratch);
+        free(scratch);
+    }
+    c->last_dJ = colmax(c->dJcol, c->ncol);
+    return LSX_OK;
+}
+
+int lsx_formal_sol_gamma(lsx_ctx* c, double* dJ)
+{
+    int rc = lsx_formal_sol_gamma_async(c);
+    if (rc) return rc;
+    if (dJ) *dJ = c->last_dJ;
+    return LSX_OK;
+}
+
+/* dense solve A x = b, A column-major N x N, LU with partial pivoting in the order
+ * of LAPACK dgetf2 + dgetrs (what scipy.linalg.solve -> dgesv does, rh_method.py:739).
+ * returns 0 ok, 1 singular. */
+static int gesv(int N, double* A, double* b)
+{
+    for (int j = 0; j < N; ++j) {
+        int p = j;
+        double amax = fabs(A[j + j * N]);
+        for (int i = j + 1; i < N; ++i) {
+            double v = fabs(A[i + j * N]);
+            if (v > amax) { amax = v; p = i; }
+        }
+        if (A[p + j * N] == 0.0) return 1;
+        if (p != j) {
+            for (int q = 0; q < N; ++q) { double t = A[j + q * N]; A[j + q * N] = A[p + q * N]; A[p + q * N] = t; }
+            double t = b[j]; b[j] = b[p]; b[p] = t;
+        }
+        double r = 1.0 / A[j + j * N];
+        for (int i = j + 1; i < N; ++i) A[i + j * N] *= r;
+        for (int q = j + 1; q < N; ++q) {
+            double ajq = A[j + q * N];
+            for (int i = j + 1; i < N; ++i) A[i + q * N] -= A[i + j * N] * ajq;
+        }
+    }
+    for (int j = 0; j < N; ++j) /* L y = b */
+        for (int i = j + 1; i < N; ++i) b[i] -= A[i + j * N] * b[j];
+    for (int j = N - 1; j >= 0; --j) { /* U x = y */
+        b[j] /= A[j + j * N];
+        for (int i = 0; i < j; ++i) b[i] -= A[i + j * N] * b[j];
+    }
+    return 0;
+}
+
+/* ---- rh_method.py:710-745 for one column ----------------------------------- */
+static int stat_equil_column(lsx_ctx* c, int col)
+{
+    const int Ns = c->Nspace;
+    double maxRel = 0.0;
+    int nan = 0, singular = 0;
+    double A[32 * 32], b[32], nOld[32];
+    for (int a = 0; a < c->Natoms; ++a) {
+        const int Nl = c->Nlevel[a];
+        double* n = c->n + ((size_t)col * c->NLtot + c->lev_off[a]) * Ns;
+        const double* G = c->Gamma + ((size_t)col * c->NL2tot + c->lev2_off[a]) * Ns;
+        const double* nTot = c->nTotal + ((size_t)col * c->Natoms + a) * Ns;
+        for (int k = 0; k < Ns; ++k) {
+            int iE = 0; /* np.argmax: first maximum */
+            for (int l = 1; l < Nl; ++l)
+                if (n[(size_t)l * Ns + k] > n[(size_t)iE * Ns + k]) iE = l;
+            for (int i = 0; i < Nl; ++i)
+                for (int j = 0; j < Nl; ++j) A[i + j * Nl] = (i == iE) ? 1.0 : G[((size_t)i * Nl + j) * Ns + k];
+            for (int i = 0; i < Nl; ++i) { b[i] = 0.0; nOld[i] = n[(size_t)i * Ns + k]; }
+            b[iE] = nTot[k];
+            if (gesv(Nl, A, b)) { singular = 1; continue; }
+            for (int i = 0; i < Nl; ++i) {
+                double ch = fabs(1.0 - nOld[i] / b[i]);
+                if (ch != ch) nan = 1;
+                else if (ch > maxRel) maxRel = ch;
+                n[(size_t)i * Ns + k] = b[i];
+            }
+        }
+    }
+    c->dPcol[col] = nan ? NAN : maxRel;
+    return singular;
+}
+
+int lsx_stat_equil_async(lsx_ctx* c)
+{
+    if (!c) return fail(LSX_EINVAL, "null ctx");
+    for (int a = 0; a < c->Natoms; ++a)
+        if (c->Nlevel[a] > 32) return fail(LSX_EUNSUPPORTED, "oracle stat_equil: Nlevel > 32");
+    int sing = 0;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(c->nthreads) reduction(| : sing)
+#endif
+    for (int col = 0; col < c->ncol; ++col) sing |= stat_equil_column(c, col);
+    c->last_dP = colmax(c->dPcol, c->ncol);
+    if (sing) return fail(LSX_ESINGULAR, "stat_equil: singular system");
+    return LSX_OK;
+}
+
+int lsx_stat_equil(lsx_ctx* c, double* dP)
+{
+    int rc = lsx_stat_equil_async(c);
+    if (rc) return rc;
+    if (dP) *dP = c->last_dP;
+    return LSX_OK;
+}
+
+int lsx_sync(lsx_ctx* c, double* dJ, double* dP)
+{
+    if (!c) return fail(LSX_EINVAL, "null ctx");
+    if (dJ) *dJ = c->last_dJ;
+    if (dP) *dP = c->last_dP;
+    return LSX_OK;
+}
+
+static int locate(lsx_ctx* c, int what, double** base, size_t* per)
+{
+    size_t Ns = c->Nspace;
+    switch (what) {
+    case LSX_I: *base = c->I; *per = (size_t)c->Nspect * c->Nrays; break;
+    case LSX_J: *base = c->J; *per = (size_t)c->Nspect * Ns; break;
+    case LSX_N: *base = c->n; *per = (size_t)c->NLtot * Ns; break;
+    case LSX_GAMMA: *base = c->Gamma; *per = (size_t)c->NL2tot * Ns; break;
+    case LSX_DJ_COL: *base = c->dJcol; *per = 1; break;
+    case LSX_DPOPS_COL: *base = c->dPcol; *per = 1; break;
+    case LSX_NSTAR: *base = c->nStar; *per = (size_t)c->NLtot * Ns; break;
+    case LSX_C: *base = c->C; *per = (size_t)c->NL2tot * Ns; break;
+    case LSX_RIJ: *base = c->Rij; *per = (size_t)c->Ntrans * Ns; break;
+    case LSX_RJI: *base = c->Rji; *per = (size_t)c->Ntrans * Ns; break;
+    default: return 1;
+    }
+    return 0;
+}
+
+int lsx_get(lsx_ctx* c, int32_t what, int32_t col0, int32_t ncol, double* dst, size_t nbytes)
+{
+    double* base; size_t per;
+    if (!c || !dst || col0 < 0 || ncol < 1 || col0 + ncol > c->ncol) return fail(LSX_EINVAL, "lsx_get: bad range");
+    if (locate(c, what, &base, &per)) return fail(LSX_EINVAL, "lsx_get: unknown item");
+    if (nbytes != per * ncol * 8) return fail(LSX_EINVAL, "lsx_get: nbytes does not match the item's shape");
+    memcpy(dst, base + per * col0, nbytes);
+    return LSX_OK;
+}
+
+int lsx_set(lsx_ctx* c, int32_t what, int32_t col0, int32_t ncol, const double* src, size_t nbytes)
+{
+    double* base; size_t per;
+    if (!c || !src || col0 < 0 || ncol < 1 || col0 + ncol > c->ncol) return fail(LSX_EINVAL, "lsx_set: bad range");
+    if (what != LSX_N && what != LSX_J) return fail(LSX_EINVAL, "lsx_set: only LSX_N and LSX_J are writable");
+    locate(c, what, &base, &per);
+    if (nbytes != per * ncol * 8) return fail(LSX_EINVAL, "lsx_set: nbytes does not match the item's shape");
+    memcpy(base + per * col0, src, nbytes);
+    return LSX_OK;
+}
+
+#include <time.h>
+int lsx_time_formal_sol(lsx_ctx* c, int32_t warmup, int32_t reps, double* ms_total, double* ms_sweep)
+{
+    if (!c || reps < 1) return fail(LSX_EINVAL, "lsx_time_formal_sol: bad argument");
+    for (int i = 0; i < warmup; ++i) lsx_formal_sol_gamma_async(c);
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int i = 0; i < reps; ++i) lsx_formal_sol_gamma_async(c);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    double ms = ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6) / reps;
+    if (ms_total) *ms_total = ms;
+    if (ms_sweep) *ms_sweep = ms;
+    return LSX_OK;
+}
+
+/* B_alg = 8 Ns [P SNl + 2 Nspect (bg) + 2 Nspect (Jdag, J) + 1 (sigma) + NLtot (n)
+ *                          + 2 NL2tot (C, Gamma) + 6] + 8 Nspect Nrays */
+double lsx_algorithmic_bytes_per_column(const lsx_ctx* c)
+{
+    double P = c->phi_compact ? 1.0 : 2.0 * c->Nrays;
+    double per_depth = P * c->SNl + 4.0 * c->Nspect + (c->sca_per_lambda ? c->Nspect : 1.0) + c->NLtot + 2.0 * c->NL2tot + 6.0;
+    return 8.0 * c->Nspace * per_depth + 8.0 * c->Nspect * c->Nrays;
+}

@@ -1,0 +1,351 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by importing the UNMODIFIED
+reference from /root/reference (build container only; the reference never
+travels to the GPU box -- only the numeric .npz files written here do).
+
+The reference imports numba / astropy / specutils at module top; none is
+installed in this image, so harness-side stand-ins from tests/golden/_refstubs
+are put on sys.path (numba.njit == identity, i.e. the reference's pure-Python
+semantics).  One numpy-2 compatibility patch is applied at run time, nothing
+under /root/reference is touched:
+  * atomic_model.avoid_recursion_eq     returns False for shape-mismatched
+    arrays (numpy<1.25 semantics; only used for list membership in setup).
+(np.bool, used at rh_method.py:124, exists again in numpy 2.x.)
+
+Usage:  python tests/golden/make_golden.py [units] [falc_ca] [falc_cah] [falc_ca_vlos] [rf] [all]
+"""
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get('LIGHTSPINNER_REF', '/root/reference')
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(HERE, '_refstubs'))
+sys.path.insert(0, REF)
+
+import numpy as np  # noqa: E402
+
+import atomic_model  # noqa: E402
+
+_orig_eq = atomic_model.avoid_recursion_eq
+
+
+def _compat_eq(a, b):
+    if isinstance(a, np.ndarray):
+        if not isinstance(b, np.ndarray) or a.shape != b.shape:
+            return False
+    return _orig_eq(a, b)
+
+
+atomic_model.avoid_recursion_eq = _compat_eq
+
+import formal_solver  # noqa: E402
+from fal import Falc82  # noqa: E402
+from rh_atoms import CaII_atom, H_6_atom  # noqa: E402
+from atomic_set import RadiativeSet  # noqa: E402
+from rh_method import Context  # noqa: E402
+from background import Background  # noqa: E402
+from atomic_model import AtomicLine  # noqa: E402
+
+
+# ----------------------------------------------------------------------------
+def build_ctx(active, vlos=None, temp_pert=None, start_pops=None, nrays=5):
+    """Reproduces the setup of test.py:8-18 / response_fn.py:23-37."""
+    ac = Falc82()
+    ac.quadrature(nrays)
+    if temp_pert is not None:
+        k, dT = temp_pert
+        ac.temperature[k] += dT  # Quantity in K; same as response_fn.py:26
+    if vlos is not None:
+        ac.vlos[:] = vlos  # m/s (constructor already converted to SI)
+    atmos = ac.convert_scales()
+    aSet = RadiativeSet([CaII_atom(), H_6_atom()])
+    aSet.set_active(*active)
+    spect = aSet.compute_wavelength_grid()
+    eqPops = aSet.compute_eq_pops(atmos)
+    if start_pops is not None:
+        for name, p in start_pops.items():
+            eqPops[name].pops = np.copy(p)
+    background = Background(atmos, spect)
+    ctx = Context(atmos, spect, eqPops, background)
+    return ctx
+
+
+def dump_inputs(ctx, full_phi=False, phi_sample_only=False):
+    """Flat dict of the post-setup hot-path inputs."""
+    atmos, spect, bg = ctx.atmos, ctx.spect, ctx.background
+    d = {}
+    d['wavelength'] = np.array(spect.wavelength)
+    for k in ('muz', 'wmu', 'height', 'temperature', 'ne', 'vlos', 'vturb', 'nHTot'):
+        d[k] = np.array(getattr(atmos, k), dtype=np.float64)
+    d['bg_chi'] = np.array(bg.chi)
+    d['bg_eta'] = np.array(bg.eta)
+    sca = np.array(bg.sca)
+    if np.all(sca == sca[0:1]):
+        d['bg_sca'] = sca[0].copy()
+    else:
+        d['bg_sca'] = sca
+    d['hGround'] = np.array(ctx.eqPops['H'].n[0])
+    names = []
+    t_atom, t_isline, t_i, t_j, t_nblue, t_nl = [], [], [], [], [], []
+    t_A, t_Bji, t_Bij, t_l0 = [], [], [], []
+    t_active = []
+    kr = 0
+    for a, atom in enumerate(ctx.activeAtoms):
+        # compute_collisions is re-run at the top of every FS call; C is a pure
+        # function of the atmosphere (rh_method.py:474-487), capture it here.
+        atom.compute_collisions()
+        names.append(atom.atomicModel.name)
+        d['a%d_nStar' % a] = np.array(atom.nStar)
+        d['a%d_nTotal' % a] = np.array(atom.nTotal)
+        d['a%d_n0' % a] = np.array(atom.n)
+        d['a%d_C' % a] = np.array(atom.C)
+        d['a%d_vBroad' % a] = np.array(atom.vBroad)
+        d['a%d_weight' % a] = np.float64(atom.atomicTable[atom.atomicModel.name].weight)
+        for t in atom.trans:
+            t_atom.append(a)
+            t_isline.append(1 if t.isLine else 0)
+            t_i.append(t.i)
+            t_j.append(t.j)
+            t_nblue.append(int(t.Nblue))
+            t_nl.append(t.wavelength.shape[0])
+            t_active.append(np.array(t.active, dtype=np.bool_))
+            d['t%d_wavelength' % kr] = np.array(t.wavelength)
+            if t.isLine:
+                t_A.append(t.Aji); t_Bji.append(t.Bji); t_Bij.append(t.Bij); t_l0.append(t.lambda0)
+                d['t%d_wphi' % kr] = np.array(t.wphi)
+                aDamp, _ = t.transModel.damping(atmos, atom.vBroad, atom.hPops.n[0])
+                d['t%d_aDamp' % kr] = np.array(aDamp)
+                phi = np.array(t.phi)
+                same = np.all(phi == phi[:, :1, :1, :])
+                if phi_sample_only:
+                    d['t%d_phi_sample' % kr] = phi[::7, :, :, ::9].copy()
+                elif same and not full_phi:
+                    d['t%d_phi' % kr] = phi[:, 0, 0, :].copy()
+                else:
+                    d['t%d_phi' % kr] = phi
+            else:
+                t_A.append(0.0); t_Bji.append(0.0); t_Bij.append(0.0); t_l0.append(0.0)
+                d['t%d_alpha' % kr] = np.array(t.alpha)
+            kr += 1
+    d['atom_names'] = np.array(names)
+    d['t_atom'] = np.array(t_atom, dtype=np.int32)
+    d['t_isline'] = np.array(t_isline, dtype=np.int32)
+    d['t_i'] = np.array(t_i, dtype=np.int32)
+    d['t_j'] = np.array(t_j, dtype=np.int32)
+    d['t_Nblue'] = np.array(t_nblue, dtype=np.int32)
+    d['t_Nlambda'] = np.array(t_nl, dtype=np.int32)
+    d['t_Aji'] = np.array(t_A); d['t_Bji'] = np.array(t_Bji)
+    d['t_Bij'] = np.array(t_Bij); d['t_lambda0'] = np.array(t_l0)
+    d['t_active'] = np.array(t_active)
+    return d
+
+
+def snap_fs(ctx, d, tag, dJ, with_rates=False):
+    d['%s_J' % tag] = ctx.J.copy()
+    d['%s_I' % tag] = ctx.I.copy()
+    d['%s_dJ' % tag] = np.float64(dJ)
+    for a, atom in enumerate(ctx.activeAtoms):
+        d['%s_Gamma_a%d' % (tag, a)] = atom.Gamma.copy()
+    if with_rates:
+        kr = 0
+        for atom in ctx.activeAtoms:
+            for t in atom.trans:
+                d['%s_Rij_t%d' % (tag, kr)] = t.Rij.copy()
+                d['%s_Rji_t%d' % (tag, kr)] = t.Rji.copy()
+                kr += 1
+
+
+def snap_se(ctx, d, tag, dPops):
+    d['%s_dPops' % tag] = np.float64(dPops)
+    for a, atom in enumerate(ctx.activeAtoms):
+        d['%s_n_a%d' % (tag, a)] = atom.n.copy()
+
+
+def run_mali(ctx, d, snap_iters=(1, 2, 3, 4, 5), max_iter=500, stop_after=None, log=None):
+    """The driver loop of test.py:20-29 with snapshots."""
+    dJ, dPops, i = 1.0, 1.0, 0
+    traj_dJ, traj_dP = [], []
+    t0 = time.time()
+    while dJ > 2e-3 or dPops > 1e-3:
+        i += 1
+        dJ = ctx.formal_sol_gamma_matrices()
+        if i in snap_iters:
+            snap_fs(ctx, d, 'fs%d' % i, dJ, with_rates=(i <= 2))
+        if i > 3:
+            dPops = ctx.stat_equil()
+            if i in snap_iters:
+                snap_se(ctx, d, 'se%d' % i, dPops)
+        traj_dJ.append(dJ)
+        traj_dP.append(dPops if i > 3 else np.nan)
+        if log:
+            print('%s it %03d dJ %.6e dPops %.6e  (%.1fs)' % (log, i, dJ, dPops, time.time() - t0), flush=True)
+        if stop_after is not None and i >= stop_after:
+            break
+        if i >= max_iter:
+            break
+    d['traj_dJ'] = np.array(traj_dJ)
+    d['traj_dPops'] = np.array(traj_dP)
+    d['n_iter'] = np.int32(i)
+    return i
+
+
+def save(name, d):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **d)
+    print('wrote %s (%.1f kB)' % (path, os.path.getsize(path) / 1e3), flush=True)
+
+
+# ----------------------------------------------------------------------------
+def gen_units():
+    """w2 / piecewise_1d_impl / piecewise_linear_1d / planck unit vectors."""
+    from utils import planck
+    d = {}
+    dt = np.concatenate([np.logspace(-12, 9, 400),
+                         [5e-4, np.nextafter(5e-4, 0), np.nextafter(5e-4, 1),
+                          50.0, np.nextafter(50.0, 0), np.nextafter(50.0, 100.0), 0.0]])
+    d['w2_dtau'] = dt
+    d['w2_out'] = np.array([formal_solver.w2(x) for x in dt])
+    rng = np.random.default_rng(20260101)
+    cases = []
+    for c, N in enumerate([3, 4, 5, 17, 82, 82, 82, 83, 200, 41]):
+        z = np.sort(rng.uniform(-1e5, 2e6, N))[::-1].copy()
+        logchi = np.cumsum(rng.normal(0.15, 0.3, N)) + rng.uniform(-16, -9)
+        chi = np.exp(logchi)
+        if c == 5:
+            chi *= 1e6  # mostly saturated branch
+        if c == 6:
+            chi *= 1e-6  # mostly Taylor branch
+        S = np.exp(rng.normal(-20, 1.0, N)) * np.linspace(0.1, 3.0, N)
+        mu = float(rng.uniform(0.04, 1.0))
+        for toFrom in (False, True):
+            Istart = float(rng.uniform(0, 1e-8)) if toFrom else 0.0
+            I, Psi = formal_solver.piecewise_1d_impl(mu, toFrom, Istart, z, chi, S)
+            tag = 'pw%d_%d' % (c, int(toFrom))
+            d[tag + '_z'] = z; d[tag + '_chi'] = chi; d[tag + '_S'] = S
+            d[tag + '_mu'] = np.float64(mu); d[tag + '_Istart'] = np.float64(Istart)
+            d[tag + '_I'] = I; d[tag + '_Psi'] = Psi
+        cases.append(N)
+    d['pw_N'] = np.array(cases, dtype=np.int32)
+
+    # piecewise_linear_1d with boundary conditions on a duck-typed atmosphere
+    class A:
+        pass
+    at = A()
+    at.Nspace = 82
+    at.muz = np.array([0.2, 0.9])
+    at.height = np.sort(rng.uniform(-1e5, 2e6, 82))[::-1].copy()
+    at.temperature = np.linspace(4000.0, 9500.0, 82)
+    chi = np.exp(np.cumsum(rng.normal(0.2, 0.3, 82)) - 14)
+    S = np.exp(rng.normal(-19, 0.5, 82))
+    d['pl_height'] = at.height; d['pl_temperature'] = at.temperature; d['pl_muz'] = at.muz
+    d['pl_chi'] = chi; d['pl_S'] = S
+    wavs = np.array([30.0, 393.4, 854.2, 2000.0])
+    d['pl_wav'] = wavs
+    for wi, wav in enumerate(wavs):
+        for mu in range(2):
+            for toFrom in (False, True):
+                r = formal_solver.piecewise_linear_1d(at, mu, toFrom, wav, chi, S)
+                d['pl_I_%d_%d_%d' % (wi, mu, int(toFrom))] = r.I
+                d['pl_Psi_%d_%d_%d' % (wi, mu, int(toFrom))] = r.PsiStar
+    T = np.array([3000.0, 4500.0, 6000.0, 9000.0, 1e5])
+    d['planck_T'] = T
+    d['planck_wav'] = wavs
+    d['planck_B'] = np.array([planck(T, w) for w in wavs])
+    save('units.npz', d)
+
+
+def gen_falc_ca():
+    ctx = build_ctx(['Ca'])
+    d = dump_inputs(ctx)
+    n = run_mali(ctx, d, log='falc_ca')
+    snap_fs(ctx, d, 'conv', d['traj_dJ'][-1])
+    snap_se(ctx, d, 'conv', d['traj_dPops'][-1])
+    print('falc_ca converged in', n)
+    save('falc_ca.npz', d)
+    return ctx
+
+
+def gen_falc_cah(stop_after=8):
+    ctx = build_ctx(['Ca', 'H'])
+    d = dump_inputs(ctx)
+    run_mali(ctx, d, snap_iters=(1, 2, 4, 5), stop_after=stop_after, log='falc_cah')
+    snap_fs(ctx, d, 'last', d['traj_dJ'][-1])
+    snap_se(ctx, d, 'last', d['traj_dPops'][-1])
+    # keep the fixture small: drop the bulky intermediate J snapshots except fs1/fs2/last
+    for k in list(d.keys()):
+        if k in ('fs4_J', 'fs5_J'):
+            del d[k]
+    save('falc_cah.npz', d)
+
+
+def gen_falc_ca_vlos():
+    """Non-zero line-of-sight velocity: phi is genuinely 4-D (rh_method.py:229-240).
+    Only the ingredients of phi (aDamp, vBroad, vlos) plus a strided sample of the
+    reference's phi are stored; tests rebuild phi with the same scipy wofz."""
+    k = np.arange(82)
+    vlos = 4.0e3 * np.sin(2 * np.pi * k / 41.0) * np.exp(-((k - 35.0) / 25.0) ** 2) + 1.5e3
+    ctx = build_ctx(['Ca'], vlos=vlos)
+    d = dump_inputs(ctx, phi_sample_only=True)
+    run_mali(ctx, d, snap_iters=(1, 2, 4, 5), stop_after=6, log='falc_ca_vlos')
+    snap_fs(ctx, d, 'last', d['traj_dJ'][-1])
+    snap_se(ctx, d, 'last', d['traj_dPops'][-1])
+    # the unperturbed-layout quantities identical to falc_ca are kept (file is self-contained)
+    save('falc_ca_vlos.npz', d)
+
+
+def gen_rf(ks=(20, 48, 70)):
+    """response_fn.py:23-67 for a handful of depth indices: delta-encoded inputs
+    (only the depth-k entries differ) + converged emergent I."""
+    base = build_ctx(['Ca'])
+    dbase = dump_inputs(base)
+    tmp = {}
+    run_mali(base, tmp, snap_iters=(), log='rf_base')
+    out = {'ks': np.array(ks, dtype=np.int32), 'tempPert': np.float64(50.0)}
+    out['base_I'] = base.I.copy()
+    out['base_n'] = base.activeAtoms[0].n.copy()
+    out['base_niter'] = tmp['n_iter']
+    startPops = {'Ca': base.eqPops['Ca'].n}
+    for k in ks:
+        for sgn, tag in ((+1, 'p'), (-1, 'm')):
+            ctx = build_ctx(['Ca'], temp_pert=(k, sgn * 25.0), start_pops=startPops)
+            dp = dump_inputs(ctx)
+            # delta encode: store every array that differs from base, verifying where it differs
+            for key, v in dp.items():
+                b = dbase[key]
+                if v.dtype.kind in 'US' or v.dtype.kind in 'ib':
+                    assert np.array_equal(v, b), key
+                    continue
+                if key.endswith('_n0'):
+                    continue  # warm start = base_n
+                if np.array_equal(v, b):
+                    continue
+                diff = (v != b)
+                where_k = np.zeros_like(diff)
+                where_k[..., k] = True
+                if key == 'height':
+                    # uniform shift only: |dz| must be bitwise identical
+                    assert np.array_equal(np.diff(v), np.diff(b)), 'height diff changed'
+                    continue
+                assert not np.any(diff & ~where_k), 'non-local change in %s' % key
+                out['k%d%s_%s' % (k, tag, key)] = v[..., k].copy()
+            t2 = {}
+            n = run_mali(ctx, t2, snap_iters=(), log='rf_k%d%s' % (k, tag))
+            out['k%d%s_I' % (k, tag)] = ctx.I.copy()
+            out['k%d%s_n' % (k, tag)] = ctx.activeAtoms[0].n.copy()
+            out['k%d%s_niter' % (k, tag)] = np.int32(n)
+            out['k%d%s_traj_dJ' % (k, tag)] = t2['traj_dJ']
+            out['k%d%s_traj_dPops' % (k, tag)] = t2['traj_dPops']
+    save('rf_ca.npz', out)
+
+
+if __name__ == '__main__':
+    what = sys.argv[1:] or ['all']
+    if 'all' in what:
+        what = ['units', 'falc_ca', 'falc_cah', 'falc_ca_vlos', 'rf']
+    for w in what:
+        t0 = time.time()
+        {'units': gen_units, 'falc_ca': gen_falc_ca, 'falc_cah': gen_falc_cah,
+         'falc_ca_vlos': gen_falc_ca_vlos, 'rf': gen_rf}[w]()
+        print('%s done in %.1fs' % (w, time.time() - t0), flush=True)
