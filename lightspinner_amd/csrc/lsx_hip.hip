@@ -1,0 +1,1012 @@
+// lsx_hip.hip -- host runtime of the lsx C ABI (include/lsx.h) on HIP + the small kernels
+// around the sweep: upload-time re-layout, Gamma epilogue, statistical equilibrium,
+// convergence reductions, stand-alone batched formal solver.  gfx950 only.
+//
+// Reference lines restated here:
+//   rh_method.py:587-590, 698-708  Gamma = C prologue, diagonal fix-up, dJ      (k_gamma_finish)
+//   rh_method.py:710-745           stat_equil                                   (k_stat_equil)
+//   rh_method.py:453-454           continuum g_ij table                          (k_build_gijc)
+//   formal_solver.py:46-212        stand-alone piecewise_linear_1d               (k_piecewise)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lsx.h"
+#include "lsx_dev.h"
+
+// launchers defined in lsx_sweep.hip, one translation unit per rays-per-lane M
+#define DECL_SWEEP(M) extern "C" hipError_t lsx_launch_sweep_m##M(const SweepParams*, int, int, size_t, hipStream_t);
+DECL_SWEEP(1) DECL_SWEEP(2) DECL_SWEEP(3) DECL_SWEEP(4) DECL_SWEEP(5) DECL_SWEEP(8)
+#undef DECL_SWEEP
+
+namespace {
+
+constexpr double kCLight = 2.99792458E+08;
+constexpr double kHPlanck = 6.6260755E-34;
+constexpr double kKBoltzmann = 1.380658E-23;
+constexpr double kNM_TO_M = 1.0E-09;
+constexpr double kHC = kHPlanck * kCLight;
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail(LSX_EDEVICE, "%s: %s", #expr, hipGetErrorString(e_));  \
+    } while (0)
+
+// ------------------------------------------------------------------------------- kernels
+// out[b][c][r] = in[b][r][c]
+__global__ void k_transpose(const double* __restrict__ in, double* __restrict__ out, int R, int Cc)
+{
+    __shared__ double tile[32][33];
+    const size_t b = blockIdx.z;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y; // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        if (r < R && c < Cc) tile[j][tx] = in[(b * R + r) * Cc + c];
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (r < R && c < Cc) out[(b * Cc + c) * R + r] = tile[tx][j];
+    }
+}
+
+// one line's profile: in [col][lt][mu][dir][k]  ->  out [col][k][dir][mu][lt]
+// (compact: in [col][lt][k] -> out [col][k][lt]; pass Nrays = 1, ndir = 1)
+__global__ void k_pack_phi(const double* __restrict__ in, double* __restrict__ out, int Nlam, int Nrays, int ndir,
+                           int Ns, size_t in_col_stride, size_t out_col_stride)
+{
+    const size_t col = blockIdx.y;
+    const size_t total = (size_t)Nlam * Nrays * ndir * Ns;
+    for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        size_t r = o;
+        const int lt = r % Nlam; r /= Nlam;
+        const int mu = r % Nrays; r /= Nrays;
+        const int d = r % ndir; r /= ndir;
+        const int k = (int)r;
+        out[col * out_col_stride + o] = in[col * in_col_stride + (((size_t)lt * Nrays + mu) * ndir + d) * Ns + k];
+    }
+}
+
+// g_ij of a continuum (rh_method.py:453-454): out[col][k][lt]
+__global__ void k_build_gijc(const double* __restrict__ nStar, const double* __restrict__ temperature,
+                             const double* __restrict__ wavelength, double* __restrict__ out, int li, int lj, int Nblue,
+                             int Nlam, int Ns, int NLtot, size_t out_col_stride)
+{
+    const size_t col = blockIdx.y;
+    const double hc_k = kHC / (kKBoltzmann * kNM_TO_M);
+    const int total = Nlam * Ns;
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gridDim.x * blockDim.x) {
+        const int lt = o % Nlam, k = o / Nlam;
+        const double nsi = nStar[(col * NLtot + li) * Ns + k];
+        const double nsj = nStar[(col * NLtot + lj) * Ns + k];
+        const double T = temperature[col * Ns + k];
+        out[col * out_col_stride + o] = nsi / nsj * exp(-hc_k / wavelength[Nblue + lt] / T);
+    }
+}
+
+struct FinishParams {
+    int Nspace, Natoms, NL2tot, ncol, ntile, nslot_total;
+    const int* Nlevel;      // [Natoms]
+    const int* lev2_off;    // [Natoms]
+    const DevTile* tiles;
+    const int* tile_slots;
+    const DevTrans* trans;
+    const double* C;
+    const double* Gpart;
+    const double* dJpart;
+    double* Gamma;
+    double* dJcol;
+};
+
+// Gamma = C + sum of the sweep's slabs in (tile, slot, entry, direction) order; then the
+// diagonal (rh_method.py:587-590, 698-703).  One thread per (column, depth).
+__global__ void k_gamma_finish(const FinishParams f)
+{
+    const int Ns = f.Nspace;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)f.ncol * Ns) return;
+    const int col = gid / Ns, k = gid % Ns;
+    double* G = f.Gamma + (size_t)col * f.NL2tot * Ns + k;
+    const double* Cm = f.C + (size_t)col * f.NL2tot * Ns + k;
+    for (int e = 0; e < f.NL2tot; ++e) G[(size_t)e * Ns] = 0.0 + Cm[(size_t)e * Ns];
+    const double* P = f.Gpart + (size_t)col * f.nslot_total * 4 * Ns + k;
+    for (int t = 0; t < f.ntile; ++t) {
+        const DevTile tl = f.tiles[t];
+        for (int u = 0; u < tl.nslot; ++u) {
+            const DevTrans& tr = f.trans[f.tile_slots[tl.slot0 + u]];
+            const double* q = P + (size_t)(tl.slot0 + u) * 4 * Ns;
+            double gij = G[(size_t)tr.gam_ij * Ns], gji = G[(size_t)tr.gam_ji * Ns];
+            gij += q[0];
+            gij += q[(size_t)Ns];
+            gji += q[(size_t)2 * Ns];
+            gji += q[(size_t)3 * Ns];
+            G[(size_t)tr.gam_ij * Ns] = gij;
+            G[(size_t)tr.gam_ji * Ns] = gji;
+        }
+    }
+    for (int a = 0; a < f.Natoms; ++a) {
+        const int Nl = f.Nlevel[a];
+        double* Ga = G + (size_t)f.lev2_off[a] * Ns;
+        for (int i = 0; i < Nl; ++i) Ga[(size_t)(i * Nl + i) * Ns] = 0.0;
+        for (int i = 0; i < Nl; ++i) {
+            double s = 0.0;
+            for (int l = 0; l < Nl; ++l) s += Ga[(size_t)(l * Nl + i) * Ns];
+            Ga[(size_t)(i * Nl + i) * Ns] = -s;
+        }
+    }
+    if (k == 0) { // per-column dJ: max over the column's tiles, NaN propagating (rh_method.py:705-706)
+        double m = 0.0;
+        for (int t = 0; t < f.ntile; ++t) {
+            const double v = f.dJpart[(size_t)col * f.ntile + t];
+            m = (v != v || m != m) ? __builtin_nan("") : fmax(m, v);
+        }
+        f.dJcol[col] = m;
+    }
+}
+
+__device__ __forceinline__ void atomic_max_nonneg(double* addr, double v)
+{
+    // for non-negative doubles (and +NaN) the IEEE bit pattern orders like the value; NaN wins
+    atomicMax(reinterpret_cast<unsigned long long*>(addr),
+              static_cast<unsigned long long>(__double_as_longlong(fabs(v))));
+}
+
+// rh_method.py:710-745.  One thread per (column, depth) of one atom; the Nl x Nl system of
+// each thread lives in a thread-private LDS column (A[e][tid]) -- dense LU with partial
+// pivoting in the operation order of LAPACK dgetf2/dgetrs.
+__global__ void k_stat_equil(const double* __restrict__ Gamma, const double* __restrict__ nTotal, double* __restrict__ n,
+                             double* __restrict__ dPcol, int* __restrict__ singular, int Nl, int lev_off, int lev2_off,
+                             int atom, int Natoms, int NLtot, int NL2tot, int Ns, int ncol)
+{
+    extern __shared__ double sm[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const long gid = (long)blockIdx.x * nt + tid;
+    if (gid >= (long)ncol * Ns) return;
+    const int col = gid / Ns, k = gid % Ns;
+    double* A = sm + tid;                       // A[(i + j*Nl) * nt]
+    double* b = sm + (size_t)Nl * Nl * nt + tid; // b[i * nt]
+    double* nOld = b + (size_t)Nl * nt;
+    double* nk = n + ((size_t)col * NLtot + lev_off) * Ns + k;
+    const double* G = Gamma + ((size_t)col * NL2tot + lev2_off) * Ns + k;
+
+    int iE = 0;
+    double nmax = nk[0];
+    for (int l = 0; l < Nl; ++l) {
+        const double v = nk[(size_t)l * Ns];
+        nOld[l * nt] = v;
+        if (v > nmax) { nmax = v; iE = l; }      // np.argmax: first maximum
+    }
+    for (int i = 0; i < Nl; ++i)
+        for (int j = 0; j < Nl; ++j) A[(i + j * Nl) * nt] = (i == iE) ? 1.0 : G[(size_t)(i * Nl + j) * Ns];
+    for (int i = 0; i < Nl; ++i) b[i * nt] = 0.0;
+    b[iE * nt] = nTotal[((size_t)col * Natoms + atom) * Ns + k];
+
+    bool sing = false;
+    for (int j = 0; j < Nl && !sing; ++j) {
+        int pv = j;
+        double amax = fabs(A[(j + j * Nl) * nt]);
+        for (int i = j + 1; i < Nl; ++i) {
+            const double v = fabs(A[(i + j * Nl) * nt]);
+            if (v > amax) { amax = v; pv = i; }
+        }
+        if (A[(pv + j * Nl) * nt] == 0.0 || amax != amax) { sing = true; break; }
+        if (pv != j) {
+            for (int q = 0; q < Nl; ++q) {
+                const double t = A[(j + q * Nl) * nt];
+                A[(j + q * Nl) * nt] = A[(pv + q * Nl) * nt];
+                A[(pv + q * Nl) * nt] = t;
+            }
+            const double t = b[j * nt]; b[j * nt] = b[pv * nt]; b[pv * nt] = t;
+        }
+        const double r = 1.0 / A[(j + j * Nl) * nt];
+        for (int i = j + 1; i < Nl; ++i) A[(i + j * Nl) * nt] *= r;
+        for (int q = j + 1; q < Nl; ++q) {
+            const double ajq = A[(j + q * Nl) * nt];
+            for (int i = j + 1; i < Nl; ++i) A[(i + q * Nl) * nt] -= A[(i + j * Nl) * nt] * ajq;
+        }
+    }
+    if (sing) { atomicOr(singular, 1); return; }
+    for (int j = 0; j < Nl; ++j)
+        for (int i = j + 1; i < Nl; ++i) b[i * nt] -= A[(i + j * Nl) * nt] * b[j * nt];
+    for (int j = Nl - 1; j >= 0; --j) {
+        b[j * nt] /= A[(j + j * Nl) * nt];
+        for (int i = 0; i < j; ++i) b[i * nt] -= A[(i + j * Nl) * nt] * b[j * nt];
+    }
+    double mx = 0.0;
+    for (int i = 0; i < Nl; ++i) {
+        const double nn = b[i * nt];
+        const double ch = fabs(1.0 - nOld[i * nt] / nn);
+        mx = (ch != ch || mx != mx) ? __builtin_nan("") : fmax(mx, ch);
+        nk[(size_t)i * Ns] = nn;
+    }
+    atomic_max_nonneg(&dPcol[col], mx);
+}
+
+// out[0] = NaN-propagating max of v[0..n)
+__global__ void k_reduce_max(const double* __restrict__ v, int n, double* __restrict__ out)
+{
+    __shared__ double sh[256];
+    double m = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double x = v[i];
+        m = (x != x || m != m) ? __builtin_nan("") : fmax(m, x);
+    }
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            const double a = sh[threadIdx.x], b = sh[threadIdx.x + s];
+            sh[threadIdx.x] = (a != a || b != b) ? __builtin_nan("") : fmax(a, b);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+// formal_solver.py:14-212 for independent rays (one ray per thread, [ray][k] layout)
+__device__ __forceinline__ void dev_w2(double dtau, double& w0, double& w1)
+{
+    if (dtau < 5e-4) {
+        w0 = dtau * (1.0 - 0.5 * dtau);
+        w1 = (dtau * dtau) * (0.5 - dtau / 3.0);
+    } else if (dtau > 50.0) {
+        w0 = 1.0;
+        w1 = 1.0;
+    } else {
+        const double e = exp(-dtau);
+        w0 = 1.0 - e;
+        w1 = w0 - dtau * e;
+    }
+}
+__device__ __forceinline__ double dev_planck(double temp, double wav)
+{
+    const double hc_Tkla = kHC / (kKBoltzmann * kNM_TO_M * wav) / temp;
+    const double x = kNM_TO_M * wav;
+    return (2.0 * kHC) / (x * x * x) / (exp(hc_Tkla) - 1.0);
+}
+__global__ void k_piecewise(int nray, int Ns, const double* __restrict__ z, const double* __restrict__ T,
+                            const double* __restrict__ mu, const int* __restrict__ to_obs, const double* __restrict__ wav,
+                            const double* __restrict__ chi, const double* __restrict__ S, double* __restrict__ I,
+                            double* __restrict__ Psi)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nray) return;
+    const double* c = chi + (size_t)r * Ns;
+    const double* s = S + (size_t)r * Ns;
+    double* Io = I + (size_t)r * Ns;
+    double* Po = Psi + (size_t)r * Ns;
+    const double zmu = 1.0 / mu[r];
+    const int up = to_obs[r];
+    const int dk = up ? -1 : 1, kS = up ? Ns - 1 : 0, kE = up ? 0 : Ns - 1;
+    double dtau = 0.5 * (c[kS] + c[kS + dk]) * zmu * fabs(z[kS] - z[kS + dk]);
+    double Iu = 0.0;
+    if (up) {
+        const double dt0 = zmu * (c[kS] + c[kS + dk]) * 0.5 * fabs(z[kS] - z[kS + dk]);
+        const double B0 = dev_planck(T[Ns - 2], wav[r]), B1 = dev_planck(T[Ns - 1], wav[r]);
+        Iu = B1 - (B0 - B1) / dt0;
+    }
+    double dS = (s[kS] - s[kS + dk]) / dtau;
+    Io[kS] = Iu;
+    Po[kS] = 0.0;
+    double w0 = 0.0, w1 = 0.0;
+    for (int k = kS + dk; k != kE; k += dk) {
+        dev_w2(dtau, w0, w1);
+        const double Ik = Iu * (1.0 - w0) + w0 * s[k] + w1 * dS;
+        Io[k] = Ik;
+        Po[k] = (w0 - w1 / dtau) / c[k];
+        const double dt2 = 0.5 * (c[k] + c[k + dk]) * zmu * fabs(z[k] - z[k + dk]);
+        dS = (s[k] - s[k + dk]) / dt2;
+        dtau = dt2;
+        Iu = Ik;
+    }
+    Io[kE] = (1.0 - w0) * Iu + w0 * s[kE - dk] + w1 * dS; // stale w, S[kE-dk]: formal_solver.py:138
+    Po[kE] = (w0 - w1 / dtau) / c[kE];
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------- context
+struct SweepClass {
+    int umax;
+    std::vector<int> tiles;
+    int* d_tiles = nullptr;
+    double alg_bytes_per_col = 0.0; // algorithmic HBM bytes this class's tiles touch, per column
+    double ms_accum = 0.0;          // accumulated kernel time (lsx_time_formal_sol)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+struct lsx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int Nspace = 0, Nrays = 0, Nspect = 0, Natoms = 0, Ntrans = 0, ncol = 0, M = 0;
+    int NLtot = 0, NL2tot = 0, Nlines = 0, SNl = 0, SNc = 0;
+    int sca_per_lambda = 0, phi_compact = 0;
+    std::vector<int> Nlevel, lev_off, lev2_off;
+    std::vector<lsx_transition> trans;
+    std::vector<DevTrans> htrans;
+    std::vector<DevTile> tiles;
+    std::vector<int> tile_slots, tile_levels;
+    std::vector<SweepClass> classes;
+    size_t lds_bytes = 0;
+    // device: column independent
+    double *d_wavelength = nullptr, *d_zmu = nullptr, *d_wmuh = nullptr, *d_wl = nullptr, *d_alpha = nullptr,
+           *d_u_la = nullptr;
+    uint8_t* d_active = nullptr;
+    DevTrans* d_trans = nullptr;
+    DevTile* d_tiles = nullptr;
+    int *d_tile_slots = nullptr, *d_tile_levels = nullptr, *d_Nlevel = nullptr, *d_lev2_off = nullptr;
+    // device: per column
+    double *d_height = nullptr, *d_temperature = nullptr, *d_nStar = nullptr, *d_nTotal = nullptr, *d_n = nullptr,
+           *d_C = nullptr, *d_Gamma = nullptr, *d_wphi = nullptr, *d_bgchi = nullptr, *d_bgeta = nullptr,
+           *d_sca = nullptr, *d_phi = nullptr, *d_gijc = nullptr, *d_J[2] = {nullptr, nullptr}, *d_I = nullptr,
+           *d_Gpart = nullptr, *d_dJpart = nullptr, *d_dJcol = nullptr, *d_dPcol = nullptr, *d_max = nullptr;
+    int* d_singular = nullptr;
+    int jcur = 0; // d_J[jcur] holds the current J (Jdag of the next call)
+    size_t phi_col = 0, gijc_col = 0, sca_col = 0;
+    // staging
+    double* d_stage = nullptr;
+    size_t stage_doubles = 0;
+    double* h_pinned = nullptr; // [0] dJ max, [1] dPops max, [2] singular flag (as double bits of an int)
+    double last_dJ = 0.0, last_dP = 0.0;
+    bool fs_pending = false, se_pending = false;
+    hipEvent_t evA = nullptr, evB = nullptr;
+};
+
+namespace {
+
+template <typename T>
+int dmalloc(T** p, size_t count)
+{
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
+    if (e != hipSuccess) return fail(LSX_EDEVICE, "hipMalloc(%zu bytes): %s", count * sizeof(T), hipGetErrorString(e));
+    return LSX_OK;
+}
+
+template <typename T>
+int upload(T** dptr, const std::vector<T>& v, hipStream_t st)
+{
+    int rc = dmalloc(dptr, v.size());
+    if (rc) return rc;
+    if (!v.empty()) HIPCHK(hipMemcpyAsync(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    return LSX_OK;
+}
+
+int ensure_stage(lsx_ctx* c, size_t doubles)
+{
+    if (doubles <= c->stage_doubles) return LSX_OK;
+    if (c->d_stage) HIPCHK(hipFree(c->d_stage));
+    c->d_stage = nullptr;
+    c->stage_doubles = 0;
+    int rc = dmalloc(&c->d_stage, doubles);
+    if (rc) return rc;
+    c->stage_doubles = doubles;
+    return LSX_OK;
+}
+
+int launch_transpose(lsx_ctx* c, const double* in, double* out, int B, int R, int Cc)
+{
+    dim3 grid((Cc + 31) / 32, (R + 31) / 32, B), block(32, 8);
+    hipLaunchKernelGGL(k_transpose, grid, block, 0, c->stream, in, out, R, Cc);
+    HIPCHK(hipGetLastError());
+    return LSX_OK;
+}
+
+double wlambda(const lsx_ctx* c, const std::vector<double>& wave, const lsx_transition& t, int lt)
+{
+    // rh_method.py:157-196 (single index form)
+    (void)c;
+    const double* wl = wave.data() + t.Nblue;
+    const double dopplerWidth = t.is_line ? kCLight / t.lambda0 : 1.0;
+    const int N = t.Nlambda;
+    if (lt == 0) return 0.5 * (wl[1] - wl[0]) * dopplerWidth;
+    if (lt == N - 1) return 0.5 * (wl[N - 1] - wl[N - 2]) * dopplerWidth;
+    return 0.5 * (wl[lt + 1] - wl[lt - 1]) * dopplerWidth;
+}
+
+const int kUmaxClasses[] = {2, 4, 8, 12};
+
+} // namespace
+
+extern "C" {
+
+const char* lsx_last_error(void) { return g_err.c_str(); }
+const char* lsx_backend_name(void) { return "hip-gfx950"; }
+int32_t lsx_abi_version(void) { return LSX_ABI_VERSION; }
+
+void lsx_destroy(lsx_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void* ptrs[] = {c->d_wavelength, c->d_zmu, c->d_wmuh, c->d_wl, c->d_alpha, c->d_u_la, c->d_active, c->d_trans,
+                    c->d_tiles, c->d_tile_slots, c->d_tile_levels, c->d_Nlevel, c->d_lev2_off, c->d_height,
+                    c->d_temperature, c->d_nStar, c->d_nTotal, c->d_n, c->d_C, c->d_Gamma, c->d_wphi, c->d_bgchi,
+                    c->d_bgeta, c->d_sca, c->d_phi, c->d_gijc, c->d_J[0], c->d_J[1], c->d_I, c->d_Gpart, c->d_dJpart,
+                    c->d_dJcol, c->d_dPcol, c->d_max, c->d_singular, c->d_stage};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto& k : c->classes) {
+        if (k.d_tiles) (void)hipFree(k.d_tiles);
+        if (k.ev0) (void)hipEventDestroy(k.ev0);
+        if (k.ev1) (void)hipEventDestroy(k.ev1);
+    }
+    if (c->evA) (void)hipEventDestroy(c->evA);
+    if (c->evB) (void)hipEventDestroy(c->evB);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream, lsx_ctx** out)
+{
+    if (!d || !out || ncol < 1) return fail(LSX_EINVAL, "lsx_create: null argument or ncol < 1");
+    if (d->abi_version != LSX_ABI_VERSION) return fail(LSX_EINVAL, "lsx_create: ABI version mismatch");
+    if (d->Nspace < 3) return fail(LSX_EINVAL, "lsx_create: Nspace must be >= 3 (formal_solver.py:120-139)");
+    if (d->Nrays < 1 || d->Nspect < 1 || d->Natoms < 1 || d->Ntrans < 0) return fail(LSX_EINVAL, "lsx_create: bad dimensions");
+    if (d->Nrays > 8) return fail(LSX_EUNSUPPORTED, "lsx_create: Nrays > 8 is not supported by this build");
+    if (d->Natoms > LSX_MAX_ATOMS) return fail(LSX_EUNSUPPORTED, "lsx_create: more than %d active atoms", LSX_MAX_ATOMS);
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(LSX_EDEVICE, "lsx_create: no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(LSX_EINVAL, "lsx_create: device %d out of range (%d visible)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+
+    lsx_ctx* c = new lsx_ctx();
+    c->device = device;
+    if (stream) {
+        c->stream = reinterpret_cast<hipStream_t>(stream);
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return fail(LSX_EDEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        c->own_stream = true;
+    }
+    c->Nspace = d->Nspace; c->Nrays = d->Nrays; c->Nspect = d->Nspect; c->Natoms = d->Natoms;
+    c->Ntrans = d->Ntrans; c->ncol = ncol;
+    c->sca_per_lambda = d->sca_per_lambda ? 1 : 0;
+    c->phi_compact = d->phi_compact ? 1 : 0;
+    c->M = d->Nrays <= 5 ? d->Nrays : 8;
+    const int Ns = c->Nspace, Nspect = c->Nspect;
+    for (int a = 0; a < c->Natoms; ++a) {
+        if (d->Nlevel[a] < 2) { lsx_destroy(c); return fail(LSX_EINVAL, "lsx_create: Nlevel < 2"); }
+        c->Nlevel.push_back(d->Nlevel[a]);
+        c->lev_off.push_back(c->NLtot);
+        c->lev2_off.push_back(c->NL2tot);
+        c->NLtot += d->Nlevel[a];
+        c->NL2tot += d->Nlevel[a] * d->Nlevel[a];
+    }
+    if (c->NLtot > LSX_MAX_LEVELS) { lsx_destroy(c); return fail(LSX_EUNSUPPORTED, "lsx_create: more than %d levels in total", LSX_MAX_LEVELS); }
+
+    std::vector<double> wave(d->wavelength, d->wavelength + Nspect);
+    std::vector<double> wl, alpha;
+    std::vector<uint8_t> active(d->active, d->active + (size_t)c->Ntrans * Nspect);
+    int alpha_in = 0;
+    for (int t = 0; t < c->Ntrans; ++t) {
+        const lsx_transition& tr = d->trans[t];
+        if (tr.atom < 0 || tr.atom >= c->Natoms || tr.i < 0 || tr.j >= c->Nlevel[tr.atom] || tr.i >= tr.j || tr.Nblue < 0 ||
+            tr.Nlambda < 2 || tr.Nblue + tr.Nlambda > Nspect) {
+            lsx_destroy(c);
+            return fail(LSX_EINVAL, "lsx_create: inconsistent transition table entry %d", t);
+        }
+        c->trans.push_back(tr);
+        DevTrans h{};
+        h.atom = tr.atom; h.is_line = tr.is_line ? 1 : 0;
+        h.li = c->lev_off[tr.atom] + tr.i; h.lj = c->lev_off[tr.atom] + tr.j;
+        h.Nblue = tr.Nblue; h.Nlam = tr.Nlambda;
+        h.wl_off = (int)wl.size();
+        const int Nl = c->Nlevel[tr.atom];
+        h.gam_ij = c->lev2_off[tr.atom] + tr.i * Nl + tr.j;
+        h.gam_ji = c->lev2_off[tr.atom] + tr.j * Nl + tr.i;
+        if (tr.is_line) {
+            h.phi_off = c->SNl; h.line_idx = c->Nlines;
+            c->SNl += tr.Nlambda; c->Nlines++;
+            h.cB = (0.25 * kHC / M_PI) * tr.Bij; // rh_method.py:268,279
+            h.gij = tr.Bji / tr.Bij;             // :450
+            h.AB = tr.Aji / tr.Bji;              // :281
+            for (int lt = 0; lt < tr.Nlambda; ++lt) { wl.push_back(wlambda(c, wave, tr, lt)); alpha.push_back(0.0); }
+        } else {
+            h.cont_off = c->SNc;
+            c->SNc += tr.Nlambda;
+            for (int lt = 0; lt < tr.Nlambda; ++lt) {
+                wl.push_back(wlambda(c, wave, tr, lt) / wave[tr.Nblue + lt] / kHPlanck); // :455
+                alpha.push_back(d->alpha[alpha_in + lt]);
+            }
+            alpha_in += tr.Nlambda;
+        }
+        c->htrans.push_back(h);
+    }
+    // ---- tile schedule: 32 consecutive wavelengths per wavefront
+    for (int la0 = 0; la0 < Nspect; la0 += LSX_HALF) {
+        DevTile tl{};
+        tl.la0 = la0;
+        tl.nla = std::min(LSX_HALF, Nspect - la0);
+        tl.slot0 = (int)c->tile_slots.size();
+        tl.lev0 = (int)c->tile_levels.size();
+        std::vector<int> levs;
+        for (int t = 0; t < c->Ntrans; ++t) {
+            bool any = false;
+            for (int la = la0; la < la0 + tl.nla; ++la) any = any || active[(size_t)t * Nspect + la];
+            if (!any) continue;
+            c->tile_slots.push_back(t);
+            tl.nslot++;
+            tl.natom_mask |= 1 << c->htrans[t].atom;
+            for (int lev : {c->htrans[t].li, c->htrans[t].lj})
+                if (std::find(levs.begin(), levs.end(), lev) == levs.end()) levs.push_back(lev);
+        }
+        tl.nlev = (int)levs.size();
+        c->tile_levels.insert(c->tile_levels.end(), levs.begin(), levs.end());
+        int umax = 0;
+        for (int k : kUmaxClasses)
+            if (!umax && tl.nslot <= k) umax = k;
+        if (!umax) {
+            lsx_destroy(c);
+            return fail(LSX_EUNSUPPORTED, "lsx_create: %d transitions overlap within wavelengths [%d, %d); this build handles 12",
+                        tl.nslot, la0, la0 + tl.nla);
+        }
+        SweepClass* k = nullptr;
+        for (auto& q : c->classes)
+            if (q.umax == umax) k = &q;
+        if (!k) { c->classes.push_back(SweepClass()); k = &c->classes.back(); k->umax = umax; }
+        k->tiles.push_back((int)c->tiles.size());
+        // algorithmic bytes of this tile: profiles + bg chi, eta + Jdag, J over its wavelengths, + emergent I
+        const double P = c->phi_compact ? 1.0 : 2.0 * c->Nrays;
+        double npts = 0;
+        for (int u = 0; u < tl.nslot; ++u) {
+            const int t = c->tile_slots[tl.slot0 + u];
+            if (!c->htrans[t].is_line) continue;
+            for (int la = la0; la < la0 + tl.nla; ++la) npts += active[(size_t)t * Nspect + la] ? 1 : 0;
+        }
+        k->alg_bytes_per_col += 8.0 * Ns * (P * npts + (c->sca_per_lambda ? 5.0 : 4.0) * tl.nla) + 8.0 * tl.nla * c->Nrays;
+        c->tiles.push_back(tl);
+    }
+    std::sort(c->classes.begin(), c->classes.end(), [](const SweepClass& a, const SweepClass& b) { return a.tiles.size() > b.tiles.size(); });
+    c->lds_bytes = (size_t)(2 * c->NLtot + c->Natoms) * LSX_WAVE * sizeof(double);
+
+    // ---- uploads of the column independent tables
+    std::vector<double> zmu(c->M, 1.0), wmuh(c->M, 0.0), u_la(Nspect);
+    for (int m = 0; m < c->Nrays; ++m) { zmu[m] = 1.0 / d->muz[m]; wmuh[m] = 0.5 * d->wmu[m]; }
+    for (int la = 0; la < Nspect; ++la) u_la[la] = 2.0 * kHC / std::pow(kNM_TO_M * wave[la], 3.0); // :286
+    int rc = LSX_OK;
+#define TRY(x) do { rc = (x); if (rc) { lsx_destroy(c); return rc; } } while (0)
+    TRY(upload(&c->d_wavelength, wave, c->stream));
+    TRY(upload(&c->d_zmu, zmu, c->stream));
+    TRY(upload(&c->d_wmuh, wmuh, c->stream));
+    TRY(upload(&c->d_wl, wl, c->stream));
+    TRY(upload(&c->d_alpha, alpha, c->stream));
+    TRY(upload(&c->d_u_la, u_la, c->stream));
+    TRY(upload(&c->d_active, active, c->stream));
+    TRY(upload(&c->d_trans, c->htrans, c->stream));
+    TRY(upload(&c->d_tiles, c->tiles, c->stream));
+    TRY(upload(&c->d_tile_slots, c->tile_slots, c->stream));
+    TRY(upload(&c->d_tile_levels, c->tile_levels, c->stream));
+    TRY(upload(&c->d_Nlevel, c->Nlevel, c->stream));
+    TRY(upload(&c->d_lev2_off, c->lev2_off, c->stream));
+    for (auto& k : c->classes) {
+        TRY(upload(&k.d_tiles, k.tiles, c->stream));
+        if (hipEventCreate(&k.ev0) != hipSuccess || hipEventCreate(&k.ev1) != hipSuccess) { lsx_destroy(c); return fail(LSX_EDEVICE, "hipEventCreate"); }
+    }
+    if (hipEventCreate(&c->evA) != hipSuccess || hipEventCreate(&c->evB) != hipSuccess) { lsx_destroy(c); return fail(LSX_EDEVICE, "hipEventCreate"); }
+
+    // ---- per-column storage
+    const size_t nc = ncol;
+    c->phi_col = (size_t)c->SNl * (c->phi_compact ? 1 : 2 * (size_t)c->Nrays) * Ns;
+    c->gijc_col = (size_t)c->SNc * Ns;
+    c->sca_col = (size_t)(c->sca_per_lambda ? Nspect : 1) * Ns;
+    TRY(dmalloc(&c->d_height, nc * Ns));
+    TRY(dmalloc(&c->d_temperature, nc * Ns));
+    TRY(dmalloc(&c->d_nStar, nc * c->NLtot * Ns));
+    TRY(dmalloc(&c->d_nTotal, nc * c->Natoms * Ns));
+    TRY(dmalloc(&c->d_n, nc * c->NLtot * Ns));
+    TRY(dmalloc(&c->d_C, nc * c->NL2tot * Ns));
+    TRY(dmalloc(&c->d_Gamma, nc * c->NL2tot * Ns));
+    TRY(dmalloc(&c->d_wphi, nc * c->Nlines * Ns));
+    TRY(dmalloc(&c->d_bgchi, nc * Nspect * Ns));
+    TRY(dmalloc(&c->d_bgeta, nc * Nspect * Ns));
+    TRY(dmalloc(&c->d_sca, nc * c->sca_col));
+    TRY(dmalloc(&c->d_phi, nc * c->phi_col));
+    TRY(dmalloc(&c->d_gijc, nc * c->gijc_col));
+    TRY(dmalloc(&c->d_J[0], nc * Nspect * Ns));
+    TRY(dmalloc(&c->d_J[1], nc * Nspect * Ns));
+    TRY(dmalloc(&c->d_I, nc * Nspect * c->Nrays));
+    TRY(dmalloc(&c->d_Gpart, nc * c->tile_slots.size() * 4 * Ns));
+    TRY(dmalloc(&c->d_dJpart, nc * c->tiles.size()));
+    TRY(dmalloc(&c->d_dJcol, nc));
+    TRY(dmalloc(&c->d_dPcol, nc));
+    TRY(dmalloc(&c->d_max, 4));
+    TRY(dmalloc(&c->d_singular, 1));
+#undef TRY
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), 4 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+        lsx_destroy(c);
+        return fail(LSX_EDEVICE, "hipHostMalloc failed");
+    }
+    (void)hipMemsetAsync(c->d_J[0], 0, nc * Nspect * Ns * 8, c->stream);
+    (void)hipMemsetAsync(c->d_J[1], 0, nc * Nspect * Ns * 8, c->stream);
+    (void)hipMemsetAsync(c->d_I, 0, nc * Nspect * c->Nrays * 8, c->stream);
+    (void)hipMemsetAsync(c->d_Gamma, 0, nc * c->NL2tot * Ns * 8, c->stream);
+    (void)hipMemsetAsync(c->d_dJcol, 0, nc * 8, c->stream);
+    (void)hipMemsetAsync(c->d_dPcol, 0, nc * 8, c->stream);
+    (void)hipMemsetAsync(c->d_max, 0, 4 * 8, c->stream);
+    (void)hipMemsetAsync(c->d_singular, 0, sizeof(int), c->stream);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *out = c;
+    return LSX_OK;
+}
+
+int lsx_set_columns(lsx_ctx* c, int32_t col0, int32_t ncol, const lsx_columns* s)
+{
+    if (!c || !s || col0 < 0 || ncol < 1 || col0 + ncol > c->ncol) return fail(LSX_EINVAL, "lsx_set_columns: bad range");
+    if (!s->height || !s->temperature || !s->nStar || !s->nTotal || !s->n || !s->C || !s->bg_chi || !s->bg_eta || !s->bg_sca ||
+        (c->Nlines && (!s->phi || !s->wphi)))
+        return fail(LSX_EINVAL, "lsx_set_columns: null array pointer");
+    HIPCHK(hipSetDevice(c->device));
+    const int Ns = c->Nspace, Nspect = c->Nspect;
+    const size_t o = col0;
+    auto h2d = [&](double* dst, const double* src, size_t per, size_t cnt) -> int {
+        HIPCHK(hipMemcpyAsync(dst, src, per * cnt * 8, hipMemcpyHostToDevice, c->stream));
+        return LSX_OK;
+    };
+    int rc;
+#define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
+    TRY(h2d(c->d_height + o * Ns, s->height, Ns, ncol));
+    TRY(h2d(c->d_temperature + o * Ns, s->temperature, Ns, ncol));
+    TRY(h2d(c->d_nStar + o * c->NLtot * Ns, s->nStar, (size_t)c->NLtot * Ns, ncol));
+    TRY(h2d(c->d_nTotal + o * c->Natoms * Ns, s->nTotal, (size_t)c->Natoms * Ns, ncol));
+    TRY(h2d(c->d_n + o * c->NLtot * Ns, s->n, (size_t)c->NLtot * Ns, ncol));
+    TRY(h2d(c->d_C + o * c->NL2tot * Ns, s->C, (size_t)c->NL2tot * Ns, ncol));
+    if (c->Nlines) TRY(h2d(c->d_wphi + o * c->Nlines * Ns, s->wphi, (size_t)c->Nlines * Ns, ncol));
+
+    // arrays that change layout go through the staging buffer in sub-chunks (<= 256 MiB of staging)
+    const size_t per_col_max = std::max<size_t>({(size_t)Nspect * Ns, c->phi_col, (size_t)1});
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(ncol, ((size_t)32 << 20) / per_col_max));
+    TRY(ensure_stage(c, chunk * per_col_max));
+    for (size_t b0 = 0; b0 < (size_t)ncol; b0 += chunk) {
+        const size_t nb = std::min(chunk, (size_t)ncol - b0);
+        const size_t cc = o + b0;
+        // background opacity / emissivity: [la][k] -> [k][la]
+        TRY(h2d(c->d_stage, s->bg_chi + b0 * Nspect * Ns, (size_t)Nspect * Ns, nb));
+        TRY(launch_transpose(c, c->d_stage, c->d_bgchi + cc * Nspect * Ns, (int)nb, Nspect, Ns));
+        TRY(h2d(c->d_stage, s->bg_eta + b0 * Nspect * Ns, (size_t)Nspect * Ns, nb));
+        TRY(launch_transpose(c, c->d_stage, c->d_bgeta + cc * Nspect * Ns, (int)nb, Nspect, Ns));
+        if (c->sca_per_lambda) {
+            TRY(h2d(c->d_stage, s->bg_sca + b0 * Nspect * Ns, (size_t)Nspect * Ns, nb));
+            TRY(launch_transpose(c, c->d_stage, c->d_sca + cc * c->sca_col, (int)nb, Nspect, Ns));
+        } else {
+            TRY(h2d(c->d_sca + cc * Ns, s->bg_sca + b0 * Ns, Ns, nb));
+        }
+        // line profiles: [lt][mu][dir][k] -> [k][dir][mu][lt] per line
+        if (c->Nlines) {
+            TRY(h2d(c->d_stage, s->phi + b0 * c->phi_col, c->phi_col, nb));
+            const int R = c->phi_compact ? 1 : c->Nrays, D = c->phi_compact ? 1 : 2;
+            for (int t = 0; t < c->Ntrans; ++t) {
+                const DevTrans& h = c->htrans[t];
+                if (!h.is_line) continue;
+                const size_t off = (size_t)h.phi_off * R * D * Ns;
+                const size_t total = (size_t)h.Nlam * R * D * Ns;
+                dim3 grid((unsigned)std::min<size_t>((total + 255) / 256, 1024), (unsigned)nb);
+                hipLaunchKernelGGL(k_pack_phi, grid, dim3(256), 0, c->stream, c->d_stage + off, c->d_phi + cc * c->phi_col + off,
+                                   h.Nlam, R, D, Ns, c->phi_col, c->phi_col);
+                HIPCHK(hipGetLastError());
+            }
+        }
+        // continuum g_ij tables
+        for (int t = 0; t < c->Ntrans; ++t) {
+            const DevTrans& h = c->htrans[t];
+            if (h.is_line) continue;
+            dim3 grid((h.Nlam * Ns + 255) / 256, (unsigned)nb);
+            hipLaunchKernelGGL(k_build_gijc, grid, dim3(256), 0, c->stream, c->d_nStar + cc * c->NLtot * Ns,
+                               c->d_temperature + cc * Ns, c->d_wavelength, c->d_gijc + cc * c->gijc_col + (size_t)h.cont_off * Ns,
+                               h.li, h.lj, h.Nblue, h.Nlam, Ns, c->NLtot, c->gijc_col);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipStreamSynchronize(c->stream)); // the staging buffer is re-used by the next sub-chunk
+    }
+#undef TRY
+    // J starts at 0 (rh_method.py:562); so do I and the convergence monitors of these columns
+    HIPCHK(hipMemsetAsync(c->d_J[c->jcur] + o * Nspect * Ns, 0, (size_t)ncol * Nspect * Ns * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_I + o * Nspect * c->Nrays, 0, (size_t)ncol * Nspect * c->Nrays * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_Gamma + o * c->NL2tot * Ns, 0, (size_t)ncol * c->NL2tot * Ns * 8, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LSX_OK;
+}
+
+static int enqueue_fs(lsx_ctx* c, bool timed)
+{
+    HIPCHK(hipSetDevice(c->device));
+    SweepParams p{};
+    p.Nspace = c->Nspace; p.Nrays = c->Nrays; p.Nspect = c->Nspect; p.Natoms = c->Natoms; p.Ntrans = c->Ntrans;
+    p.ncol = c->ncol; p.NLtot = c->NLtot; p.NL2tot = c->NL2tot; p.Nlines = c->Nlines;
+    p.sca_per_lambda = c->sca_per_lambda; p.phi_mu_stride_is_zero = c->phi_compact;
+    p.nslot_total = (int)c->tile_slots.size(); p.ntile_total = (int)c->tiles.size();
+    p.wavelength = c->d_wavelength; p.zmu = c->d_zmu; p.wmuh = c->d_wmuh; p.wl = c->d_wl; p.alpha = c->d_alpha;
+    p.u_la = c->d_u_la; p.active = c->d_active; p.trans = c->d_trans; p.tiles = c->d_tiles;
+    p.tile_slots = c->d_tile_slots; p.tile_levels = c->d_tile_levels;
+    p.phi_col_stride = (int64_t)c->phi_col; p.gijc_col_stride = (int64_t)c->gijc_col;
+    p.height = c->d_height; p.temperature = c->d_temperature; p.n = c->d_n; p.wphi = c->d_wphi;
+    p.bgchi_T = c->d_bgchi; p.bgeta_T = c->d_bgeta; p.sca = c->d_sca; p.phi_T = c->d_phi; p.gijc_T = c->d_gijc;
+    p.Jdag_T = c->d_J[c->jcur]; p.Jnew_T = c->d_J[c->jcur ^ 1];
+    p.Iout = c->d_I; p.Gpart = c->d_Gpart; p.dJpart = c->d_dJpart;
+
+    for (auto& k : c->classes) {
+        p.class_tiles = k.d_tiles;
+        p.n_class_tiles = (int)k.tiles.size();
+        const long nblocks = (long)k.tiles.size() * c->ncol;
+        if (nblocks > 0x7fffffffL) return fail(LSX_EUNSUPPORTED, "grid too large");
+        if (timed) HIPCHK(hipEventRecord(k.ev0, c->stream));
+        hipError_t e;
+        switch (c->M) {
+        case 1: e = lsx_launch_sweep_m1(&p, k.umax, (int)nblocks, c->lds_bytes, c->stream); break;
+        case 2: e = lsx_launch_sweep_m2(&p, k.umax, (int)nblocks, c->lds_bytes, c->stream); break;
+        case 3: e = lsx_launch_sweep_m3(&p, k.umax, (int)nblocks, c->lds_bytes, c->stream); break;
+        case 4: e = lsx_launch_sweep_m4(&p, k.umax, (int)nblocks, c->lds_bytes, c->stream); break;
+        case 5: e = lsx_launch_sweep_m5(&p, k.umax, (int)nblocks, c->lds_bytes, c->stream); break;
+        default: e = lsx_launch_sweep_m8(&p, k.umax, (int)nblocks, c->lds_bytes, c->stream); break;
+        }
+        if (e != hipSuccess) return fail(LSX_EDEVICE, "sweep launch (UMAX=%d, M=%d): %s", k.umax, c->M, hipGetErrorString(e));
+        if (timed) HIPCHK(hipEventRecord(k.ev1, c->stream));
+    }
+    FinishParams f{};
+    f.Nspace = c->Nspace; f.Natoms = c->Natoms; f.NL2tot = c->NL2tot; f.ncol = c->ncol; f.ntile = (int)c->tiles.size();
+    f.nslot_total = (int)c->tile_slots.size(); f.Nlevel = c->d_Nlevel; f.lev2_off = c->d_lev2_off; f.tiles = c->d_tiles;
+    f.tile_slots = c->d_tile_slots; f.trans = c->d_trans; f.C = c->d_C; f.Gpart = c->d_Gpart; f.dJpart = c->d_dJpart;
+    f.Gamma = c->d_Gamma; f.dJcol = c->d_dJcol;
+    const long nthreads = (long)c->ncol * c->Nspace;
+    hipLaunchKernelGGL(k_gamma_finish, dim3((unsigned)((nthreads + 127) / 128)), dim3(128), 0, c->stream, f);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, c->stream, c->d_dJcol, c->ncol, c->d_max);
+    HIPCHK(hipGetLastError());
+    c->jcur ^= 1;
+    c->fs_pending = true;
+    return LSX_OK;
+}
+
+int lsx_formal_sol_gamma_async(lsx_ctx* c)
+{
+    if (!c) return fail(LSX_EINVAL, "null ctx");
+    return enqueue_fs(c, false);
+}
+
+int lsx_stat_equil_async(lsx_ctx* c)
+{
+    if (!c) return fail(LSX_EINVAL, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemsetAsync(c->d_dPcol, 0, (size_t)c->ncol * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_singular, 0, sizeof(int), c->stream));
+    const long nthreads = (long)c->ncol * c->Nspace;
+    for (int a = 0; a < c->Natoms; ++a) {
+        const int Nl = c->Nlevel[a];
+        const int nt = 64;
+        const size_t sm = (size_t)(Nl * Nl + 2 * Nl) * nt * sizeof(double);
+        if (sm > 160 * 1024) return fail(LSX_EUNSUPPORTED, "stat_equil: Nlevel = %d needs %zu B of LDS", Nl, sm);
+        hipLaunchKernelGGL(k_stat_equil, dim3((unsigned)((nthreads + nt - 1) / nt)), dim3(nt), sm, c->stream, c->d_Gamma,
+                           c->d_nTotal, c->d_n, c->d_dPcol, c->d_singular, Nl, c->lev_off[a], c->lev2_off[a], a, c->Natoms,
+                           c->NLtot, c->NL2tot, c->Nspace, c->ncol);
+        HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, c->stream, c->d_dPcol, c->ncol, c->d_max + 1);
+    HIPCHK(hipGetLastError());
+    c->se_pending = true;
+    return LSX_OK;
+}
+
+int lsx_sync(lsx_ctx* c, double* dJ, double* dP)
+{
+    if (!c) return fail(LSX_EINVAL, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    int sing = 0;
+    if (c->fs_pending || c->se_pending) {
+        HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_max, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(c->h_pinned + 2, c->d_singular, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->fs_pending) c->last_dJ = c->h_pinned[0];
+        if (c->se_pending) {
+            c->last_dP = c->h_pinned[1];
+            memcpy(&sing, c->h_pinned + 2, sizeof(int));
+        }
+        c->fs_pending = c->se_pending = false;
+    } else {
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    if (dJ) *dJ = c->last_dJ;
+    if (dP) *dP = c->last_dP;
+    if (sing) return fail(LSX_ESINGULAR, "stat_equil: singular matrix (cf. LinAlgError at rh_method.py:739)");
+    return LSX_OK;
+}
+
+int lsx_formal_sol_gamma(lsx_ctx* c, double* dJ)
+{
+    int rc = lsx_formal_sol_gamma_async(c);
+    if (rc) return rc;
+    return lsx_sync(c, dJ, nullptr);
+}
+
+int lsx_stat_equil(lsx_ctx* c, double* dP)
+{
+    int rc = lsx_stat_equil_async(c);
+    if (rc) return rc;
+    return lsx_sync(c, nullptr, dP);
+}
+
+int lsx_get(lsx_ctx* c, int32_t what, int32_t col0, int32_t ncol, double* dst, size_t nbytes)
+{
+    if (!c || !dst || col0 < 0 || ncol < 1 || col0 + ncol > c->ncol) return fail(LSX_EINVAL, "lsx_get: bad range");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t Ns = c->Nspace;
+    const double* base = nullptr;
+    size_t per = 0;
+    switch (what) {
+    case LSX_I: base = c->d_I; per = (size_t)c->Nspect * c->Nrays; break;
+    case LSX_J: per = (size_t)c->Nspect * Ns; break;
+    case LSX_N: base = c->d_n; per = (size_t)c->NLtot * Ns; break;
+    case LSX_GAMMA: base = c->d_Gamma; per = (size_t)c->NL2tot * Ns; break;
+    case LSX_DJ_COL: base = c->d_dJcol; per = 1; break;
+    case LSX_DPOPS_COL: base = c->d_dPcol; per = 1; break;
+    case LSX_NSTAR: base = c->d_nStar; per = (size_t)c->NLtot * Ns; break;
+    case LSX_C: base = c->d_C; per = (size_t)c->NL2tot * Ns; break;
+    case LSX_RIJ:
+    case LSX_RJI:
+        return fail(LSX_EUNSUPPORTED, "lsx_get: radiative rates Rij/Rji are not produced by the HIP backend "
+                                      "(they feed nothing in the reference, rh_method.py:691-692)");
+    default: return fail(LSX_EINVAL, "lsx_get: unknown item %d", what);
+    }
+    if (nbytes != per * ncol * 8) return fail(LSX_EINVAL, "lsx_get: nbytes does not match the item's shape");
+    if (what == LSX_J) { // device holds J depth-major: [k][la] -> [la][k]
+        const size_t chunk = std::max<size_t>(1, std::min<size_t>(ncol, ((size_t)32 << 20) / per));
+        int rc = ensure_stage(c, chunk * per);
+        if (rc) return rc;
+        for (size_t b0 = 0; b0 < (size_t)ncol; b0 += chunk) {
+            const size_t nb = std::min(chunk, (size_t)ncol - b0);
+            rc = launch_transpose(c, c->d_J[c->jcur] + (col0 + b0) * per, c->d_stage, (int)nb, (int)Ns, c->Nspect);
+            if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(dst + b0 * per, c->d_stage, nb * per * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+        return LSX_OK;
+    }
+    HIPCHK(hipMemcpyAsync(dst, base + per * col0, nbytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LSX_OK;
+}
+
+int lsx_set(lsx_ctx* c, int32_t what, int32_t col0, int32_t ncol, const double* src, size_t nbytes)
+{
+    if (!c || !src || col0 < 0 || ncol < 1 || col0 + ncol > c->ncol) return fail(LSX_EINVAL, "lsx_set: bad range");
+    if (what != LSX_N && what != LSX_J) return fail(LSX_EINVAL, "lsx_set: only LSX_N and LSX_J are writable");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t Ns = c->Nspace;
+    const size_t per = (what == LSX_N ? (size_t)c->NLtot : (size_t)c->Nspect) * Ns;
+    if (nbytes != per * ncol * 8) return fail(LSX_EINVAL, "lsx_set: nbytes does not match the item's shape");
+    if (what == LSX_N) {
+        HIPCHK(hipMemcpyAsync(c->d_n + per * col0, src, nbytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return LSX_OK;
+    }
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(ncol, ((size_t)32 << 20) / per));
+    int rc = ensure_stage(c, chunk * per);
+    if (rc) return rc;
+    for (size_t b0 = 0; b0 < (size_t)ncol; b0 += chunk) {
+        const size_t nb = std::min(chunk, (size_t)ncol - b0);
+        HIPCHK(hipMemcpyAsync(c->d_stage, src + b0 * per, nb * per * 8, hipMemcpyHostToDevice, c->stream));
+        rc = launch_transpose(c, c->d_stage, c->d_J[c->jcur] + (col0 + b0) * per, (int)nb, c->Nspect, (int)Ns);
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return LSX_OK;
+}
+
+int lsx_piecewise_linear_1d(int32_t device, int32_t nray, int32_t Nspace, const double* height, const double* temperature,
+                            const double* mu, const int32_t* to_obs, const double* wav, const double* chi, const double* S,
+                            double* I, double* PsiStar)
+{
+    if (nray < 0 || Nspace < 3) return fail(LSX_EINVAL, "lsx_piecewise_linear_1d: need Nspace >= 3");
+    if (nray == 0) return LSX_OK;
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(LSX_EINVAL, "lsx_piecewise_linear_1d: bad device");
+    HIPCHK(hipSetDevice(device));
+    const size_t Ns = Nspace, nr = nray;
+    double *dz = nullptr, *dT = nullptr, *dmu = nullptr, *dwav = nullptr, *dchi = nullptr, *dS = nullptr, *dI = nullptr, *dP = nullptr;
+    int* dto = nullptr;
+    int rc = LSX_OK;
+    auto cleanup = [&]() { for (void* q : {(void*)dz, (void*)dT, (void*)dmu, (void*)dwav, (void*)dchi, (void*)dS, (void*)dI, (void*)dP, (void*)dto}) if (q) (void)hipFree(q); };
+#define TRYC(x) do { rc = (x); if (rc) { cleanup(); return rc; } } while (0)
+#define HIPC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(LSX_EDEVICE, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
+    TRYC(dmalloc(&dz, Ns)); TRYC(dmalloc(&dT, Ns)); TRYC(dmalloc(&dmu, nr)); TRYC(dmalloc(&dwav, nr)); TRYC(dmalloc(&dto, nr));
+    TRYC(dmalloc(&dchi, nr * Ns)); TRYC(dmalloc(&dS, nr * Ns)); TRYC(dmalloc(&dI, nr * Ns)); TRYC(dmalloc(&dP, nr * Ns));
+    HIPC(hipMemcpy(dz, height, Ns * 8, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(dT, temperature, Ns * 8, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(dmu, mu, nr * 8, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(dwav, wav, nr * 8, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(dto, to_obs, nr * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(dchi, chi, nr * Ns * 8, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(dS, S, nr * Ns * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_piecewise, dim3((nray + 63) / 64), dim3(64), 0, 0, nray, Nspace, dz, dT, dmu, dto, dwav, dchi, dS, dI, dP);
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpy(I, dI, nr * Ns * 8, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(PsiStar, dP, nr * Ns * 8, hipMemcpyDeviceToHost));
+#undef TRYC
+#undef HIPC
+    cleanup();
+    return LSX_OK;
+}
+
+int lsx_time_formal_sol(lsx_ctx* c, int32_t warmup, int32_t reps, double* ms_total, double* ms_sweep)
+{
+    if (!c || reps < 1 || warmup < 0) return fail(LSX_EINVAL, "lsx_time_formal_sol: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    for (int i = 0; i < warmup; ++i)
+        if ((rc = enqueue_fs(c, false))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto& k : c->classes) k.ms_accum = 0.0;
+    double tot = 0.0;
+    for (int i = 0; i < reps; ++i) {
+        HIPCHK(hipEventRecord(c->evA, c->stream));
+        if ((rc = enqueue_fs(c, true))) return rc;
+        HIPCHK(hipEventRecord(c->evB, c->stream));
+        HIPCHK(hipEventSynchronize(c->evB));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, c->evA, c->evB));
+        tot += ms;
+        for (auto& k : c->classes) {
+            HIPCHK(hipEventElapsedTime(&ms, k.ev0, k.ev1));
+            k.ms_accum += ms;
+        }
+    }
+    double sw = 0.0;
+    for (auto& k : c->classes) { k.ms_accum /= reps; sw += k.ms_accum; }
+    if (ms_total) *ms_total = tot / reps;
+    if (ms_sweep) *ms_sweep = sw;
+    return lsx_sync(c, nullptr, nullptr);
+}
+
+// HIP-only introspection used by bench.py: per sweep-kernel instantiation (UMAX class)
+// the tile count, algorithmic bytes per column and the average time of the last
+// lsx_time_formal_sol.  Returns the number of classes.
+int lsx_hip_sweep_classes(lsx_ctx* c, int32_t cap, int32_t* umax, int32_t* ntiles, double* alg_bytes_per_col, double* ms)
+{
+    if (!c) return 0;
+    int n = 0;
+    for (auto& k : c->classes) {
+        if (n < cap) {
+            if (umax) umax[n] = k.umax;
+            if (ntiles) ntiles[n] = (int)k.tiles.size();
+            if (alg_bytes_per_col) alg_bytes_per_col[n] = k.alg_bytes_per_col;
+            if (ms) ms[n] = k.ms_accum;
+        }
+        ++n;
+    }
+    return n;
+}
+
+// B_alg = 8 Ns [P SNl + 2 Nspect (bg) + 2 Nspect (Jdag, J) + 1 (sigma) + NLtot (n)
+//                          + 2 NL2tot (C, Gamma) + 6] + 8 Nspect Nrays
+double lsx_algorithmic_bytes_per_column(const lsx_ctx* c)
+{
+    const double P = c->phi_compact ? 1.0 : 2.0 * c->Nrays;
+    const double per_depth = P * c->SNl + 4.0 * c->Nspect + (c->sca_per_lambda ? c->Nspect : 1.0) + c->NLtot + 2.0 * c->NL2tot + 6.0;
+    return 8.0 * c->Nspace * per_depth + 8.0 * c->Nspect * c->Nrays;
+}
+
+} // extern "C"

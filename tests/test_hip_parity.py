@@ -1,0 +1,182 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the oracle on the
+same inputs and against the golden vectors generated from the reference.  Run on an MI355X:
+    python -m pytest tests -m gpu
+Tolerances (float64, stated per SURVEY 8d; see test_oracle_golden.py for why Ca+H needs 3e-11):
+    single FS call:  J, I relative <= tol ; Gamma off-diagonal <= 10 tol, diagonal <= tol of column max
+    tol = 1e-12 (FALC CaII), 3e-11 (FALC Ca+H)
+    converged D1 loop: same iteration count, max|dn/n|, |dJ/J|, |dI/I| <= 1e-6
+"""
+import numpy as np
+import pytest
+
+from conftest import golden, relerr, gamma_err
+from lightspinner_amd import fixtures, Engine, _capi, drivers
+from lightspinner_amd.problem import ColumnBlock
+
+pytestmark = pytest.mark.gpu
+
+
+class Adapter:
+    def __init__(self, eng):
+        self.eng = eng
+    def formal_sol_gamma_matrices(self):
+        return self.eng.formal_sol_gamma()
+    def stat_equil(self):
+        return self.eng.stat_equil()
+
+
+def test_backend_is_hip(hip_lib):
+    assert hip_lib.backend == 'hip-gfx950'
+
+
+def test_piecewise_linear_1d_units(hip_lib, oracle_lib):
+    d = np.load(golden('units.npz'))
+    chi, S = d['pl_chi'], d['pl_S']
+    rays = [(wi, mu, tf) for wi in range(4) for mu in range(2) for tf in (0, 1)]
+    args = (d['pl_height'], d['pl_temperature'], [d['pl_muz'][m] for _, m, _ in rays], [tf for *_, tf in rays],
+            [d['pl_wav'][w] for w, _, _ in rays], np.tile(chi, (len(rays), 1)), np.tile(S, (len(rays), 1)))
+    I, Psi = hip_lib.piecewise_linear_1d(*args)
+    Io, Po = oracle_lib.piecewise_linear_1d(*args)
+    for r, (wi, mu, tf) in enumerate(rays):
+        assert relerr(I[r], d['pl_I_%d_%d_%d' % (wi, mu, tf)]) < 5e-12
+        assert np.allclose(Psi[r], d['pl_Psi_%d_%d_%d' % (wi, mu, tf)], rtol=5e-12, atol=0)
+    assert relerr(I, Io) < 5e-12
+    # ragged / minimum sizes: N = 3 executes the loop body once
+    rng = np.random.default_rng(7)
+    for N in (3, 4, 5, 83, 200):
+        z = np.sort(rng.uniform(-1e5, 2e6, N))[::-1].copy()
+        T = np.linspace(4000, 9000, N)
+        chi = np.exp(np.cumsum(rng.normal(0.2, 0.4, (6, N)), axis=1) - 15)
+        S = np.exp(rng.normal(-19, 0.5, (6, N)))
+        a = (z, T, rng.uniform(0.05, 1, 6), [0, 1, 0, 1, 1, 0], rng.uniform(30, 2000, 6), chi, S)
+        I, Psi = hip_lib.piecewise_linear_1d(*a)
+        Io, Po = oracle_lib.piecewise_linear_1d(*a)
+        assert relerr(I, Io, floor=1e-300) < 1e-11 and np.allclose(Psi, Po, rtol=1e-11, atol=0)
+
+
+@pytest.mark.parametrize('name,compact,tol', [('falc_ca.npz', True, 1e-12), ('falc_ca.npz', False, 1e-12),
+                                              ('falc_cah.npz', True, 3e-11), ('falc_cah.npz', False, 3e-11)])
+def test_single_calls_match_reference_and_oracle(hip_lib, oracle_lib, name, compact, tol):
+    prob, block, d = fixtures.load_problem_npz(golden(name), phi_compact=compact)
+    eng = Engine(prob, 1, lib=hip_lib)
+    ora = Engine(prob, 1, lib=oracle_lib)
+    eng.set_columns(0, block)
+    ora.set_columns(0, block)
+    for it in range(1, 6):
+        dJ = eng.formal_sol_gamma()
+        dJo = ora.formal_sol_gamma()
+        tight = it < 5
+        assert dJ == pytest.approx(dJo, rel=1e-9 if tight else 1e-6)
+        J, I, G = eng.get(_capi.LSX_J)[0], eng.get(_capi.LSX_I)[0], eng.get(_capi.LSX_GAMMA)[0]
+        Jo, Io, Go = ora.get(_capi.LSX_J)[0], ora.get(_capi.LSX_I)[0], ora.get(_capi.LSX_GAMMA)[0]
+        assert relerr(J, Jo) < (tol if tight else 1e-7)
+        assert relerr(I, Io) < (tol if tight else 1e-7)
+        off, diag = gamma_err(G, Go, prob)
+        assert off < (10 * tol if tight else 1e-6) and diag < (tol if tight else 1e-7), (it, off, diag)
+        tag = 'fs%d' % it
+        if tag + '_I' in d:   # golden vectors of the reference itself
+            assert relerr(I, d[tag + '_I']) < (tol if tight else 1e-7)
+            if tag + '_J' in d:
+                assert relerr(J, d[tag + '_J']) < (tol if tight else 1e-7)
+            off, diag = gamma_err(G, fixtures.gamma_from_raw(d, tag, prob), prob)
+            assert off < (10 * tol if tight else 1e-6) and diag < (tol if tight else 1e-7)
+        if it > 3:
+            dP, dPo = eng.stat_equil(), ora.stat_equil()
+            assert dP == pytest.approx(dPo, rel=1e-7)
+            assert relerr(eng.get(_capi.LSX_N)[0], ora.get(_capi.LSX_N)[0]) < 1e-7
+            if 'se%d_dPops' % it in d:
+                assert relerr(eng.get(_capi.LSX_N)[0], fixtures.pops_from_raw(d, 'se%d' % it, prob)) < 1e-7
+    eng.close()
+
+
+def test_nonzero_vlos(hip_lib):
+    prob, block, d = fixtures.load_problem_npz(golden('falc_ca_vlos.npz'))
+    eng = Engine(prob, 1, lib=hip_lib)
+    eng.set_columns(0, block)
+    for it in range(1, 5):
+        dJ = eng.formal_sol_gamma()
+        tag = 'fs%d' % it
+        if tag + '_dJ' in d:
+            assert dJ == pytest.approx(float(d[tag + '_dJ']), rel=1e-9)
+            assert relerr(eng.get(_capi.LSX_I)[0], d[tag + '_I']) < 1e-12
+            assert relerr(eng.get(_capi.LSX_J)[0], d[tag + '_J']) < 1e-12
+            off, diag = gamma_err(eng.get(_capi.LSX_GAMMA)[0], fixtures.gamma_from_raw(d, tag, prob), prob)
+            assert off < 1e-11 and diag < 1e-12
+        if it > 3:
+            eng.stat_equil()
+
+
+def test_falc_ca_converges_like_the_reference(hip_lib):
+    """config C2: 46 iterations, same trajectory, same converged n, J, I (test.py:20-29)."""
+    prob, block, d = fixtures.load_problem_npz(golden('falc_ca.npz'))
+    eng = Engine(prob, 1, lib=hip_lib)
+    eng.set_columns(0, block)
+    h = drivers.iterate_mali(Adapter(eng))
+    assert h.converged and h.n_iter == 46
+    assert np.allclose(h.dJ, d['traj_dJ'], rtol=1e-6)
+    assert np.allclose(h.dPops[3:], d['traj_dPops'][3:], rtol=1e-6)
+    assert relerr(eng.get(_capi.LSX_N)[0], fixtures.pops_from_raw(d, 'conv', prob)) < 1e-6
+    assert relerr(eng.get(_capi.LSX_J)[0], d['conv_J']) < 1e-6
+    assert relerr(eng.get(_capi.LSX_I)[0], d['conv_I']) < 1e-6
+
+
+def test_columns_are_independent_and_bitwise_reproducible(hip_lib, oracle_lib):
+    """Many columns = many Contexts side by side: every column must give exactly the bits it gives
+    alone, whatever its position in the batch (this is what makes multi-GPU sharding exact)."""
+    from lightspinner_amd import synth
+    prob, block, d = fixtures.load_problem_npz(golden('falc_ca.npz'))
+    batch = synth.perturbed_columns(prob, block, d, ncol=7, seed=1234, vlos_sigma=0.0)
+    eng = Engine(prob, 7, lib=hip_lib)
+    eng.set_columns(0, batch)
+    ora = Engine(prob, 7, lib=oracle_lib)
+    ora.set_columns(0, batch)
+    for it in range(5):
+        eng.formal_sol_gamma(); ora.formal_sol_gamma()
+        if it > 2:
+            eng.stat_equil(); ora.stat_equil()
+    J, I, n = eng.get(_capi.LSX_J), eng.get(_capi.LSX_I), eng.get(_capi.LSX_N)
+    assert relerr(J, ora.get(_capi.LSX_J)) < 1e-7 and relerr(I, ora.get(_capi.LSX_I)) < 1e-7
+    assert relerr(n, ora.get(_capi.LSX_N)) < 1e-7
+    # column 0 is the unperturbed FALC column
+    single = Engine(prob, 1, lib=hip_lib)
+    for c in (0, 3, 6):
+        single.set_columns(0, batch.slice(c, c + 1))
+        for it in range(5):
+            single.formal_sol_gamma()
+            if it > 2:
+                single.stat_equil()
+        assert np.array_equal(single.get(_capi.LSX_J)[0], J[c])
+        assert np.array_equal(single.get(_capi.LSX_I)[0], I[c])
+        assert np.array_equal(single.get(_capi.LSX_N)[0], n[c])
+    # per-column convergence monitors
+    assert eng.get(_capi.LSX_DJ_COL).shape == (7,)
+    assert np.max(eng.get(_capi.LSX_DJ_COL)) == pytest.approx(eng.sync()[0])
+
+
+def test_warm_start_and_set_get_roundtrip(hip_lib):
+    prob, block, d = fixtures.load_problem_npz(golden('falc_ca.npz'))
+    eng = Engine(prob, 2, lib=hip_lib)
+    eng.set_columns(0, ColumnBlock.concatenate([block, block]))
+    n = fixtures.pops_from_raw(d, 'conv', prob)
+    eng.set(_capi.LSX_N, n[None], col0=1)
+    assert np.array_equal(eng.get(_capi.LSX_N, 1, 1)[0], n)
+    J = d['conv_J']
+    eng.set(_capi.LSX_J, J[None], col0=1)
+    assert np.array_equal(eng.get(_capi.LSX_J, 1, 1)[0], J)
+    assert np.all(eng.get(_capi.LSX_J, 0, 1) == 0)
+    # a converged start stays converged: one MALI iteration moves nothing beyond the thresholds
+    dJ = eng.formal_sol_gamma()
+    dJc = eng.get(_capi.LSX_DJ_COL)
+    assert dJc[1] < 2e-3 and dJc[0] == 1.0 and dJ == 1.0
+
+
+def test_error_conventions(hip_lib):
+    prob, block, d = fixtures.load_problem_npz(golden('falc_ca.npz'))
+    eng = Engine(prob, 1, lib=hip_lib)
+    with pytest.raises(_capi.LsxError):
+        eng.get(_capi.LSX_J, col0=1, ncol=1)
+    eng.set_columns(0, block)
+    with pytest.raises(np.linalg.LinAlgError):   # Gamma all zero -> singular, rh_method.py:739
+        eng.stat_equil()
+    with pytest.raises(_capi.LsxError):
+        eng.get(_capi.LSX_RIJ)
