@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MALI formal-solution hot path on MI355X.
+
+A "step" = one MALI iteration (formal_sol_gamma_matrices + stat_equil, rh_method.py:565,710)
+over every atmosphere column resident on the GPU.  Workload (config.workload):
+  c3 (default)  1000 FALC-perturbed CaII columns per GPU, ray-dependent line profiles
+                (BASELINE.json configs[2]; weak scaling: columns per GPU fixed)
+  c2            the single FALC CaII column (configs[1]; 45 wavefronts -- latency bound by
+                construction, reported inside every run as `falc_single_column`)
+  c4            FALC-perturbed Ca+H columns (configs[3] per-GPU share, 1250 columns)
+value = depth-points x wavelengths x rays updated per second, whole job.
+Inputs are resident in HBM before the timed region.  One JSON line on stdout (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def _gen_chunk(args):
+    path, first, n, seed, vlos_sigma, compact = args
+    from lightspinner_amd import fixtures, synth
+    prob, block, raw = fixtures.load_problem_npz(path, phi_compact=compact)
+    return synth.perturbed_columns(prob, block, raw, ncol=n, seed=seed, first=first, vlos_sigma=vlos_sigma)
+
+
+def generate_columns(path, first, ncol, compact, nproc, seed=1234, chunk=25):
+    """synthetic ensemble columns [first, first+ncol) (before the GPU is touched: fork is safe)"""
+    from lightspinner_amd.problem import ColumnBlock
+    jobs = [(path, first + c0, min(chunk, ncol - c0), seed, 0.0 if compact else 2.0e3, compact)
+            for c0 in range(0, ncol, chunk)]
+    if nproc > 1 and len(jobs) > 1:
+        import multiprocessing as mp
+        with mp.get_context('fork').Pool(min(nproc, len(jobs))) as pool:
+            blocks = pool.map(_gen_chunk, jobs)
+    else:
+        blocks = [_gen_chunk(j) for j in jobs]
+    return ColumnBlock.concatenate(blocks)
+
+
+def cpu_baseline(prob, batch, seconds_target=12.0):
+    """The oracle (C restatement, kind 'port') on a bounded sample of the same workload, on this
+    host's cores, OpenMP over columns.  Checker/baseline only -- never the product path."""
+    import oracle
+    from lightspinner_amd import Engine
+    lib = oracle.load()
+    cores = os.cpu_count() or 1
+    nsample = min(batch.ncol, max(cores, 32))
+    eng = Engine(prob, nsample, lib=lib)
+    eng.set_columns(0, batch.slice(0, nsample))
+    out = {}
+    for label, nthreads in (('1thread', 1), ('allcores', cores)):
+        lib.check(lib.dll.lsx_oracle_set_threads(eng._h, nthreads))
+        # calibrate with one iteration, then run ~seconds_target/2 each
+        t0 = time.perf_counter()
+        eng.formal_sol_gamma(); eng.stat_equil()
+        t1 = time.perf_counter() - t0
+        iters = int(max(1, min(200, (seconds_target / 2) / max(t1, 1e-6))))
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            eng.formal_sol_gamma()
+            eng.stat_equil()
+        dt = time.perf_counter() - t0
+        out[label] = dict(value=prob.work_units_per_column() * nsample * iters / dt, iters=iters, seconds=dt,
+                          threads=nthreads)
+    eng.close()
+    return dict(value=out['allcores']['value'], unit='point-updates/s', cores=cores, kind='port',
+                sample='%d columns of the same workload x %d MALI iterations (FS+SE), OpenMP over columns; '
+                       'single thread: %.4g point-updates/s' % (nsample, out['allcores']['iters'], out['1thread']['value']),
+                value_1thread=out['1thread']['value'])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='c3', choices=['c2', 'c3', 'c4'])
+    ap.add_argument('--columns', type=int, default=None, help='columns per GPU (default 1000 / 1 / 1250)')
+    ap.add_argument('--compact-phi', action='store_true', help='vlos == 0: ray independent profiles (P = 1)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--kernel-reps', type=int, default=10)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+    fixture = os.path.join(ROOT, 'tests', 'golden', 'falc_cah.npz' if args.workload == 'c4' else 'falc_ca.npz')
+    ncol = args.columns or {'c2': 1, 'c3': 1000, 'c4': 1250}[args.workload]
+    compact = args.compact_phi or args.workload == 'c2'
+
+    # ---- host-side input generation, before any GPU initialisation -------------------
+    from lightspinner_amd import fixtures, Engine, _capi, drivers
+    from lightspinner_amd.parallel import MaxReducer
+    prob, base, raw = fixtures.load_problem_npz(fixture, phi_compact=compact)
+    t0 = time.time()
+    nproc = max(1, (os.cpu_count() or 1) // max(1, world))
+    batch = generate_columns(fixture, rank * ncol, ncol, compact, nproc) if ncol > 1 else base
+    t_gen = time.time() - t0
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(prob, batch)
+
+    # ---- GPU ---------------------------------------------------------------------------
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    dev = torch.device('cuda', local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    lib = _capi.load_hip_library()
+    eng = Engine(prob, ncol, device=local_rank, stream=stream or None, lib=lib)
+    t0 = time.time()
+    for c0 in range(0, ncol, 100):
+        eng.set_columns(c0, batch.slice(c0, min(ncol, c0 + 100)))
+    t_up = time.time() - t0
+    upload_bytes = sum(getattr(batch, k).nbytes for k in ('phi', 'bg_chi', 'bg_eta', 'C', 'n', 'nStar'))
+    reducer = MaxReducer(device=dev)
+
+    def step():
+        dJ = eng.formal_sol_gamma()
+        dP = eng.stat_equil()
+        return reducer(dJ, dP)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dJ, dP = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    units = prob.work_units_per_column() * ncol * world * args.steps
+    result = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel, HIP events on the kernel's own stream ----
+        ms_total, ms_sweep = eng.time_formal_sol(2, args.kernel_reps)
+        import ctypes as C
+        lib.dll.lsx_hip_info.argtypes = [C.c_void_p, C.c_int32]
+        lib.dll.lsx_hip_info.restype = C.c_double
+        info = lambda w: float(lib.dll.lsx_hip_info(eng._h, w))
+        balg = eng.algorithmic_bytes_per_column()      # SURVEY 8d formula, whole FS call
+        bsweep = info(0)                               # the part of it the sweep kernel itself moves
+        peak = 8000.0
+        kernel = 'lsx_sweep_kernel'
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(args.workload, {}).get('hbm_bytes_per_launch_per_column')
+                traffic = traffic * ncol if traffic is not None else None
+            except Exception:
+                traffic = None
+        ach = bsweep * ncol / (ms_sweep * 1e-3) / 1e9
+        roofline = dict(bound='hbm', kernel=kernel, achieved=ach, peak=peak, unit='GB/s', frac=ach / peak, traffic=traffic,
+                        alg_bytes_per_launch=bsweep * ncol, avg_launch_ms=ms_sweep,
+                        fs_call=dict(ms=ms_total, ms_sweep_kernel=ms_sweep, ms_epilogue_kernels=info(4), alg_bytes=balg * ncol,
+                                     achieved_GBps=balg * ncol / (ms_total * 1e-3) / 1e9,
+                                     frac=balg * ncol / (ms_total * 1e-3) / 1e9 / peak),
+                        point_updates_per_sec_kernel=prob.work_units_per_column() * ncol / (ms_sweep * 1e-3),
+                        tiles_per_column=info(1), wavelengths_per_tile=info(3), lds_bytes_per_workgroup=info(2),
+                        slab_bytes_per_column=info(5),
+                        note='fp64 VALU work (~150 flop per 13 algorithmic bytes, SURVEY 8d) bounds this kernel as much as '
+                             'HBM does; achieved = algorithmic bytes / HIP-event duration on the launch stream')
+
+        # ---- parity + single-column (C2) numbers in the same run -----------------------
+        p1, b1, r1 = fixtures.load_problem_npz(os.path.join(ROOT, 'tests', 'golden', 'falc_ca.npz'))
+        e1 = Engine(p1, 1, device=local_rank, stream=stream or None, lib=lib)
+        e1.set_columns(0, b1)
+
+        class A:
+            def formal_sol_gamma_matrices(self): return e1.formal_sol_gamma()
+            def stat_equil(self): return e1.stat_equil()
+        t0 = time.perf_counter()
+        h = drivers.iterate_mali(A())
+        t_c2 = time.perf_counter() - t0
+        nref = fixtures.pops_from_raw(r1, 'conv', p1)
+        n1 = e1.get(_capi.LSX_N)[0]
+        single = dict(n_iter=h.n_iter, converged=h.converged, seconds=t_c2, mali_iters_per_sec=h.n_iter / t_c2,
+                      point_updates_per_sec=p1.work_units_per_column() * h.n_iter / t_c2,
+                      max_dn_over_n_vs_ref=float(np.max(np.abs(n1 - nref) / np.abs(nref))),
+                      max_dI_over_I_vs_ref=float(np.max(np.abs(e1.get(_capi.LSX_I)[0] - r1['conv_I']) / np.abs(r1['conv_I']))),
+                      reference_python_iters_per_sec=0.9)
+        e1.close()
+
+        result = dict(metric='depth_points_x_wavelengths_x_rays_per_sec', value=units / dt, unit='point-updates/s',
+                      n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
+                      higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
+                      config=dict(workload={'c2': 'C2: single FALC 82-depth CaII column, 5 rays',
+                                            'c3': 'C3: %d FALC-perturbed CaII columns per GPU, 82 depth x 287 wavelengths x 5 rays x 2 directions' % ncol,
+                                            'c4': 'C4 share: %d FALC-perturbed Ca+H columns per GPU, 82 depth x 777 wavelengths x 5 rays x 2' % ncol}[args.workload],
+                                  columns_per_gpu=ncol, columns_total=ncol * world, Nspace=prob.Nspace, Nspect=prob.Nspect,
+                                  Nrays=prob.Nrays, profiles='compact (vlos=0)' if compact else 'ray dependent (vlos!=0)',
+                                  parallelism='columns sharded over %d GPU(s); RCCL all-reduce(MAX) of (dJ, dPops) per iteration' % world),
+                      mali_iters_per_sec=args.steps / dt, column_iters_per_sec=args.steps * ncol * world / dt,
+                      last_dJ=dJ, last_dPops=dP,
+                      roofline=roofline, cpu_baseline=cpu, falc_single_column=single,
+                      max_dn_over_n_vs_ref=single['max_dn_over_n_vs_ref'],
+                      setup=dict(generate_s=t_gen, upload_s=t_up, upload_GB=upload_bytes / 1e9,
+                                 note='PCIe-inclusive upload is outside the timed region (inputs resident in HBM)'))
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,31 +1,32 @@
-// lsx_dev.h -- device-side data model shared by the host runtime (lsx_hip.cpp) and the
-// kernels (lsx_kernels.hip, lsx_sweep.hip).  gfx950 / wave64 only.
+// lsx_dev.h -- device-side data model shared by the host runtime (lsx_hip.hip) and the
+// sweep kernel (lsx_sweep.hip).  gfx950 / wave64 only.
 //
 // HBM layout (all float64, one block per context, index order left = slowest):
-//   per column, "depth-major" (k-major) so that the 32 wavelength-lanes of a half-wave read
-//   consecutive addresses at a fixed depth (the sweep is serial in k inside a lane):
+//   per column, "depth-major" (k-major): at a fixed depth the wavelength-lanes of a wavefront
+//   read consecutive addresses (the sweep is serial in k inside a lane):
 //     bgchi_T, bgeta_T   [col][k][la]
 //     J_T[2]             [col][k][la]            ping-pong: Jdag <- previous call
 //     sca                [col][k]  (or [col][k][la] when sca_per_lambda)
-//     phi_T              [col] { per line: [k][dir][mu][lt] }   (compact: [k][lt], mu/dir strides 0)
+//     phi_T              [col] { per line: [k][dir][mu][lt] }   (compact: [k][lt])
 //     gijc_T             [col] { per continuum: [k][lt] }       g_ij of (26) in [U01], built at upload
-//   per column, reference layout (level-major, read with half-wave-uniform addresses):
+//   per column, reference layout (level-major; the sweep reads them with wave-uniform
+//   addresses through the scalar cache):
 //     n, nStar           [col][NLtot][k]
 //     C, Gamma           [col][NL2tot][k]
 //     wphi               [col][Nlines][k]
 //   outputs of the sweep:
 //     Iout               [col][la][mu]
 //     Gpart              [col][slot][e=ij,ji][dir][k]     one value per (tile-slot, depth, dir): no atomics
-//     dJpart             [col][tile]
+//     dJpart             [col][tile][dir]
 #pragma once
 #include <stdint.h>
 
 #define LSX_WAVE 64
-#define LSX_HALF 32       // wavelengths per tile = lanes per direction
 #define LSX_MAX_ATOMS 8
-#define LSX_MAX_LEVELS 64 // NLtot cap for the lane-private LDS level arrays
+#define LSX_MAX_FAST 32   // fast continua per tile (activity bit mask in one VGPR)
+#define LSX_MAX_PER_RAY 32
 
-struct DevTrans {           // one radiative transition, column independent
+struct DevTrans {           // one radiative transition, column independent (host + Gamma epilogue)
     int32_t atom, is_line;
     int32_t li, lj;         // global level index (lev_off[atom] + i / j)
     int32_t Nblue, Nlam;
@@ -39,13 +40,46 @@ struct DevTrans {           // one radiative transition, column independent
     double AB;              // lines: Aji / Bji                          rh_method.py:281
 };
 
-struct DevTile {            // 32 consecutive wavelengths x both directions = one wavefront
-    int32_t la0, nla;       // first global wavelength index, count (<= 32)
-    int32_t nslot;          // transitions that are active somewhere in the tile
+// level-bookkeeping flags of a slot inside its tile (atom.chi / atom.U / atom.eta of
+// rh_method.py:616-627 are only materialised, in lane-private LDS cells, where two transitions
+// of the tile actually share a level or an atom)
+enum {
+    SLOT_LINE = 1,
+    SLOT_LI_CELL = 2,      // lower level shared with another slot  -> chi_lev[i] via cell
+    SLOT_LJ_CELL = 4,      // upper level shared                    -> chi_lev[j], U_lev[j] via cells
+    SLOT_UI_READ = 8,      // some slot's upper level is this slot's lower level (U_lev[i] != 0)
+    SLOT_ETA_CELL = 16,    // another slot of the same atom in the tile -> eta_atom via cell
+    SLOT_CHI_I_FIRST = 32, // first writer of the cell in execution order (store, else add)
+    SLOT_CHI_J_FIRST = 64,
+    SLOT_U_J_FIRST = 128,
+    SLOT_ETA_FIRST = 256
+};
+
+// One transition as one tile sees it ("slot"); wave-uniform, read through the scalar cache.
+// A tile's slots are ordered: per-ray slots first (lines, then continua of atoms that have
+// a line in the tile), then "fast" continua (atoms without a line in the tile: their
+// opacity, emissivity and level bookkeeping do not depend on the ray).
+struct DevSlot {
+    int32_t flags;
+    int32_t li, lj;        // global level ids (rows of n)
+    int32_t ci, cj, ca;    // tile-local LDS cell ids: level cells of i and j, atom cell
+    int32_t Nblue, Nlam;
+    int32_t base;          // element offset of the transition's block inside the column's phi_T / gijc_T
+    int32_t wl_off;        // into wl / alpha
+    int32_t trans;         // row of the `active` table
+    int32_t wphi_off;      // lines: line_idx * Nspace
+    double cB;             // lines: (hc/4pi) Bij                    Vij = cB phi        rh_method.py:279
+    double g;              // lines: Bji/Bij                         Vji = g Vij         :280, :450
+    double Vc;             // lines: g cB
+    double Uc;             // lines: (Aji/Bji) g cB                  Uji = Uc phi        :281
+};
+
+struct DevTile {            // L consecutive wavelengths (L = 64 / Nrays) of one column
+    int32_t la0, nla;       // first global wavelength index, count (<= L)
+    int32_t nP;             // per-ray slots
+    int32_t nF;             // fast continua
     int32_t slot0;          // first entry in the slot table / first Gpart slab
-    int32_t nlev, lev0;     // levels those transitions touch: count, first entry in tile_levels
-    int32_t natom_mask;     // bit a set: atom a has a slot in this tile
-    int32_t pad;
+    int32_t pad0, pad1, pad2;
 };
 
 struct SweepParams {
@@ -53,23 +87,21 @@ struct SweepParams {
     int32_t Nspace, Nrays, Nspect, Natoms, Ntrans, ncol;
     int32_t NLtot, NL2tot, Nlines;
     int32_t sca_per_lambda;
-    int32_t phi_mu_stride_is_zero; // compact profile
+    int32_t phi_compact;
     int32_t nslot_total, ntile_total;
+    int32_t L;                  // wavelengths per tile
+    int32_t ncell_lev, ncell_atom, nstash; // LDS layout: [2*ncell_lev level cells][ncell_atom][nstash][1 exchange row]
+    int32_t pad;
     // column-independent tables
     const double* wavelength;   // [Nspect]
-    const double* zmu;          // [M] 1/muz                (1 for padded rays)
-    const double* wmuh;         // [M] 0.5*wmu              (0 for padded rays)   rh_method.py:661
-    const double* wl;           // per (transition, lt): wlambda(lt) (lines) | wlambda(lt)/lambda/h (continua)
+    const double* zmu;          // [Nrays] 1/muz
+    const double* wmuh;         // [Nrays] 0.5*wmu                              rh_method.py:661
+    const double* wl;           // per (transition, lt): wlambda(lt)/hc (lines) | wlambda(lt)/lambda/h (continua)
     const double* alpha;        // per (transition, lt) (continua; 0 for lines)
-    const double* u_la;         // [Nspect] 2hc/lambda^3                  rh_method.py:286
+    const double* u_la;         // [Nspect] 2hc/lambda^3                        rh_method.py:286
     const uint8_t* active;      // [Ntrans][Nspect]
-    const DevTrans* trans;
     const DevTile* tiles;
-    const int32_t* tile_slots;  // transition id per slot
-    const int32_t* tile_levels; // global level ids per tile
-    const int32_t* class_tiles; // tile ids of the launched UMAX class
-    int32_t n_class_tiles;
-    int32_t pad0;
+    const DevSlot* slots;       // per (tile, slot) parameters
     // per-column strides (in doubles)
     int64_t phi_col_stride, gijc_col_stride;
     // per-column arrays

@@ -20,10 +20,8 @@
 #include "../../include/lsx.h"
 #include "lsx_dev.h"
 
-// launchers defined in lsx_sweep.hip, one translation unit per rays-per-lane M
-#define DECL_SWEEP(M) extern "C" hipError_t lsx_launch_sweep_m##M(const SweepParams*, int, int, size_t, hipStream_t);
-DECL_SWEEP(1) DECL_SWEEP(2) DECL_SWEEP(3) DECL_SWEEP(4) DECL_SWEEP(5) DECL_SWEEP(8)
-#undef DECL_SWEEP
+// launcher defined in lsx_sweep.hip
+extern "C" hipError_t lsx_launch_sweep(const SweepParams*, int, size_t, hipStream_t);
 
 namespace {
 
@@ -133,7 +131,7 @@ __global__ void k_gamma_finish(const FinishParams f)
     const double* P = f.Gpart + (size_t)col * f.nslot_total * 4 * Ns + k;
     for (int t = 0; t < f.ntile; ++t) {
         const DevTile tl = f.tiles[t];
-        for (int u = 0; u < tl.nslot; ++u) {
+        for (int u = 0; u < tl.nP + tl.nF; ++u) {
             const DevTrans& tr = f.trans[f.tile_slots[tl.slot0 + u]];
             const double* q = P + (size_t)(tl.slot0 + u) * 4 * Ns;
             double gij = G[(size_t)tr.gam_ij * Ns], gji = G[(size_t)tr.gam_ji * Ns];
@@ -157,8 +155,8 @@ __global__ void k_gamma_finish(const FinishParams f)
     }
     if (k == 0) { // per-column dJ: max over the column's tiles, NaN propagating (rh_method.py:705-706)
         double m = 0.0;
-        for (int t = 0; t < f.ntile; ++t) {
-            const double v = f.dJpart[(size_t)col * f.ntile + t];
+        for (int t = 0; t < 2 * f.ntile; ++t) {
+            const double v = f.dJpart[(size_t)col * 2 * f.ntile + t];
             m = (v != v || m != m) ? __builtin_nan("") : fmax(m, v);
         }
         f.dJcol[col] = m;
@@ -327,28 +325,23 @@ __global__ void k_piecewise(int nray, int Ns, const double* __restrict__ z, cons
 } // namespace
 
 // ------------------------------------------------------------------------------- context
-struct SweepClass {
-    int umax;
-    std::vector<int> tiles;
-    int* d_tiles = nullptr;
-    double alg_bytes_per_col = 0.0; // algorithmic HBM bytes this class's tiles touch, per column
-    double ms_accum = 0.0;          // accumulated kernel time (lsx_time_formal_sol)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-};
-
 struct lsx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    int Nspace = 0, Nrays = 0, Nspect = 0, Natoms = 0, Ntrans = 0, ncol = 0, M = 0;
+    int Nspace = 0, Nrays = 0, Nspect = 0, Natoms = 0, Ntrans = 0, ncol = 0;
     int NLtot = 0, NL2tot = 0, Nlines = 0, SNl = 0, SNc = 0;
     int sca_per_lambda = 0, phi_compact = 0;
     std::vector<int> Nlevel, lev_off, lev2_off;
     std::vector<lsx_transition> trans;
     std::vector<DevTrans> htrans;
     std::vector<DevTile> tiles;
-    std::vector<int> tile_slots, tile_levels;
-    std::vector<SweepClass> classes;
+    std::vector<int> tile_slots;
+    std::vector<DevSlot> slots;
+    DevSlot* d_slots = nullptr;
+    int L = 0, ncell_lev = 0, ncell_atom = 0, nstash = 0;
+    double ms_sweep = 0.0, ms_finish = 0.0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     size_t lds_bytes = 0;
     // device: column independent
     double *d_wavelength = nullptr, *d_zmu = nullptr, *d_wmuh = nullptr, *d_wl = nullptr, *d_alpha = nullptr,
@@ -356,7 +349,7 @@ struct lsx_ctx {
     uint8_t* d_active = nullptr;
     DevTrans* d_trans = nullptr;
     DevTile* d_tiles = nullptr;
-    int *d_tile_slots = nullptr, *d_tile_levels = nullptr, *d_Nlevel = nullptr, *d_lev2_off = nullptr;
+    int *d_tile_slots = nullptr, *d_Nlevel = nullptr, *d_lev2_off = nullptr;
     // device: per column
     double *d_height = nullptr, *d_temperature = nullptr, *d_nStar = nullptr, *d_nTotal = nullptr, *d_n = nullptr,
            *d_C = nullptr, *d_Gamma = nullptr, *d_wphi = nullptr, *d_bgchi = nullptr, *d_bgeta = nullptr,
@@ -426,7 +419,6 @@ double wlambda(const lsx_ctx* c, const std::vector<double>& wave, const lsx_tran
     return 0.5 * (wl[lt + 1] - wl[lt - 1]) * dopplerWidth;
 }
 
-const int kUmaxClasses[] = {2, 4, 8, 12};
 
 } // namespace
 
@@ -442,17 +434,14 @@ void lsx_destroy(lsx_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_wavelength, c->d_zmu, c->d_wmuh, c->d_wl, c->d_alpha, c->d_u_la, c->d_active, c->d_trans,
-                    c->d_tiles, c->d_tile_slots, c->d_tile_levels, c->d_Nlevel, c->d_lev2_off, c->d_height,
+                    c->d_tiles, c->d_slots, c->d_tile_slots, c->d_Nlevel, c->d_lev2_off, c->d_height,
                     c->d_temperature, c->d_nStar, c->d_nTotal, c->d_n, c->d_C, c->d_Gamma, c->d_wphi, c->d_bgchi,
                     c->d_bgeta, c->d_sca, c->d_phi, c->d_gijc, c->d_J[0], c->d_J[1], c->d_I, c->d_Gpart, c->d_dJpart,
                     c->d_dJcol, c->d_dPcol, c->d_max, c->d_singular, c->d_stage};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    for (auto& k : c->classes) {
-        if (k.d_tiles) (void)hipFree(k.d_tiles);
-        if (k.ev0) (void)hipEventDestroy(k.ev0);
-        if (k.ev1) (void)hipEventDestroy(k.ev1);
-    }
+    for (hipEvent_t e : {c->ev0, c->ev1, c->ev2})
+        if (e) (void)hipEventDestroy(e);
     if (c->evA) (void)hipEventDestroy(c->evA);
     if (c->evB) (void)hipEventDestroy(c->evB);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -466,7 +455,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     if (d->abi_version != LSX_ABI_VERSION) return fail(LSX_EINVAL, "lsx_create: ABI version mismatch");
     if (d->Nspace < 3) return fail(LSX_EINVAL, "lsx_create: Nspace must be >= 3 (formal_solver.py:120-139)");
     if (d->Nrays < 1 || d->Nspect < 1 || d->Natoms < 1 || d->Ntrans < 0) return fail(LSX_EINVAL, "lsx_create: bad dimensions");
-    if (d->Nrays > 8) return fail(LSX_EUNSUPPORTED, "lsx_create: Nrays > 8 is not supported by this build");
+    if (d->Nrays > LSX_WAVE) return fail(LSX_EUNSUPPORTED, "lsx_create: Nrays > 64 is not supported by this build");
     if (d->Natoms > LSX_MAX_ATOMS) return fail(LSX_EUNSUPPORTED, "lsx_create: more than %d active atoms", LSX_MAX_ATOMS);
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
@@ -487,7 +476,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     c->Ntrans = d->Ntrans; c->ncol = ncol;
     c->sca_per_lambda = d->sca_per_lambda ? 1 : 0;
     c->phi_compact = d->phi_compact ? 1 : 0;
-    c->M = d->Nrays <= 5 ? d->Nrays : 8;
+    c->L = LSX_WAVE / d->Nrays;
     const int Ns = c->Nspace, Nspect = c->Nspect;
     for (int a = 0; a < c->Natoms; ++a) {
         if (d->Nlevel[a] < 2) { lsx_destroy(c); return fail(LSX_EINVAL, "lsx_create: Nlevel < 2"); }
@@ -497,7 +486,6 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         c->NLtot += d->Nlevel[a];
         c->NL2tot += d->Nlevel[a] * d->Nlevel[a];
     }
-    if (c->NLtot > LSX_MAX_LEVELS) { lsx_destroy(c); return fail(LSX_EUNSUPPORTED, "lsx_create: more than %d levels in total", LSX_MAX_LEVELS); }
 
     std::vector<double> wave(d->wavelength, d->wavelength + Nspect);
     std::vector<double> wl, alpha;
@@ -525,7 +513,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
             h.cB = (0.25 * kHC / M_PI) * tr.Bij; // rh_method.py:268,279
             h.gij = tr.Bji / tr.Bij;             // :450
             h.AB = tr.Aji / tr.Bji;              // :281
-            for (int lt = 0; lt < tr.Nlambda; ++lt) { wl.push_back(wlambda(c, wave, tr, lt)); alpha.push_back(0.0); }
+            for (int lt = 0; lt < tr.Nlambda; ++lt) { wl.push_back(wlambda(c, wave, tr, lt) / kHC); alpha.push_back(0.0); } // :451
         } else {
             h.cont_off = c->SNc;
             c->SNc += tr.Nlambda;
@@ -537,55 +525,107 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         }
         c->htrans.push_back(h);
     }
-    // ---- tile schedule: 32 consecutive wavelengths per wavefront
-    for (int la0 = 0; la0 < Nspect; la0 += LSX_HALF) {
+    // ---- tile schedule: L = 64/Nrays consecutive wavelengths per wavefront pair
+    const int P_line = c->phi_compact ? 1 : 2 * c->Nrays;
+    for (int la0 = 0; la0 < Nspect; la0 += c->L) {
         DevTile tl{};
         tl.la0 = la0;
-        tl.nla = std::min(LSX_HALF, Nspect - la0);
+        tl.nla = std::min(c->L, Nspect - la0);
         tl.slot0 = (int)c->tile_slots.size();
-        tl.lev0 = (int)c->tile_levels.size();
-        std::vector<int> levs;
+        std::vector<int> lines, conts;
+        unsigned atoms_with_line = 0;
         for (int t = 0; t < c->Ntrans; ++t) {
             bool any = false;
             for (int la = la0; la < la0 + tl.nla; ++la) any = any || active[(size_t)t * Nspect + la];
             if (!any) continue;
-            c->tile_slots.push_back(t);
-            tl.nslot++;
-            tl.natom_mask |= 1 << c->htrans[t].atom;
-            for (int lev : {c->htrans[t].li, c->htrans[t].lj})
-                if (std::find(levs.begin(), levs.end(), lev) == levs.end()) levs.push_back(lev);
+            if (c->htrans[t].is_line) { lines.push_back(t); atoms_with_line |= 1u << c->htrans[t].atom; }
+            else conts.push_back(t);
         }
-        tl.nlev = (int)levs.size();
-        c->tile_levels.insert(c->tile_levels.end(), levs.begin(), levs.end());
-        int umax = 0;
-        for (int k : kUmaxClasses)
-            if (!umax && tl.nslot <= k) umax = k;
-        if (!umax) {
+        // per-ray slots: lines, then continua of atoms that have a line in the tile; fast: the other continua
+        std::vector<int> per_ray = lines, fast;
+        for (int t : conts) ((atoms_with_line >> c->htrans[t].atom) & 1u ? per_ray : fast).push_back(t);
+        if ((int)per_ray.size() > LSX_MAX_PER_RAY || (int)fast.size() > LSX_MAX_FAST) {
             lsx_destroy(c);
-            return fail(LSX_EUNSUPPORTED, "lsx_create: %d transitions overlap within wavelengths [%d, %d); this build handles 12",
-                        tl.nslot, la0, la0 + tl.nla);
+            return fail(LSX_EUNSUPPORTED, "lsx_create: more than %d overlapping transitions in wavelengths [%d, %d)",
+                        LSX_MAX_PER_RAY, la0, la0 + tl.nla);
         }
-        SweepClass* k = nullptr;
-        for (auto& q : c->classes)
-            if (q.umax == umax) k = &q;
-        if (!k) { c->classes.push_back(SweepClass()); k = &c->classes.back(); k->umax = umax; }
-        k->tiles.push_back((int)c->tiles.size());
-        // algorithmic bytes of this tile: profiles + bg chi, eta + Jdag, J over its wavelengths, + emergent I
-        const double P = c->phi_compact ? 1.0 : 2.0 * c->Nrays;
-        double npts = 0;
-        for (int u = 0; u < tl.nslot; ++u) {
-            const int t = c->tile_slots[tl.slot0 + u];
-            if (!c->htrans[t].is_line) continue;
-            for (int la = la0; la < la0 + tl.nla; ++la) npts += active[(size_t)t * Nspect + la] ? 1 : 0;
+        tl.nP = (int)per_ray.size();
+        tl.nF = (int)fast.size();
+        std::vector<int> order = per_ray;
+        order.insert(order.end(), fast.begin(), fast.end());
+        // tile-local cell ids
+        std::vector<int> lev_ids, atom_ids;
+        auto local = [](std::vector<int>& v, int x) {
+            auto it = std::find(v.begin(), v.end(), x);
+            if (it != v.end()) return (int)(it - v.begin());
+            v.push_back(x);
+            return (int)v.size() - 1;
+        };
+        // first-writer bookkeeping follows the execution order of a sweep step: the fast loop, then pass 1
+        std::vector<int> exec = fast;
+        exec.insert(exec.end(), per_ray.begin(), per_ray.end());
+        std::vector<int> chi_written, u_written, eta_written;
+        auto seen = [](std::vector<int>& v, int x) { bool sn = std::find(v.begin(), v.end(), x) != v.end(); if (!sn) v.push_back(x); return sn; };
+        std::vector<int> first_flags(c->Ntrans, 0);
+        auto share_flags = [&](int t) {
+            const DevTrans& h = c->htrans[t];
+            int nli = 0, nlj = 0, natom = 0, uiread = 0;
+            for (int v : order) {
+                const DevTrans& o = c->htrans[v];
+                if (o.li == h.li || o.lj == h.li) nli++;
+                if (o.li == h.lj || o.lj == h.lj) nlj++;
+                if (o.atom == h.atom) natom++;
+                if (o.lj == h.li) uiread = 1;
+            }
+            int f = h.is_line ? SLOT_LINE : 0;
+            if (nli > 1) f |= SLOT_LI_CELL;
+            if (nlj > 1) f |= SLOT_LJ_CELL;
+            if (uiread) f |= SLOT_UI_READ;
+            if (natom > 1) f |= SLOT_ETA_CELL;
+            return f;
+        };
+        for (int t : exec) {
+            const DevTrans& h = c->htrans[t];
+            int f = share_flags(t);
+            if ((f & SLOT_LI_CELL) && !seen(chi_written, h.li)) f |= SLOT_CHI_I_FIRST;
+            if (f & SLOT_LJ_CELL) {
+                if (!seen(chi_written, h.lj)) f |= SLOT_CHI_J_FIRST;
+                if (!seen(u_written, h.lj)) f |= SLOT_U_J_FIRST;
+            }
+            if ((f & SLOT_ETA_CELL) && !seen(eta_written, h.atom)) f |= SLOT_ETA_FIRST;
+            first_flags[t] = f;
         }
-        k->alg_bytes_per_col += 8.0 * Ns * (P * npts + (c->sca_per_lambda ? 5.0 : 4.0) * tl.nla) + 8.0 * tl.nla * c->Nrays;
+        for (int t : order) {
+            const DevTrans& h = c->htrans[t];
+            DevSlot sl{};
+            sl.flags = first_flags[t];
+            sl.li = h.li; sl.lj = h.lj;
+            sl.ci = local(lev_ids, h.li); sl.cj = local(lev_ids, h.lj); sl.ca = local(atom_ids, h.atom);
+            sl.Nblue = h.Nblue; sl.Nlam = h.Nlam; sl.wl_off = h.wl_off; sl.trans = t;
+            if (h.is_line) {
+                sl.base = h.phi_off * P_line * Ns;
+                sl.wphi_off = h.line_idx * Ns;
+                sl.cB = h.cB; sl.g = h.gij; sl.Vc = h.gij * h.cB; sl.Uc = h.AB * (h.gij * h.cB);
+            } else {
+                sl.base = h.cont_off * Ns;
+            }
+            c->slots.push_back(sl);
+            c->tile_slots.push_back(t);
+        }
+        c->ncell_lev = std::max(c->ncell_lev, (int)lev_ids.size());
+        c->ncell_atom = std::max(c->ncell_atom, (int)atom_ids.size());
+        c->nstash = std::max(c->nstash, tl.nP);
         c->tiles.push_back(tl);
     }
-    std::sort(c->classes.begin(), c->classes.end(), [](const SweepClass& a, const SweepClass& b) { return a.tiles.size() > b.tiles.size(); });
-    c->lds_bytes = (size_t)(2 * c->NLtot + c->Natoms) * LSX_WAVE * sizeof(double);
+    c->ncell_lev = std::max(c->ncell_lev, 1);
+    c->ncell_atom = std::max(c->ncell_atom, 1);
+    c->nstash = std::max(c->nstash, 1);
+    // per wave: level cells, atom cells, stash, angle-sum row; + two cross-wave exchange rows
+    c->lds_bytes = (size_t)(2 * (2 * c->ncell_lev + c->ncell_atom + c->nstash + 1) + 2) * LSX_WAVE * sizeof(double);
+    if (c->lds_bytes > 64 * 1024) { lsx_destroy(c); return fail(LSX_EUNSUPPORTED, "lsx_create: tile needs %zu B of LDS", c->lds_bytes); }
 
     // ---- uploads of the column independent tables
-    std::vector<double> zmu(c->M, 1.0), wmuh(c->M, 0.0), u_la(Nspect);
+    std::vector<double> zmu(c->Nrays, 1.0), wmuh(c->Nrays, 0.0), u_la(Nspect);
     for (int m = 0; m < c->Nrays; ++m) { zmu[m] = 1.0 / d->muz[m]; wmuh[m] = 0.5 * d->wmu[m]; }
     for (int la = 0; la < Nspect; ++la) u_la[la] = 2.0 * kHC / std::pow(kNM_TO_M * wave[la], 3.0); // :286
     int rc = LSX_OK;
@@ -600,13 +640,10 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     TRY(upload(&c->d_trans, c->htrans, c->stream));
     TRY(upload(&c->d_tiles, c->tiles, c->stream));
     TRY(upload(&c->d_tile_slots, c->tile_slots, c->stream));
-    TRY(upload(&c->d_tile_levels, c->tile_levels, c->stream));
+    TRY(upload(&c->d_slots, c->slots, c->stream));
     TRY(upload(&c->d_Nlevel, c->Nlevel, c->stream));
     TRY(upload(&c->d_lev2_off, c->lev2_off, c->stream));
-    for (auto& k : c->classes) {
-        TRY(upload(&k.d_tiles, k.tiles, c->stream));
-        if (hipEventCreate(&k.ev0) != hipSuccess || hipEventCreate(&k.ev1) != hipSuccess) { lsx_destroy(c); return fail(LSX_EDEVICE, "hipEventCreate"); }
-    }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess) { lsx_destroy(c); return fail(LSX_EDEVICE, "hipEventCreate"); }
     if (hipEventCreate(&c->evA) != hipSuccess || hipEventCreate(&c->evB) != hipSuccess) { lsx_destroy(c); return fail(LSX_EDEVICE, "hipEventCreate"); }
 
     // ---- per-column storage
@@ -631,7 +668,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     TRY(dmalloc(&c->d_J[1], nc * Nspect * Ns));
     TRY(dmalloc(&c->d_I, nc * Nspect * c->Nrays));
     TRY(dmalloc(&c->d_Gpart, nc * c->tile_slots.size() * 4 * Ns));
-    TRY(dmalloc(&c->d_dJpart, nc * c->tiles.size()));
+    TRY(dmalloc(&c->d_dJpart, nc * 2 * c->tiles.size()));
     TRY(dmalloc(&c->d_dJcol, nc));
     TRY(dmalloc(&c->d_dPcol, nc));
     TRY(dmalloc(&c->d_max, 4));
@@ -737,35 +774,24 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
     SweepParams p{};
     p.Nspace = c->Nspace; p.Nrays = c->Nrays; p.Nspect = c->Nspect; p.Natoms = c->Natoms; p.Ntrans = c->Ntrans;
     p.ncol = c->ncol; p.NLtot = c->NLtot; p.NL2tot = c->NL2tot; p.Nlines = c->Nlines;
-    p.sca_per_lambda = c->sca_per_lambda; p.phi_mu_stride_is_zero = c->phi_compact;
+    p.sca_per_lambda = c->sca_per_lambda; p.phi_compact = c->phi_compact;
     p.nslot_total = (int)c->tile_slots.size(); p.ntile_total = (int)c->tiles.size();
+    p.L = c->L; p.ncell_lev = c->ncell_lev; p.ncell_atom = c->ncell_atom; p.nstash = c->nstash;
     p.wavelength = c->d_wavelength; p.zmu = c->d_zmu; p.wmuh = c->d_wmuh; p.wl = c->d_wl; p.alpha = c->d_alpha;
-    p.u_la = c->d_u_la; p.active = c->d_active; p.trans = c->d_trans; p.tiles = c->d_tiles;
-    p.tile_slots = c->d_tile_slots; p.tile_levels = c->d_tile_levels;
+    p.u_la = c->d_u_la; p.active = c->d_active; p.tiles = c->d_tiles; p.slots = c->d_slots;
     p.phi_col_stride = (int64_t)c->phi_col; p.gijc_col_stride = (int64_t)c->gijc_col;
     p.height = c->d_height; p.temperature = c->d_temperature; p.n = c->d_n; p.wphi = c->d_wphi;
     p.bgchi_T = c->d_bgchi; p.bgeta_T = c->d_bgeta; p.sca = c->d_sca; p.phi_T = c->d_phi; p.gijc_T = c->d_gijc;
     p.Jdag_T = c->d_J[c->jcur]; p.Jnew_T = c->d_J[c->jcur ^ 1];
     p.Iout = c->d_I; p.Gpart = c->d_Gpart; p.dJpart = c->d_dJpart;
 
-    for (auto& k : c->classes) {
-        p.class_tiles = k.d_tiles;
-        p.n_class_tiles = (int)k.tiles.size();
-        const long nblocks = (long)k.tiles.size() * c->ncol;
-        if (nblocks > 0x7fffffffL) return fail(LSX_EUNSUPPORTED, "grid too large");
-        if (timed) HIPCHK(hipEventRecord(k.ev0, c->stream));
-        hipError_t e;
-        switch (c->M) {
-        case 1: e = lsx_launch_sweep_m1(&p, k.umax, (int)nblocks, c->lds_bytes, c->stream); break;
-        case 2: e = lsx_launch_sweep_m2(&p, k.umax, (int)nblocks, c->lds_bytes, c->stream); break;
-        case 3: e = lsx_launch_sweep_m3(&p, k.umax, (int)nblocks, c->lds_bytes, c->stream); break;
-        case 4: e = lsx_launch_sweep_m4(&p, k.umax, (int)nblocks, c->lds_bytes, c->stream); break;
-        case 5: e = lsx_launch_sweep_m5(&p, k.umax, (int)nblocks, c->lds_bytes, c->stream); break;
-        default: e = lsx_launch_sweep_m8(&p, k.umax, (int)nblocks, c->lds_bytes, c->stream); break;
-        }
-        if (e != hipSuccess) return fail(LSX_EDEVICE, "sweep launch (UMAX=%d, M=%d): %s", k.umax, c->M, hipGetErrorString(e));
-        if (timed) HIPCHK(hipEventRecord(k.ev1, c->stream));
-    }
+    const long nblocks = (long)c->tiles.size() * c->ncol;
+    if (nblocks > 0x7fffffffL) return fail(LSX_EUNSUPPORTED, "grid too large");
+    if (timed) HIPCHK(hipEventRecord(c->ev0, c->stream));
+    hipError_t e = lsx_launch_sweep(&p, (int)nblocks, c->lds_bytes, c->stream);
+    if (e != hipSuccess) return fail(LSX_EDEVICE, "sweep launch: %s", hipGetErrorString(e));
+    if (timed) HIPCHK(hipEventRecord(c->ev1, c->stream));
+
     FinishParams f{};
     f.Nspace = c->Nspace; f.Natoms = c->Natoms; f.NL2tot = c->NL2tot; f.ncol = c->ncol; f.ntile = (int)c->tiles.size();
     f.nslot_total = (int)c->tile_slots.size(); f.Nlevel = c->d_Nlevel; f.lev2_off = c->d_lev2_off; f.tiles = c->d_tiles;
@@ -776,6 +802,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, c->stream, c->d_dJcol, c->ncol, c->d_max);
     HIPCHK(hipGetLastError());
+    if (timed) HIPCHK(hipEventRecord(c->ev2, c->stream));
     c->jcur ^= 1;
     c->fs_pending = true;
     return LSX_OK;
@@ -959,8 +986,7 @@ int lsx_time_formal_sol(lsx_ctx* c, int32_t warmup, int32_t reps, double* ms_tot
     for (int i = 0; i < warmup; ++i)
         if ((rc = enqueue_fs(c, false))) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
-    for (auto& k : c->classes) k.ms_accum = 0.0;
-    double tot = 0.0;
+    double tot = 0.0, sw = 0.0, fin = 0.0;
     for (int i = 0; i < reps; ++i) {
         HIPCHK(hipEventRecord(c->evA, c->stream));
         if ((rc = enqueue_fs(c, true))) return rc;
@@ -969,35 +995,34 @@ int lsx_time_formal_sol(lsx_ctx* c, int32_t warmup, int32_t reps, double* ms_tot
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, c->evA, c->evB));
         tot += ms;
-        for (auto& k : c->classes) {
-            HIPCHK(hipEventElapsedTime(&ms, k.ev0, k.ev1));
-            k.ms_accum += ms;
-        }
+        HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        sw += ms;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev1, c->ev2));
+        fin += ms;
     }
-    double sw = 0.0;
-    for (auto& k : c->classes) { k.ms_accum /= reps; sw += k.ms_accum; }
+    c->ms_sweep = sw / reps;
+    c->ms_finish = fin / reps;
     if (ms_total) *ms_total = tot / reps;
-    if (ms_sweep) *ms_sweep = sw;
+    if (ms_sweep) *ms_sweep = c->ms_sweep;
     return lsx_sync(c, nullptr, nullptr);
 }
 
-// HIP-only introspection used by bench.py: per sweep-kernel instantiation (UMAX class)
-// the tile count, algorithmic bytes per column and the average time of the last
-// lsx_time_formal_sol.  Returns the number of classes.
-int lsx_hip_sweep_classes(lsx_ctx* c, int32_t cap, int32_t* umax, int32_t* ntiles, double* alg_bytes_per_col, double* ms)
+// HIP-only introspection used by bench.py.  what: 0 = algorithmic bytes per column the sweep
+// kernel itself must move (B_alg without the C read / Gamma write of the epilogue), 1 = tiles per
+// column, 2 = LDS bytes per workgroup, 3 = wavelengths per tile, 4 = ms of the epilogue kernels in the
+// last lsx_time_formal_sol, 5 = slab bytes per column (extra, non-algorithmic traffic of the design)
+double lsx_hip_info(const lsx_ctx* c, int32_t what)
 {
-    if (!c) return 0;
-    int n = 0;
-    for (auto& k : c->classes) {
-        if (n < cap) {
-            if (umax) umax[n] = k.umax;
-            if (ntiles) ntiles[n] = (int)k.tiles.size();
-            if (alg_bytes_per_col) alg_bytes_per_col[n] = k.alg_bytes_per_col;
-            if (ms) ms[n] = k.ms_accum;
-        }
-        ++n;
+    if (!c) return 0.0;
+    switch (what) {
+    case 0: return lsx_algorithmic_bytes_per_column(c) - 8.0 * c->Nspace * 2.0 * c->NL2tot;
+    case 1: return (double)c->tiles.size();
+    case 2: return (double)c->lds_bytes;
+    case 3: return (double)c->L;
+    case 4: return c->ms_finish;
+    case 5: return 8.0 * c->Nspace * 4.0 * (double)c->tile_slots.size();
+    default: return 0.0;
     }
-    return n;
 }
 
 // B_alg = 8 Ns [P SNl + 2 Nspect (bg) + 2 Nspect (Jdag, J) + 1 (sigma) + NLtot (n)

@@ -8,31 +8,30 @@
 //   utils.py:17-22         (planck, lower boundary condition)
 //
 // Work decomposition (MI355X-first, not the reference's loop nest):
-//   * one wavefront = one TILE = 32 consecutive wavelengths x 2 directions of ONE column.
-//     lanes 0-31 walk down (k = 0..N-1), lanes 32-63 walk up (k = N-1..0): the depth
-//     recurrence stays serial inside a lane, both halves advance in lock step.
-//   * the Nrays mu-angles of a wavelength are advanced INSIDE the lane (unrolled, M
-//     independent recurrences = ILP; the angle quadrature for J and Gamma is an in-register
-//     sum, no cross-lane traffic).
-//   * the wavelength quadrature for Gamma is one half-wave reduction per (transition, depth);
-//     lane 31 / 63 store the result into a per-(tile, transition, direction, depth) slab.
-//     Every slab element is written exactly once -> no atomics, bitwise reproducible, and the
-//     result does not depend on how columns are distributed over GPUs.
-//   * all per-(lambda, depth) inputs are depth-major in HBM, so at a fixed depth the 32
-//     lanes of a half-wave read 256 consecutive bytes; every input byte is read once.
-//   * the per-level "effective opacity"/U bookkeeping of overlapping transitions
-//     (atom.chi / atom.U / atom.eta, rh_method.py:616-627) lives in lane-private LDS columns
-//     (address = level*64 + lane: conflict free, no barriers -- a workgroup is one wave).
-//
-// Template: UMAX = max transitions overlapping in the tile (register arrays are statically
-// indexed by unrolling to UMAX with a wave-uniform guard), M = rays per lane (Nrays padded
-// with zero-weight rays).
+//   * one LANE = one ray (wavelength, mu); one WAVEFRONT = one direction of a TILE of
+//     L = 64/Nrays consecutive wavelengths x all Nrays angles of ONE column (lane = mu*L + j);
+//     one WORKGROUP = the two directions of that tile (wave 0 sweeps down, wave 1 sweeps up).
+//     The depth recurrence is serial inside a lane; the depth index k is WAVE-UNIFORM, so
+//     every per-(transition, depth) quantity (level populations, line normalisation, geometry)
+//     is fetched through the scalar cache and costs no vector registers.
+//   * per-lane state is one ray (I_upwind, chi, S, dtau of the previous depth): ~8 VGPRs;
+//     occupancy, not unrolling, hides HBM latency.
+//   * all per-(lambda, depth) inputs are depth-major in HBM: at a fixed depth the L lanes of one
+//     angle read L consecutive doubles; every input byte is read once per call.
+//   * angle quadrature (J, and the ray sums the fast continua need): Nrays-lane strided sum
+//     through one LDS row.  Wavelength+angle quadrature of Gamma: one wave reduction (DPP) per
+//     (transition, depth); lane 63 stores it into a per-(tile, transition, direction, depth)
+//     slab.  Every slab element is written exactly once -> no atomics, bitwise reproducible,
+//     independent of how columns are distributed over GPUs.
+//   * the per-level "effective opacity"/U bookkeeping of overlapping transitions (atom.chi /
+//     atom.U / atom.eta, rh_method.py:616-627) lives in lane-private LDS cells, and only where two
+//     transitions of the tile really share a level or an atom (host-computed flags).
+//   * transitions of a tile come in two kinds.  PER-RAY slots (lines, and continua of an atom
+//     that has a line in the tile) go through both passes.  FAST continua (atoms with no line in
+//     the tile) are ray independent: their Gamma integrand is affine in I and Psi* with
+//     ray-independent coefficients, so it follows from sum_mu w I and sum_mu w Psi*.
 #include <hip/hip_runtime.h>
 #include "lsx_dev.h"
-
-#ifndef LSX_WAVES_PER_EU
-#define LSX_WAVES_PER_EU
-#endif
 
 namespace {
 
@@ -44,17 +43,36 @@ constexpr double kNM_TO_M = 1.0E-09;
 constexpr double kHC = kHPlanck * kCLight;
 constexpr double kPi = 3.14159265358979323846;
 
-// formal_solver.py:14-44, branch free: all three forms are evaluated and selected, so a
-// wavefront never diverges on the optical-depth regime.
+// wave-uniform data is read through the constant address space: the compiler then uses scalar
+// loads (s_load) and scalar address arithmetic even though the kernel also stores to global
+// memory (a plain global pointer would be treated as possibly clobbered -> vector loads).
+// Legal because nothing read this way is written while the kernel runs.
+#define LSX_CONST(T, ptr) ((const __attribute__((address_space(4))) T*)(ptr))
+
+// 1/x: v_rcp_f64 seed + two Newton steps (~1 ulp; 5 instructions instead of the ~12 of an
+// IEEE division).  The reference divides; the difference is at the last-bit level.
+__device__ __forceinline__ double rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// formal_solver.py:14-44.  The three regimes are selected per lane; the exponential is skipped
+// for the whole wavefront when no lane is in the middle regime (top / bottom of the atmosphere).
 __device__ __forceinline__ void w2(double dtau, double& w0, double& w1)
 {
-    const double e = exp(-dtau);
-    const double a0 = 1.0 - e;
-    const double a1 = a0 - dtau * e;
-    const double t0 = dtau * (1.0 - 0.5 * dtau);
-    const double t1 = (dtau * dtau) * (0.5 - dtau / 3.0);
     const bool small = dtau < 5e-4;
     const bool large = dtau > 50.0;
+    double a0 = 1.0, a1 = 1.0;
+    if (__builtin_amdgcn_ballot_w64(!(small || large)) != 0) {
+        const double e = exp(-dtau);
+        a0 = 1.0 - e;
+        a1 = a0 - dtau * e;
+    }
+    const double t0 = dtau * (1.0 - 0.5 * dtau);
+    const double t1 = (dtau * dtau) * (0.5 - dtau * (1.0 / 3.0));
     w0 = small ? t0 : (large ? 1.0 : a0);
     w1 = small ? t1 : (large ? 1.0 : a1);
 }
@@ -68,59 +86,101 @@ __device__ __forceinline__ double planck(double temp, double wav)
     return twohnu3_c2 / (exp(hc_Tkla) - 1.0);
 }
 
-// sum over the 32 lanes of each half-wave (xor 1..16 never crosses bit 5); all lanes get it
-__device__ __forceinline__ double half_sum(double v)
+#ifdef LSX_REDUCE_SHFL
+__device__ __forceinline__ double wave_sum(double v) // total in every lane
 {
 #pragma unroll
-    for (int m = 1; m < LSX_HALF; m <<= 1) v += __shfl_xor(v, m, LSX_WAVE);
+    for (int m = 1; m < LSX_WAVE; m <<= 1) v += __shfl_xor(v, m, LSX_WAVE);
     return v;
+}
+#else
+// DPP (VALU cross-lane moves, no LDS crossbar traffic).  The total of the 64 lanes ends up in
+// lane 63 (the lane that stores it).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+    v += dpp_f64<0xB1, 0xf>(v);  // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E, 0xf>(v);  // quad_perm [2,3,0,1]: every lane of a quad holds the quad sum
+    v += dpp_f64<0x141, 0xf>(v); // row_half_mirror: 8-lane sums
+    v += dpp_f64<0x140, 0xf>(v); // row_mirror: 16-lane (row) sums in every lane of the row
+    v += dpp_f64<0x142, 0xa>(v); // row_bcast15 into rows 1 and 3: lane 31 = rows 0+1, lane 63 = rows 2+3
+    v += dpp_f64<0x143, 0xc>(v); // row_bcast31 into rows 2 and 3: lane 63 = all four rows
+    return v;
+}
+#endif
+
+__device__ __forceinline__ double nanmax(double a, double b)
+{
+    // max that propagates NaN like numpy's ndarray.max (rh_method.py:706)
+    return (a != a || b != b) ? __builtin_nan("") : fmax(a, b);
 }
 
 __device__ __forceinline__ double wave_max_nan(double v)
 {
-    // max that propagates NaN like numpy's ndarray.max (rh_method.py:706)
 #pragma unroll
-    for (int m = 1; m < LSX_WAVE; m <<= 1) {
-        const double o = __shfl_xor(v, m, LSX_WAVE);
-        v = (v != v || o != o) ? __builtin_nan("") : fmax(v, o);
-    }
+    for (int m = 1; m < LSX_WAVE; m <<= 1) v = nanmax(v, __shfl_xor(v, m, LSX_WAVE));
     return v;
 }
 
-__device__ __forceinline__ void lds_add(double* p, double v)
+// lane-private LDS cell: first writer of a pass stores, later writers add (DS add, no return)
+__device__ __forceinline__ void cell_acc(double* p, double v, bool first)
 {
-    // lane-private location: a plain DS add (no return) is enough, nobody else touches it
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (first) *p = v;
+    else __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 } // namespace
 
-template <int UMAX, int M>
-__global__ void __launch_bounds__(LSX_WAVE) LSX_WAVES_PER_EU lsx_sweep_kernel(const SweepParams p)
+__global__ void __launch_bounds__(2 * LSX_WAVE) lsx_sweep_kernel(const SweepParams p)
 {
     extern __shared__ double lds[];
-    const int lane = threadIdx.x;
-    const int hl = lane & (LSX_HALF - 1);
-    const int dir = lane >> 5; // 0: down (toFrom False), 1: up (toFrom True)
-    const int col = blockIdx.x / p.n_class_tiles;
-    const int tile_id = p.class_tiles[blockIdx.x - col * p.n_class_tiles];
-    const DevTile tile = p.tiles[tile_id];
-    const int U = tile.nslot;
+    const int lane = threadIdx.x & (LSX_WAVE - 1);
+    const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0: down (toFrom False), 1: up (True)
+    const int ntile = p.ntile_total;
+    const int col = blockIdx.x / ntile;
+    const int tile_id = blockIdx.x - col * ntile;
+    const auto* tilep = LSX_CONST(DevTile, p.tiles) + tile_id;
+    const int la0 = tilep->la0, nla = tilep->nla, slot0 = tilep->slot0;
+    const int nP = tilep->nP, nF = tilep->nF;
+    const auto* slots = LSX_CONST(DevSlot, p.slots) + slot0;   // [0, nP): per-ray, [nP, nP+nF): fast
+    const auto* fslots = slots + nP;
     const int Ns = p.Nspace;
     const int Nspect = p.Nspect;
     const int Nrays = p.Nrays;
-    const bool valid = hl < tile.nla;
-    const int la = tile.la0 + (valid ? hl : 0);
+    const int L = p.L;
 
-    // lane-private LDS columns: lchi[level], lU[level], leta[atom]
-    double* const lchi = lds + lane;
-    double* const lU = lds + p.NLtot * LSX_WAVE + lane;
-    double* const leta = lds + 2 * p.NLtot * LSX_WAVE + lane;
+    // lane -> ray.  Lanes without a ray shadow a real one (finite arithmetic) and are masked out of
+    // every store and reduction.
+    const int mu_raw = lane / L;
+    const int j_raw = lane - mu_raw * L;
+    const bool valid = mu_raw < Nrays && j_raw < nla;
+    const int mu = mu_raw < Nrays ? mu_raw : Nrays - 1;
+    const int j = j_raw < nla ? j_raw : nla - 1;
+    const int la = la0 + j;
+    const bool lead = valid && mu_raw == 0; // one lane per wavelength: owns J[la, k]
 
-    // column bases (wave-uniform 64-bit), everything below is indexed with 32-bit offsets
-    const double* __restrict__ n_col = p.n + (size_t)col * p.NLtot * Ns;
-    const double* __restrict__ wphi_col = p.wphi + (size_t)col * p.Nlines * Ns;
-    const double* __restrict__ z = p.height + (size_t)col * Ns;
+    // LDS rows (64 doubles each), private to this wave except the two exchange rows at the end
+    const int rows = 2 * p.ncell_lev + p.ncell_atom + p.nstash + 1;
+    double* const wrow = lds + (size_t)dir * rows * LSX_WAVE + lane;
+#define CCHI(c) wrow[(2 * (c)) * LSX_WAVE]
+#define CU(c) wrow[(2 * (c) + 1) * LSX_WAVE]
+#define CETA(a) wrow[(2 * p.ncell_lev + (a)) * LSX_WAVE]
+#define STASH(u) wrow[(2 * p.ncell_lev + p.ncell_atom + (u)) * LSX_WAVE]
+    double* const xrow = lds + (size_t)dir * rows * LSX_WAVE + (size_t)(rows - 1) * LSX_WAVE; // angle sums
+    double* const xwg = lds + (size_t)2 * rows * LSX_WAVE;                                    // [2][64] cross-wave
+
+    // column bases; wave-uniform reads go through the scalar cache
+    const auto* n_col = LSX_CONST(double, p.n + (size_t)col * p.NLtot * Ns);
+    const auto* wphi_col = LSX_CONST(double, p.wphi + (size_t)col * p.Nlines * Ns);
+    const auto* z = LSX_CONST(double, p.height + (size_t)col * Ns);
+    const auto* tcol = LSX_CONST(double, p.temperature + (size_t)col * Ns);
     const double* __restrict__ bgchi = p.bgchi_T + (size_t)col * Ns * Nspect;
     const double* __restrict__ bgeta = p.bgeta_T + (size_t)col * Ns * Nspect;
     const double* __restrict__ Jdag = p.Jdag_T + (size_t)col * Ns * Nspect;
@@ -128,244 +188,248 @@ __global__ void __launch_bounds__(LSX_WAVE) LSX_WAVES_PER_EU lsx_sweep_kernel(co
     const double* __restrict__ sca = p.sca + (size_t)col * (p.sca_per_lambda ? (size_t)Ns * Nspect : (size_t)Ns);
     const double* __restrict__ phi_col = p.phi_T + (size_t)col * p.phi_col_stride;
     const double* __restrict__ gijc_col = p.gijc_T + (size_t)col * p.gijc_col_stride;
-    double* __restrict__ gpart = p.Gpart + ((size_t)col * p.nslot_total + tile.slot0) * 4 * Ns;
-    const int32_t* __restrict__ slots = p.tile_slots + tile.slot0;
-    const int32_t* __restrict__ tlev = p.tile_levels + tile.lev0;
+    double* __restrict__ gpart = p.Gpart + ((size_t)col * p.nslot_total + slot0) * 4 * Ns;
 
     const double wav = p.wavelength[la];
     const double u_la = p.u_la[la];
-    const bool compact = p.phi_mu_stride_is_zero != 0;
+    const double zmu_l = p.zmu[mu];
+    const double wmuh_l = valid ? p.wmuh[mu] : 0.0;
+    const double wq_l = wmuh_l * (4.0 * kPi);
+    const bool compact = p.phi_compact != 0;
+    const int kS = dir ? Ns - 1 : 0;
+    const int dk = dir ? -1 : 1;
+    // ray part of a line-profile index: ((k*2 + dir)*Nrays + mu) * Nlam + lt
+    const int raysel = compact ? 0 : dir * Nrays + mu;
+    const int kmul = compact ? 1 : 2 * Nrays;
 
-    // per-slot lane state: local wavelength index, -1 when the transition is not active here
-    int lt[UMAX];
-#pragma unroll
-    for (int u = 0; u < UMAX; ++u) {
-        lt[u] = -1;
-        if (u < U) {
-            const int t = slots[u];
-            const DevTrans& tr = p.trans[t];
-            const int l = la - tr.Nblue;
-            const bool a = valid && l >= 0 && l < tr.Nlam && p.active[t * Nspect + la] != 0;
-            lt[u] = a ? l : -1;
-        }
+    // activity bits of this lane's wavelength
+    unsigned pact = 0, fact = 0;
+    for (int u = 0; u < nP; ++u) {
+        const int l = la - slots[u].Nblue;
+        if (l >= 0 && l < slots[u].Nlam && p.active[slots[u].trans * Nspect + la] != 0) pact |= 1u << u;
+    }
+    for (int f = 0; f < nF; ++f) {
+        const int l = la - fslots[f].Nblue;
+        if (l >= 0 && l < fslots[f].Nlam && p.active[fslots[f].trans * Nspect + la] != 0) fact |= 1u << f;
     }
 
-    // element offset of phi(line, depth kk, this lane's direction, ray m, this lane's wavelength)
-    auto phi_at = [&](const DevTrans& tr, int kk, int m, int l) -> double {
-        const int idx = compact ? tr.phi_off * Ns + kk * tr.Nlam + l
-                                : tr.phi_off * 2 * Nrays * Ns + ((kk * 2 + dir) * Nrays + m) * tr.Nlam + l;
-        return phi_col[idx];
-    };
-
-    // total opacity at depth kk for every ray (needed one depth ahead for the lower boundary
-    // condition only, formal_solver.py:204-207)
-    auto chi_only = [&](int kk, double (&chi)[M]) {
-        const double bc = valid ? bgchi[kk * Nspect + la] : 1.0;
-#pragma unroll
-        for (int m = 0; m < M; ++m) chi[m] = 0.0;
-#pragma unroll
-        for (int u = 0; u < UMAX; ++u) {
-            if (u < U) {
-                const DevTrans& tr = p.trans[slots[u]];
-                const double ni = n_col[tr.li * Ns + kk];
-                const double nj = n_col[tr.lj * Ns + kk];
-                if (tr.is_line) {
-#pragma unroll
-                    for (int m = 0; m < M; ++m) {
-                        double phv = 0.0;
-                        if (lt[u] >= 0 && m < Nrays) phv = phi_at(tr, kk, m, lt[u]);
-                        const double Vij = tr.cB * phv;
-                        const double Vji = tr.gij * Vij;
-                        chi[m] += ni * Vij - nj * Vji;
-                    }
-                } else {
-                    double g = 0.0, al = 0.0;
-                    if (lt[u] >= 0) {
-                        g = gijc_col[tr.cont_off * Ns + kk * tr.Nlam + lt[u]];
-                        al = p.alpha[tr.wl_off + lt[u]];
-                    }
-                    const double c = ni * al - nj * (g * al);
-#pragma unroll
-                    for (int m = 0; m < M; ++m) chi[m] += c;
-                }
+    // total opacity at depth kk (boundary-condition look-ahead, formal_solver.py:204-207)
+    auto chi_at = [&](int kk) -> double {
+        double c = bgchi[kk * Nspect + la];
+        for (int u = 0; u < nP + nF; ++u) {
+            const double ni = n_col[slots[u].li * Ns + kk];
+            const double nj = n_col[slots[u].lj * Ns + kk];
+            const bool a = u < nP ? (pact >> u) & 1u : (fact >> (u - nP)) & 1u;
+            const int l = a ? la - slots[u].Nblue : 0;
+            const int Nlam = slots[u].Nlam;
+            if (slots[u].flags & SLOT_LINE) {
+                const double pv = a ? phi_col[slots[u].base + (kk * kmul + raysel) * Nlam + l] : 0.0;
+                c += (slots[u].cB * (ni - slots[u].g * nj)) * pv;
+            } else {
+                const double g = a ? gijc_col[slots[u].base + kk * Nlam + l] : 0.0;
+                const double alf = a ? p.alpha[slots[u].wl_off + l] : 0.0;
+                c += ni * alf - nj * (g * alf);
             }
         }
-#pragma unroll
-        for (int m = 0; m < M; ++m) chi[m] += bc;
+        return c;
     };
 
     // ---- boundary conditions: formal_solver.py:203-209 -------------------------------
-    double Iu[M];        // upwind intensity
-    {
-        const int kS = dir ? Ns - 1 : 0;
-        const int dk = dir ? -1 : 1;
-        double c0[M], c1[M];
-        chi_only(kS, c0);
-        chi_only(kS + dk, c1);
-        const double dz = fabs(z[kS] - z[kS + dk]);
-        const double B0 = planck(p.temperature[(size_t)col * Ns + Ns - 2], wav);
-        const double B1 = planck(p.temperature[(size_t)col * Ns + Ns - 1], wav);
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            const double dtau_uw = p.zmu[m] * (c0[m] + c1[m]) * 0.5 * dz;
-            Iu[m] = dir ? (B1 - (B0 - B1) / dtau_uw) : 0.0;
-        }
+    double Iu = 0.0;
+    if (dir) {
+        const double c0 = chi_at(kS), c1 = chi_at(kS + dk);
+        const double dtau_uw = zmu_l * (c0 + c1) * 0.5 * fabs(z[kS] - z[kS + dk]);
+        const double B0 = planck(tcol[Ns - 2], wav);
+        const double B1 = planck(tcol[Ns - 1], wav);
+        Iu = B1 - (B0 - B1) / dtau_uw;
     }
 
-    double chi_prev[M], S_prev[M], dtau_prev[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) { chi_prev[m] = 1.0; S_prev[m] = 0.0; dtau_prev[m] = 1.0; }
-
+    double chi_prev = 1.0, S_prev = 0.0, dtau_prev = 1.0;
     double dJ = 0.0;
+    double zprev = z[kS];
 
     for (int s = 0; s < Ns; ++s) {
-        const int k = dir ? Ns - 1 - s : s;
+        const int k = kS + dk * s;
         const int kl = k * Nspect + la;
-        const double bc = valid ? bgchi[kl] : 1.0;
-        const double be = valid ? bgeta[kl] : 0.0;
-        const double jd = valid ? Jdag[kl] : 0.0;
-        const double sc = sca[p.sca_per_lambda ? kl : k];
-        const double scaJ = valid ? sc * jd : 0.0;
-        const double dz = (s > 0) ? fabs(z[dir ? k + 1 : k - 1] - z[k]) : 0.0;
+        const double jd = Jdag[kl];
+        const double zk = z[k];
+        const double hdzm = (0.5 * fabs(zprev - zk)) * zmu_l;
+        zprev = zk;
+        double chiTot = bgchi[kl];
+        double etaTot = bgeta[kl] + (p.sca_per_lambda ? sca[kl] : LSX_CONST(double, sca)[k]) * jd;
 
-        // per-slot depth values shared by all rays of the lane
-        //   line:      a0 = n_i, a1 = n_j
-        //   continuum: a0 = Vij (= alpha), a1 = Vji, a2 = chi, a3 = eta   (ray independent)
-        double a0[UMAX], a1[UMAX], a2[UMAX], a3[UMAX];
-#pragma unroll
-        for (int u = 0; u < UMAX; ++u) {
-            a0[u] = a1[u] = a2[u] = a3[u] = 0.0;
-            if (u < U) {
-                const DevTrans& tr = p.trans[slots[u]];
-                const double ni = n_col[tr.li * Ns + k];
-                const double nj = n_col[tr.lj * Ns + k];
-                if (tr.is_line) {
-                    a0[u] = ni;
-                    a1[u] = nj;
-                } else if (lt[u] >= 0) {
-                    const double g = gijc_col[tr.cont_off * Ns + k * tr.Nlam + lt[u]];
-                    const double al = p.alpha[tr.wl_off + lt[u]];
-                    const double Vji = g * al;              // rh_method.py:284-285
-                    a0[u] = al;
-                    a1[u] = Vji;
-                    a2[u] = ni * al - nj * Vji;             // :613
-                    a3[u] = nj * (u_la * Vji);              // :614, :286
-                }
+        // ---- fast continua: opacity, emissivity, level cells (ray independent) ----------
+        for (int f = 0; f < nF; ++f) {
+            const int fl = fslots[f].flags;
+            const double ni = n_col[fslots[f].li * Ns + k];
+            const double nj = n_col[fslots[f].lj * Ns + k];
+            const bool a = (fact >> f) & 1u;
+            const int l = a ? la - fslots[f].Nblue : 0;
+            const double g = a ? gijc_col[fslots[f].base + k * fslots[f].Nlam + l] : 0.0;
+            const double alf = a ? p.alpha[fslots[f].wl_off + l] : 0.0;
+            const double Vji = g * alf;                 // rh_method.py:284-285
+            const double chi = ni * alf - nj * Vji;     // :613
+            const double Uji = u_la * Vji;              // :286
+            const double eta = nj * Uji;                // :614
+            if (fl & SLOT_LI_CELL) cell_acc(&CCHI(fslots[f].ci), chi, fl & SLOT_CHI_I_FIRST);   // :619
+            if (fl & SLOT_LJ_CELL) {
+                cell_acc(&CCHI(fslots[f].cj), -chi, fl & SLOT_CHI_J_FIRST);                     // :620
+                cell_acc(&CU(fslots[f].cj), Uji, fl & SLOT_U_J_FIRST);                          // :622
             }
+            if (fl & SLOT_ETA_CELL) cell_acc(&CETA(fslots[f].ca), eta, fl & SLOT_ETA_FIRST);    // :627
+            chiTot += chi;
+            etaTot += eta;
         }
 
-        double acc1[UMAX], acc2[UMAX];
-#pragma unroll
-        for (int u = 0; u < UMAX; ++u) acc1[u] = acc2[u] = 0.0;
-        double Jsum = 0.0;
-
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            // ---- pass 1: uv + opacity/emissivity (rh_method.py:601-627) ----
-            for (int q = 0; q < tile.nlev; ++q) {
-                const int l = tlev[q];
-                lchi[l * LSX_WAVE] = 0.0;
-                lU[l * LSX_WAVE] = 0.0;
-            }
-            for (int a = 0; a < p.Natoms; ++a) leta[a * LSX_WAVE] = 0.0;
-
-            double Vij[UMAX], Vji[UMAX];
-            double chiTot = 0.0, etaTot = 0.0;
-#pragma unroll
-            for (int u = 0; u < UMAX; ++u) {
-                Vij[u] = Vji[u] = 0.0;
-                if (u < U) {
-                    const DevTrans& tr = p.trans[slots[u]];
-                    double chi, eta, Uji;
-                    if (tr.is_line) {
-                        double phv = 0.0;
-                        if (lt[u] >= 0 && m < Nrays) phv = phi_at(tr, k, m, lt[u]);
-                        Vij[u] = tr.cB * phv;               // :279
-                        Vji[u] = tr.gij * Vij[u];           // :280
-                        Uji = tr.AB * Vji[u];               // :281
-                        chi = a0[u] * Vij[u] - a1[u] * Vji[u];
-                        eta = a1[u] * Uji;
-                    } else {
-                        Vij[u] = a0[u];
-                        Vji[u] = a1[u];
-                        Uji = u_la * Vji[u];
-                        chi = a2[u];
-                        eta = a3[u];
-                    }
-                    lds_add(&lchi[tr.li * LSX_WAVE], chi);   // :619
-                    lds_add(&lchi[tr.lj * LSX_WAVE], -chi);  // :620
-                    lds_add(&lU[tr.lj * LSX_WAVE], Uji);     // :622
-                    lds_add(&leta[tr.atom * LSX_WAVE], eta); // :627
-                    chiTot += chi;
-                    etaTot += eta;
-                }
-            }
-            chiTot += bc;                                   // :630
-            const double S = (etaTot + be + scaJ) / chiTot; // :632
-
-            // ---- formal solution at this depth (formal_solver.py:107-139) ----
-            double I, Lam;
-            if (s == 0) {
-                I = Iu[m];
-                Lam = 0.0;
+        // ---- pass 1: opacity / emissivity of the per-ray transitions (rh_method.py:601-627) ----
+        for (int u = 0; u < nP; ++u) {
+            const int fl = slots[u].flags;
+            const double ni = n_col[slots[u].li * Ns + k];
+            const double nj = n_col[slots[u].lj * Ns + k];
+            const bool a = (pact >> u) & 1u;
+            const int l = a ? la - slots[u].Nblue : 0;
+            const int Nlam = slots[u].Nlam;
+            double pv, chi, eta, Uji;
+            if (fl & SLOT_LINE) {
+                pv = a ? phi_col[slots[u].base + (k * kmul + raysel) * Nlam + l] : 0.0;
+                chi = (slots[u].cB * (ni - slots[u].g * nj)) * pv;   // n_i Vij - n_j Vji, :279-280, :613
+                Uji = slots[u].Uc * pv;                              // :281
+                eta = nj * Uji;                                      // :614
             } else {
-                const double dtau = 0.5 * (chi_prev[m] + chiTot) * p.zmu[m] * dz;
-                const double dS = (S_prev[m] - S) / dtau;
-                // formal_solver.py:138-139: the end point re-uses the PREVIOUS interval's w and
-                // S[kEnd - dk] with the fresh dS, dtau (reference behaviour, reproduced deliberately)
-                const bool last = (s == Ns - 1);
-                double w0, w1;
-                w2(last ? dtau_prev[m] : dtau, w0, w1);
-                I = Iu[m] * (1.0 - w0) + w0 * (last ? S_prev[m] : S) + w1 * dS;
-                Lam = w0 - w1 / dtau;
-                dtau_prev[m] = dtau;
+                const double g = a ? gijc_col[slots[u].base + k * Nlam + l] : 0.0;
+                const double alf = a ? p.alpha[slots[u].wl_off + l] : 0.0;
+                pv = g * alf;                                        // Vji
+                chi = ni * alf - nj * pv;
+                Uji = u_la * pv;
+                eta = nj * Uji;
             }
-            const double Psi = Lam / chiTot;
-            Iu[m] = I;
-            chi_prev[m] = chiTot;
-            S_prev[m] = S;
-            Jsum += p.wmuh[m] * I;                          // :640
-            if (s == Ns - 1 && dir == 1 && valid && m < Nrays)  // emergent intensity, :638
-                p.Iout[((size_t)col * Nspect + la) * Nrays + m] = I;
+            STASH(u) = pv;
+            if (fl & SLOT_LI_CELL) cell_acc(&CCHI(slots[u].ci), chi, fl & SLOT_CHI_I_FIRST);
+            if (fl & SLOT_LJ_CELL) {
+                cell_acc(&CCHI(slots[u].cj), -chi, fl & SLOT_CHI_J_FIRST);
+                cell_acc(&CU(slots[u].cj), Uji, fl & SLOT_U_J_FIRST);
+            }
+            if (fl & SLOT_ETA_CELL) cell_acc(&CETA(slots[u].ca), eta, fl & SLOT_ETA_FIRST);
+            chiTot += chi;
+            etaTot += eta;
+        }
+        const double rchi = rcp(chiTot);
+        const double S = etaTot * rchi;                 // :632
 
-            // ---- pass 2: Gamma integrands (rh_method.py:643-681) ----
-            const double wq = p.wmuh[m] * 4.0 * kPi;
-#pragma unroll
-            for (int u = 0; u < UMAX; ++u) {
-                if (u < U) {
-                    const DevTrans& tr = p.trans[slots[u]];
-                    const double Ieff = I - Psi * leta[tr.atom * LSX_WAVE];
-                    const double chi_i = lchi[tr.li * LSX_WAVE];
-                    const double chi_j = lchi[tr.lj * LSX_WAVE];
-                    const double U_i = lU[tr.li * LSX_WAVE];
-                    const double U_j = lU[tr.lj * LSX_WAVE];
-                    const double Uji = (tr.is_line ? tr.AB : u_la) * Vji[u];
-                    const double g1 = (Uji + Vji[u] * Ieff) - (chi_i * Psi * U_j);
-                    const double g2 = (Vij[u] * Ieff) - (chi_j * Psi * U_i);
-                    acc1[u] += wq * g1;
-                    acc2[u] += wq * g2;
-                }
+        // ---- formal solution at this depth (formal_solver.py:107-139) ----
+        double I, Lam;
+        if (s == 0) {
+            I = Iu;
+            Lam = 0.0;
+        } else {
+            const double dtau = (chi_prev + chiTot) * hdzm;
+            const double rdt = rcp(dtau);
+            const double dS = (S_prev - S) * rdt;
+            // formal_solver.py:138-139: the end point re-uses the PREVIOUS interval's w and
+            // S[kEnd - dk] with the fresh dS, dtau (reference behaviour, reproduced deliberately)
+            const bool last = (s == Ns - 1);
+            double w0, w1;
+            w2(last ? dtau_prev : dtau, w0, w1);
+            const double Sx = last ? S_prev : S;
+            I = Iu * (1.0 - w0) + w0 * Sx + w1 * dS;
+            Lam = w0 - w1 * rdt;
+            dtau_prev = dtau;
+        }
+        const double Psi = Lam * rchi;
+        Iu = I;
+        chi_prev = chiTot;
+        S_prev = S;
+        if (s == Ns - 1 && dir == 1 && valid)            // emergent intensity, :638
+            p.Iout[((size_t)col * Nspect + la) * Nrays + mu] = I;
+
+        // ---- angle quadrature of this wavelength: J (:640) and the two ray sums of the fast path ----
+        xrow[lane] = wmuh_l * I;
+        __builtin_amdgcn_wave_barrier();
+        double Jsum = 0.0;
+        for (int m = 0; m < Nrays; ++m) Jsum += xrow[m * L + j];
+        double sPsi = 0.0;
+        if (nF > 0) {
+            __builtin_amdgcn_wave_barrier();
+            xrow[lane] = wq_l * Psi;
+            __builtin_amdgcn_wave_barrier();
+            for (int m = 0; m < Nrays; ++m) sPsi += xrow[m * L + j];
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- pass 2: Gamma integrands of the per-ray transitions (rh_method.py:643-681) ----
+        for (int u = 0; u < nP; ++u) {
+            const int fl = slots[u].flags;
+            const double ni = n_col[slots[u].li * Ns + k];
+            const double nj = n_col[slots[u].lj * Ns + k];
+            const bool a = (pact >> u) & 1u;
+            const int l = a ? la - slots[u].Nblue : 0;
+            const double pv = STASH(u);
+            double Vij, Vji, Uji, chi, wla;
+            wla = a ? p.wl[slots[u].wl_off + l] : 0.0;               // :451, :455
+            if (fl & SLOT_LINE) {
+                Vij = slots[u].cB * pv;
+                Vji = slots[u].Vc * pv;
+                Uji = slots[u].Uc * pv;
+                chi = (slots[u].cB * (ni - slots[u].g * nj)) * pv;
+                wla *= wphi_col[slots[u].wphi_off + k];
+            } else {
+                Vij = a ? p.alpha[slots[u].wl_off + l] : 0.0;
+                Vji = pv;
+                Uji = u_la * pv;
+                chi = ni * Vij - nj * pv;
+            }
+            const double eta = nj * Uji;
+            const double etaA = (fl & SLOT_ETA_CELL) ? CETA(slots[u].ca) : eta;
+            const double chi_i = (fl & SLOT_LI_CELL) ? CCHI(slots[u].ci) : chi;
+            const double chi_j = (fl & SLOT_LJ_CELL) ? CCHI(slots[u].cj) : -chi;
+            const double U_j = (fl & SLOT_LJ_CELL) ? CU(slots[u].cj) : Uji;
+            const double U_i = (fl & SLOT_UI_READ) ? CU(slots[u].ci) : 0.0;
+            const double Ieff = I - Psi * etaA;                            // :652
+            const double g1 = (Uji + Vji * Ieff) - (chi_i * Psi) * U_j;    // :677
+            const double g2 = (Vij * Ieff) - (chi_j * Psi) * U_i;          // :680
+            const double wt = (a && valid) ? wq_l * wla : 0.0;             // :665
+            const double r1 = wave_sum(wt * g1);
+            const double r2 = wave_sum(wt * g2);
+            if (lane == LSX_WAVE - 1) {
+                double* g = gpart + (u * 4 + dir) * Ns + k; // [slot][e][dir][k]
+                g[0] = r1;          // e = 0: Gamma[i][j]
+                g[2 * Ns] = r2;     // e = 1: Gamma[j][i]
             }
         }
 
-        // ---- wavelength quadrature: one half-wave reduction per (slot, entry) ----
-#pragma unroll
-        for (int u = 0; u < UMAX; ++u) {
-            if (u < U) {
-                const DevTrans& tr = p.trans[slots[u]];
-                double wla = 0.0;
-                if (lt[u] >= 0) {
-                    const double wl = p.wl[tr.wl_off + lt[u]];
-                    wla = tr.is_line ? wl * wphi_col[tr.line_idx * Ns + k] / kHC : wl; // :451,455
-                }
-                const double v1 = (lt[u] >= 0) ? acc1[u] * wla : 0.0;
-                const double v2 = (lt[u] >= 0) ? acc2[u] * wla : 0.0;
-                const double r1 = half_sum(v1);
-                const double r2 = half_sum(v2);
-                if (hl == LSX_HALF - 1) {
-                    double* g = gpart + (u * 4 + dir) * Ns + k; // [slot][e][dir][k]
-                    g[0] = r1;          // e = 0: Gamma[i][j]
-                    g[2 * Ns] = r2;     // e = 1: Gamma[j][i]
+        // ---- fast continua: Gamma integrand from the ray sums (one lane per wavelength) ----
+        if (nF > 0) {
+            const double sI = Jsum * (4.0 * kPi);       // sum_mu (w_mu/2 4pi) I
+            double sW = 0.0;
+            for (int m = 0; m < Nrays; ++m) sW += LSX_CONST(double, p.wmuh)[m] * (4.0 * kPi);
+            for (int f = 0; f < nF; ++f) {
+                const int fl = fslots[f].flags;
+                const double ni = n_col[fslots[f].li * Ns + k];
+                const double nj = n_col[fslots[f].lj * Ns + k];
+                const bool a = (fact >> f) & 1u;
+                const int l = a ? la - fslots[f].Nblue : 0;
+                const double g = a ? gijc_col[fslots[f].base + k * fslots[f].Nlam + l] : 0.0;
+                const double alf = a ? p.alpha[fslots[f].wl_off + l] : 0.0;
+                const double wla = a ? p.wl[fslots[f].wl_off + l] : 0.0;
+                const double Vji = g * alf;
+                const double Uji = u_la * Vji;
+                const double chi = ni * alf - nj * Vji;
+                const double eta = nj * Uji;
+                const double etaA = (fl & SLOT_ETA_CELL) ? CETA(fslots[f].ca) : eta;
+                const double chi_i = (fl & SLOT_LI_CELL) ? CCHI(fslots[f].ci) : chi;
+                const double chi_j = (fl & SLOT_LJ_CELL) ? CCHI(fslots[f].cj) : -chi;
+                const double U_j = (fl & SLOT_LJ_CELL) ? CU(fslots[f].cj) : Uji;
+                const double U_i = (fl & SLOT_UI_READ) ? CU(fslots[f].ci) : 0.0;
+                const double sIe = sI - etaA * sPsi;                       // sum_mu w (I - Psi eta)
+                const double g1 = (Uji * sW + Vji * sIe) - (chi_i * U_j) * sPsi;
+                const double g2 = (alf * sIe) - (chi_j * U_i) * sPsi;
+                const double wt = (a && lead) ? wla : 0.0;
+                const double r1 = wave_sum(wt * g1);
+                const double r2 = wave_sum(wt * g2);
+                if (lane == LSX_WAVE - 1) {
+                    double* gp = gpart + ((nP + f) * 4 + dir) * Ns + k;
+                    gp[0] = r1;
+                    gp[2 * Ns] = r2;
                 }
             }
         }
@@ -373,52 +437,35 @@ __global__ void __launch_bounds__(LSX_WAVE) LSX_WAVES_PER_EU lsx_sweep_kernel(co
         // ---- J: the two directions meet at depth k at different steps ----
         const int s2 = 2 * s, nm1 = Ns - 1;
         if (s2 < nm1) {
-            if (valid) Jnew[kl] = Jsum;                       // first visitor stores its half
-        } else {
-            double Jv;
-            if (s2 == nm1) {                                  // odd Nspace: both halves are at the same k
-                Jv = Jsum + __shfl_xor(Jsum, LSX_HALF, LSX_WAVE);
-            } else {
-                if (s2 == nm1 + 1 || s2 == nm1 + 2)
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); // partner half's stores
-                Jv = (valid ? Jnew[kl] : 1.0) + Jsum;
-            }
-            if (valid && (s2 > nm1 || dir == 0)) {
+            if (lead) Jnew[kl] = Jsum;                        // first visitor stores its half
+        } else if (s2 == nm1) {                               // odd Nspace: both waves are at the same k
+            if (lead) xwg[dir * LSX_WAVE + j] = Jsum;
+            __syncthreads();
+            if (lead && dir == 0) {
+                const double Jv = Jsum + xwg[LSX_WAVE + j];
                 Jnew[kl] = Jv;
-                const double d = fabs(1.0 - jd / Jv);         // :705
-                dJ = (d != d || dJ != dJ) ? __builtin_nan("") : fmax(dJ, d);
+                dJ = nanmax(dJ, fabs(1.0 - jd / Jv));         // :705
+            }
+        } else {
+            if (s2 == nm1 + 1 || s2 == nm1 + 2) __syncthreads(); // the partner wave's first-half stores
+            if (lead) {
+                const double Jv = Jnew[kl] + Jsum;
+                Jnew[kl] = Jv;
+                dJ = nanmax(dJ, fabs(1.0 - jd / Jv));         // :705
             }
         }
     }
 
-    const double dJw = wave_max_nan(dJ);
-    if (lane == 0) p.dJpart[(size_t)col * p.ntile_total + tile_id] = dJw;
+    const double dJw = wave_max_nan(lead ? dJ : 0.0);
+    if (lane == 0) p.dJpart[((size_t)col * ntile + tile_id) * 2 + dir] = dJw;
+#undef CCHI
+#undef CU
+#undef CETA
+#undef STASH
 }
 
-// ---------------------------------------------------------------------------------------
-// explicit instantiations + C launchers (one translation unit per M keeps builds parallel)
-#ifndef LSX_M
-#error "compile with -DLSX_M=<rays per lane>"
-#endif
-
-template <int UMAX>
-static hipError_t launch_u(const SweepParams& p, int nblocks, size_t lds_bytes, hipStream_t st)
+extern "C" hipError_t lsx_launch_sweep(const SweepParams* p, int nblocks, size_t lds_bytes, hipStream_t st)
 {
-    hipLaunchKernelGGL((lsx_sweep_kernel<UMAX, LSX_M>), dim3(nblocks), dim3(LSX_WAVE), lds_bytes, st, p);
+    hipLaunchKernelGGL(lsx_sweep_kernel, dim3(nblocks), dim3(2 * LSX_WAVE), lds_bytes, st, *p);
     return hipGetLastError();
-}
-
-#define LSX_CAT2(a, b) a##b
-#define LSX_CAT(a, b) LSX_CAT2(a, b)
-
-extern "C" hipError_t LSX_CAT(lsx_launch_sweep_m, LSX_M)(const SweepParams* p, int umax, int nblocks,
-                                                          size_t lds_bytes, hipStream_t st)
-{
-    switch (umax) {
-    case 2: return launch_u<2>(*p, nblocks, lds_bytes, st);
-    case 4: return launch_u<4>(*p, nblocks, lds_bytes, st);
-    case 8: return launch_u<8>(*p, nblocks, lds_bytes, st);
-    case 12: return launch_u<12>(*p, nblocks, lds_bytes, st);
-    default: return hipErrorInvalidValue;
-    }
 }
