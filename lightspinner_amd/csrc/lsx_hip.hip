@@ -600,7 +600,10 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
             DevSlot sl{};
             sl.flags = first_flags[t];
             sl.li = h.li; sl.lj = h.lj;
-            sl.ci = local(lev_ids, h.li); sl.cj = local(lev_ids, h.lj); sl.ca = local(atom_ids, h.atom);
+            // cells exist only for levels / atoms that two transitions of the tile share
+            sl.ci = (sl.flags & (SLOT_LI_CELL | SLOT_UI_READ)) ? local(lev_ids, h.li) : 0;
+            sl.cj = (sl.flags & SLOT_LJ_CELL) ? local(lev_ids, h.lj) : 0;
+            sl.ca = (sl.flags & SLOT_ETA_CELL) ? local(atom_ids, h.atom) : 0;
             sl.Nblue = h.Nblue; sl.Nlam = h.Nlam; sl.wl_off = h.wl_off; sl.trans = t;
             if (h.is_line) {
                 sl.base = h.phi_off * P_line * Ns;

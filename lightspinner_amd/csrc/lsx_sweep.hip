@@ -144,8 +144,18 @@ __global__ void __launch_bounds__(2 * LSX_WAVE) lsx_sweep_kernel(const SweepPara
     const int lane = threadIdx.x & (LSX_WAVE - 1);
     const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0: down (toFrom False), 1: up (True)
     const int ntile = p.ntile_total;
-    const int col = blockIdx.x / ntile;
-    const int tile_id = blockIdx.x - col * ntile;
+    // XCD-aware block -> (column, tile): workgroups are dealt round-robin over the 8 XCDs (b and
+    // b+8 share one), so give every XCD a contiguous range of (column, tile) pairs: neighbouring
+    // tiles of a column share 128-B lines of the depth-major arrays and should meet in ONE L2.
+    // A different placement would change speed only, never results.
+    int vb;
+    {
+        const int nb = gridDim.x, x = blockIdx.x & 7, q = blockIdx.x >> 3;
+        const int nb8 = nb >> 3, rem = nb & 7;
+        vb = x * nb8 + (x < rem ? x : rem) + q;
+    }
+    const int col = vb / ntile;
+    const int tile_id = vb - col * ntile;
     const auto* tilep = LSX_CONST(DevTile, p.tiles) + tile_id;
     const int la0 = tilep->la0, nla = tilep->nla, slot0 = tilep->slot0;
     const int nP = tilep->nP, nF = tilep->nF;
