@@ -119,4 +119,5 @@ struct SweepParams {
     double* Iout;
     double* Gpart;
     double* dJpart;
+    double* debug;              // diagnostic builds only
 };

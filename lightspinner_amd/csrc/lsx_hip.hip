@@ -356,6 +356,7 @@ struct lsx_ctx {
            *d_sca = nullptr, *d_phi = nullptr, *d_gijc = nullptr, *d_J[2] = {nullptr, nullptr}, *d_I = nullptr,
            *d_Gpart = nullptr, *d_dJpart = nullptr, *d_dJcol = nullptr, *d_dPcol = nullptr, *d_max = nullptr;
     int* d_singular = nullptr;
+    double* d_debug = nullptr;   // 64 x 16 x 8 B, diagnostic builds of the sweep kernel write stamps here
     int jcur = 0; // d_J[jcur] holds the current J (Jdag of the next call)
     size_t phi_col = 0, gijc_col = 0, sca_col = 0;
     // staging
@@ -437,7 +438,7 @@ void lsx_destroy(lsx_ctx* c)
                     c->d_tiles, c->d_slots, c->d_tile_slots, c->d_Nlevel, c->d_lev2_off, c->d_height,
                     c->d_temperature, c->d_nStar, c->d_nTotal, c->d_n, c->d_C, c->d_Gamma, c->d_wphi, c->d_bgchi,
                     c->d_bgeta, c->d_sca, c->d_phi, c->d_gijc, c->d_J[0], c->d_J[1], c->d_I, c->d_Gpart, c->d_dJpart,
-                    c->d_dJcol, c->d_dPcol, c->d_max, c->d_singular, c->d_stage};
+                    c->d_dJcol, c->d_dPcol, c->d_max, c->d_singular, c->d_stage, c->d_debug};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : {c->ev0, c->ev1, c->ev2})
@@ -624,7 +625,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     c->ncell_atom = std::max(c->ncell_atom, 1);
     c->nstash = std::max(c->nstash, 1);
     // per wave: level cells, atom cells, stash, angle-sum row; + two cross-wave exchange rows
-    c->lds_bytes = (size_t)(2 * (2 * c->ncell_lev + c->ncell_atom + c->nstash + 1) + 2) * LSX_WAVE * sizeof(double);
+    c->lds_bytes = (size_t)(2 * (2 * c->ncell_lev + c->ncell_atom + 1) + 2) * LSX_WAVE * sizeof(double);
     if (c->lds_bytes > 64 * 1024) { lsx_destroy(c); return fail(LSX_EUNSUPPORTED, "lsx_create: tile needs %zu B of LDS", c->lds_bytes); }
 
     // ---- uploads of the column independent tables
@@ -676,6 +677,8 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     TRY(dmalloc(&c->d_dPcol, nc));
     TRY(dmalloc(&c->d_max, 4));
     TRY(dmalloc(&c->d_singular, 1));
+    TRY(dmalloc(&c->d_debug, 64 * 16));
+    (void)hipMemsetAsync(c->d_debug, 0, 64 * 16 * 8, c->stream);
 #undef TRY
     if (hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), 4 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
         lsx_destroy(c);
@@ -786,7 +789,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
     p.height = c->d_height; p.temperature = c->d_temperature; p.n = c->d_n; p.wphi = c->d_wphi;
     p.bgchi_T = c->d_bgchi; p.bgeta_T = c->d_bgeta; p.sca = c->d_sca; p.phi_T = c->d_phi; p.gijc_T = c->d_gijc;
     p.Jdag_T = c->d_J[c->jcur]; p.Jnew_T = c->d_J[c->jcur ^ 1];
-    p.Iout = c->d_I; p.Gpart = c->d_Gpart; p.dJpart = c->d_dJpart;
+    p.Iout = c->d_I; p.Gpart = c->d_Gpart; p.dJpart = c->d_dJpart; p.debug = c->d_debug;
 
     const long nblocks = (long)c->tiles.size() * c->ncol;
     if (nblocks > 0x7fffffffL) return fail(LSX_EUNSUPPORTED, "grid too large");
@@ -1026,6 +1029,16 @@ double lsx_hip_info(const lsx_ctx* c, int32_t what)
     case 5: return 8.0 * c->Nspace * 4.0 * (double)c->tile_slots.size();
     default: return 0.0;
     }
+}
+
+// diagnostic: copy the sweep kernel's stamp buffer (64 records x 16 x u64) to host
+int lsx_hip_debug_read(lsx_ctx* c, unsigned long long* out)
+{
+    if (!c || !out) return fail(LSX_EINVAL, "null");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->d_debug, 64 * 16 * 8, hipMemcpyDeviceToHost));
+    return LSX_OK;
 }
 
 // B_alg = 8 Ns [P SNl + 2 Nspect (bg) + 2 Nspect (Jdag, J) + 1 (sigma) + NLtot (n)

@@ -138,27 +138,42 @@ __device__ __forceinline__ void cell_acc(double* p, double v, bool first)
 
 } // namespace
 
-__global__ void __launch_bounds__(2 * LSX_WAVE) lsx_sweep_kernel(const SweepParams p)
+#ifndef LSX_WAVES_PER_EU
+#define LSX_WAVES_PER_EU 5
+#endif
+// wave-uniform copy of a slot's parameters (one batch of scalar loads, then registers)
+struct SlotS {
+    int flags, noff_i, noff_j, ci, cj, ca, Nblue, Nlam, base, wl_off, wphi_off, trans;
+    double cB, g, Vc, Uc;
+};
+__device__ __forceinline__ SlotS load_slot(const __attribute__((address_space(4))) DevSlot* q, int Ns)
+{
+    SlotS r;
+    r.flags = q->flags; r.noff_i = q->li * Ns; r.noff_j = q->lj * Ns;
+    r.ci = q->ci; r.cj = q->cj; r.ca = q->ca; r.Nblue = q->Nblue; r.Nlam = q->Nlam; r.base = q->base;
+    r.wl_off = q->wl_off; r.wphi_off = q->wphi_off; r.trans = q->trans;
+    r.cB = q->cB; r.g = q->g; r.Vc = q->Vc; r.Uc = q->Uc;
+    return r;
+}
+
+// NPT >= 0: the tile's per-ray slot count as a compile-time constant: slot state lives in registers,
+// every load of a depth step is issued in one batch at the top of the step (one wait), the two
+// passes are pure VALU + LDS.  NPT < 0: generic tile (runtime slot loops, loads in place).
+template <int NPT>
+__device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb)
 {
     extern __shared__ double lds[];
+    constexpr bool STATIC = NPT >= 0;
+    constexpr int NS = NPT > 0 ? NPT : 1;
     const int lane = threadIdx.x & (LSX_WAVE - 1);
     const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0: down (toFrom False), 1: up (True)
     const int ntile = p.ntile_total;
-    // XCD-aware block -> (column, tile): workgroups are dealt round-robin over the 8 XCDs (b and
-    // b+8 share one), so give every XCD a contiguous range of (column, tile) pairs: neighbouring
-    // tiles of a column share 128-B lines of the depth-major arrays and should meet in ONE L2.
-    // A different placement would change speed only, never results.
-    int vb;
-    {
-        const int nb = gridDim.x, x = blockIdx.x & 7, q = blockIdx.x >> 3;
-        const int nb8 = nb >> 3, rem = nb & 7;
-        vb = x * nb8 + (x < rem ? x : rem) + q;
-    }
     const int col = vb / ntile;
     const int tile_id = vb - col * ntile;
     const auto* tilep = LSX_CONST(DevTile, p.tiles) + tile_id;
     const int la0 = tilep->la0, nla = tilep->nla, slot0 = tilep->slot0;
-    const int nP = tilep->nP, nF = tilep->nF;
+    const int nP = STATIC ? NPT : tilep->nP;
+    const int nF = tilep->nF;
     const auto* slots = LSX_CONST(DevSlot, p.slots) + slot0;   // [0, nP): per-ray, [nP, nP+nF): fast
     const auto* fslots = slots + nP;
     const int Ns = p.Nspace;
@@ -177,12 +192,11 @@ __global__ void __launch_bounds__(2 * LSX_WAVE) lsx_sweep_kernel(const SweepPara
     const bool lead = valid && mu_raw == 0; // one lane per wavelength: owns J[la, k]
 
     // LDS rows (64 doubles each), private to this wave except the two exchange rows at the end
-    const int rows = 2 * p.ncell_lev + p.ncell_atom + p.nstash + 1;
+    const int rows = 2 * p.ncell_lev + p.ncell_atom + 1;
     double* const wrow = lds + (size_t)dir * rows * LSX_WAVE + lane;
 #define CCHI(c) wrow[(2 * (c)) * LSX_WAVE]
 #define CU(c) wrow[(2 * (c) + 1) * LSX_WAVE]
 #define CETA(a) wrow[(2 * p.ncell_lev + (a)) * LSX_WAVE]
-#define STASH(u) wrow[(2 * p.ncell_lev + p.ncell_atom + (u)) * LSX_WAVE]
     double* const xrow = lds + (size_t)dir * rows * LSX_WAVE + (size_t)(rows - 1) * LSX_WAVE; // angle sums
     double* const xwg = lds + (size_t)2 * rows * LSX_WAVE;                                    // [2][64] cross-wave
 
@@ -223,21 +237,40 @@ __global__ void __launch_bounds__(2 * LSX_WAVE) lsx_sweep_kernel(const SweepPara
         if (l >= 0 && l < fslots[f].Nlam && p.active[fslots[f].trans * Nspect + la] != 0) fact |= 1u << f;
     }
 
+    // static path: per-slot lane state in registers
+    //   idx0: element index of (depth 0, this ray, this wavelength) in phi_T (line) / gijc_T (continuum)
+    //   wl: wavelength quadrature weight, al: alpha (continua)
+    int idx0[NS], kstr[NS];
+    double wlv[NS], alv[NS];
+    if constexpr (STATIC) {
+#pragma unroll
+        for (int u = 0; u < NPT; ++u) {
+            const bool a = (pact >> u) & 1u;
+            const int l = a ? la - slots[u].Nblue : 0;
+            const int Nlam = slots[u].Nlam;
+            const bool line = (slots[u].flags & SLOT_LINE) != 0;
+            idx0[u] = slots[u].base + (line ? raysel * Nlam : 0) + l;
+            kstr[u] = line ? kmul * Nlam : Nlam;
+            wlv[u] = a ? p.wl[slots[u].wl_off + l] : 0.0;
+            alv[u] = (a && !line) ? p.alpha[slots[u].wl_off + l] : 0.0;
+        }
+    }
+
     // total opacity at depth kk (boundary-condition look-ahead, formal_solver.py:204-207)
     auto chi_at = [&](int kk) -> double {
         double c = bgchi[kk * Nspect + la];
         for (int u = 0; u < nP + nF; ++u) {
-            const double ni = n_col[slots[u].li * Ns + kk];
-            const double nj = n_col[slots[u].lj * Ns + kk];
+            const SlotS sl = load_slot(slots + u, Ns);
+            const double ni = n_col[sl.noff_i + kk];
+            const double nj = n_col[sl.noff_j + kk];
             const bool a = u < nP ? (pact >> u) & 1u : (fact >> (u - nP)) & 1u;
-            const int l = a ? la - slots[u].Nblue : 0;
-            const int Nlam = slots[u].Nlam;
-            if (slots[u].flags & SLOT_LINE) {
-                const double pv = a ? phi_col[slots[u].base + (kk * kmul + raysel) * Nlam + l] : 0.0;
-                c += (slots[u].cB * (ni - slots[u].g * nj)) * pv;
+            const int l = a ? la - sl.Nblue : 0;
+            if (sl.flags & SLOT_LINE) {
+                const double pv = a ? phi_col[sl.base + (kk * kmul + raysel) * sl.Nlam + l] : 0.0;
+                c += (sl.cB * (ni - sl.g * nj)) * pv;
             } else {
-                const double g = a ? gijc_col[slots[u].base + kk * Nlam + l] : 0.0;
-                const double alf = a ? p.alpha[slots[u].wl_off + l] : 0.0;
+                const double g = a ? gijc_col[sl.base + kk * sl.Nlam + l] : 0.0;
+                const double alf = a ? p.alpha[sl.wl_off + l] : 0.0;
                 c += ni * alf - nj * (g * alf);
             }
         }
@@ -257,72 +290,126 @@ __global__ void __launch_bounds__(2 * LSX_WAVE) lsx_sweep_kernel(const SweepPara
     double chi_prev = 1.0, S_prev = 0.0, dtau_prev = 1.0;
     double dJ = 0.0;
     double zprev = z[kS];
+    double sW = 0.0;
+    for (int m = 0; m < Nrays; ++m) sW += LSX_CONST(double, p.wmuh)[m] * (4.0 * kPi);
+    // diagnostic build only (-DLSX_STAMPS): per-segment shader-clock totals of a few sample waves go
+    // to p.debug, a buffer nothing else reads (cdna_hip_programming.md, In-kernel stamps)
+#ifdef LSX_STAMPS
+    unsigned long long T[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0, t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+#define STAMP(i)                                                                                          \
+    do {                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        T[i] += t1 - t0;                                                                                  \
+        t0 = t1;                                                                                          \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
 
     for (int s = 0; s < Ns; ++s) {
         const int k = kS + dk * s;
         const int kl = k * Nspect + la;
+        // ---- every HBM / table read of the per-ray slots for this depth, in one batch ----
         const double jd = Jdag[kl];
+        double chiTot = bgchi[kl];
+        const double be_l = bgeta[kl];
+        double sv[NS], sni[NS], snj[NS], swp[NS];
+        if constexpr (STATIC) {
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                const bool a = (pact >> u) & 1u;
+                const bool line = (slots[u].flags & SLOT_LINE) != 0;
+                const double* tab = line ? phi_col : gijc_col;
+                sv[u] = a ? tab[idx0[u] + k * kstr[u]] : 0.0;
+                sni[u] = n_col[slots[u].li * Ns + k];
+                snj[u] = n_col[slots[u].lj * Ns + k];
+                swp[u] = line ? wphi_col[slots[u].wphi_off + k] : 1.0;
+            }
+        }
         const double zk = z[k];
         const double hdzm = (0.5 * fabs(zprev - zk)) * zmu_l;
         zprev = zk;
-        double chiTot = bgchi[kl];
-        double etaTot = bgeta[kl] + (p.sca_per_lambda ? sca[kl] : LSX_CONST(double, sca)[k]) * jd;
+        double etaTot = be_l + (p.sca_per_lambda ? sca[kl] : LSX_CONST(double, sca)[k]) * jd;
+        STAMP(0);
 
         // ---- fast continua: opacity, emissivity, level cells (ray independent) ----------
         for (int f = 0; f < nF; ++f) {
-            const int fl = fslots[f].flags;
-            const double ni = n_col[fslots[f].li * Ns + k];
-            const double nj = n_col[fslots[f].lj * Ns + k];
+            const SlotS sl = load_slot(fslots + f, Ns);
+            const int fl = sl.flags;
+            const double ni = n_col[sl.noff_i + k];
+            const double nj = n_col[sl.noff_j + k];
             const bool a = (fact >> f) & 1u;
-            const int l = a ? la - fslots[f].Nblue : 0;
-            const double g = a ? gijc_col[fslots[f].base + k * fslots[f].Nlam + l] : 0.0;
-            const double alf = a ? p.alpha[fslots[f].wl_off + l] : 0.0;
+            const int l = a ? la - sl.Nblue : 0;
+            const double g = a ? gijc_col[sl.base + k * sl.Nlam + l] : 0.0;
+            const double alf = a ? p.alpha[sl.wl_off + l] : 0.0;
             const double Vji = g * alf;                 // rh_method.py:284-285
             const double chi = ni * alf - nj * Vji;     // :613
             const double Uji = u_la * Vji;              // :286
             const double eta = nj * Uji;                // :614
-            if (fl & SLOT_LI_CELL) cell_acc(&CCHI(fslots[f].ci), chi, fl & SLOT_CHI_I_FIRST);   // :619
+            if (fl & SLOT_LI_CELL) cell_acc(&CCHI(sl.ci), chi, fl & SLOT_CHI_I_FIRST);   // :619
             if (fl & SLOT_LJ_CELL) {
-                cell_acc(&CCHI(fslots[f].cj), -chi, fl & SLOT_CHI_J_FIRST);                     // :620
-                cell_acc(&CU(fslots[f].cj), Uji, fl & SLOT_U_J_FIRST);                          // :622
+                cell_acc(&CCHI(sl.cj), -chi, fl & SLOT_CHI_J_FIRST);                     // :620
+                cell_acc(&CU(sl.cj), Uji, fl & SLOT_U_J_FIRST);                          // :622
             }
-            if (fl & SLOT_ETA_CELL) cell_acc(&CETA(fslots[f].ca), eta, fl & SLOT_ETA_FIRST);    // :627
+            if (fl & SLOT_ETA_CELL) cell_acc(&CETA(sl.ca), eta, fl & SLOT_ETA_FIRST);    // :627
             chiTot += chi;
             etaTot += eta;
         }
+        STAMP(1);
 
         // ---- pass 1: opacity / emissivity of the per-ray transitions (rh_method.py:601-627) ----
-        for (int u = 0; u < nP; ++u) {
-            const int fl = slots[u].flags;
-            const double ni = n_col[slots[u].li * Ns + k];
-            const double nj = n_col[slots[u].lj * Ns + k];
-            const bool a = (pact >> u) & 1u;
-            const int l = a ? la - slots[u].Nblue : 0;
-            const int Nlam = slots[u].Nlam;
-            double pv, chi, eta, Uji;
+        //   kept for pass 2 (static path): pv = phi | Vji, chi, Uji
+        double spv[NS], schi[NS], sUji[NS];
+        auto pass1 = [&](const SlotS& sl, double v, double ni, double nj, double alf, double& pv, double& chi,
+                         double& Uji) {
+            const int fl = sl.flags;
             if (fl & SLOT_LINE) {
-                pv = a ? phi_col[slots[u].base + (k * kmul + raysel) * Nlam + l] : 0.0;
-                chi = (slots[u].cB * (ni - slots[u].g * nj)) * pv;   // n_i Vij - n_j Vji, :279-280, :613
-                Uji = slots[u].Uc * pv;                              // :281
-                eta = nj * Uji;                                      // :614
+                pv = v;
+                chi = (sl.cB * (ni - sl.g * nj)) * pv;   // n_i Vij - n_j Vji, :279-280, :613
+                Uji = sl.Uc * pv;                        // :281
             } else {
-                const double g = a ? gijc_col[slots[u].base + k * Nlam + l] : 0.0;
-                const double alf = a ? p.alpha[slots[u].wl_off + l] : 0.0;
-                pv = g * alf;                                        // Vji
+                pv = v * alf;                            // Vji = g_ij alpha, :284-285
                 chi = ni * alf - nj * pv;
-                Uji = u_la * pv;
-                eta = nj * Uji;
+                Uji = u_la * pv;                         // :286
             }
-            STASH(u) = pv;
-            if (fl & SLOT_LI_CELL) cell_acc(&CCHI(slots[u].ci), chi, fl & SLOT_CHI_I_FIRST);
+            const double eta = nj * Uji;                 // :614
+            if (fl & SLOT_LI_CELL) cell_acc(&CCHI(sl.ci), chi, fl & SLOT_CHI_I_FIRST);
             if (fl & SLOT_LJ_CELL) {
-                cell_acc(&CCHI(slots[u].cj), -chi, fl & SLOT_CHI_J_FIRST);
-                cell_acc(&CU(slots[u].cj), Uji, fl & SLOT_U_J_FIRST);
+                cell_acc(&CCHI(sl.cj), -chi, fl & SLOT_CHI_J_FIRST);
+                cell_acc(&CU(sl.cj), Uji, fl & SLOT_U_J_FIRST);
             }
-            if (fl & SLOT_ETA_CELL) cell_acc(&CETA(slots[u].ca), eta, fl & SLOT_ETA_FIRST);
+            if (fl & SLOT_ETA_CELL) cell_acc(&CETA(sl.ca), eta, fl & SLOT_ETA_FIRST);
             chiTot += chi;
             etaTot += eta;
+        };
+        if constexpr (STATIC) {
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                const SlotS sl = load_slot(slots + u, Ns);
+                pass1(sl, sv[u], sni[u], snj[u], alv[u], spv[u], schi[u], sUji[u]);
+            }
+        } else {
+            for (int u = 0; u < nP; ++u) {
+                const SlotS sl = load_slot(slots + u, Ns);
+                const double ni = n_col[sl.noff_i + k];
+                const double nj = n_col[sl.noff_j + k];
+                const bool a = (pact >> u) & 1u;
+                const int l = a ? la - sl.Nblue : 0;
+                double v, alf = 0.0;
+                if (sl.flags & SLOT_LINE) {
+                    v = a ? phi_col[sl.base + (k * kmul + raysel) * sl.Nlam + l] : 0.0;
+                } else {
+                    v = a ? gijc_col[sl.base + k * sl.Nlam + l] : 0.0;
+                    alf = a ? p.alpha[sl.wl_off + l] : 0.0;
+                }
+                double pv, chi, Uji;
+                pass1(sl, v, ni, nj, alf, pv, chi, Uji);
+            }
         }
+        STAMP(2);
         const double rchi = rcp(chiTot);
         const double S = etaTot * rchi;                 // :632
 
@@ -351,6 +438,7 @@ __global__ void __launch_bounds__(2 * LSX_WAVE) lsx_sweep_kernel(const SweepPara
         S_prev = S;
         if (s == Ns - 1 && dir == 1 && valid)            // emergent intensity, :638
             p.Iout[((size_t)col * Nspect + la) * Nrays + mu] = I;
+        STAMP(3);
 
         // ---- angle quadrature of this wavelength: J (:640) and the two ray sums of the fast path ----
         xrow[lane] = wmuh_l * I;
@@ -365,35 +453,19 @@ __global__ void __launch_bounds__(2 * LSX_WAVE) lsx_sweep_kernel(const SweepPara
             for (int m = 0; m < Nrays; ++m) sPsi += xrow[m * L + j];
         }
         __builtin_amdgcn_wave_barrier();
+        STAMP(4);
 
         // ---- pass 2: Gamma integrands of the per-ray transitions (rh_method.py:643-681) ----
-        for (int u = 0; u < nP; ++u) {
-            const int fl = slots[u].flags;
-            const double ni = n_col[slots[u].li * Ns + k];
-            const double nj = n_col[slots[u].lj * Ns + k];
-            const bool a = (pact >> u) & 1u;
-            const int l = a ? la - slots[u].Nblue : 0;
-            const double pv = STASH(u);
-            double Vij, Vji, Uji, chi, wla;
-            wla = a ? p.wl[slots[u].wl_off + l] : 0.0;               // :451, :455
-            if (fl & SLOT_LINE) {
-                Vij = slots[u].cB * pv;
-                Vji = slots[u].Vc * pv;
-                Uji = slots[u].Uc * pv;
-                chi = (slots[u].cB * (ni - slots[u].g * nj)) * pv;
-                wla *= wphi_col[slots[u].wphi_off + k];
-            } else {
-                Vij = a ? p.alpha[slots[u].wl_off + l] : 0.0;
-                Vji = pv;
-                Uji = u_la * pv;
-                chi = ni * Vij - nj * pv;
-            }
+        auto pass2 = [&](const SlotS& sl, int u, bool a, double pv, double chi, double Uji, double Vij, double nj,
+                         double wla) {
+            const int fl = sl.flags;
+            const double Vji = (fl & SLOT_LINE) ? sl.Vc * pv : pv;
             const double eta = nj * Uji;
-            const double etaA = (fl & SLOT_ETA_CELL) ? CETA(slots[u].ca) : eta;
-            const double chi_i = (fl & SLOT_LI_CELL) ? CCHI(slots[u].ci) : chi;
-            const double chi_j = (fl & SLOT_LJ_CELL) ? CCHI(slots[u].cj) : -chi;
-            const double U_j = (fl & SLOT_LJ_CELL) ? CU(slots[u].cj) : Uji;
-            const double U_i = (fl & SLOT_UI_READ) ? CU(slots[u].ci) : 0.0;
+            const double etaA = (fl & SLOT_ETA_CELL) ? CETA(sl.ca) : eta;
+            const double chi_i = (fl & SLOT_LI_CELL) ? CCHI(sl.ci) : chi;
+            const double chi_j = (fl & SLOT_LJ_CELL) ? CCHI(sl.cj) : -chi;
+            const double U_j = (fl & SLOT_LJ_CELL) ? CU(sl.cj) : Uji;
+            const double U_i = (fl & SLOT_UI_READ) ? CU(sl.ci) : 0.0;
             const double Ieff = I - Psi * etaA;                            // :652
             const double g1 = (Uji + Vji * Ieff) - (chi_i * Psi) * U_j;    // :677
             const double g2 = (Vij * Ieff) - (chi_j * Psi) * U_i;          // :680
@@ -405,31 +477,63 @@ __global__ void __launch_bounds__(2 * LSX_WAVE) lsx_sweep_kernel(const SweepPara
                 g[0] = r1;          // e = 0: Gamma[i][j]
                 g[2 * Ns] = r2;     // e = 1: Gamma[j][i]
             }
+        };
+        if constexpr (STATIC) {
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                const SlotS sl = load_slot(slots + u, Ns);
+                const bool line = (sl.flags & SLOT_LINE) != 0;
+                const double Vij = line ? sl.cB * spv[u] : alv[u];
+                pass2(sl, u, (pact >> u) & 1u, spv[u], schi[u], sUji[u], Vij, snj[u], wlv[u] * swp[u]); // :451, :455
+            }
+        } else {
+            for (int u = 0; u < nP; ++u) {
+                const SlotS sl = load_slot(slots + u, Ns);
+                const double ni = n_col[sl.noff_i + k];
+                const double nj = n_col[sl.noff_j + k];
+                const bool a = (pact >> u) & 1u;
+                const int l = a ? la - sl.Nblue : 0;
+                double wla = a ? p.wl[sl.wl_off + l] : 0.0;
+                double pv, Vij, Uji, chi;
+                if (sl.flags & SLOT_LINE) {
+                    pv = a ? phi_col[sl.base + (k * kmul + raysel) * sl.Nlam + l] : 0.0; // L1/L2 hit
+                    Vij = sl.cB * pv;
+                    Uji = sl.Uc * pv;
+                    chi = (sl.cB * (ni - sl.g * nj)) * pv;
+                    wla *= wphi_col[sl.wphi_off + k];
+                } else {
+                    Vij = a ? p.alpha[sl.wl_off + l] : 0.0;
+                    pv = (a ? gijc_col[sl.base + k * sl.Nlam + l] : 0.0) * Vij;          // Vji
+                    Uji = u_la * pv;
+                    chi = ni * Vij - nj * pv;
+                }
+                pass2(sl, u, a, pv, chi, Uji, Vij, nj, wla);
+            }
         }
+        STAMP(5);
 
         // ---- fast continua: Gamma integrand from the ray sums (one lane per wavelength) ----
         if (nF > 0) {
             const double sI = Jsum * (4.0 * kPi);       // sum_mu (w_mu/2 4pi) I
-            double sW = 0.0;
-            for (int m = 0; m < Nrays; ++m) sW += LSX_CONST(double, p.wmuh)[m] * (4.0 * kPi);
             for (int f = 0; f < nF; ++f) {
-                const int fl = fslots[f].flags;
-                const double ni = n_col[fslots[f].li * Ns + k];
-                const double nj = n_col[fslots[f].lj * Ns + k];
+                const SlotS sl = load_slot(fslots + f, Ns);
+                const int fl = sl.flags;
+                const double ni = n_col[sl.noff_i + k];
+                const double nj = n_col[sl.noff_j + k];
                 const bool a = (fact >> f) & 1u;
-                const int l = a ? la - fslots[f].Nblue : 0;
-                const double g = a ? gijc_col[fslots[f].base + k * fslots[f].Nlam + l] : 0.0;
-                const double alf = a ? p.alpha[fslots[f].wl_off + l] : 0.0;
-                const double wla = a ? p.wl[fslots[f].wl_off + l] : 0.0;
+                const int l = a ? la - sl.Nblue : 0;
+                const double g = a ? gijc_col[sl.base + k * sl.Nlam + l] : 0.0;
+                const double alf = a ? p.alpha[sl.wl_off + l] : 0.0;
+                const double wla = a ? p.wl[sl.wl_off + l] : 0.0;
                 const double Vji = g * alf;
                 const double Uji = u_la * Vji;
                 const double chi = ni * alf - nj * Vji;
                 const double eta = nj * Uji;
-                const double etaA = (fl & SLOT_ETA_CELL) ? CETA(fslots[f].ca) : eta;
-                const double chi_i = (fl & SLOT_LI_CELL) ? CCHI(fslots[f].ci) : chi;
-                const double chi_j = (fl & SLOT_LJ_CELL) ? CCHI(fslots[f].cj) : -chi;
-                const double U_j = (fl & SLOT_LJ_CELL) ? CU(fslots[f].cj) : Uji;
-                const double U_i = (fl & SLOT_UI_READ) ? CU(fslots[f].ci) : 0.0;
+                const double etaA = (fl & SLOT_ETA_CELL) ? CETA(sl.ca) : eta;
+                const double chi_i = (fl & SLOT_LI_CELL) ? CCHI(sl.ci) : chi;
+                const double chi_j = (fl & SLOT_LJ_CELL) ? CCHI(sl.cj) : -chi;
+                const double U_j = (fl & SLOT_LJ_CELL) ? CU(sl.cj) : Uji;
+                const double U_i = (fl & SLOT_UI_READ) ? CU(sl.ci) : 0.0;
                 const double sIe = sI - etaA * sPsi;                       // sum_mu w (I - Psi eta)
                 const double g1 = (Uji * sW + Vji * sIe) - (chi_i * U_j) * sPsi;
                 const double g2 = (alf * sIe) - (chi_j * U_i) * sPsi;
@@ -443,6 +547,7 @@ __global__ void __launch_bounds__(2 * LSX_WAVE) lsx_sweep_kernel(const SweepPara
                 }
             }
         }
+        STAMP(6);
 
         // ---- J: the two directions meet at depth k at different steps ----
         const int s2 = 2 * s, nm1 = Ns - 1;
@@ -466,12 +571,41 @@ __global__ void __launch_bounds__(2 * LSX_WAVE) lsx_sweep_kernel(const SweepPara
         }
     }
 
+#ifdef LSX_STAMPS
+    STAMP(7);
+    if (lane == 0 && dir == 0 && p.debug && (vb % 997) == 5 && vb / 997 < 64) {
+        unsigned long long* D = (unsigned long long*)p.debug + (size_t)(vb / 997) * 16;
+        for (int i = 0; i < 8; ++i) D[i] = T[i];
+        D[8] = tile_id; D[9] = nP; D[10] = nF; D[11] = col;
+    }
+#endif
+#undef STAMP
     const double dJw = wave_max_nan(lead ? dJ : 0.0);
     if (lane == 0) p.dJpart[((size_t)col * ntile + tile_id) * 2 + dir] = dJw;
 #undef CCHI
 #undef CU
 #undef CETA
-#undef STASH
+}
+
+__global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(LSX_WAVES_PER_EU)))
+lsx_sweep_kernel(const SweepParams p)
+{
+    int vb;
+    {
+        const int nb = gridDim.x, x = blockIdx.x & 7, q = blockIdx.x >> 3;
+        const int nb8 = nb >> 3, rem = nb & 7;
+        vb = x * nb8 + (x < rem ? x : rem) + q;
+    }
+    const int tile_id = vb % p.ntile_total;
+    const int nP = (LSX_CONST(DevTile, p.tiles) + tile_id)->nP;
+#ifndef LSX_NO_SPECIALIZE
+    if (nP == 0) sweep_tile<0>(p, vb);
+    else if (nP == 1) sweep_tile<1>(p, vb);
+    else if (nP == 2) sweep_tile<2>(p, vb);
+    else if (nP == 3) sweep_tile<3>(p, vb);
+    else
+#endif
+        sweep_tile<-1>(p, vb);
 }
 
 extern "C" hipError_t lsx_launch_sweep(const SweepParams* p, int nblocks, size_t lds_bytes, hipStream_t st)
