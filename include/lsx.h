@@ -149,6 +149,13 @@ int lsx_get(lsx_ctx* ctx, int32_t what, int32_t col0, int32_t ncol, double* dst,
 int lsx_set(lsx_ctx* ctx, int32_t what, int32_t col0, int32_t ncol, const double* src,
             size_t nbytes);
 
+/* Per-column convergence: columns whose byte is 0 are frozen -- the following
+ * formal_sol_gamma / stat_equil calls neither read nor write them, and their DJ_COL / DPOPS_COL
+ * read 0.  This is how a batch reproduces what the reference does when it runs one Context per
+ * column until `dJ <= 2e-3 and dPops <= 1e-3` (test.py:23, response_fn.py:15): every column
+ * performs exactly the iterations it would perform alone.  active == NULL: all columns active. */
+int lsx_set_active_columns(lsx_ctx* ctx, const uint8_t* active);
+
 /* formal_solver.piecewise_linear_1d for `nray` independent rays sharing one depth
  * grid (formal_solver.py:144-212).  chi, S: [nray][Nspace]; mu, wav: [nray];
  * to_obs: [nray] (1 = up-going/toFrom True); temperature: [Nspace] (only the last

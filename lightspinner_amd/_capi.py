@@ -48,7 +48,7 @@ REQUIRED_SYMBOLS = (
     'lsx_create', 'lsx_destroy', 'lsx_set_columns', 'lsx_formal_sol_gamma', 'lsx_stat_equil',
     'lsx_formal_sol_gamma_async', 'lsx_stat_equil_async', 'lsx_sync', 'lsx_get', 'lsx_set',
     'lsx_piecewise_linear_1d', 'lsx_time_formal_sol', 'lsx_last_error', 'lsx_backend_name',
-    'lsx_abi_version', 'lsx_algorithmic_bytes_per_column',
+    'lsx_abi_version', 'lsx_algorithmic_bytes_per_column', 'lsx_set_active_columns',
 )
 
 
@@ -104,6 +104,7 @@ class LsxLibrary:
         d.lsx_set.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp, C.c_size_t]
         d.lsx_piecewise_linear_1d.argtypes = [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp,
                                               C.POINTER(C.c_int32), _dp, _dp, _dp, _dp, _dp]
+        d.lsx_set_active_columns.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
         d.lsx_time_formal_sol.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp]
         d.lsx_algorithmic_bytes_per_column.argtypes = [C.c_void_p]
         d.lsx_algorithmic_bytes_per_column.restype = C.c_double

@@ -119,5 +119,6 @@ struct SweepParams {
     double* Iout;
     double* Gpart;
     double* dJpart;
+    const uint8_t* colmask;     // per-column activity (frozen columns exit at once), or null
     double* debug;              // diagnostic builds only
 };

@@ -115,6 +115,7 @@ struct FinishParams {
     const double* dJpart;
     double* Gamma;
     double* dJcol;
+    const uint8_t* colmask;
 };
 
 // Gamma = C + sum of the sweep's slabs in (tile, slot, entry, direction) order; then the
@@ -125,6 +126,10 @@ __global__ void k_gamma_finish(const FinishParams f)
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long)f.ncol * Ns) return;
     const int col = gid / Ns, k = gid % Ns;
+    if (f.colmask && !f.colmask[col]) {
+        if (k == 0) f.dJcol[col] = 0.0;
+        return;
+    }
     double* G = f.Gamma + (size_t)col * f.NL2tot * Ns + k;
     const double* Cm = f.C + (size_t)col * f.NL2tot * Ns + k;
     for (int e = 0; e < f.NL2tot; ++e) G[(size_t)e * Ns] = 0.0 + Cm[(size_t)e * Ns];
@@ -175,13 +180,14 @@ __device__ __forceinline__ void atomic_max_nonneg(double* addr, double v)
 // pivoting in the operation order of LAPACK dgetf2/dgetrs.
 __global__ void k_stat_equil(const double* __restrict__ Gamma, const double* __restrict__ nTotal, double* __restrict__ n,
                              double* __restrict__ dPcol, int* __restrict__ singular, int Nl, int lev_off, int lev2_off,
-                             int atom, int Natoms, int NLtot, int NL2tot, int Ns, int ncol)
+                             int atom, int Natoms, int NLtot, int NL2tot, int Ns, int ncol, const uint8_t* __restrict__ colmask)
 {
     extern __shared__ double sm[];
     const int tid = threadIdx.x, nt = blockDim.x;
     const long gid = (long)blockIdx.x * nt + tid;
     if (gid >= (long)ncol * Ns) return;
     const int col = gid / Ns, k = gid % Ns;
+    if (colmask && !colmask[col]) return;
     double* A = sm + tid;                       // A[(i + j*Nl) * nt]
     double* b = sm + (size_t)Nl * Nl * nt + tid; // b[i * nt]
     double* nOld = b + (size_t)Nl * nt;
@@ -356,6 +362,7 @@ struct lsx_ctx {
            *d_sca = nullptr, *d_phi = nullptr, *d_gijc = nullptr, *d_J[2] = {nullptr, nullptr}, *d_I = nullptr,
            *d_Gpart = nullptr, *d_dJpart = nullptr, *d_dJcol = nullptr, *d_dPcol = nullptr, *d_max = nullptr;
     int* d_singular = nullptr;
+    uint8_t* d_colmask = nullptr; // per-column activity, nullptr = all active
     double* d_debug = nullptr;   // 64 x 16 x 8 B, diagnostic builds of the sweep kernel write stamps here
     int jcur = 0; // d_J[jcur] holds the current J (Jdag of the next call)
     size_t phi_col = 0, gijc_col = 0, sca_col = 0;
@@ -438,7 +445,7 @@ void lsx_destroy(lsx_ctx* c)
                     c->d_tiles, c->d_slots, c->d_tile_slots, c->d_Nlevel, c->d_lev2_off, c->d_height,
                     c->d_temperature, c->d_nStar, c->d_nTotal, c->d_n, c->d_C, c->d_Gamma, c->d_wphi, c->d_bgchi,
                     c->d_bgeta, c->d_sca, c->d_phi, c->d_gijc, c->d_J[0], c->d_J[1], c->d_I, c->d_Gpart, c->d_dJpart,
-                    c->d_dJcol, c->d_dPcol, c->d_max, c->d_singular, c->d_stage, c->d_debug};
+                    c->d_dJcol, c->d_dPcol, c->d_max, c->d_singular, c->d_stage, c->d_debug, c->d_colmask};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : {c->ev0, c->ev1, c->ev2})
@@ -789,7 +796,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
     p.height = c->d_height; p.temperature = c->d_temperature; p.n = c->d_n; p.wphi = c->d_wphi;
     p.bgchi_T = c->d_bgchi; p.bgeta_T = c->d_bgeta; p.sca = c->d_sca; p.phi_T = c->d_phi; p.gijc_T = c->d_gijc;
     p.Jdag_T = c->d_J[c->jcur]; p.Jnew_T = c->d_J[c->jcur ^ 1];
-    p.Iout = c->d_I; p.Gpart = c->d_Gpart; p.dJpart = c->d_dJpart; p.debug = c->d_debug;
+    p.Iout = c->d_I; p.Gpart = c->d_Gpart; p.dJpart = c->d_dJpart; p.debug = c->d_debug; p.colmask = c->d_colmask;
 
     const long nblocks = (long)c->tiles.size() * c->ncol;
     if (nblocks > 0x7fffffffL) return fail(LSX_EUNSUPPORTED, "grid too large");
@@ -802,7 +809,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
     f.Nspace = c->Nspace; f.Natoms = c->Natoms; f.NL2tot = c->NL2tot; f.ncol = c->ncol; f.ntile = (int)c->tiles.size();
     f.nslot_total = (int)c->tile_slots.size(); f.Nlevel = c->d_Nlevel; f.lev2_off = c->d_lev2_off; f.tiles = c->d_tiles;
     f.tile_slots = c->d_tile_slots; f.trans = c->d_trans; f.C = c->d_C; f.Gpart = c->d_Gpart; f.dJpart = c->d_dJpart;
-    f.Gamma = c->d_Gamma; f.dJcol = c->d_dJcol;
+    f.Gamma = c->d_Gamma; f.dJcol = c->d_dJcol; f.colmask = c->d_colmask;
     const long nthreads = (long)c->ncol * c->Nspace;
     hipLaunchKernelGGL(k_gamma_finish, dim3((unsigned)((nthreads + 127) / 128)), dim3(128), 0, c->stream, f);
     HIPCHK(hipGetLastError());
@@ -834,12 +841,30 @@ int lsx_stat_equil_async(lsx_ctx* c)
         if (sm > 160 * 1024) return fail(LSX_EUNSUPPORTED, "stat_equil: Nlevel = %d needs %zu B of LDS", Nl, sm);
         hipLaunchKernelGGL(k_stat_equil, dim3((unsigned)((nthreads + nt - 1) / nt)), dim3(nt), sm, c->stream, c->d_Gamma,
                            c->d_nTotal, c->d_n, c->d_dPcol, c->d_singular, Nl, c->lev_off[a], c->lev2_off[a], a, c->Natoms,
-                           c->NLtot, c->NL2tot, c->Nspace, c->ncol);
+                           c->NLtot, c->NL2tot, c->Nspace, c->ncol, c->d_colmask);
         HIPCHK(hipGetLastError());
     }
     hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, c->stream, c->d_dPcol, c->ncol, c->d_max + 1);
     HIPCHK(hipGetLastError());
     c->se_pending = true;
+    return LSX_OK;
+}
+
+int lsx_set_active_columns(lsx_ctx* c, const uint8_t* active)
+{
+    if (!c) return fail(LSX_EINVAL, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (!active) {
+        if (c->d_colmask) HIPCHK(hipFree(c->d_colmask));
+        c->d_colmask = nullptr;
+        return LSX_OK;
+    }
+    if (!c->d_colmask) {
+        int rc = dmalloc(&c->d_colmask, (size_t)c->ncol);
+        if (rc) return rc;
+    }
+    HIPCHK(hipMemcpy(c->d_colmask, active, (size_t)c->ncol, hipMemcpyHostToDevice));
     return LSX_OK;
 }
 

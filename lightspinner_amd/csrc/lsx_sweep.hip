@@ -597,6 +597,7 @@ lsx_sweep_kernel(const SweepParams p)
         vb = x * nb8 + (x < rem ? x : rem) + q;
     }
     const int tile_id = vb % p.ntile_total;
+    if (p.colmask && LSX_CONST(uint8_t, p.colmask)[vb / p.ntile_total] == 0) return; // frozen column
     const int nP = (LSX_CONST(DevTile, p.tiles) + tile_id)->nP;
 #ifndef LSX_NO_SPECIALIZE
     if (nP == 0) sweep_tile<0>(p, vb);

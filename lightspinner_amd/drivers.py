@@ -54,3 +54,41 @@ def response_function(I_plus, I_minus, I_base, mu_index=-1):
     Ip = np.asarray(I_plus)[:, :, mu_index].T      # [Nspect][Nspace]
     Im = np.asarray(I_minus)[:, :, mu_index].T
     return (Ip - Im) / np.asarray(I_base)[:, mu_index][:, None]
+
+
+def iterate_mali_columns(engine, dJ_tol=2e-3, dPops_tol=1e-3, n_lambda_only=3, max_iter=500, all_done=None, log=None):
+    """Many independent columns, each with the reference's own stopping rule: a column is frozen
+    (lsx_set_active_columns) as soon as ITS dJ <= 2e-3 and dPops <= 1e-3, so it performs exactly the
+    iterations a single-column reference Context would (test.py:20-29, response_fn.py:11-21).
+
+    engine: problem.Engine.  all_done(bool) -> bool: hook for the multi-GPU driver (logical AND over
+    ranks).  Returns the number of iterations each column took ([ncol] int array)."""
+    from . import _capi
+    ncol = engine.ncol
+    active = np.ones(ncol, dtype=bool)
+    dP = np.ones(ncol)
+    n_iter = np.zeros(ncol, dtype=np.int64)
+    i = 0
+    engine.set_active_columns(None)
+    while True:
+        i += 1
+        engine.formal_sol_gamma()
+        dJ = engine.get(_capi.LSX_DJ_COL)
+        if i > n_lambda_only:
+            engine.stat_equil()
+            dP = np.where(active, engine.get(_capi.LSX_DPOPS_COL), dP)
+        n_iter[active] = i
+        still = (dJ > dJ_tol) | (dP > dPops_tol)
+        active &= still | ~np.isfinite(dJ) | ~np.isfinite(dP)
+        if i >= max_iter:
+            active[:] = False
+        done = not active.any()
+        if all_done is not None:
+            done = all_done(done)
+        if log:
+            log('Iteration %.3d: %d of %d columns still iterating' % (i, int(active.sum()), ncol))
+        if done:
+            break
+        engine.set_active_columns(active)
+    engine.set_active_columns(None)
+    return n_iter

@@ -200,6 +200,16 @@ class Engine:
         ncol = arr.shape[0]
         self.lib.check(self.lib.dll.lsx_set(self._h, what, int(col0), ncol, _ptr(arr), arr.nbytes))
 
+    def set_active_columns(self, mask=None):
+        """freeze columns whose mask entry is False (None: all active)"""
+        if mask is None:
+            self.lib.check(self.lib.dll.lsx_set_active_columns(self._h, None))
+            return
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        if m.shape != (self.ncol,):
+            raise ValueError('mask must have one entry per column')
+        self.lib.check(self.lib.dll.lsx_set_active_columns(self._h, m.ctypes.data_as(C.POINTER(C.c_uint8))))
+
     # -- hot path -------------------------------------------------------------
     def formal_sol_gamma(self) -> float:
         v = C.c_double()

@@ -59,6 +59,7 @@ struct lsx_ctx {
     double *height, *temperature, *nStar, *nTotal, *n, *C, *bg_chi, *bg_eta, *bg_sca, *phi, *wphi;
     double *J, *I, *Gamma, *Rij, *Rji, *dJcol, *dPcol;
     int nthreads;
+    uint8_t* colmask; /* NULL = all active */
     double last_dJ, last_dP;
 };
 
@@ -138,6 +139,7 @@ void lsx_destroy(lsx_ctx* c)
     free(c->trans); free(c->active); free(c->alpha); free(c->alpha_off); free(c->phi_off); free(c->line_idx);
     free(c->height); free(c->temperature); free(c->nStar); free(c->nTotal); free(c->n); free(c->C);
     free(c->bg_chi); free(c->bg_eta); free(c->bg_sca); free(c->phi); free(c->wphi);
+    free(c->colmask);
     free(c->J); free(c->I); free(c->Gamma); free(c->Rij); free(c->Rji); free(c->dJcol); free(c->dPcol);
     free(c);
 }
@@ -505,7 +507,10 @@ int lsx_formal_sol_gamma_async(lsx_ctx* c)
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 1)
 #endif
-        for (int col = 0; col < c->ncol; ++col) formal_sol_gamma_column(c, col, scratch);
+        for (int col = 0; col < c->ncol; ++col) {
+            if (c->colmask && !c->colmask[col]) { c->dJcol[col] = 0.0; continue; }
+            formal_sol_gamma_column(c, col, scratch);
+        }
         free(scratch);
     }
     c->last_dJ = colmax(c->dJcol, c->ncol);
@@ -595,7 +600,10 @@ int lsx_stat_equil_async(lsx_ctx* c)
 #ifdef _OPENMP
 #pragma omp parallel for num_threads(c->nthreads) reduction(| : sing)
 #endif
-    for (int col = 0; col < c->ncol; ++col) sing |= stat_equil_column(c, col);
+    for (int col = 0; col < c->ncol; ++col) {
+        if (c->colmask && !c->colmask[col]) { c->dPcol[col] = 0.0; continue; }
+        sing |= stat_equil_column(c, col);
+    }
     c->last_dP = colmax(c->dPcol, c->ncol);
     if (sing) return fail(LSX_ESINGULAR, "stat_equil: singular system");
     return LSX_OK;
@@ -606,6 +614,18 @@ int lsx_stat_equil(lsx_ctx* c, double* dP)
     int rc = lsx_stat_equil_async(c);
     if (rc) return rc;
     if (dP) *dP = c->last_dP;
+    return LSX_OK;
+}
+
+int lsx_set_active_columns(lsx_ctx* c, const uint8_t* active)
+{
+    if (!c) return fail(LSX_EINVAL, "null ctx");
+    free(c->colmask);
+    c->colmask = NULL;
+    if (active) {
+        c->colmask = (uint8_t*)malloc((size_t)c->ncol);
+        memcpy(c->colmask, active, (size_t)c->ncol);
+    }
     return LSX_OK;
 }
 

@@ -1,0 +1,136 @@
+"""CPU tests of the host side: C-ABI export surface, the drop-in Context (packing, aliasing,
+warm start, error behaviour) with the oracle bound as a checker, sharding helpers, synthetic
+columns.  No GPU needed."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import golden, relerr, gamma_err, ROOT
+from helpers import build_fakes
+from lightspinner_amd import _capi, fixtures, synth, drivers
+from lightspinner_amd.parallel import shard_columns
+from lightspinner_amd.rh_method import Context
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, 'include', 'lsx.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    return sorted(set(re.findall(r'\b(lsx_[a-z0-9_]+)\s*\(', hdr)))
+
+
+def test_header_and_binding_agree():
+    assert _declared_symbols() == sorted(_capi.REQUIRED_SYMBOLS)
+
+
+def test_hip_library_exports_every_declared_symbol():
+    """the product .so must be built in-tree and export the whole ABI (no compute call here)"""
+    import ctypes
+    path = _capi.hip_library_path()
+    assert os.path.exists(path), 'run __graft_entry__.build() first'
+    dll = ctypes.CDLL(path)
+    for s in _declared_symbols():
+        assert hasattr(dll, s), s
+    lib = _capi.LsxLibrary(path)
+    assert lib.backend == 'hip-gfx950'
+
+
+def test_oracle_exports_the_same_abi(oracle_lib):
+    for s in _declared_symbols():
+        assert hasattr(oracle_lib.dll, s), s
+
+
+def test_hip_engine_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    prob, block, _ = fixtures.load_problem_npz(golden('falc_ca.npz'))
+    from lightspinner_amd import Engine
+    with pytest.raises(_capi.LsxError):
+        Engine(prob, 1)     # default library = HIP; there is no CPU fallback
+
+
+def test_context_dropin_matches_reference_golden(oracle_lib):
+    d = dict(np.load(golden('falc_ca.npz')))
+    atmos, spect, eq, bg = build_fakes(d)
+    ctx = Context(atmos, spect, eq, bg, lib=oracle_lib)
+    assert atmos.nondim_calls == 1                                   # rh_method.py:553
+    assert ctx.problem.phi_compact and not ctx.problem.sca_per_lambda
+    atom = ctx.activeAtoms[0]
+    assert atom.n is eq['CA'].pops                                   # aliasing contract, rh_method.py:412-416
+    assert relerr(atom.trans[0].phi[:, 0, 0, :], d['t0_phi']) < 1e-13 and relerr(atom.trans[0].wphi, d['t0_wphi']) < 1e-13
+    for it in range(1, 6):
+        dJ = ctx.formal_sol_gamma_matrices()
+        assert dJ == pytest.approx(float(d['fs%d_dJ' % it]), rel=1e-8)
+        assert relerr(ctx.I, d['fs%d_I' % it]) < (1e-12 if it < 5 else 1e-8)
+        assert relerr(ctx.J, d['fs%d_J' % it]) < (1e-12 if it < 5 else 1e-8)
+        assert atom.Gamma.shape == d['fs%d_Gamma_a0' % it].shape
+        if it > 3:
+            n_before = atom.n
+            dP = ctx.stat_equil()
+            assert dP == pytest.approx(float(d['se%d_dPops' % it]), rel=1e-7)
+            assert atom.n is n_before and eq['CA'].n is atom.n       # updated in place
+            assert relerr(atom.n, d['se%d_n_a0' % it]) < 1e-7
+    with pytest.raises(AttributeError):
+        atom.trans[0].Rij
+
+
+def test_context_warm_start_and_host_edits(oracle_lib):
+    d = dict(np.load(golden('falc_ca.npz')))
+    atmos, spect, eq, bg = build_fakes(d, start_pops=[d['conv_n_a0']])
+    ctx = Context(atmos, spect, eq, bg, lib=oracle_lib)
+    assert np.array_equal(ctx.activeAtoms[0].n, d['conv_n_a0'])      # response_fn.py:33
+    ctx.J[...] = d['conv_J']                                         # caller edits are honoured
+    dJ = ctx.formal_sol_gamma_matrices()
+    assert dJ < 2e-3
+    ctx.activeAtoms[0].n[...] = d['a0_nStar']                        # back to LTE in place
+    ctx.formal_sol_gamma_matrices()
+    dP = ctx.stat_equil()
+    assert dP > 0.1
+
+
+def test_context_two_active_atoms_order_and_shapes(oracle_lib):
+    d = dict(np.load(golden('falc_cah.npz')))
+    atmos, spect, eq, bg = build_fakes(d)
+    ctx = Context(atmos, spect, eq, bg, lib=oracle_lib)
+    assert [a.atomicModel.name for a in ctx.activeAtoms] == ['H', 'CA']   # ascending atomic weight
+    assert ctx.problem.Ntrans == 25 and ctx.problem.Nspect == 777
+    dJ = ctx.formal_sol_gamma_matrices()
+    assert dJ == 1.0
+    assert relerr(ctx.I, d['fs1_I']) < 3e-11
+    for a in range(2):
+        off, diag = gamma_err(ctx.activeAtoms[a].Gamma.reshape(-1, 82), d['fs1_Gamma_a%d' % a].reshape(-1, 82),
+                              type('P', (), dict(Natoms=1, Nlevel=[6], lev2_off=[0], Nspace=82)))
+        assert off < 3e-10 and diag < 3e-11
+
+
+def test_shard_columns_partitions_exactly():
+    for total in (0, 1, 7, 8, 165, 1000, 10000):
+        for world in (1, 2, 3, 8):
+            parts = [shard_columns(total, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and sum(n for _, n in parts) == total
+            for (f0, n0), (f1, _) in zip(parts, parts[1:]):
+                assert f1 == f0 + n0
+            assert max(n for _, n in parts) - min(n for _, n in parts) <= 1
+
+
+def test_synthetic_columns_are_deterministic_per_absolute_index():
+    prob, block, raw = fixtures.load_problem_npz(golden('falc_ca.npz'), phi_compact=False)
+    whole = synth.perturbed_columns(prob, block, raw, ncol=5, seed=7)
+    part = synth.perturbed_columns(prob, block, raw, ncol=2, seed=7, first=3)
+    for k in ('bg_chi', 'n', 'C', 'phi', 'wphi'):
+        assert np.array_equal(getattr(whole, k)[3:5], getattr(part, k))
+    assert np.array_equal(whole.phi[0], block.phi[0])               # column 0 is FALC itself
+    assert not np.array_equal(whole.phi[1], whole.phi[2])
+    assert np.any(whole.phi[1][:, 0, 0, :] != whole.phi[1][:, 0, 1, :])   # vlos != 0: direction dependent
+
+
+def test_response_function_formula():
+    """response_fn.py:59-67"""
+    rng = np.random.default_rng(0)
+    Ip, Im = rng.random((82, 10, 5)), rng.random((82, 10, 5))
+    Ib = rng.random((10, 5)) + 1
+    rf = drivers.response_function(Ip, Im, Ib)
+    assert rf.shape == (10, 82)
+    assert rf[3, 40] == pytest.approx((Ip[40, 3, 4] - Im[40, 3, 4]) / Ib[3, 4])

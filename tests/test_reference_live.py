@@ -1,0 +1,42 @@
+"""Drop-in check against the LIVE reference (build container only: /root/reference is absent on the
+GPU box, where this file skips).  The reference's own objects are handed to both Contexts."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, relerr
+
+REF = os.environ.get('LIGHTSPINNER_REF', '/root/reference')
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason='reference not mounted')
+
+
+def test_context_against_live_reference(oracle_lib):
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    argv, sys.argv = sys.argv, ['x']
+    try:
+        import make_golden as mg          # sets up the stand-ins and imports the reference modules
+    finally:
+        sys.argv = argv
+    from lightspinner_amd.rh_method import Context
+
+    ref = mg.build_ctx(['Ca'])
+    # a second, independent set of reference objects for our Context (Context mutates eqPops in place)
+    mine_src = mg.build_ctx(['Ca'])
+    mine = Context(mine_src.atmos, mine_src.spect, mine_src.eqPops, mine_src.background, lib=oracle_lib)
+    assert mine.activeAtoms[0].n is mine_src.eqPops['Ca'].n
+    for t_ref, t_mine in zip(ref.activeAtoms[0].trans, mine.activeAtoms[0].trans):
+        assert t_ref.Nblue == t_mine.Nblue and np.array_equal(t_ref.active, t_mine.active)
+        if t_ref.isLine:
+            assert relerr(t_mine.phi, t_ref.phi) < 1e-13 and relerr(t_mine.wphi, t_ref.wphi) < 1e-13
+    for it in range(1, 7):
+        dJ_ref, dJ = ref.formal_sol_gamma_matrices(), mine.formal_sol_gamma_matrices()
+        assert dJ == pytest.approx(dJ_ref, rel=1e-8)
+        tol = 1e-12 if it < 5 else 1e-8
+        assert relerr(mine.J, ref.J) < tol and relerr(mine.I, ref.I) < tol
+        assert relerr(mine.activeAtoms[0].C, ref.activeAtoms[0].C, floor=1e-300) < 1e-13
+        if it > 3:
+            dP_ref, dP = ref.stat_equil(), mine.stat_equil()
+            assert dP == pytest.approx(dP_ref, rel=1e-7)
+            assert relerr(mine_src.eqPops['Ca'].n, ref.eqPops['Ca'].n) < 1e-7
