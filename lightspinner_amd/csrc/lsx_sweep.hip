@@ -597,7 +597,16 @@ lsx_sweep_kernel(const SweepParams p)
         vb = x * nb8 + (x < rem ? x : rem) + q;
     }
     const int tile_id = vb % p.ntile_total;
-    if (p.colmask && LSX_CONST(uint8_t, p.colmask)[vb / p.ntile_total] == 0) return; // frozen column
+    if (p.colmask && LSX_CONST(uint8_t, p.colmask)[vb / p.ntile_total] == 0) {
+        // frozen column: nothing is computed; J only moves to the other half of the ping-pong pair
+        const auto* tp = LSX_CONST(DevTile, p.tiles) + tile_id;
+        const size_t cbase = (size_t)(vb / p.ntile_total) * p.Nspace * p.Nspect;
+        for (int e = threadIdx.x; e < tp->nla * p.Nspace; e += 2 * LSX_WAVE) {
+            const int k = e / tp->nla, la = tp->la0 + e - k * tp->nla;
+            p.Jnew_T[cbase + (size_t)k * p.Nspect + la] = p.Jdag_T[cbase + (size_t)k * p.Nspect + la];
+        }
+        return;
+    }
     const int nP = (LSX_CONST(DevTile, p.tiles) + tile_id)->nP;
 #ifndef LSX_NO_SPECIALIZE
     if (nP == 0) sweep_tile<0>(p, vb);
