@@ -268,6 +268,21 @@ __global__ void k_reduce_max(const double* __restrict__ v, int n, double* __rest
     if (threadIdx.x == 0) out[0] = sh[0];
 }
 
+// FETCH_SIZE calibration (profiles/calibrate.py): read `rows` x `seg` doubles exactly once in the sweep
+// kernel's access shape -- one wave-instruction = 64/seg segments of `seg` consecutive doubles (8 B per
+// lane), the segments `stride` doubles apart -- and fold them into one value per wave.
+__global__ void k_calib_read(const double* __restrict__ buf, double* __restrict__ out, int seg, long stride, long nwave_rows)
+{
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int per = 64 / seg;
+    const int r = lane / seg, j = lane - r * seg;
+    double acc = 0.0;
+    if (r < per)
+        for (long q = 0; q < nwave_rows; ++q) acc += buf[((wave * nwave_rows + q) * per + r) * stride + j];
+    if (acc == 1.2345e300) out[wave] = acc; // keep the loads alive
+}
+
 // formal_solver.py:14-212 for independent rays (one ray per thread, [ray][k] layout)
 __device__ __forceinline__ void dev_w2(double dtau, double& w0, double& w1)
 {
@@ -1054,6 +1069,28 @@ double lsx_hip_info(const lsx_ctx* c, int32_t what)
     case 5: return 8.0 * c->Nspace * 4.0 * (double)c->tile_slots.size();
     default: return 0.0;
     }
+}
+
+// diagnostic: stream `gib` GiB once in the sweep's access shape (see k_calib_read); returns the bytes read
+double lsx_hip_calibrate_read(int32_t device, double gib, int32_t seg)
+{
+    if (hipSetDevice(device) != hipSuccess || seg < 1 || seg > 64) return 0.0;
+    const int per = 64 / seg;
+    const long stride = 96;                 // doubles between segments (a 768-B row pitch, like a 96-point line)
+    const long nwave_rows = 64;
+    const long waves = (long)(gib * 1073741824.0 / 8.0 / (double)(nwave_rows * per * stride));
+    const size_t n = (size_t)waves * nwave_rows * per * stride;
+    double *buf = nullptr, *out = nullptr;
+    if (hipMalloc((void**)&buf, n * 8) != hipSuccess) return 0.0;
+    if (hipMalloc((void**)&out, (size_t)waves * 8) != hipSuccess) { (void)hipFree(buf); return 0.0; }
+    (void)hipMemset(buf, 0, n * 8);
+    (void)hipMemset(out, 0, (size_t)waves * 8);
+    (void)hipDeviceSynchronize();
+    hipLaunchKernelGGL(k_calib_read, dim3((unsigned)(waves / 4)), dim3(256), 0, 0, buf, out, seg, stride, nwave_rows);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(buf);
+    (void)hipFree(out);
+    return (double)(waves / 4 * 4) * nwave_rows * per * seg * 8.0;
 }
 
 // diagnostic: copy the sweep kernel's stamp buffer (64 records x 16 x u64) to host
