@@ -2,13 +2,15 @@
 // sweep kernel (lsx_sweep.hip).  gfx950 / wave64 only.
 //
 // HBM layout (all float64, one block per context, index order left = slowest):
-//   per column, "depth-major" (k-major): at a fixed depth the wavelength-lanes of a wavefront
-//   read consecutive addresses (the sweep is serial in k inside a lane):
-//     bgchi_T, bgeta_T   [col][k][la]
-//     J_T[2]             [col][k][la]            ping-pong: Jdag <- previous call
-//     sca                [col][k]  (or [col][k][la] when sca_per_lambda)
-//     phi_T              [col] { per line: [k][dir][mu][lt] }   (compact: [k][lt])
-//     gijc_T             [col] { per continuum: [k][lt] }       g_ij of (26) in [U01], built at upload
+//   per column, TILE-major then depth-major: everything one wavefront (tile, direction) reads is
+//   one contiguous stream in the order it walks the depths, private to that tile (no 128-B line is
+//   shared between workgroups), j = wavelength index inside the tile, L = tile width:
+//     bgchi_T, bgeta_T   [col][tile][k][j<L]
+//     J_T[2]             [col][tile][k][j<L]      ping-pong: Jdag <- previous call
+//     sca                [col][k]  (or [col][tile][k][j] when sca_per_lambda)
+//     phi_T              [col] { per (tile, line slot): [k][dir][mu][l<len] }   (compact: [k][l])
+//     gijc_T             [col] { per (tile, continuum slot): [k][l<len] }  g_ij of (26) in [U01], built at upload
+//   where the slot's block covers the len wavelengths of the tile inside the transition's range
 //   per column, reference layout (level-major; the sweep reads them with wave-uniform
 //   addresses through the scalar cache):
 //     n, nStar           [col][NLtot][k]
@@ -64,7 +66,8 @@ struct DevSlot {
     int32_t li, lj;        // global level ids (rows of n)
     int32_t ci, cj, ca;    // tile-local LDS cell ids: level cells of i and j, atom cell
     int32_t Nblue, Nlam;
-    int32_t base;          // element offset of the transition's block inside the column's phi_T / gijc_T
+    int32_t base;          // element offset of this (tile, transition) block inside the column's phi_T / gijc_T
+    int32_t first, len;    // global index of the block's first wavelength, number of wavelengths in the block
     int32_t wl_off;        // into wl / alpha
     int32_t trans;         // row of the `active` table
     int32_t wphi_off;      // lines: line_idx * Nspace

@@ -69,37 +69,53 @@ __global__ void k_transpose(const double* __restrict__ in, double* __restrict__ 
     }
 }
 
-// one line's profile: in [col][lt][mu][dir][k]  ->  out [col][k][dir][mu][lt]
-// (compact: in [col][lt][k] -> out [col][k][lt]; pass Nrays = 1, ndir = 1)
-__global__ void k_pack_phi(const double* __restrict__ in, double* __restrict__ out, int Nlam, int Nrays, int ndir,
+// one (tile, line) block of the profile: in [col][lt][mu][dir][k] (rows lt0 .. lt0+len of the line)
+//   ->  out [col]{block: [k][dir][mu][l<len]}     (compact: pass Nrays = 1, ndir = 1)
+__global__ void k_pack_phi(const double* __restrict__ in, double* __restrict__ out, int lt0, int len, int Nrays, int ndir,
                            int Ns, size_t in_col_stride, size_t out_col_stride)
 {
     const size_t col = blockIdx.y;
-    const size_t total = (size_t)Nlam * Nrays * ndir * Ns;
+    const size_t total = (size_t)len * Nrays * ndir * Ns;
     for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
         size_t r = o;
-        const int lt = r % Nlam; r /= Nlam;
+        const int l = r % len; r /= len;
         const int mu = r % Nrays; r /= Nrays;
         const int d = r % ndir; r /= ndir;
         const int k = (int)r;
-        out[col * out_col_stride + o] = in[col * in_col_stride + (((size_t)lt * Nrays + mu) * ndir + d) * Ns + k];
+        out[col * out_col_stride + o] = in[col * in_col_stride + (((size_t)(lt0 + l) * Nrays + mu) * ndir + d) * Ns + k];
     }
 }
 
-// g_ij of a continuum (rh_method.py:453-454): out[col][k][lt]
+// g_ij of a continuum (rh_method.py:453-454) for one (tile, continuum) block: out[col]{[k][l<len]}
 __global__ void k_build_gijc(const double* __restrict__ nStar, const double* __restrict__ temperature,
-                             const double* __restrict__ wavelength, double* __restrict__ out, int li, int lj, int Nblue,
-                             int Nlam, int Ns, int NLtot, size_t out_col_stride)
+                             const double* __restrict__ wavelength, double* __restrict__ out, int li, int lj, int first,
+                             int len, int Ns, int NLtot, size_t out_col_stride)
 {
     const size_t col = blockIdx.y;
     const double hc_k = kHC / (kKBoltzmann * kNM_TO_M);
-    const int total = Nlam * Ns;
+    const int total = len * Ns;
     for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gridDim.x * blockDim.x) {
-        const int lt = o % Nlam, k = o / Nlam;
+        const int l = o % len, k = o / len;
         const double nsi = nStar[(col * NLtot + li) * Ns + k];
         const double nsj = nStar[(col * NLtot + lj) * Ns + k];
         const double T = temperature[col * Ns + k];
-        out[col * out_col_stride + o] = nsi / nsj * exp(-hc_k / wavelength[Nblue + lt] / T);
+        out[col * out_col_stride + o] = nsi / nsj * exp(-hc_k / wavelength[first + l] / T);
+    }
+}
+
+// [col][la][k] (reference layout)  <->  [col][tile][k][j<L] (tile-major streams); unused j are zero
+__global__ void k_tiles_pack(const double* __restrict__ in, double* __restrict__ out, const DevTile* __restrict__ tiles,
+                             int ntile, int L, int Ns, int Nspect, bool unpack)
+{
+    const size_t col = blockIdx.y;
+    const int total = ntile * Ns * L;
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gridDim.x * blockDim.x) {
+        const int j = o % L, k = (o / L) % Ns, t = o / (L * Ns);
+        const bool in_tile = j < tiles[t].nla;
+        const size_t ref = (col * Nspect + (size_t)(tiles[t].la0 + j)) * Ns + k;
+        const size_t til = col * (size_t)total + o;
+        if (unpack) { if (in_tile) out[ref] = in[til]; }
+        else out[til] = in_tile ? in[ref] : 0.0;
     }
 }
 
@@ -380,7 +396,7 @@ struct lsx_ctx {
     uint8_t* d_colmask = nullptr; // per-column activity, nullptr = all active
     double* d_debug = nullptr;   // 64 x 16 x 8 B, diagnostic builds of the sweep kernel write stamps here
     int jcur = 0; // d_J[jcur] holds the current J (Jdag of the next call)
-    size_t phi_col = 0, gijc_col = 0, sca_col = 0;
+    size_t phi_col = 0, phi_in_col = 0, gijc_col = 0, sca_col = 0, til_col = 0;
     // staging
     double* d_stage = nullptr;
     size_t stage_doubles = 0;
@@ -426,6 +442,16 @@ int launch_transpose(lsx_ctx* c, const double* in, double* out, int B, int R, in
 {
     dim3 grid((Cc + 31) / 32, (R + 31) / 32, B), block(32, 8);
     hipLaunchKernelGGL(k_transpose, grid, block, 0, c->stream, in, out, R, Cc);
+    HIPCHK(hipGetLastError());
+    return LSX_OK;
+}
+
+int launch_tiles_pack(lsx_ctx* c, const double* in, double* out, int B, bool unpack)
+{
+    const int total = (int)c->til_col;
+    dim3 grid((total + 255) / 256, B);
+    hipLaunchKernelGGL(k_tiles_pack, grid, dim3(256), 0, c->stream, in, out, c->d_tiles, (int)c->tiles.size(), c->L, c->Nspace,
+                       c->Nspect, unpack);
     HIPCHK(hipGetLastError());
     return LSX_OK;
 }
@@ -550,6 +576,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     }
     // ---- tile schedule: L = 64/Nrays consecutive wavelengths per wavefront pair
     const int P_line = c->phi_compact ? 1 : 2 * c->Nrays;
+    size_t phi_run = 0, gij_run = 0;   // running block offsets inside a column's phi_T / gijc_T
     for (int la0 = 0; la0 < Nspect; la0 += c->L) {
         DevTile tl{};
         tl.la0 = la0;
@@ -628,12 +655,17 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
             sl.cj = (sl.flags & SLOT_LJ_CELL) ? local(lev_ids, h.lj) : 0;
             sl.ca = (sl.flags & SLOT_ETA_CELL) ? local(atom_ids, h.atom) : 0;
             sl.Nblue = h.Nblue; sl.Nlam = h.Nlam; sl.wl_off = h.wl_off; sl.trans = t;
+            // the block of this (tile, transition): the tile's wavelengths inside the transition's range
+            sl.first = std::max(tl.la0, h.Nblue);
+            sl.len = std::min(tl.la0 + tl.nla, h.Nblue + h.Nlam) - sl.first;
             if (h.is_line) {
-                sl.base = h.phi_off * P_line * Ns;
+                sl.base = (int)phi_run;
+                phi_run += (size_t)sl.len * P_line * Ns;
                 sl.wphi_off = h.line_idx * Ns;
                 sl.cB = h.cB; sl.g = h.gij; sl.Vc = h.gij * h.cB; sl.Uc = h.AB * (h.gij * h.cB);
             } else {
-                sl.base = h.cont_off * Ns;
+                sl.base = (int)gij_run;
+                gij_run += (size_t)sl.len * Ns;
             }
             c->slots.push_back(sl);
             c->tile_slots.push_back(t);
@@ -674,9 +706,12 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
 
     // ---- per-column storage
     const size_t nc = ncol;
-    c->phi_col = (size_t)c->SNl * (c->phi_compact ? 1 : 2 * (size_t)c->Nrays) * Ns;
-    c->gijc_col = (size_t)c->SNc * Ns;
-    c->sca_col = (size_t)(c->sca_per_lambda ? Nspect : 1) * Ns;
+    c->phi_in_col = (size_t)c->SNl * (c->phi_compact ? 1 : 2 * (size_t)c->Nrays) * Ns; // as handed over (rh_method.py:224)
+    c->phi_col = phi_run;                                    // as stored: sum of the (tile, line) blocks
+    c->gijc_col = gij_run;
+    c->til_col = c->tiles.size() * (size_t)c->L * Ns;        // one tile-major [tile][k][j] array
+    c->sca_col = c->sca_per_lambda ? c->til_col : (size_t)Ns;
+    if (c->phi_col > 0x7fffffff || c->gijc_col > 0x7fffffff) { lsx_destroy(c); return fail(LSX_EUNSUPPORTED, "column too large for 32-bit offsets"); }
     TRY(dmalloc(&c->d_height, nc * Ns));
     TRY(dmalloc(&c->d_temperature, nc * Ns));
     TRY(dmalloc(&c->d_nStar, nc * c->NLtot * Ns));
@@ -685,13 +720,13 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     TRY(dmalloc(&c->d_C, nc * c->NL2tot * Ns));
     TRY(dmalloc(&c->d_Gamma, nc * c->NL2tot * Ns));
     TRY(dmalloc(&c->d_wphi, nc * c->Nlines * Ns));
-    TRY(dmalloc(&c->d_bgchi, nc * Nspect * Ns));
-    TRY(dmalloc(&c->d_bgeta, nc * Nspect * Ns));
+    TRY(dmalloc(&c->d_bgchi, nc * c->til_col));
+    TRY(dmalloc(&c->d_bgeta, nc * c->til_col));
     TRY(dmalloc(&c->d_sca, nc * c->sca_col));
     TRY(dmalloc(&c->d_phi, nc * c->phi_col));
     TRY(dmalloc(&c->d_gijc, nc * c->gijc_col));
-    TRY(dmalloc(&c->d_J[0], nc * Nspect * Ns));
-    TRY(dmalloc(&c->d_J[1], nc * Nspect * Ns));
+    TRY(dmalloc(&c->d_J[0], nc * c->til_col));
+    TRY(dmalloc(&c->d_J[1], nc * c->til_col));
     TRY(dmalloc(&c->d_I, nc * Nspect * c->Nrays));
     TRY(dmalloc(&c->d_Gpart, nc * c->tile_slots.size() * 4 * Ns));
     TRY(dmalloc(&c->d_dJpart, nc * 2 * c->tiles.size()));
@@ -706,8 +741,8 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         lsx_destroy(c);
         return fail(LSX_EDEVICE, "hipHostMalloc failed");
     }
-    (void)hipMemsetAsync(c->d_J[0], 0, nc * Nspect * Ns * 8, c->stream);
-    (void)hipMemsetAsync(c->d_J[1], 0, nc * Nspect * Ns * 8, c->stream);
+    (void)hipMemsetAsync(c->d_J[0], 0, nc * c->til_col * 8, c->stream);
+    (void)hipMemsetAsync(c->d_J[1], 0, nc * c->til_col * 8, c->stream);
     (void)hipMemsetAsync(c->d_I, 0, nc * Nspect * c->Nrays * 8, c->stream);
     (void)hipMemsetAsync(c->d_Gamma, 0, nc * c->NL2tot * Ns * 8, c->stream);
     (void)hipMemsetAsync(c->d_dJcol, 0, nc * 8, c->stream);
@@ -743,53 +778,52 @@ int lsx_set_columns(lsx_ctx* c, int32_t col0, int32_t ncol, const lsx_columns* s
     if (c->Nlines) TRY(h2d(c->d_wphi + o * c->Nlines * Ns, s->wphi, (size_t)c->Nlines * Ns, ncol));
 
     // arrays that change layout go through the staging buffer in sub-chunks (<= 256 MiB of staging)
-    const size_t per_col_max = std::max<size_t>({(size_t)Nspect * Ns, c->phi_col, (size_t)1});
+    const size_t per_col_max = std::max<size_t>({(size_t)Nspect * Ns, c->phi_in_col, (size_t)1});
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(ncol, ((size_t)32 << 20) / per_col_max));
     TRY(ensure_stage(c, chunk * per_col_max));
     for (size_t b0 = 0; b0 < (size_t)ncol; b0 += chunk) {
         const size_t nb = std::min(chunk, (size_t)ncol - b0);
         const size_t cc = o + b0;
-        // background opacity / emissivity: [la][k] -> [k][la]
+        // background opacity / emissivity: [la][k] -> tile-major [tile][k][j]
         TRY(h2d(c->d_stage, s->bg_chi + b0 * Nspect * Ns, (size_t)Nspect * Ns, nb));
-        TRY(launch_transpose(c, c->d_stage, c->d_bgchi + cc * Nspect * Ns, (int)nb, Nspect, Ns));
+        TRY(launch_tiles_pack(c, c->d_stage, c->d_bgchi + cc * c->til_col, (int)nb, false));
         TRY(h2d(c->d_stage, s->bg_eta + b0 * Nspect * Ns, (size_t)Nspect * Ns, nb));
-        TRY(launch_transpose(c, c->d_stage, c->d_bgeta + cc * Nspect * Ns, (int)nb, Nspect, Ns));
+        TRY(launch_tiles_pack(c, c->d_stage, c->d_bgeta + cc * c->til_col, (int)nb, false));
         if (c->sca_per_lambda) {
             TRY(h2d(c->d_stage, s->bg_sca + b0 * Nspect * Ns, (size_t)Nspect * Ns, nb));
-            TRY(launch_transpose(c, c->d_stage, c->d_sca + cc * c->sca_col, (int)nb, Nspect, Ns));
+            TRY(launch_tiles_pack(c, c->d_stage, c->d_sca + cc * c->sca_col, (int)nb, false));
         } else {
             TRY(h2d(c->d_sca + cc * Ns, s->bg_sca + b0 * Ns, Ns, nb));
         }
-        // line profiles: [lt][mu][dir][k] -> [k][dir][mu][lt] per line
+        // line profiles: rows [lt][mu][dir][k] of a line -> one [k][dir][mu][l] block per (tile, line)
         if (c->Nlines) {
-            TRY(h2d(c->d_stage, s->phi + b0 * c->phi_col, c->phi_col, nb));
+            TRY(h2d(c->d_stage, s->phi + b0 * c->phi_in_col, c->phi_in_col, nb));
             const int R = c->phi_compact ? 1 : c->Nrays, D = c->phi_compact ? 1 : 2;
-            for (int t = 0; t < c->Ntrans; ++t) {
-                const DevTrans& h = c->htrans[t];
-                if (!h.is_line) continue;
-                const size_t off = (size_t)h.phi_off * R * D * Ns;
-                const size_t total = (size_t)h.Nlam * R * D * Ns;
-                dim3 grid((unsigned)std::min<size_t>((total + 255) / 256, 1024), (unsigned)nb);
-                hipLaunchKernelGGL(k_pack_phi, grid, dim3(256), 0, c->stream, c->d_stage + off, c->d_phi + cc * c->phi_col + off,
-                                   h.Nlam, R, D, Ns, c->phi_col, c->phi_col);
+            for (const DevSlot& sl : c->slots) {
+                if (!(sl.flags & SLOT_LINE) || sl.len <= 0) continue;
+                const DevTrans& h = c->htrans[sl.trans];
+                const size_t in_off = (size_t)h.phi_off * R * D * Ns;
+                const size_t total = (size_t)sl.len * R * D * Ns;
+                dim3 grid((unsigned)std::min<size_t>((total + 255) / 256, 256), (unsigned)nb);
+                hipLaunchKernelGGL(k_pack_phi, grid, dim3(256), 0, c->stream, c->d_stage + in_off, c->d_phi + cc * c->phi_col + sl.base,
+                                   sl.first - h.Nblue, sl.len, R, D, Ns, c->phi_in_col, c->phi_col);
                 HIPCHK(hipGetLastError());
             }
         }
-        // continuum g_ij tables
-        for (int t = 0; t < c->Ntrans; ++t) {
-            const DevTrans& h = c->htrans[t];
-            if (h.is_line) continue;
-            dim3 grid((h.Nlam * Ns + 255) / 256, (unsigned)nb);
+        // continuum g_ij tables, one block per (tile, continuum)
+        for (const DevSlot& sl : c->slots) {
+            if ((sl.flags & SLOT_LINE) || sl.len <= 0) continue;
+            dim3 grid((sl.len * Ns + 255) / 256, (unsigned)nb);
             hipLaunchKernelGGL(k_build_gijc, grid, dim3(256), 0, c->stream, c->d_nStar + cc * c->NLtot * Ns,
-                               c->d_temperature + cc * Ns, c->d_wavelength, c->d_gijc + cc * c->gijc_col + (size_t)h.cont_off * Ns,
-                               h.li, h.lj, h.Nblue, h.Nlam, Ns, c->NLtot, c->gijc_col);
+                               c->d_temperature + cc * Ns, c->d_wavelength, c->d_gijc + cc * c->gijc_col + sl.base, sl.li, sl.lj,
+                               sl.first, sl.len, Ns, c->NLtot, c->gijc_col);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipStreamSynchronize(c->stream)); // the staging buffer is re-used by the next sub-chunk
     }
 #undef TRY
     // J starts at 0 (rh_method.py:562); so do I and the convergence monitors of these columns
-    HIPCHK(hipMemsetAsync(c->d_J[c->jcur] + o * Nspect * Ns, 0, (size_t)ncol * Nspect * Ns * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_J[c->jcur] + o * c->til_col, 0, (size_t)ncol * c->til_col * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->d_I + o * Nspect * c->Nrays, 0, (size_t)ncol * Nspect * c->Nrays * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->d_Gamma + o * c->NL2tot * Ns, 0, (size_t)ncol * c->NL2tot * Ns * 8, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -950,7 +984,7 @@ int lsx_get(lsx_ctx* c, int32_t what, int32_t col0, int32_t ncol, double* dst, s
         if (rc) return rc;
         for (size_t b0 = 0; b0 < (size_t)ncol; b0 += chunk) {
             const size_t nb = std::min(chunk, (size_t)ncol - b0);
-            rc = launch_transpose(c, c->d_J[c->jcur] + (col0 + b0) * per, c->d_stage, (int)nb, (int)Ns, c->Nspect);
+            rc = launch_tiles_pack(c, c->d_J[c->jcur] + (col0 + b0) * c->til_col, c->d_stage, (int)nb, true);
             if (rc) return rc;
             HIPCHK(hipMemcpyAsync(dst + b0 * per, c->d_stage, nb * per * 8, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
@@ -981,7 +1015,7 @@ int lsx_set(lsx_ctx* c, int32_t what, int32_t col0, int32_t ncol, const double* 
     for (size_t b0 = 0; b0 < (size_t)ncol; b0 += chunk) {
         const size_t nb = std::min(chunk, (size_t)ncol - b0);
         HIPCHK(hipMemcpyAsync(c->d_stage, src + b0 * per, nb * per * 8, hipMemcpyHostToDevice, c->stream));
-        rc = launch_transpose(c, c->d_stage, c->d_J[c->jcur] + (col0 + b0) * per, (int)nb, c->Nspect, (int)Ns);
+        rc = launch_tiles_pack(c, c->d_stage, c->d_J[c->jcur] + (col0 + b0) * c->til_col, (int)nb, false);
         if (rc) return rc;
         HIPCHK(hipStreamSynchronize(c->stream));
     }

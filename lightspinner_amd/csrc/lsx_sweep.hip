@@ -143,14 +143,14 @@ __device__ __forceinline__ void cell_acc(double* p, double v, bool first)
 #endif
 // wave-uniform copy of a slot's parameters (one batch of scalar loads, then registers)
 struct SlotS {
-    int flags, noff_i, noff_j, ci, cj, ca, Nblue, Nlam, base, wl_off, wphi_off, trans;
+    int flags, noff_i, noff_j, ci, cj, ca, Nblue, Nlam, base, first, len, wl_off, wphi_off, trans;
     double cB, g, Vc, Uc;
 };
 __device__ __forceinline__ SlotS load_slot(const __attribute__((address_space(4))) DevSlot* q, int Ns)
 {
     SlotS r;
     r.flags = q->flags; r.noff_i = q->li * Ns; r.noff_j = q->lj * Ns;
-    r.ci = q->ci; r.cj = q->cj; r.ca = q->ca; r.Nblue = q->Nblue; r.Nlam = q->Nlam; r.base = q->base;
+    r.ci = q->ci; r.cj = q->cj; r.ca = q->ca; r.Nblue = q->Nblue; r.Nlam = q->Nlam; r.base = q->base; r.first = q->first; r.len = q->len;
     r.wl_off = q->wl_off; r.wphi_off = q->wphi_off; r.trans = q->trans;
     r.cB = q->cB; r.g = q->g; r.Vc = q->Vc; r.Uc = q->Uc;
     return r;
@@ -205,11 +205,13 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb)
     const auto* wphi_col = LSX_CONST(double, p.wphi + (size_t)col * p.Nlines * Ns);
     const auto* z = LSX_CONST(double, p.height + (size_t)col * Ns);
     const auto* tcol = LSX_CONST(double, p.temperature + (size_t)col * Ns);
-    const double* __restrict__ bgchi = p.bgchi_T + (size_t)col * Ns * Nspect;
-    const double* __restrict__ bgeta = p.bgeta_T + (size_t)col * Ns * Nspect;
-    const double* __restrict__ Jdag = p.Jdag_T + (size_t)col * Ns * Nspect;
-    double* __restrict__ Jnew = p.Jnew_T + (size_t)col * Ns * Nspect;
-    const double* __restrict__ sca = p.sca + (size_t)col * (p.sca_per_lambda ? (size_t)Ns * Nspect : (size_t)Ns);
+    // tile-major streams of this (column, tile): [k][j]
+    const size_t tbase = ((size_t)col * ntile + tile_id) * Ns * L;
+    const double* __restrict__ bgchi = p.bgchi_T + tbase;
+    const double* __restrict__ bgeta = p.bgeta_T + tbase;
+    const double* __restrict__ Jdag = p.Jdag_T + tbase;
+    double* __restrict__ Jnew = p.Jnew_T + tbase;
+    const double* __restrict__ sca = p.sca_per_lambda ? p.sca + tbase : p.sca + (size_t)col * Ns;
     const double* __restrict__ phi_col = p.phi_T + (size_t)col * p.phi_col_stride;
     const double* __restrict__ gijc_col = p.gijc_T + (size_t)col * p.gijc_col_stride;
     double* __restrict__ gpart = p.Gpart + ((size_t)col * p.nslot_total + slot0) * 4 * Ns;
@@ -249,8 +251,11 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb)
             const int l = a ? la - slots[u].Nblue : 0;
             const int Nlam = slots[u].Nlam;
             const bool line = (slots[u].flags & SLOT_LINE) != 0;
-            idx0[u] = slots[u].base + (line ? raysel * Nlam : 0) + l;
-            kstr[u] = line ? kmul * Nlam : Nlam;
+            const int len = slots[u].len;
+            const int lb = a ? la - slots[u].first : 0;      // position inside the (tile, transition) block
+            (void)Nlam;
+            idx0[u] = slots[u].base + (line ? raysel * len : 0) + lb;
+            kstr[u] = line ? kmul * len : len;
             wlv[u] = a ? p.wl[slots[u].wl_off + l] : 0.0;
             alv[u] = (a && !line) ? p.alpha[slots[u].wl_off + l] : 0.0;
         }
@@ -258,18 +263,19 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb)
 
     // total opacity at depth kk (boundary-condition look-ahead, formal_solver.py:204-207)
     auto chi_at = [&](int kk) -> double {
-        double c = bgchi[kk * Nspect + la];
+        double c = bgchi[kk * L + j];
         for (int u = 0; u < nP + nF; ++u) {
             const SlotS sl = load_slot(slots + u, Ns);
             const double ni = n_col[sl.noff_i + kk];
             const double nj = n_col[sl.noff_j + kk];
             const bool a = u < nP ? (pact >> u) & 1u : (fact >> (u - nP)) & 1u;
             const int l = a ? la - sl.Nblue : 0;
+            const int lb = a ? la - sl.first : 0;
             if (sl.flags & SLOT_LINE) {
-                const double pv = a ? phi_col[sl.base + (kk * kmul + raysel) * sl.Nlam + l] : 0.0;
+                const double pv = a ? phi_col[sl.base + (kk * kmul + raysel) * sl.len + lb] : 0.0;
                 c += (sl.cB * (ni - sl.g * nj)) * pv;
             } else {
-                const double g = a ? gijc_col[sl.base + kk * sl.Nlam + l] : 0.0;
+                const double g = a ? gijc_col[sl.base + kk * sl.len + lb] : 0.0;
                 const double alf = a ? p.alpha[sl.wl_off + l] : 0.0;
                 c += ni * alf - nj * (g * alf);
             }
@@ -311,7 +317,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb)
 
     for (int s = 0; s < Ns; ++s) {
         const int k = kS + dk * s;
-        const int kl = k * Nspect + la;
+        const int kl = k * L + j;                       // position in the tile-major [k][j] streams
         // ---- every HBM / table read of the per-ray slots for this depth, in one batch ----
         const double jd = Jdag[kl];
         double chiTot = bgchi[kl];
@@ -343,7 +349,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb)
             const double nj = n_col[sl.noff_j + k];
             const bool a = (fact >> f) & 1u;
             const int l = a ? la - sl.Nblue : 0;
-            const double g = a ? gijc_col[sl.base + k * sl.Nlam + l] : 0.0;
+            const double g = a ? gijc_col[sl.base + k * sl.len + (la - sl.first)] : 0.0;
             const double alf = a ? p.alpha[sl.wl_off + l] : 0.0;
             const double Vji = g * alf;                 // rh_method.py:284-285
             const double chi = ni * alf - nj * Vji;     // :613
@@ -400,9 +406,9 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb)
                 const int l = a ? la - sl.Nblue : 0;
                 double v, alf = 0.0;
                 if (sl.flags & SLOT_LINE) {
-                    v = a ? phi_col[sl.base + (k * kmul + raysel) * sl.Nlam + l] : 0.0;
+                    v = a ? phi_col[sl.base + (k * kmul + raysel) * sl.len + (la - sl.first)] : 0.0;
                 } else {
-                    v = a ? gijc_col[sl.base + k * sl.Nlam + l] : 0.0;
+                    v = a ? gijc_col[sl.base + k * sl.len + (la - sl.first)] : 0.0;
                     alf = a ? p.alpha[sl.wl_off + l] : 0.0;
                 }
                 double pv, chi, Uji;
@@ -496,14 +502,14 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb)
                 double wla = a ? p.wl[sl.wl_off + l] : 0.0;
                 double pv, Vij, Uji, chi;
                 if (sl.flags & SLOT_LINE) {
-                    pv = a ? phi_col[sl.base + (k * kmul + raysel) * sl.Nlam + l] : 0.0; // L1/L2 hit
+                    pv = a ? phi_col[sl.base + (k * kmul + raysel) * sl.len + (la - sl.first)] : 0.0; // L1/L2 hit
                     Vij = sl.cB * pv;
                     Uji = sl.Uc * pv;
                     chi = (sl.cB * (ni - sl.g * nj)) * pv;
                     wla *= wphi_col[sl.wphi_off + k];
                 } else {
                     Vij = a ? p.alpha[sl.wl_off + l] : 0.0;
-                    pv = (a ? gijc_col[sl.base + k * sl.Nlam + l] : 0.0) * Vij;          // Vji
+                    pv = (a ? gijc_col[sl.base + k * sl.len + (la - sl.first)] : 0.0) * Vij;          // Vji
                     Uji = u_la * pv;
                     chi = ni * Vij - nj * pv;
                 }
@@ -522,7 +528,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb)
                 const double nj = n_col[sl.noff_j + k];
                 const bool a = (fact >> f) & 1u;
                 const int l = a ? la - sl.Nblue : 0;
-                const double g = a ? gijc_col[sl.base + k * sl.Nlam + l] : 0.0;
+                const double g = a ? gijc_col[sl.base + k * sl.len + (la - sl.first)] : 0.0;
                 const double alf = a ? p.alpha[sl.wl_off + l] : 0.0;
                 const double wla = a ? p.wl[sl.wl_off + l] : 0.0;
                 const double Vji = g * alf;
@@ -599,12 +605,8 @@ lsx_sweep_kernel(const SweepParams p)
     const int tile_id = vb % p.ntile_total;
     if (p.colmask && LSX_CONST(uint8_t, p.colmask)[vb / p.ntile_total] == 0) {
         // frozen column: nothing is computed; J only moves to the other half of the ping-pong pair
-        const auto* tp = LSX_CONST(DevTile, p.tiles) + tile_id;
-        const size_t cbase = (size_t)(vb / p.ntile_total) * p.Nspace * p.Nspect;
-        for (int e = threadIdx.x; e < tp->nla * p.Nspace; e += 2 * LSX_WAVE) {
-            const int k = e / tp->nla, la = tp->la0 + e - k * tp->nla;
-            p.Jnew_T[cbase + (size_t)k * p.Nspect + la] = p.Jdag_T[cbase + (size_t)k * p.Nspect + la];
-        }
+        const size_t tb = (size_t)vb * p.Nspace * p.L;    // vb = col * ntile + tile
+        for (int e = threadIdx.x; e < p.Nspace * p.L; e += 2 * LSX_WAVE) p.Jnew_T[tb + e] = p.Jdag_T[tb + e];
         return;
     }
     const int nP = (LSX_CONST(DevTile, p.tiles) + tile_id)->nP;
