@@ -8,7 +8,7 @@
 //     bgchi_T, bgeta_T   [col][tile][k][j<L]
 //     J_T[2]             [col][tile][k][j<L]      ping-pong: Jdag <- previous call
 //     sca                [col][k]  (or [col][tile][k][j] when sca_per_lambda)
-//     phi_T              [col] { per (tile, line slot): [k][dir][mu][l<len] }   (compact: [k][l])
+//     phi_T              [col] { per (tile, line slot): [dir][k][mu][l<len] }   (compact: [k][l])
 //     gijc_T             [col] { per (tile, continuum slot): [k][l<len] }  g_ij of (26) in [U01], built at upload
 //   where the slot's block covers the len wavelengths of the tile inside the transition's range
 //   per column, reference layout (level-major; the sweep reads them with wave-uniform
@@ -94,7 +94,7 @@ struct SweepParams {
     int32_t nslot_total, ntile_total;
     int32_t L;                  // wavelengths per tile
     int32_t ncell_lev, ncell_atom, nstash; // LDS layout: [2*ncell_lev level cells][ncell_atom][nstash][1 exchange row]
-    int32_t pad;
+    int32_t n_class_tiles;      // tiles of the launched class
     // column-independent tables
     const double* wavelength;   // [Nspect]
     const double* zmu;          // [Nrays] 1/muz
@@ -105,6 +105,7 @@ struct SweepParams {
     const uint8_t* active;      // [Ntrans][Nspect]
     const DevTile* tiles;
     const DevSlot* slots;       // per (tile, slot) parameters
+    const int32_t* class_tiles; // tile ids of the launched class
     // per-column strides (in doubles)
     int64_t phi_col_stride, gijc_col_stride;
     // per-column arrays

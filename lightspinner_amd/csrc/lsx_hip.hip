@@ -21,7 +21,7 @@
 #include "lsx_dev.h"
 
 // launcher defined in lsx_sweep.hip
-extern "C" hipError_t lsx_launch_sweep(const SweepParams*, int, size_t, hipStream_t);
+extern "C" hipError_t lsx_launch_sweep(const SweepParams*, int, int, size_t, hipStream_t);
 
 namespace {
 
@@ -70,7 +70,7 @@ __global__ void k_transpose(const double* __restrict__ in, double* __restrict__ 
 }
 
 // one (tile, line) block of the profile: in [col][lt][mu][dir][k] (rows lt0 .. lt0+len of the line)
-//   ->  out [col]{block: [k][dir][mu][l<len]}     (compact: pass Nrays = 1, ndir = 1)
+//   ->  out [col]{block: [dir][k][mu][l<len]}     (compact: pass Nrays = 1, ndir = 1)
 __global__ void k_pack_phi(const double* __restrict__ in, double* __restrict__ out, int lt0, int len, int Nrays, int ndir,
                            int Ns, size_t in_col_stride, size_t out_col_stride)
 {
@@ -80,8 +80,8 @@ __global__ void k_pack_phi(const double* __restrict__ in, double* __restrict__ o
         size_t r = o;
         const int l = r % len; r /= len;
         const int mu = r % Nrays; r /= Nrays;
-        const int d = r % ndir; r /= ndir;
-        const int k = (int)r;
+        const int k = r % Ns; r /= Ns;
+        const int d = (int)r;
         out[col * out_col_stride + o] = in[col * in_col_stride + (((size_t)(lt0 + l) * Nrays + mu) * ndir + d) * Ns + k];
     }
 }
@@ -362,6 +362,16 @@ __global__ void k_piecewise(int nray, int Ns, const double* __restrict__ z, cons
 } // namespace
 
 // ------------------------------------------------------------------------------- context
+struct SweepClass {           // tiles that run the same kernel instantiation, launched on their own stream
+    int npt = -1;              // compile-time per-ray slot count, -1 = generic
+    std::vector<int> tiles;
+    int* d_tiles = nullptr;
+    int ncell_lev = 1, ncell_atom = 1;
+    size_t lds_bytes = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+};
+
 struct lsx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -376,7 +386,9 @@ struct lsx_ctx {
     std::vector<int> tile_slots;
     std::vector<DevSlot> slots;
     DevSlot* d_slots = nullptr;
-    int L = 0, ncell_lev = 0, ncell_atom = 0, nstash = 0;
+    int L = 0;
+    std::vector<SweepClass> classes;
+    hipEvent_t ev_fork = nullptr;
     double ms_sweep = 0.0, ms_finish = 0.0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     size_t lds_bytes = 0;
@@ -489,6 +501,12 @@ void lsx_destroy(lsx_ctx* c)
                     c->d_dJcol, c->d_dPcol, c->d_max, c->d_singular, c->d_stage, c->d_debug, c->d_colmask};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    for (auto& k : c->classes) {
+        if (k.d_tiles) (void)hipFree(k.d_tiles);
+        if (k.done) (void)hipEventDestroy(k.done);
+        if (k.stream) { (void)hipStreamSynchronize(k.stream); (void)hipStreamDestroy(k.stream); }
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (hipEvent_t e : {c->ev0, c->ev1, c->ev2})
         if (e) (void)hipEventDestroy(e);
     if (c->evA) (void)hipEventDestroy(c->evA);
@@ -670,17 +688,26 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
             c->slots.push_back(sl);
             c->tile_slots.push_back(t);
         }
-        c->ncell_lev = std::max(c->ncell_lev, (int)lev_ids.size());
-        c->ncell_atom = std::max(c->ncell_atom, (int)atom_ids.size());
-        c->nstash = std::max(c->nstash, tl.nP);
+        const int npt = tl.nP <= 3 ? tl.nP : -1;
+        SweepClass* k = nullptr;
+        for (auto& q : c->classes)
+            if (q.npt == npt) k = &q;
+        if (!k) { c->classes.push_back(SweepClass()); k = &c->classes.back(); k->npt = npt; }
+        k->tiles.push_back((int)c->tiles.size());
+        k->ncell_lev = std::max(k->ncell_lev, (int)lev_ids.size());
+        k->ncell_atom = std::max(k->ncell_atom, (int)atom_ids.size());
         c->tiles.push_back(tl);
     }
-    c->ncell_lev = std::max(c->ncell_lev, 1);
-    c->ncell_atom = std::max(c->ncell_atom, 1);
-    c->nstash = std::max(c->nstash, 1);
-    // per wave: level cells, atom cells, stash, angle-sum row; + two cross-wave exchange rows
-    c->lds_bytes = (size_t)(2 * (2 * c->ncell_lev + c->ncell_atom + 1) + 2) * LSX_WAVE * sizeof(double);
-    if (c->lds_bytes > 64 * 1024) { lsx_destroy(c); return fail(LSX_EUNSUPPORTED, "lsx_create: tile needs %zu B of LDS", c->lds_bytes); }
+    // heaviest class first (its workgroups are enqueued first; the light classes fill the gaps)
+    std::sort(c->classes.begin(), c->classes.end(), [](const SweepClass& a, const SweepClass& b) { return a.tiles.size() > b.tiles.size(); });
+    for (auto& k : c->classes) {
+        // per wave: level cells, atom cells, angle-sum row; + two cross-wave exchange rows; + the static
+        // path's per-depth table of wave-uniform operands, Nspace x (3 npt + 2) doubles
+        k.lds_bytes = (size_t)(2 * (2 * k.ncell_lev + k.ncell_atom + 1) + 2) * LSX_WAVE * sizeof(double) +
+                      (size_t)(k.npt >= 0 ? Ns * (3 * k.npt + 2) : 0) * sizeof(double);
+        if (k.lds_bytes > 64 * 1024) { lsx_destroy(c); return fail(LSX_EUNSUPPORTED, "lsx_create: a tile needs %zu B of LDS", k.lds_bytes); }
+        c->lds_bytes = std::max(c->lds_bytes, k.lds_bytes);
+    }
 
     // ---- uploads of the column independent tables
     std::vector<double> zmu(c->Nrays, 1.0), wmuh(c->Nrays, 0.0), u_la(Nspect);
@@ -701,6 +728,11 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     TRY(upload(&c->d_slots, c->slots, c->stream));
     TRY(upload(&c->d_Nlevel, c->Nlevel, c->stream));
     TRY(upload(&c->d_lev2_off, c->lev2_off, c->stream));
+    for (auto& k : c->classes) {
+        TRY(upload(&k.d_tiles, k.tiles, c->stream));
+        if (hipStreamCreateWithFlags(&k.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&k.done, hipEventDisableTiming) != hipSuccess) { lsx_destroy(c); return fail(LSX_EDEVICE, "class stream"); }
+    }
+    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { lsx_destroy(c); return fail(LSX_EDEVICE, "hipEventCreate"); }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess) { lsx_destroy(c); return fail(LSX_EDEVICE, "hipEventCreate"); }
     if (hipEventCreate(&c->evA) != hipSuccess || hipEventCreate(&c->evB) != hipSuccess) { lsx_destroy(c); return fail(LSX_EDEVICE, "hipEventCreate"); }
 
@@ -838,7 +870,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
     p.ncol = c->ncol; p.NLtot = c->NLtot; p.NL2tot = c->NL2tot; p.Nlines = c->Nlines;
     p.sca_per_lambda = c->sca_per_lambda; p.phi_compact = c->phi_compact;
     p.nslot_total = (int)c->tile_slots.size(); p.ntile_total = (int)c->tiles.size();
-    p.L = c->L; p.ncell_lev = c->ncell_lev; p.ncell_atom = c->ncell_atom; p.nstash = c->nstash;
+    p.L = c->L;
     p.wavelength = c->d_wavelength; p.zmu = c->d_zmu; p.wmuh = c->d_wmuh; p.wl = c->d_wl; p.alpha = c->d_alpha;
     p.u_la = c->d_u_la; p.active = c->d_active; p.tiles = c->d_tiles; p.slots = c->d_slots;
     p.phi_col_stride = (int64_t)c->phi_col; p.gijc_col_stride = (int64_t)c->gijc_col;
@@ -847,11 +879,40 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
     p.Jdag_T = c->d_J[c->jcur]; p.Jnew_T = c->d_J[c->jcur ^ 1];
     p.Iout = c->d_I; p.Gpart = c->d_Gpart; p.dJpart = c->d_dJpart; p.debug = c->d_debug; p.colmask = c->d_colmask;
 
-    const long nblocks = (long)c->tiles.size() * c->ncol;
-    if (nblocks > 0x7fffffffL) return fail(LSX_EUNSUPPORTED, "grid too large");
     if (timed) HIPCHK(hipEventRecord(c->ev0, c->stream));
-    hipError_t e = lsx_launch_sweep(&p, (int)nblocks, c->lds_bytes, c->stream);
-    if (e != hipSuccess) return fail(LSX_EDEVICE, "sweep launch: %s", hipGetErrorString(e));
+    // small batches: one fused launch (n_class_tiles == ntile, identity tile list is not needed)
+    if (c->ncol < 32) {
+        const long nblocks = (long)c->tiles.size() * c->ncol;
+        p.class_tiles = nullptr;
+        p.n_class_tiles = (int)c->tiles.size();
+        p.ncell_lev = 1; p.ncell_atom = 1;
+        for (auto& k : c->classes) { p.ncell_lev = std::max(p.ncell_lev, k.ncell_lev); p.ncell_atom = std::max(p.ncell_atom, k.ncell_atom); }
+        int npt_max = -1;
+        for (auto& k : c->classes) npt_max = std::max(npt_max, k.npt);
+        const size_t lds = (size_t)(2 * (2 * p.ncell_lev + p.ncell_atom + 1) + 2) * LSX_WAVE * sizeof(double) +
+                           (size_t)(npt_max >= 0 ? c->Nspace * (3 * npt_max + 2) : 0) * sizeof(double);
+        hipError_t e = lsx_launch_sweep(&p, -2, (int)nblocks, lds, c->stream);
+        if (e != hipSuccess) return fail(LSX_EDEVICE, "sweep launch (fused): %s", hipGetErrorString(e));
+    } else {
+    // the classes of one call run side by side: fork from the context's stream, join back into it
+    const bool fork = c->classes.size() > 1;
+    if (fork) HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+    for (auto& k : c->classes) {
+        const long nblocks = (long)k.tiles.size() * c->ncol;
+        if (nblocks > 0x7fffffffL) return fail(LSX_EUNSUPPORTED, "grid too large");
+        p.class_tiles = k.d_tiles;
+        p.n_class_tiles = (int)k.tiles.size();
+        p.ncell_lev = k.ncell_lev; p.ncell_atom = k.ncell_atom; p.nstash = 0;
+        hipStream_t st = fork ? k.stream : c->stream;
+        if (fork) HIPCHK(hipStreamWaitEvent(st, c->ev_fork, 0));
+        hipError_t e = lsx_launch_sweep(&p, k.npt, (int)nblocks, k.lds_bytes, st);
+        if (e != hipSuccess) return fail(LSX_EDEVICE, "sweep launch (per-ray slots %d): %s", k.npt, hipGetErrorString(e));
+        if (fork) {
+            HIPCHK(hipEventRecord(k.done, st));
+            HIPCHK(hipStreamWaitEvent(c->stream, k.done, 0));
+        }
+    }
+    }
     if (timed) HIPCHK(hipEventRecord(c->ev1, c->stream));
 
     FinishParams f{};

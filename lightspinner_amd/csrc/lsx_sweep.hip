@@ -93,6 +93,17 @@ __device__ __forceinline__ double wave_sum(double v) // total in every lane
     for (int m = 1; m < LSX_WAVE; m <<= 1) v += __shfl_xor(v, m, LSX_WAVE);
     return v;
 }
+__device__ __forceinline__ double reduce_pair(double a, double b)
+{
+    const double sa = wave_sum(a), sb = wave_sum(b);
+    return (threadIdx.x & 63) == 63 ? sb : sa;
+}
+__device__ __forceinline__ double reduce_quad(double a, double b, double c, double d)
+{
+    const double sa = wave_sum(a), sb = wave_sum(b), sc = wave_sum(c), sd = wave_sum(d);
+    const int l = threadIdx.x & 63;
+    return l == 15 ? sa : (l == 31 ? sc : (l == 47 ? sb : sd));
+}
 #else
 // DPP (VALU cross-lane moves, no LDS crossbar traffic).  The total of the 64 lanes ends up in
 // lane 63 (the lane that stores it).
@@ -113,6 +124,39 @@ __device__ __forceinline__ double wave_sum(double v)
     v += dpp_f64<0x142, 0xa>(v); // row_bcast15 into rows 1 and 3: lane 31 = rows 0+1, lane 63 = rows 2+3
     v += dpp_f64<0x143, 0xc>(v); // row_bcast31 into rows 2 and 3: lane 63 = all four rows
     return v;
+}
+// Two values reduced for the price of one: v_permlane32_swap exchanges the upper half of `a` with
+// the lower half of `b`, so ONE add folds both vectors to 32 partial sums each (a's in lanes 0-31,
+// b's in lanes 32-63).  Result: lane 31 = sum(a), lane 63 = sum(b).
+__device__ __forceinline__ double fold32(double a, double b)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double row_sums(double v)   // every lane of a 16-lane row gets the row's sum
+{
+    v += dpp_f64<0xB1, 0xf>(v);
+    v += dpp_f64<0x4E, 0xf>(v);
+    v += dpp_f64<0x141, 0xf>(v);
+    v += dpp_f64<0x140, 0xf>(v);
+    return v;
+}
+__device__ __forceinline__ double reduce_pair(double a, double b)   // lane 31: sum(a), lane 63: sum(b)
+{
+    double t = row_sums(fold32(a, b));
+    t += dpp_f64<0x142, 0xa>(t);
+    return t;
+}
+// Four values: a second fold with v_permlane16_swap (odd rows of the first operand <-> even rows of
+// the second) leaves one value per 16-lane row.  Result: lane 15 = sum(a), lane 31 = sum(c),
+// lane 47 = sum(b), lane 63 = sum(d).
+__device__ __forceinline__ double reduce_quad(double a, double b, double c, double d)
+{
+    const double ab = fold32(a, b), cd = fold32(c, d);
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(ab), __double2loint(cd), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(ab), __double2hiint(cd), false, false);
+    return row_sums(__hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]));
 }
 #endif
 
@@ -139,7 +183,7 @@ __device__ __forceinline__ void cell_acc(double* p, double v, bool first)
 } // namespace
 
 #ifndef LSX_WAVES_PER_EU
-#define LSX_WAVES_PER_EU 5
+#define LSX_WAVES_PER_EU 4
 #endif
 // wave-uniform copy of a slot's parameters (one batch of scalar loads, then registers)
 struct SlotS {
@@ -159,8 +203,11 @@ __device__ __forceinline__ SlotS load_slot(const __attribute__((address_space(4)
 // NPT >= 0: the tile's per-ray slot count as a compile-time constant: slot state lives in registers,
 // every load of a depth step is issued in one batch at the top of the step (one wait), the two
 // passes are pure VALU + LDS.  NPT < 0: generic tile (runtime slot loops, loads in place).
-template <int NPT>
-__device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb)
+// NR > 0: number of rays per wavelength as a compile-time constant (angle sums unroll into independent
+// LDS reads); SCAL: the scattering coefficient may be wavelength dependent (vector load) -- otherwise
+// it is one scalar per depth.
+template <int NPT, int NR, bool SCAL>
+__device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, const int tile_id)
 {
     extern __shared__ double lds[];
     constexpr bool STATIC = NPT >= 0;
@@ -168,8 +215,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb)
     const int lane = threadIdx.x & (LSX_WAVE - 1);
     const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0: down (toFrom False), 1: up (True)
     const int ntile = p.ntile_total;
-    const int col = vb / ntile;
-    const int tile_id = vb - col * ntile;
+    const int col = vb / p.n_class_tiles;
     const auto* tilep = LSX_CONST(DevTile, p.tiles) + tile_id;
     const int la0 = tilep->la0, nla = tilep->nla, slot0 = tilep->slot0;
     const int nP = STATIC ? NPT : tilep->nP;
@@ -178,8 +224,8 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb)
     const auto* fslots = slots + nP;
     const int Ns = p.Nspace;
     const int Nspect = p.Nspect;
-    const int Nrays = p.Nrays;
-    const int L = p.L;
+    const int Nrays = NR > 0 ? NR : p.Nrays;
+    const int L = NR > 0 ? LSX_WAVE / NR : p.L;
 
     // lane -> ray.  Lanes without a ray shadow a real one (finite arithmetic) and are masked out of
     // every store and reduction.
@@ -199,6 +245,11 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb)
 #define CETA(a) wrow[(2 * p.ncell_lev + (a)) * LSX_WAVE]
     double* const xrow = lds + (size_t)dir * rows * LSX_WAVE + (size_t)(rows - 1) * LSX_WAVE; // angle sums
     double* const xwg = lds + (size_t)2 * rows * LSX_WAVE;                                    // [2][64] cross-wave
+    // static path: per-depth wave-uniform operands of the tile (n_i, n_j, wphi per slot, z, sigma) are
+    // staged once per workgroup as a depth-major table utab[k][TR] -> one address register, immediate
+    // offsets, counted LDS waits (scalar-cache loads return out of order and serialise on lgkmcnt(0))
+    constexpr int TR = STATIC ? 3 * NPT + 2 : 1;
+    double* const utab = xwg + 2 * LSX_WAVE;
 
     // column bases; wave-uniform reads go through the scalar cache
     const auto* n_col = LSX_CONST(double, p.n + (size_t)col * p.NLtot * Ns);
@@ -211,10 +262,28 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb)
     const double* __restrict__ bgeta = p.bgeta_T + tbase;
     const double* __restrict__ Jdag = p.Jdag_T + tbase;
     double* __restrict__ Jnew = p.Jnew_T + tbase;
-    const double* __restrict__ sca = p.sca_per_lambda ? p.sca + tbase : p.sca + (size_t)col * Ns;
+    const bool sca_l = SCAL && p.sca_per_lambda;
+    const double* __restrict__ sca = sca_l ? p.sca + tbase : p.sca + (size_t)col * Ns;
     const double* __restrict__ phi_col = p.phi_T + (size_t)col * p.phi_col_stride;
     const double* __restrict__ gijc_col = p.gijc_T + (size_t)col * p.gijc_col_stride;
     double* __restrict__ gpart = p.Gpart + ((size_t)col * p.nslot_total + slot0) * 4 * Ns;
+
+    if constexpr (STATIC) {
+        const double* srcs[TR];
+#pragma unroll
+        for (int u = 0; u < NPT; ++u) {
+            srcs[3 * u + 0] = p.n + (size_t)col * p.NLtot * Ns + (size_t)slots[u].li * Ns;
+            srcs[3 * u + 1] = p.n + (size_t)col * p.NLtot * Ns + (size_t)slots[u].lj * Ns;
+            srcs[3 * u + 2] = (slots[u].flags & SLOT_LINE) ? p.wphi + (size_t)col * p.Nlines * Ns + slots[u].wphi_off : nullptr;
+        }
+        srcs[3 * NPT + 0] = p.height + (size_t)col * Ns;
+        srcs[3 * NPT + 1] = sca_l ? nullptr : p.sca + (size_t)col * Ns;
+        for (int e = threadIdx.x; e < Ns; e += 2 * LSX_WAVE) {
+#pragma unroll
+            for (int r = 0; r < TR; ++r) utab[e * TR + r] = srcs[r] ? srcs[r][e] : 1.0;
+        }
+        __syncthreads();
+    }
 
     const double wav = p.wavelength[la];
     const double u_la = p.u_la[la];
@@ -224,9 +293,10 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb)
     const bool compact = p.phi_compact != 0;
     const int kS = dir ? Ns - 1 : 0;
     const int dk = dir ? -1 : 1;
-    // ray part of a line-profile index: ((k*2 + dir)*Nrays + mu) * Nlam + lt
-    const int raysel = compact ? 0 : dir * Nrays + mu;
-    const int kmul = compact ? 1 : 2 * Nrays;
+    // line-profile index inside a (tile, line) block: ((dir*Ns + k)*Nrays + mu) * len + l, i.e. one
+    // contiguous stream per direction (compact profile: k*len + l)
+    const int raysel = compact ? 0 : dir * Ns * Nrays + mu;
+    const int kmul = compact ? 1 : Nrays;
 
     // activity bits of this lane's wavelength
     unsigned pact = 0, fact = 0;
@@ -315,30 +385,58 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb)
 #define STAMP(i)
 #endif
 
-    for (int s = 0; s < Ns; ++s) {
-        const int k = kS + dk * s;
-        const int kl = k * L + j;                       // position in the tile-major [k][j] streams
-        // ---- every HBM / table read of the per-ray slots for this depth, in one batch ----
-        const double jd = Jdag[kl];
-        double chiTot = bgchi[kl];
-        const double be_l = bgeta[kl];
-        double sv[NS], sni[NS], snj[NS], swp[NS];
+    // static path: the HBM-streaming operands of a step (background, Jdag, the slots' profile / g_ij
+    // values) are requested one depth ahead.  Memory returns in order, and the static path issues no
+    // other vector load inside a step (slot constants sit in registers; the half-J read comes last),
+    // so the requests of step s+1 are in flight during the arithmetic of step s.
+    double n_bc = 0.0, n_be = 0.0, n_jd = 0.0, n_sv[NS];
+    auto stream_loads = [&](int kk, double& bc, double& be, double& jdv, double (&v)[NS]) {
+        const int kkl = kk * L + j;
+        jdv = Jdag[kkl];
+        bc = bgchi[kkl];
+        be = bgeta[kkl];
         if constexpr (STATIC) {
 #pragma unroll
             for (int u = 0; u < NPT; ++u) {
                 const bool a = (pact >> u) & 1u;
-                const bool line = (slots[u].flags & SLOT_LINE) != 0;
-                const double* tab = line ? phi_col : gijc_col;
-                sv[u] = a ? tab[idx0[u] + k * kstr[u]] : 0.0;
-                sni[u] = n_col[slots[u].li * Ns + k];
-                snj[u] = n_col[slots[u].lj * Ns + k];
-                swp[u] = line ? wphi_col[slots[u].wphi_off + k] : 1.0;
+                const double* tab = (slots[u].flags & SLOT_LINE) ? phi_col : gijc_col;
+                v[u] = a ? tab[idx0[u] + kk * kstr[u]] : 0.0;
             }
         }
-        const double zk = z[k];
+    };
+    if constexpr (STATIC) stream_loads(kS, n_bc, n_be, n_jd, n_sv);
+
+    for (int s = 0; s < Ns; ++s) {
+        const int k = kS + dk * s;
+        const int kl = k * L + j;                       // position in the tile-major [k][j] streams
+        double jd, chiTot, be_l;
+        double sv[NS], sni[NS], snj[NS], swp[NS];
+        if constexpr (STATIC) {
+            jd = n_jd; chiTot = n_bc; be_l = n_be;
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) sv[u] = n_sv[u];
+            if (s + 1 < Ns) stream_loads(k + dk, n_bc, n_be, n_jd, n_sv);
+            const double* tk = utab + k * TR;
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                sni[u] = tk[3 * u + 0];
+                snj[u] = tk[3 * u + 1];
+                swp[u] = tk[3 * u + 2];
+            }
+        } else {
+            stream_loads(k, chiTot, be_l, jd, sv);
+        }
+        double zk, scv;
+        if constexpr (STATIC) {
+            zk = utab[k * TR + 3 * NPT];
+            scv = sca_l ? sca[kl] : utab[k * TR + 3 * NPT + 1];
+        } else {
+            zk = z[k];
+            scv = sca_l ? sca[kl] : LSX_CONST(double, sca)[k];
+        }
         const double hdzm = (0.5 * fabs(zprev - zk)) * zmu_l;
         zprev = zk;
-        double etaTot = be_l + (p.sca_per_lambda ? sca[kl] : LSX_CONST(double, sca)[k]) * jd;
+        double etaTot = be_l + scv * jd;
         STAMP(0);
 
         // ---- fast continua: opacity, emissivity, level cells (ray independent) ----------
@@ -450,20 +548,22 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb)
         xrow[lane] = wmuh_l * I;
         __builtin_amdgcn_wave_barrier();
         double Jsum = 0.0;
+#pragma unroll
         for (int m = 0; m < Nrays; ++m) Jsum += xrow[m * L + j];
         double sPsi = 0.0;
         if (nF > 0) {
             __builtin_amdgcn_wave_barrier();
             xrow[lane] = wq_l * Psi;
             __builtin_amdgcn_wave_barrier();
+#pragma unroll
             for (int m = 0; m < Nrays; ++m) sPsi += xrow[m * L + j];
         }
         __builtin_amdgcn_wave_barrier();
         STAMP(4);
 
         // ---- pass 2: Gamma integrands of the per-ray transitions (rh_method.py:643-681) ----
-        auto pass2 = [&](const SlotS& sl, int u, bool a, double pv, double chi, double Uji, double Vij, double nj,
-                         double wla) {
+        auto pass2 = [&](const SlotS& sl, bool a, double pv, double chi, double Uji, double Vij, double nj, double wla,
+                         double& wg1, double& wg2) {
             const int fl = sl.flags;
             const double Vji = (fl & SLOT_LINE) ? sl.Vc * pv : pv;
             const double eta = nj * Uji;
@@ -476,21 +576,35 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb)
             const double g1 = (Uji + Vji * Ieff) - (chi_i * Psi) * U_j;    // :677
             const double g2 = (Vij * Ieff) - (chi_j * Psi) * U_i;          // :680
             const double wt = (a && valid) ? wq_l * wla : 0.0;             // :665
-            const double r1 = wave_sum(wt * g1);
-            const double r2 = wave_sum(wt * g2);
-            if (lane == LSX_WAVE - 1) {
-                double* g = gpart + (u * 4 + dir) * Ns + k; // [slot][e][dir][k]
-                g[0] = r1;          // e = 0: Gamma[i][j]
-                g[2 * Ns] = r2;     // e = 1: Gamma[j][i]
-            }
+            wg1 = wt * g1;
+            wg2 = wt * g2;
         };
+        // store the reductions of slot u: Gpart[slot][e][dir][k], e = 0: Gamma[i][j], e = 1: Gamma[j][i]
+        auto gslot = [&](int u, int e) -> double* { return gpart + ((u * 2 + e) * 2 + dir) * Ns + k; };
         if constexpr (STATIC) {
+            double w1[NS], w2v[NS];
 #pragma unroll
             for (int u = 0; u < NPT; ++u) {
                 const SlotS sl = load_slot(slots + u, Ns);
                 const bool line = (sl.flags & SLOT_LINE) != 0;
                 const double Vij = line ? sl.cB * spv[u] : alv[u];
-                pass2(sl, u, (pact >> u) & 1u, spv[u], schi[u], sUji[u], Vij, snj[u], wlv[u] * swp[u]); // :451, :455
+                pass2(sl, (pact >> u) & 1u, spv[u], schi[u], sUji[u], Vij, snj[u], wlv[u] * swp[u], w1[u], w2v[u]); // :451, :455
+            }
+            if constexpr (NPT == 1) {
+                const double t = reduce_pair(w1[0], w2v[0]);
+                if (lane == 31) *gslot(0, 0) = t;
+                if (lane == 63) *gslot(0, 1) = t;
+            } else if constexpr (NPT >= 2) {
+                const double t = reduce_quad(w1[0], w2v[0], w1[1], w2v[1]);
+                if (lane == 15) *gslot(0, 0) = t;
+                if (lane == 47) *gslot(0, 1) = t;
+                if (lane == 31) *gslot(1, 0) = t;
+                if (lane == 63) *gslot(1, 1) = t;
+                if constexpr (NPT == 3) {
+                    const double t2 = reduce_pair(w1[2], w2v[2]);
+                    if (lane == 31) *gslot(2, 0) = t2;
+                    if (lane == 63) *gslot(2, 1) = t2;
+                }
             }
         } else {
             for (int u = 0; u < nP; ++u) {
@@ -513,7 +627,11 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb)
                     Uji = u_la * pv;
                     chi = ni * Vij - nj * pv;
                 }
-                pass2(sl, u, a, pv, chi, Uji, Vij, nj, wla);
+                double wg1, wg2;
+                pass2(sl, a, pv, chi, Uji, Vij, nj, wla, wg1, wg2);
+                const double t = reduce_pair(wg1, wg2);
+                if (lane == 31) *gslot(u, 0) = t;
+                if (lane == 63) *gslot(u, 1) = t;
             }
         }
         STAMP(5);
@@ -544,13 +662,9 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb)
                 const double g1 = (Uji * sW + Vji * sIe) - (chi_i * U_j) * sPsi;
                 const double g2 = (alf * sIe) - (chi_j * U_i) * sPsi;
                 const double wt = (a && lead) ? wla : 0.0;
-                const double r1 = wave_sum(wt * g1);
-                const double r2 = wave_sum(wt * g2);
-                if (lane == LSX_WAVE - 1) {
-                    double* gp = gpart + ((nP + f) * 4 + dir) * Ns + k;
-                    gp[0] = r1;
-                    gp[2 * Ns] = r2;
-                }
+                const double t = reduce_pair(wt * g1, wt * g2);
+                if (lane == 31) *gslot(nP + f, 0) = t;
+                if (lane == 63) *gslot(nP + f, 1) = t;
             }
         }
         STAMP(6);
@@ -593,35 +707,74 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb)
 #undef CETA
 }
 
-__global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(LSX_WAVES_PER_EU)))
+// One kernel per (NPT, NR, SCAL) class; the host launches the classes of a call on separate streams
+// so they share the machine (a class alone would leave a tail).
+// register budget per class: tiles without per-ray slots fit 5 waves/SIMD, the others 4 (more would spill)
+#define LSX_WPE(NPT) ((NPT) == 0 ? LSX_WAVES_PER_EU + 1 : LSX_WAVES_PER_EU)
+template <int NPT, int NR, bool SCAL>
+__global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(LSX_WPE(NPT))))
 lsx_sweep_kernel(const SweepParams p)
 {
+    // XCD-aware block -> (column, tile): workgroups are dealt round-robin over the 8 XCDs (b and
+    // b+8 share one), so every XCD gets a contiguous range of (column, tile) pairs.  A different
+    // placement would change speed only, never results.
     int vb;
     {
         const int nb = gridDim.x, x = blockIdx.x & 7, q = blockIdx.x >> 3;
         const int nb8 = nb >> 3, rem = nb & 7;
         vb = x * nb8 + (x < rem ? x : rem) + q;
     }
-    const int tile_id = vb % p.ntile_total;
-    if (p.colmask && LSX_CONST(uint8_t, p.colmask)[vb / p.ntile_total] == 0) {
+    const int col = vb / p.n_class_tiles;
+    const int tile_id = LSX_CONST(int32_t, p.class_tiles)[vb - col * p.n_class_tiles];
+    if (p.colmask && LSX_CONST(uint8_t, p.colmask)[col] == 0) {
         // frozen column: nothing is computed; J only moves to the other half of the ping-pong pair
-        const size_t tb = (size_t)vb * p.Nspace * p.L;    // vb = col * ntile + tile
+        const size_t tb = ((size_t)col * p.ntile_total + tile_id) * p.Nspace * p.L;
+        for (int e = threadIdx.x; e < p.Nspace * p.L; e += 2 * LSX_WAVE) p.Jnew_T[tb + e] = p.Jdag_T[tb + e];
+        return;
+    }
+    sweep_tile<NPT, NR, SCAL>(p, vb, tile_id);
+}
+
+// Small batches (a few columns) are latency bound: one launch that dispatches on the tile's class inside
+// beats five tiny launches on five streams.
+template <int NR, bool SCAL>
+__global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(LSX_WAVES_PER_EU)))
+lsx_sweep_kernel_all(const SweepParams p)
+{
+    const int vb = blockIdx.x;
+    const int col = vb / p.ntile_total;
+    const int tile_id = vb - col * p.ntile_total;
+    if (p.colmask && LSX_CONST(uint8_t, p.colmask)[col] == 0) {
+        const size_t tb = (size_t)vb * p.Nspace * p.L;
         for (int e = threadIdx.x; e < p.Nspace * p.L; e += 2 * LSX_WAVE) p.Jnew_T[tb + e] = p.Jdag_T[tb + e];
         return;
     }
     const int nP = (LSX_CONST(DevTile, p.tiles) + tile_id)->nP;
-#ifndef LSX_NO_SPECIALIZE
-    if (nP == 0) sweep_tile<0>(p, vb);
-    else if (nP == 1) sweep_tile<1>(p, vb);
-    else if (nP == 2) sweep_tile<2>(p, vb);
-    else if (nP == 3) sweep_tile<3>(p, vb);
-    else
-#endif
-        sweep_tile<-1>(p, vb);
+    if (nP == 0) sweep_tile<0, NR, SCAL>(p, vb, tile_id);
+    else if (nP == 1) sweep_tile<1, NR, SCAL>(p, vb, tile_id);
+    else if (nP == 2) sweep_tile<2, NR, SCAL>(p, vb, tile_id);
+    else if (nP == 3) sweep_tile<3, NR, SCAL>(p, vb, tile_id);
+    else sweep_tile<-1, NR, SCAL>(p, vb, tile_id);
 }
 
-extern "C" hipError_t lsx_launch_sweep(const SweepParams* p, int nblocks, size_t lds_bytes, hipStream_t st)
+template <int NR, bool SCAL>
+static void launch_class(const SweepParams& p, int npt, dim3 g, dim3 b, size_t lds_bytes, hipStream_t st)
 {
-    hipLaunchKernelGGL(lsx_sweep_kernel, dim3(nblocks), dim3(2 * LSX_WAVE), lds_bytes, st, *p);
+    switch (npt) {
+    case -2: hipLaunchKernelGGL((lsx_sweep_kernel_all<NR, SCAL>), g, b, lds_bytes, st, p); break;
+    case 0: hipLaunchKernelGGL((lsx_sweep_kernel<0, NR, SCAL>), g, b, lds_bytes, st, p); break;
+    case 1: hipLaunchKernelGGL((lsx_sweep_kernel<1, NR, SCAL>), g, b, lds_bytes, st, p); break;
+    case 2: hipLaunchKernelGGL((lsx_sweep_kernel<2, NR, SCAL>), g, b, lds_bytes, st, p); break;
+    case 3: hipLaunchKernelGGL((lsx_sweep_kernel<3, NR, SCAL>), g, b, lds_bytes, st, p); break;
+    default: hipLaunchKernelGGL((lsx_sweep_kernel<-1, NR, SCAL>), g, b, lds_bytes, st, p); break;
+    }
+}
+
+extern "C" hipError_t lsx_launch_sweep(const SweepParams* p, int npt, int nblocks, size_t lds_bytes, hipStream_t st)
+{
+    const dim3 g(nblocks), b(2 * LSX_WAVE);
+    if (!p->sca_per_lambda && p->Nrays == 5) launch_class<5, false>(*p, npt, g, b, lds_bytes, st);
+    else if (!p->sca_per_lambda && p->Nrays == 3) launch_class<3, false>(*p, npt, g, b, lds_bytes, st);
+    else launch_class<0, true>(*p, npt, g, b, lds_bytes, st);
     return hipGetLastError();
 }
