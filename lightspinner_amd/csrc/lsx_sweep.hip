@@ -390,6 +390,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     // other vector load inside a step (slot constants sit in registers; the half-J read comes last),
     // so the requests of step s+1 are in flight during the arithmetic of step s.
     double n_bc = 0.0, n_be = 0.0, n_jd = 0.0, n_sv[NS];
+
     auto stream_loads = [&](int kk, double& bc, double& be, double& jdv, double (&v)[NS]) {
         const int kkl = kk * L + j;
         jdv = Jdag[kkl];
@@ -710,7 +711,13 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
 // One kernel per (NPT, NR, SCAL) class; the host launches the classes of a call on separate streams
 // so they share the machine (a class alone would leave a tail).
 // register budget per class: tiles without per-ray slots fit 5 waves/SIMD, the others 4 (more would spill)
-#define LSX_WPE(NPT) ((NPT) == 0 ? LSX_WAVES_PER_EU + 1 : LSX_WAVES_PER_EU)
+#ifndef LSX_WPE0
+#define LSX_WPE0 (LSX_WAVES_PER_EU + 1)
+#endif
+#ifndef LSX_WPE1
+#define LSX_WPE1 LSX_WAVES_PER_EU
+#endif
+#define LSX_WPE(NPT) ((NPT) == 0 ? LSX_WPE0 : ((NPT) == 1 ? LSX_WPE1 : LSX_WAVES_PER_EU))
 template <int NPT, int NR, bool SCAL>
 __global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(LSX_WPE(NPT))))
 lsx_sweep_kernel(const SweepParams p)
