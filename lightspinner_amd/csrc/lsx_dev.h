@@ -65,6 +65,7 @@ struct DevSlot {
     int32_t flags;
     int32_t li, lj;        // global level ids (rows of n)
     int32_t ci, cj, ca;    // tile-local LDS cell ids: level cells of i and j, atom cell
+    int32_t atom;          // active-atom index
     int32_t Nblue, Nlam;
     int32_t base;          // element offset of this (tile, transition) block inside the column's phi_T / gijc_T
     int32_t first, len;    // global index of the block's first wavelength, number of wavelengths in the block
@@ -115,6 +116,9 @@ struct SweepParams {
     const double* wphi;         // [col][Nlines][k]
     const double* bgchi_T;
     const double* bgeta_T;
+    const double* bgxchi_T;     // effective background of tiles with fast continua (k_fast_prepass)
+    const double* bgxeta_T;
+    double* Psi2_T;             // [dir][col][tile][k][j]  sum_mu w Psi* per direction (tiles with fast continua)
     const double* sca;
     const double* phi_T;
     const double* gijc_T;

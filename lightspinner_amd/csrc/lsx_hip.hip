@@ -184,6 +184,147 @@ __global__ void k_gamma_finish(const FinishParams f)
     }
 }
 
+// ---- fast continua (atoms with no line in the tile): ray independent, handled outside the sweep ----
+struct FastParams {
+    int Nspace, Nspect, Nrays, ncol, ntile, L, NLtot, Natoms, nslot_total, n_fast_tiles;
+    const DevTile* tiles;
+    const DevSlot* slots;
+    const int* fast_tiles;      // ids of the tiles with nF > 0
+    const uint8_t* active;
+    const double* alpha;
+    const double* wl;
+    const double* u_la;
+    const double* wmuh;
+    const double* n;            // [col][NLtot][k]
+    const double* gijc_T;
+    size_t gijc_col;
+    const double* bgchi_T;
+    const double* bgeta_T;
+    double* bgxchi_T;
+    double* bgxeta_T;
+    const double* J_T;          // the NEW J (after the sweep), tile-major
+    const double* Psi2_T;       // [dir][col][tile][k][j]
+    double* Gpart;
+    const uint8_t* colmask;
+};
+
+// one fast continuum at (lambda, depth): rh_method.py:284-286, 453-455, 613-614
+struct FastVal { double alf, Vji, Uji, chi, eta; bool a; };
+__device__ __forceinline__ FastVal fast_value(const FastParams& f, const DevSlot& sl, size_t col, int la, int k)
+{
+    FastVal v;
+    const int lt = la - sl.Nblue;
+    v.a = lt >= 0 && lt < sl.Nlam && f.active[(size_t)sl.trans * f.Nspect + la] != 0;
+    v.alf = v.Vji = v.Uji = v.chi = v.eta = 0.0;
+    if (v.a) {
+        const double ni = f.n[(col * f.NLtot + sl.li) * f.Nspace + k];
+        const double nj = f.n[(col * f.NLtot + sl.lj) * f.Nspace + k];
+        const double g = f.gijc_T[col * f.gijc_col + sl.base + (size_t)k * sl.len + (la - sl.first)];
+        v.alf = f.alpha[sl.wl_off + lt];
+        v.Vji = g * v.alf;
+        v.Uji = f.u_la[la] * v.Vji;
+        v.chi = ni * v.alf - nj * v.Vji;
+        v.eta = nj * v.Uji;
+    }
+    return v;
+}
+
+// effective background of the tiles that have fast continua: bgx = bg + sum over the tile's fast continua
+__global__ void k_fast_prepass(const FastParams f)
+{
+    const size_t col = blockIdx.z;
+    if (f.colmask && !f.colmask[col]) return;
+    const int t = f.fast_tiles[blockIdx.y];
+    const DevTile tl = f.tiles[t];
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;       // (k, j)
+    if (e >= f.Nspace * f.L) return;
+    const int k = e / f.L, j = e - k * f.L;
+    const size_t o = ((col * f.ntile + t) * f.Nspace) * f.L + e;
+    double chi = f.bgchi_T[o], eta = f.bgeta_T[o];
+    if (j < tl.nla) {
+        const int la = tl.la0 + j;
+        for (int q = 0; q < tl.nF; ++q) {
+            const FastVal v = fast_value(f, f.slots[tl.slot0 + tl.nP + q], col, la, k);
+            chi += v.chi;
+            eta += v.eta;
+        }
+    }
+    f.bgxchi_T[o] = chi;
+    f.bgxeta_T[o] = eta;
+}
+
+// Gamma slabs of the fast continua from J and Psibar (both directions summed):
+//   sum_{mu,dir} w (Uji + Vji Ieff - chi_lev_i Psi U_lev_j)  with Ieff = I - Psi eta_atom   (rh_method.py:652, 677-681)
+//   = Uji sW + Vji (sI - eta_atom sPsi) - chi_lev_i U_lev_j sPsi,   sI = 4 pi J, sPsi = sum w Psi*, sW = 4 pi sum_mu w_mu
+//   (w = (w_mu/2) 4 pi per ray and direction, rh_method.py:661-665; all sums over both directions)
+// one block per (depth chunk, fast tile, column); thread = (depth in chunk, wavelength of the tile)
+__global__ void k_fast_gamma(const FastParams f, int KC)
+{
+    extern __shared__ double sm[];
+    const size_t col = blockIdx.z;
+    if (f.colmask && !f.colmask[col]) return;
+    const int t = f.fast_tiles[blockIdx.y];
+    const DevTile tl = f.tiles[t];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int kc = tid / f.L, j = tid - kc * f.L;
+    const int k = blockIdx.x * KC + kc;
+    const bool on = kc < KC && k < f.Nspace && j < tl.nla;
+    const int ncell = 2 * f.NLtot + f.Natoms;
+    double* cell = sm + tid;                       // thread-private cells: cell[c * nt]
+    double* red = sm + (size_t)ncell * nt;         // red[(q*2 + e) * nt + tid]
+    const DevSlot* fs = f.slots + tl.slot0 + tl.nP;
+    const int la = tl.la0 + (j < tl.nla ? j : 0);
+    double sW = 0.0;
+    for (int m = 0; m < f.Nrays; ++m) sW += 2.0 * f.wmuh[m] * (4.0 * M_PI);   // both directions
+    for (int c = 0; c < ncell; ++c) cell[c * nt] = 0.0;
+    if (on) {
+        for (int q = 0; q < tl.nF; ++q) {          // atom.chi / atom.U / atom.eta of rh_method.py:616-627
+            const FastVal v = fast_value(f, fs[q], col, la, k);
+            cell[fs[q].li * nt] += v.chi;
+            cell[fs[q].lj * nt] -= v.chi;
+            cell[(f.NLtot + fs[q].lj) * nt] += v.Uji;
+            cell[(2 * f.NLtot + fs[q].atom) * nt] += v.eta;
+        }
+    }
+    double sI = 0.0, sPsi = 0.0;
+    if (on) {
+        const size_t o = ((col * f.ntile + t) * f.Nspace + k) * f.L + j;
+        const size_t dstride = (size_t)f.ncol * f.ntile * f.Nspace * f.L;
+        sI = f.J_T[o] * (4.0 * M_PI);
+        sPsi = f.Psi2_T[o] + f.Psi2_T[dstride + o];
+    }
+    for (int q = 0; q < tl.nF; ++q) {
+        double g1 = 0.0, g2 = 0.0;
+        if (on) {
+            const FastVal v = fast_value(f, fs[q], col, la, k);
+            if (v.a) {
+                const double etaA = cell[(2 * f.NLtot + fs[q].atom) * nt];
+                const double chi_i = cell[fs[q].li * nt], chi_j = cell[fs[q].lj * nt];
+                const double U_i = cell[(f.NLtot + fs[q].li) * nt], U_j = cell[(f.NLtot + fs[q].lj) * nt];
+                const double sIe = sI - etaA * sPsi;
+                const double wla = f.wl[fs[q].wl_off + (la - fs[q].Nblue)];
+                g1 = wla * ((v.Uji * sW + v.Vji * sIe) - (chi_i * U_j) * sPsi);
+                g2 = wla * ((v.alf * sIe) - (chi_j * U_i) * sPsi);
+            }
+        }
+        red[(q * 2 + 0) * nt + tid] = g1;
+        red[(q * 2 + 1) * nt + tid] = g2;
+    }
+    __syncthreads();
+    // wavelength quadrature: fixed-order sum over the tile's wavelengths, one thread per (slot, entry, depth)
+    for (int w = tid; w < tl.nF * 2 * KC; w += nt) {
+        const int kc2 = w % KC, qe = w / KC;
+        const int k2 = blockIdx.x * KC + kc2;
+        if (k2 >= f.Nspace) continue;
+        double acc = 0.0;
+        for (int jj = 0; jj < tl.nla; ++jj) acc += red[(size_t)qe * nt + kc2 * f.L + jj];
+        const int q = qe >> 1, e = qe & 1;
+        double* g = f.Gpart + (((col * f.nslot_total + tl.slot0 + tl.nP + q) * 2 + e) * 2) * f.Nspace + k2;
+        g[0] = acc;               // direction 0 carries the total
+        g[f.Nspace] = 0.0;        // direction 1
+    }
+}
+
 __device__ __forceinline__ void atomic_max_nonneg(double* addr, double v)
 {
     // for non-negative doubles (and +NaN) the IEEE bit pattern orders like the value; NaN wins
@@ -406,6 +547,10 @@ struct lsx_ctx {
            *d_Gpart = nullptr, *d_dJpart = nullptr, *d_dJcol = nullptr, *d_dPcol = nullptr, *d_max = nullptr;
     int* d_singular = nullptr;
     uint8_t* d_colmask = nullptr; // per-column activity, nullptr = all active
+    double *d_bgxchi = nullptr, *d_bgxeta = nullptr, *d_Psi2 = nullptr; // fast-continuum side arrays
+    std::vector<int> fast_tiles;
+    int* d_fast_tiles = nullptr;
+    int nF_max = 0;
     double* d_debug = nullptr;   // 64 x 16 x 8 B, diagnostic builds of the sweep kernel write stamps here
     int jcur = 0; // d_J[jcur] holds the current J (Jdag of the next call)
     size_t phi_col = 0, phi_in_col = 0, gijc_col = 0, sca_col = 0, til_col = 0;
@@ -498,7 +643,7 @@ void lsx_destroy(lsx_ctx* c)
                     c->d_tiles, c->d_slots, c->d_tile_slots, c->d_Nlevel, c->d_lev2_off, c->d_height,
                     c->d_temperature, c->d_nStar, c->d_nTotal, c->d_n, c->d_C, c->d_Gamma, c->d_wphi, c->d_bgchi,
                     c->d_bgeta, c->d_sca, c->d_phi, c->d_gijc, c->d_J[0], c->d_J[1], c->d_I, c->d_Gpart, c->d_dJpart,
-                    c->d_dJcol, c->d_dPcol, c->d_max, c->d_singular, c->d_stage, c->d_debug, c->d_colmask};
+                    c->d_dJcol, c->d_dPcol, c->d_max, c->d_singular, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& k : c->classes) {
@@ -667,7 +812,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
             const DevTrans& h = c->htrans[t];
             DevSlot sl{};
             sl.flags = first_flags[t];
-            sl.li = h.li; sl.lj = h.lj;
+            sl.li = h.li; sl.lj = h.lj; sl.atom = h.atom;
             // cells exist only for levels / atoms that two transitions of the tile share
             sl.ci = (sl.flags & (SLOT_LI_CELL | SLOT_UI_READ)) ? local(lev_ids, h.li) : 0;
             sl.cj = (sl.flags & SLOT_LJ_CELL) ? local(lev_ids, h.lj) : 0;
@@ -688,6 +833,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
             c->slots.push_back(sl);
             c->tile_slots.push_back(t);
         }
+        if (tl.nF > 0) { c->fast_tiles.push_back((int)c->tiles.size()); c->nF_max = std::max(c->nF_max, tl.nF); }
         const int npt = tl.nP <= 3 ? tl.nP : -1;
         SweepClass* k = nullptr;
         for (auto& q : c->classes)
@@ -767,6 +913,13 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     TRY(dmalloc(&c->d_max, 4));
     TRY(dmalloc(&c->d_singular, 1));
     TRY(dmalloc(&c->d_debug, 64 * 16));
+    if (!c->fast_tiles.empty()) {
+        TRY(upload(&c->d_fast_tiles, c->fast_tiles, c->stream));
+        TRY(dmalloc(&c->d_bgxchi, nc * c->til_col));
+        TRY(dmalloc(&c->d_bgxeta, nc * c->til_col));
+        TRY(dmalloc(&c->d_Psi2, 2 * nc * c->til_col));
+        (void)hipMemsetAsync(c->d_Psi2, 0, 2 * nc * c->til_col * 8, c->stream);
+    }
     (void)hipMemsetAsync(c->d_debug, 0, 64 * 16 * 8, c->stream);
 #undef TRY
     if (hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), 4 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
@@ -875,10 +1028,24 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
     p.u_la = c->d_u_la; p.active = c->d_active; p.tiles = c->d_tiles; p.slots = c->d_slots;
     p.phi_col_stride = (int64_t)c->phi_col; p.gijc_col_stride = (int64_t)c->gijc_col;
     p.height = c->d_height; p.temperature = c->d_temperature; p.n = c->d_n; p.wphi = c->d_wphi;
-    p.bgchi_T = c->d_bgchi; p.bgeta_T = c->d_bgeta; p.sca = c->d_sca; p.phi_T = c->d_phi; p.gijc_T = c->d_gijc;
+    p.bgchi_T = c->d_bgchi; p.bgeta_T = c->d_bgeta; p.bgxchi_T = c->d_bgxchi; p.bgxeta_T = c->d_bgxeta; p.Psi2_T = c->d_Psi2; p.sca = c->d_sca; p.phi_T = c->d_phi; p.gijc_T = c->d_gijc;
     p.Jdag_T = c->d_J[c->jcur]; p.Jnew_T = c->d_J[c->jcur ^ 1];
     p.Iout = c->d_I; p.Gpart = c->d_Gpart; p.dJpart = c->d_dJpart; p.debug = c->d_debug; p.colmask = c->d_colmask;
 
+    FastParams ff{};
+    const bool has_fast = !c->fast_tiles.empty();
+    if (has_fast) {
+        ff.Nspace = c->Nspace; ff.Nspect = c->Nspect; ff.Nrays = c->Nrays; ff.ncol = c->ncol; ff.ntile = (int)c->tiles.size();
+        ff.L = c->L; ff.NLtot = c->NLtot; ff.Natoms = c->Natoms; ff.nslot_total = (int)c->tile_slots.size();
+        ff.n_fast_tiles = (int)c->fast_tiles.size(); ff.tiles = c->d_tiles; ff.slots = c->d_slots; ff.fast_tiles = c->d_fast_tiles;
+        ff.active = c->d_active; ff.alpha = c->d_alpha; ff.wl = c->d_wl; ff.u_la = c->d_u_la; ff.wmuh = c->d_wmuh; ff.n = c->d_n;
+        ff.gijc_T = c->d_gijc; ff.gijc_col = c->gijc_col; ff.bgchi_T = c->d_bgchi; ff.bgeta_T = c->d_bgeta;
+        ff.bgxchi_T = c->d_bgxchi; ff.bgxeta_T = c->d_bgxeta; ff.J_T = c->d_J[c->jcur ^ 1]; ff.Psi2_T = c->d_Psi2;
+        ff.Gpart = c->d_Gpart; ff.colmask = c->d_colmask;
+        dim3 grid((c->Nspace * c->L + 255) / 256, (unsigned)c->fast_tiles.size(), (unsigned)c->ncol);
+        hipLaunchKernelGGL(k_fast_prepass, grid, dim3(256), 0, c->stream, ff);
+        HIPCHK(hipGetLastError());
+    }
     if (timed) HIPCHK(hipEventRecord(c->ev0, c->stream));
     // small batches: one fused launch (n_class_tiles == ntile, identity tile list is not needed)
     if (c->ncol < 32) {
@@ -914,6 +1081,14 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
     }
     }
     if (timed) HIPCHK(hipEventRecord(c->ev1, c->stream));
+    if (has_fast) {
+        const int KC = std::max(1, 64 / c->L), nt = 64;
+        const size_t sm = (size_t)(2 * c->NLtot + c->Natoms + 2 * c->nF_max) * nt * sizeof(double);
+        if (sm > 64 * 1024) return fail(LSX_EUNSUPPORTED, "fast-continuum epilogue needs %zu B of LDS", sm);
+        dim3 grid((c->Nspace + KC - 1) / KC, (unsigned)c->fast_tiles.size(), (unsigned)c->ncol);
+        hipLaunchKernelGGL(k_fast_gamma, grid, dim3(nt), sm, c->stream, ff, KC);
+        HIPCHK(hipGetLastError());
+    }
 
     FinishParams f{};
     f.Nspace = c->Nspace; f.Natoms = c->Natoms; f.NL2tot = c->NL2tot; f.ncol = c->ncol; f.ntile = (int)c->tiles.size();

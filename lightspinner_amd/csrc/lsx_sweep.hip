@@ -27,9 +27,12 @@
 //     atom.U / atom.eta, rh_method.py:616-627) lives in lane-private LDS cells, and only where two
 //     transitions of the tile really share a level or an atom (host-computed flags).
 //   * transitions of a tile come in two kinds.  PER-RAY slots (lines, and continua of an atom
-//     that has a line in the tile) go through both passes.  FAST continua (atoms with no line in
-//     the tile) are ray independent: their Gamma integrand is affine in I and Psi* with
-//     ray-independent coefficients, so it follows from sum_mu w I and sum_mu w Psi*.
+//     that has a line in the tile) go through both passes here.  FAST continua (atoms with no line
+//     in the tile) are ray independent and never enter this kernel: a pre-pass (k_fast_prepass)
+//     folds their opacity/emissivity into an effective background, and because their Gamma
+//     integrand is affine in I and Psi* with ray-independent coefficients, a post-pass
+//     (k_fast_gamma) forms it from J = sum w I and Psibar = sum w Psi*, which this kernel stores
+//     per direction for the tiles that have such continua.
 #include <hip/hip_runtime.h>
 #include "lsx_dev.h"
 
@@ -221,7 +224,6 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     const int nP = STATIC ? NPT : tilep->nP;
     const int nF = tilep->nF;
     const auto* slots = LSX_CONST(DevSlot, p.slots) + slot0;   // [0, nP): per-ray, [nP, nP+nF): fast
-    const auto* fslots = slots + nP;
     const int Ns = p.Nspace;
     const int Nspect = p.Nspect;
     const int Nrays = NR > 0 ? NR : p.Nrays;
@@ -258,8 +260,10 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     const auto* tcol = LSX_CONST(double, p.temperature + (size_t)col * Ns);
     // tile-major streams of this (column, tile): [k][j]
     const size_t tbase = ((size_t)col * ntile + tile_id) * Ns * L;
-    const double* __restrict__ bgchi = p.bgchi_T + tbase;
-    const double* __restrict__ bgeta = p.bgeta_T + tbase;
+    // tiles with fast continua read the effective background written by k_fast_prepass
+    const double* __restrict__ bgchi = (nF > 0 ? p.bgxchi_T : p.bgchi_T) + tbase;
+    const double* __restrict__ bgeta = (nF > 0 ? p.bgxeta_T : p.bgeta_T) + tbase;
+    double* __restrict__ psibar = p.Psi2_T + ((size_t)dir * p.ncol * ntile) * Ns * L + tbase;   // [dir][col][tile][k][j]
     const double* __restrict__ Jdag = p.Jdag_T + tbase;
     double* __restrict__ Jnew = p.Jnew_T + tbase;
     const bool sca_l = SCAL && p.sca_per_lambda;
@@ -299,14 +303,10 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     const int kmul = compact ? 1 : Nrays;
 
     // activity bits of this lane's wavelength
-    unsigned pact = 0, fact = 0;
+    unsigned pact = 0;
     for (int u = 0; u < nP; ++u) {
         const int l = la - slots[u].Nblue;
         if (l >= 0 && l < slots[u].Nlam && p.active[slots[u].trans * Nspect + la] != 0) pact |= 1u << u;
-    }
-    for (int f = 0; f < nF; ++f) {
-        const int l = la - fslots[f].Nblue;
-        if (l >= 0 && l < fslots[f].Nlam && p.active[fslots[f].trans * Nspect + la] != 0) fact |= 1u << f;
     }
 
     // static path: per-slot lane state in registers
@@ -334,11 +334,11 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     // total opacity at depth kk (boundary-condition look-ahead, formal_solver.py:204-207)
     auto chi_at = [&](int kk) -> double {
         double c = bgchi[kk * L + j];
-        for (int u = 0; u < nP + nF; ++u) {
+        for (int u = 0; u < nP; ++u) {
             const SlotS sl = load_slot(slots + u, Ns);
             const double ni = n_col[sl.noff_i + kk];
             const double nj = n_col[sl.noff_j + kk];
-            const bool a = u < nP ? (pact >> u) & 1u : (fact >> (u - nP)) & 1u;
+            const bool a = (pact >> u) & 1u;
             const int l = a ? la - sl.Nblue : 0;
             const int lb = a ? la - sl.first : 0;
             if (sl.flags & SLOT_LINE) {
@@ -366,8 +366,6 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     double chi_prev = 1.0, S_prev = 0.0, dtau_prev = 1.0;
     double dJ = 0.0;
     double zprev = z[kS];
-    double sW = 0.0;
-    for (int m = 0; m < Nrays; ++m) sW += LSX_CONST(double, p.wmuh)[m] * (4.0 * kPi);
     // diagnostic build only (-DLSX_STAMPS): per-segment shader-clock totals of a few sample waves go
     // to p.debug, a buffer nothing else reads (cdna_hip_programming.md, In-kernel stamps)
 #ifdef LSX_STAMPS
@@ -440,29 +438,6 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         double etaTot = be_l + scv * jd;
         STAMP(0);
 
-        // ---- fast continua: opacity, emissivity, level cells (ray independent) ----------
-        for (int f = 0; f < nF; ++f) {
-            const SlotS sl = load_slot(fslots + f, Ns);
-            const int fl = sl.flags;
-            const double ni = n_col[sl.noff_i + k];
-            const double nj = n_col[sl.noff_j + k];
-            const bool a = (fact >> f) & 1u;
-            const int l = a ? la - sl.Nblue : 0;
-            const double g = a ? gijc_col[sl.base + k * sl.len + (la - sl.first)] : 0.0;
-            const double alf = a ? p.alpha[sl.wl_off + l] : 0.0;
-            const double Vji = g * alf;                 // rh_method.py:284-285
-            const double chi = ni * alf - nj * Vji;     // :613
-            const double Uji = u_la * Vji;              // :286
-            const double eta = nj * Uji;                // :614
-            if (fl & SLOT_LI_CELL) cell_acc(&CCHI(sl.ci), chi, fl & SLOT_CHI_I_FIRST);   // :619
-            if (fl & SLOT_LJ_CELL) {
-                cell_acc(&CCHI(sl.cj), -chi, fl & SLOT_CHI_J_FIRST);                     // :620
-                cell_acc(&CU(sl.cj), Uji, fl & SLOT_U_J_FIRST);                          // :622
-            }
-            if (fl & SLOT_ETA_CELL) cell_acc(&CETA(sl.ca), eta, fl & SLOT_ETA_FIRST);    // :627
-            chiTot += chi;
-            etaTot += eta;
-        }
         STAMP(1);
 
         // ---- pass 1: opacity / emissivity of the per-ray transitions (rh_method.py:601-627) ----
@@ -551,13 +526,14 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         double Jsum = 0.0;
 #pragma unroll
         for (int m = 0; m < Nrays; ++m) Jsum += xrow[m * L + j];
-        double sPsi = 0.0;
-        if (nF > 0) {
+        if (nF > 0) {                                   // Psibar of this direction, for k_fast_gamma
             __builtin_amdgcn_wave_barrier();
             xrow[lane] = wq_l * Psi;
             __builtin_amdgcn_wave_barrier();
+            double sPsi = 0.0;
 #pragma unroll
             for (int m = 0; m < Nrays; ++m) sPsi += xrow[m * L + j];
+            if (lead) psibar[kl] = sPsi;
         }
         __builtin_amdgcn_wave_barrier();
         STAMP(4);
@@ -637,37 +613,6 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         }
         STAMP(5);
 
-        // ---- fast continua: Gamma integrand from the ray sums (one lane per wavelength) ----
-        if (nF > 0) {
-            const double sI = Jsum * (4.0 * kPi);       // sum_mu (w_mu/2 4pi) I
-            for (int f = 0; f < nF; ++f) {
-                const SlotS sl = load_slot(fslots + f, Ns);
-                const int fl = sl.flags;
-                const double ni = n_col[sl.noff_i + k];
-                const double nj = n_col[sl.noff_j + k];
-                const bool a = (fact >> f) & 1u;
-                const int l = a ? la - sl.Nblue : 0;
-                const double g = a ? gijc_col[sl.base + k * sl.len + (la - sl.first)] : 0.0;
-                const double alf = a ? p.alpha[sl.wl_off + l] : 0.0;
-                const double wla = a ? p.wl[sl.wl_off + l] : 0.0;
-                const double Vji = g * alf;
-                const double Uji = u_la * Vji;
-                const double chi = ni * alf - nj * Vji;
-                const double eta = nj * Uji;
-                const double etaA = (fl & SLOT_ETA_CELL) ? CETA(sl.ca) : eta;
-                const double chi_i = (fl & SLOT_LI_CELL) ? CCHI(sl.ci) : chi;
-                const double chi_j = (fl & SLOT_LJ_CELL) ? CCHI(sl.cj) : -chi;
-                const double U_j = (fl & SLOT_LJ_CELL) ? CU(sl.cj) : Uji;
-                const double U_i = (fl & SLOT_UI_READ) ? CU(sl.ci) : 0.0;
-                const double sIe = sI - etaA * sPsi;                       // sum_mu w (I - Psi eta)
-                const double g1 = (Uji * sW + Vji * sIe) - (chi_i * U_j) * sPsi;
-                const double g2 = (alf * sIe) - (chi_j * U_i) * sPsi;
-                const double wt = (a && lead) ? wla : 0.0;
-                const double t = reduce_pair(wt * g1, wt * g2);
-                if (lane == 31) *gslot(nP + f, 0) = t;
-                if (lane == 63) *gslot(nP + f, 1) = t;
-            }
-        }
         STAMP(6);
 
         // ---- J: the two directions meet at depth k at different steps ----
