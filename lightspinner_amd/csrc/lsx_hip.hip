@@ -740,10 +740,51 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     // ---- tile schedule: L = 64/Nrays consecutive wavelengths per wavefront pair
     const int P_line = c->phi_compact ? 1 : 2 * c->Nrays;
     size_t phi_run = 0, gij_run = 0;   // running block offsets inside a column's phi_T / gijc_T
-    for (int la0 = 0; la0 < Nspect; la0 += c->L) {
+    // ---- where to cut: a wavefront costs the same for 1 or L wavelengths, and roughly C(nP) per depth
+    // step with nP = per-ray slots of the tile (measured shader cycles, profiles/).  Dynamic programme over
+    // the cut positions; ties favour fewer tiles.  Any tiling gives the same results.
+    std::vector<int> cuts;
+    {
+        auto per_ray_slots = [&](int a, int b) {       // wavelengths [a, b)
+            unsigned atoms_with_line = 0;
+            int nlines = 0;
+            std::vector<int> conts;
+            for (int t = 0; t < c->Ntrans; ++t) {
+                bool any = false;
+                for (int la = a; la < b && !any; ++la) any = active[(size_t)t * Nspect + la];
+                if (!any) continue;
+                if (c->htrans[t].is_line) { nlines++; atoms_with_line |= 1u << c->htrans[t].atom; }
+                else conts.push_back(t);
+            }
+            int np = nlines;
+            for (int t : conts) np += (atoms_with_line >> c->htrans[t].atom) & 1u;
+            return np;
+        };
+        auto cost = [](int np) {
+            static const double C[] = {2500.0, 3900.0, 6600.0, 12800.0};
+            return np <= 3 ? C[np] : 14600.0 + 2500.0 * (np - 4);
+        };
+        const char* env = getenv("LSX_TILER");
+        const bool natural = env && std::string(env) == "natural";
+        std::vector<double> best(Nspect + 1, 1e300);
+        std::vector<int> from(Nspect + 1, 0);
+        best[0] = 0.0;
+        for (int i = 1; i <= Nspect; ++i)
+            for (int w = 1; w <= c->L && w <= i; ++w) {
+                if (natural && w != c->L && i != Nspect) continue;
+                if (natural && ((i - w) % c->L) != 0) continue;
+                const double v = best[i - w] + cost(per_ray_slots(i - w, i)) + 1.0;
+                if (v < best[i]) { best[i] = v; from[i] = i - w; }
+            }
+        for (int i = Nspect; i > 0; i = from[i]) cuts.push_back(from[i]);
+        std::reverse(cuts.begin(), cuts.end());
+        cuts.push_back(Nspect);
+    }
+    for (size_t ic = 0; ic + 1 < cuts.size(); ++ic) {
+        const int la0 = cuts[ic];
         DevTile tl{};
         tl.la0 = la0;
-        tl.nla = std::min(c->L, Nspect - la0);
+        tl.nla = cuts[ic + 1] - la0;
         tl.slot0 = (int)c->tile_slots.size();
         std::vector<int> lines, conts;
         unsigned atoms_with_line = 0;
