@@ -54,7 +54,8 @@ enum {
     SLOT_CHI_I_FIRST = 32, // first writer of the cell in execution order (store, else add)
     SLOT_CHI_J_FIRST = 64,
     SLOT_U_J_FIRST = 128,
-    SLOT_ETA_FIRST = 256
+    SLOT_ETA_FIRST = 256,
+    SLOT_FAST = 512        // fast continuum: handled by k_fast_prepass / k_fast_gamma, not by the sweep
 };
 
 // One transition as one tile sees it ("slot"); wave-uniform, read through the scalar cache.
@@ -83,7 +84,8 @@ struct DevTile {            // L consecutive wavelengths (L = 64 / Nrays) of one
     int32_t nP;             // per-ray slots
     int32_t nF;             // fast continua
     int32_t slot0;          // first entry in the slot table / first Gpart slab
-    int32_t pad0, pad1, pad2;
+    int32_t fast_simple;    // the fast continua need no level cells (k_fast_gamma)
+    int32_t pad1, pad2;
 };
 
 struct SweepParams {

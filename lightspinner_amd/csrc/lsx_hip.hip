@@ -103,6 +103,17 @@ __global__ void k_build_gijc(const double* __restrict__ nStar, const double* __r
     }
 }
 
+// nStar_i / nStar_j of every continuum: out[col][cont][k]
+__global__ void k_build_nsr(const double* __restrict__ nStar, double* __restrict__ out, const int* __restrict__ li,
+                            const int* __restrict__ lj, int Ncont, int Ns, int NLtot)
+{
+    const size_t col = blockIdx.y;
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < Ncont * Ns; o += gridDim.x * blockDim.x) {
+        const int k = o % Ns, q = o / Ns;
+        out[col * Ncont * Ns + o] = nStar[(col * NLtot + li[q]) * Ns + k] / nStar[(col * NLtot + lj[q]) * Ns + k];
+    }
+}
+
 // [col][la][k] (reference layout)  <->  [col][tile][k][j<L] (tile-major streams); unused j are zero
 __global__ void k_tiles_pack(const double* __restrict__ in, double* __restrict__ out, const DevTile* __restrict__ tiles,
                              int ntile, int L, int Ns, int Nspect, bool unpack)
@@ -196,8 +207,10 @@ struct FastParams {
     const double* u_la;
     const double* wmuh;
     const double* n;            // [col][NLtot][k]
-    const double* gijc_T;
-    size_t gijc_col;
+    const double* nsr;          // [col][Ncont][k]  nStar_i / nStar_j of every continuum (rh_method.py:453)
+    const double* temperature;  // [col][k]
+    const double* wavelength;   // [Nspect]
+    int Ncont, nF_max;
     const double* bgchi_T;
     const double* bgeta_T;
     double* bgxchi_T;
@@ -208,9 +221,16 @@ struct FastParams {
     const uint8_t* colmask;
 };
 
-// one fast continuum at (lambda, depth): rh_method.py:284-286, 453-455, 613-614
+// one fast continuum at (lambda, depth): rh_method.py:284-286, 453-455, 613-614.  g_ij is formed here from the
+// column's nStar ratio and the Boltzmann factor E of this (lambda, depth) -- (nStar_i / nStar_j) * exp(-hc / (k lambda T)),
+// the value k_build_gijc tabulates for the per-ray continua -- so fast continua cost no g_ij stream in HBM.
 struct FastVal { double alf, Vji, Uji, chi, eta; bool a; };
-__device__ __forceinline__ FastVal fast_value(const FastParams& f, const DevSlot& sl, size_t col, int la, int k)
+__device__ __forceinline__ double fast_boltzmann(const FastParams& f, size_t col, int la, int k)
+{
+    const double hc_k = kHC / (kKBoltzmann * kNM_TO_M);
+    return exp(-hc_k / f.wavelength[la] / f.temperature[col * f.Nspace + k]);
+}
+__device__ __forceinline__ FastVal fast_value(const FastParams& f, const DevSlot& sl, size_t col, int la, int k, double E)
 {
     FastVal v;
     const int lt = la - sl.Nblue;
@@ -219,7 +239,7 @@ __device__ __forceinline__ FastVal fast_value(const FastParams& f, const DevSlot
     if (v.a) {
         const double ni = f.n[(col * f.NLtot + sl.li) * f.Nspace + k];
         const double nj = f.n[(col * f.NLtot + sl.lj) * f.Nspace + k];
-        const double g = f.gijc_T[col * f.gijc_col + sl.base + (size_t)k * sl.len + (la - sl.first)];
+        const double g = f.nsr[col * f.Ncont * f.Nspace + sl.base + k] * E;
         v.alf = f.alpha[sl.wl_off + lt];
         v.Vji = g * v.alf;
         v.Uji = f.u_la[la] * v.Vji;
@@ -243,8 +263,9 @@ __global__ void k_fast_prepass(const FastParams f)
     double chi = f.bgchi_T[o], eta = f.bgeta_T[o];
     if (j < tl.nla) {
         const int la = tl.la0 + j;
+        const double E = fast_boltzmann(f, col, la, k);
         for (int q = 0; q < tl.nF; ++q) {
-            const FastVal v = fast_value(f, f.slots[tl.slot0 + tl.nP + q], col, la, k);
+            const FastVal v = fast_value(f, f.slots[tl.slot0 + tl.nP + q], col, la, k, E);
             chi += v.chi;
             eta += v.eta;
         }
@@ -257,7 +278,10 @@ __global__ void k_fast_prepass(const FastParams f)
 //   sum_{mu,dir} w (Uji + Vji Ieff - chi_lev_i Psi U_lev_j)  with Ieff = I - Psi eta_atom   (rh_method.py:652, 677-681)
 //   = Uji sW + Vji (sI - eta_atom sPsi) - chi_lev_i U_lev_j sPsi,   sI = 4 pi J, sPsi = sum w Psi*, sW = 4 pi sum_mu w_mu
 //   (w = (w_mu/2) 4 pi per ray and direction, rh_method.py:661-665; all sums over both directions)
-// one block per (depth chunk, fast tile, column); thread = (depth in chunk, wavelength of the tile)
+// one block per (depth chunk, fast tile, column); thread = (depth in chunk, wavelength of the tile).
+// Tiles whose fast continua are "simple" (per atom: one common upper level, distinct lower levels, none of them
+// that upper level -- every bound-free set of an ordinary model atom) need three running sums per atom and no
+// level cells; anything else takes the generic path with thread-private LDS cells.  Same arithmetic, same order.
 __global__ void k_fast_gamma(const FastParams f, int KC)
 {
     extern __shared__ double sm[];
@@ -269,46 +293,79 @@ __global__ void k_fast_gamma(const FastParams f, int KC)
     const int kc = tid / f.L, j = tid - kc * f.L;
     const int k = blockIdx.x * KC + kc;
     const bool on = kc < KC && k < f.Nspace && j < tl.nla;
-    const int ncell = 2 * f.NLtot + f.Natoms;
-    double* cell = sm + tid;                       // thread-private cells: cell[c * nt]
-    double* red = sm + (size_t)ncell * nt;         // red[(q*2 + e) * nt + tid]
+    double* red = sm;                                       // red[(q*2 + e) * nt + tid]
     const DevSlot* fs = f.slots + tl.slot0 + tl.nP;
     const int la = tl.la0 + (j < tl.nla ? j : 0);
     double sW = 0.0;
     for (int m = 0; m < f.Nrays; ++m) sW += 2.0 * f.wmuh[m] * (4.0 * M_PI);   // both directions
-    for (int c = 0; c < ncell; ++c) cell[c * nt] = 0.0;
-    if (on) {
-        for (int q = 0; q < tl.nF; ++q) {          // atom.chi / atom.U / atom.eta of rh_method.py:616-627
-            const FastVal v = fast_value(f, fs[q], col, la, k);
-            cell[fs[q].li * nt] += v.chi;
-            cell[fs[q].lj * nt] -= v.chi;
-            cell[(f.NLtot + fs[q].lj) * nt] += v.Uji;
-            cell[(2 * f.NLtot + fs[q].atom) * nt] += v.eta;
-        }
-    }
-    double sI = 0.0, sPsi = 0.0;
+    double sI = 0.0, sPsi = 0.0, E = 0.0;
     if (on) {
         const size_t o = ((col * f.ntile + t) * f.Nspace + k) * f.L + j;
         const size_t dstride = (size_t)f.ncol * f.ntile * f.Nspace * f.L;
         sI = f.J_T[o] * (4.0 * M_PI);
         sPsi = f.Psi2_T[o] + f.Psi2_T[dstride + o];
+        E = fast_boltzmann(f, col, la, k);
     }
-    for (int q = 0; q < tl.nF; ++q) {
-        double g1 = 0.0, g2 = 0.0;
+    if (tl.fast_simple) {
+        for (int q0 = 0; q0 < tl.nF;) {                     // one atom at a time
+            const int atom = fs[q0].atom;
+            int q1 = q0;
+            double chi_j = 0.0, U_j = 0.0, etaA = 0.0;      // atom.chi[j], atom.U[j], atom.eta of rh_method.py:616-627
+            for (; q1 < tl.nF && fs[q1].atom == atom; ++q1) {
+                if (on) {
+                    const FastVal v = fast_value(f, fs[q1], col, la, k, E);
+                    chi_j -= v.chi;
+                    U_j += v.Uji;
+                    etaA += v.eta;
+                }
+            }
+            for (int q = q0; q < q1; ++q) {
+                double g1 = 0.0, g2 = 0.0;
+                if (on) {
+                    const FastVal v = fast_value(f, fs[q], col, la, k, E);
+                    if (v.a) {
+                        const double chi_i = 0.0 + v.chi, U_i = 0.0;
+                        const double sIe = sI - etaA * sPsi;
+                        const double wla = f.wl[fs[q].wl_off + (la - fs[q].Nblue)];
+                        g1 = wla * ((v.Uji * sW + v.Vji * sIe) - (chi_i * U_j) * sPsi);
+                        g2 = wla * ((v.alf * sIe) - (chi_j * U_i) * sPsi);
+                    }
+                }
+                red[(q * 2 + 0) * nt + tid] = g1;
+                red[(q * 2 + 1) * nt + tid] = g2;
+            }
+            q0 = q1;
+        }
+    } else {
+        double* cell = sm + (size_t)2 * f.nF_max * nt + tid;    // thread-private cells: cell[c * nt]
+        const int ncell = 2 * f.NLtot + f.Natoms;
+        for (int c = 0; c < ncell; ++c) cell[c * nt] = 0.0;
         if (on) {
-            const FastVal v = fast_value(f, fs[q], col, la, k);
-            if (v.a) {
-                const double etaA = cell[(2 * f.NLtot + fs[q].atom) * nt];
-                const double chi_i = cell[fs[q].li * nt], chi_j = cell[fs[q].lj * nt];
-                const double U_i = cell[(f.NLtot + fs[q].li) * nt], U_j = cell[(f.NLtot + fs[q].lj) * nt];
-                const double sIe = sI - etaA * sPsi;
-                const double wla = f.wl[fs[q].wl_off + (la - fs[q].Nblue)];
-                g1 = wla * ((v.Uji * sW + v.Vji * sIe) - (chi_i * U_j) * sPsi);
-                g2 = wla * ((v.alf * sIe) - (chi_j * U_i) * sPsi);
+            for (int q = 0; q < tl.nF; ++q) {
+                const FastVal v = fast_value(f, fs[q], col, la, k, E);
+                cell[fs[q].li * nt] += v.chi;
+                cell[fs[q].lj * nt] -= v.chi;
+                cell[(f.NLtot + fs[q].lj) * nt] += v.Uji;
+                cell[(2 * f.NLtot + fs[q].atom) * nt] += v.eta;
             }
         }
-        red[(q * 2 + 0) * nt + tid] = g1;
-        red[(q * 2 + 1) * nt + tid] = g2;
+        for (int q = 0; q < tl.nF; ++q) {
+            double g1 = 0.0, g2 = 0.0;
+            if (on) {
+                const FastVal v = fast_value(f, fs[q], col, la, k, E);
+                if (v.a) {
+                    const double etaA = cell[(2 * f.NLtot + fs[q].atom) * nt];
+                    const double chi_i = cell[fs[q].li * nt], chi_j = cell[fs[q].lj * nt];
+                    const double U_i = cell[(f.NLtot + fs[q].li) * nt], U_j = cell[(f.NLtot + fs[q].lj) * nt];
+                    const double sIe = sI - etaA * sPsi;
+                    const double wla = f.wl[fs[q].wl_off + (la - fs[q].Nblue)];
+                    g1 = wla * ((v.Uji * sW + v.Vji * sIe) - (chi_i * U_j) * sPsi);
+                    g2 = wla * ((v.alf * sIe) - (chi_j * U_i) * sPsi);
+                }
+            }
+            red[(q * 2 + 0) * nt + tid] = g1;
+            red[(q * 2 + 1) * nt + tid] = g2;
+        }
     }
     __syncthreads();
     // wavelength quadrature: fixed-order sum over the tile's wavelengths, one thread per (slot, entry, depth)
@@ -550,7 +607,11 @@ struct lsx_ctx {
     double *d_bgxchi = nullptr, *d_bgxeta = nullptr, *d_Psi2 = nullptr; // fast-continuum side arrays
     std::vector<int> fast_tiles;
     int* d_fast_tiles = nullptr;
-    int nF_max = 0;
+    int *d_cont_li = nullptr, *d_cont_lj = nullptr;
+    int nF_max = 0, Ncont = 0;
+    bool fast_generic = false;
+    double* d_nsr = nullptr;     // [col][Ncont][k] nStar_i / nStar_j of the continua
+    std::vector<int> cont_li, cont_lj;
     double* d_debug = nullptr;   // 64 x 16 x 8 B, diagnostic builds of the sweep kernel write stamps here
     int jcur = 0; // d_J[jcur] holds the current J (Jdag of the next call)
     size_t phi_col = 0, phi_in_col = 0, gijc_col = 0, sca_col = 0, til_col = 0;
@@ -643,7 +704,7 @@ void lsx_destroy(lsx_ctx* c)
                     c->d_tiles, c->d_slots, c->d_tile_slots, c->d_Nlevel, c->d_lev2_off, c->d_height,
                     c->d_temperature, c->d_nStar, c->d_nTotal, c->d_n, c->d_C, c->d_Gamma, c->d_wphi, c->d_bgchi,
                     c->d_bgeta, c->d_sca, c->d_phi, c->d_gijc, c->d_J[0], c->d_J[1], c->d_I, c->d_Gpart, c->d_dJpart,
-                    c->d_dJcol, c->d_dPcol, c->d_max, c->d_singular, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles};
+                    c->d_dJcol, c->d_dPcol, c->d_max, c->d_singular, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_nsr, c->d_cont_li, c->d_cont_lj};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& k : c->classes) {
@@ -780,6 +841,10 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         std::reverse(cuts.begin(), cuts.end());
         cuts.push_back(Nspect);
     }
+    std::vector<int> cont_index(c->Ntrans, -1);
+    c->Ncont = 0;
+    for (int t = 0; t < c->Ntrans; ++t)
+        if (!c->htrans[t].is_line) cont_index[t] = c->Ncont++;
     for (size_t ic = 0; ic + 1 < cuts.size(); ++ic) {
         const int la0 = cuts[ic];
         DevTile tl{};
@@ -867,6 +932,9 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
                 phi_run += (size_t)sl.len * P_line * Ns;
                 sl.wphi_off = h.line_idx * Ns;
                 sl.cB = h.cB; sl.g = h.gij; sl.Vc = h.gij * h.cB; sl.Uc = h.AB * (h.gij * h.cB);
+            } else if (std::find(fast.begin(), fast.end(), t) != fast.end()) {
+                sl.flags |= SLOT_FAST;                       // g_ij formed on the fly from the nStar ratio table
+                sl.base = cont_index[t] * Ns;
             } else {
                 sl.base = (int)gij_run;
                 gij_run += (size_t)sl.len * Ns;
@@ -874,7 +942,20 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
             c->slots.push_back(sl);
             c->tile_slots.push_back(t);
         }
-        if (tl.nF > 0) { c->fast_tiles.push_back((int)c->tiles.size()); c->nF_max = std::max(c->nF_max, tl.nF); }
+        if (tl.nF > 0) {
+            c->fast_tiles.push_back((int)c->tiles.size());
+            c->nF_max = std::max(c->nF_max, tl.nF);
+            // simple: per atom one common upper level, distinct lower levels, no lower level equal to that upper level
+            bool simple = true;
+            for (size_t a = 0; a < fast.size() && simple; ++a)
+                for (size_t b = 0; b < fast.size() && simple; ++b) {
+                    const DevTrans &x = c->htrans[fast[a]], &y = c->htrans[fast[b]];
+                    if (x.atom != y.atom) continue;
+                    if (x.lj != y.lj || x.li == y.lj || (a != b && x.li == y.li)) simple = false;
+                }
+            tl.fast_simple = simple ? 1 : 0;
+            if (!simple) c->fast_generic = true;
+        }
         const int npt = tl.nP <= 3 ? tl.nP : -1;
         SweepClass* k = nullptr;
         for (auto& q : c->classes)
@@ -956,6 +1037,11 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     TRY(dmalloc(&c->d_debug, 64 * 16));
     if (!c->fast_tiles.empty()) {
         TRY(upload(&c->d_fast_tiles, c->fast_tiles, c->stream));
+        for (int t = 0; t < c->Ntrans; ++t)
+            if (!c->htrans[t].is_line) { c->cont_li.push_back(c->htrans[t].li); c->cont_lj.push_back(c->htrans[t].lj); }
+        TRY(upload(&c->d_cont_li, c->cont_li, c->stream));
+        TRY(upload(&c->d_cont_lj, c->cont_lj, c->stream));
+        TRY(dmalloc(&c->d_nsr, nc * c->Ncont * Ns));
         TRY(dmalloc(&c->d_bgxchi, nc * c->til_col));
         TRY(dmalloc(&c->d_bgxeta, nc * c->til_col));
         TRY(dmalloc(&c->d_Psi2, 2 * nc * c->til_col));
@@ -1038,11 +1124,17 @@ int lsx_set_columns(lsx_ctx* c, int32_t col0, int32_t ncol, const lsx_columns* s
         }
         // continuum g_ij tables, one block per (tile, continuum)
         for (const DevSlot& sl : c->slots) {
-            if ((sl.flags & SLOT_LINE) || sl.len <= 0) continue;
+            if ((sl.flags & (SLOT_LINE | SLOT_FAST)) || sl.len <= 0) continue;
             dim3 grid((sl.len * Ns + 255) / 256, (unsigned)nb);
             hipLaunchKernelGGL(k_build_gijc, grid, dim3(256), 0, c->stream, c->d_nStar + cc * c->NLtot * Ns,
                                c->d_temperature + cc * Ns, c->d_wavelength, c->d_gijc + cc * c->gijc_col + sl.base, sl.li, sl.lj,
                                sl.first, sl.len, Ns, c->NLtot, c->gijc_col);
+            HIPCHK(hipGetLastError());
+        }
+        if (c->d_nsr) {
+            dim3 grid((c->Ncont * Ns + 255) / 256, (unsigned)nb);
+            hipLaunchKernelGGL(k_build_nsr, grid, dim3(256), 0, c->stream, c->d_nStar + cc * c->NLtot * Ns,
+                               c->d_nsr + cc * c->Ncont * Ns, c->d_cont_li, c->d_cont_lj, c->Ncont, (int)Ns, c->NLtot);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipStreamSynchronize(c->stream)); // the staging buffer is re-used by the next sub-chunk
@@ -1080,7 +1172,8 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
         ff.L = c->L; ff.NLtot = c->NLtot; ff.Natoms = c->Natoms; ff.nslot_total = (int)c->tile_slots.size();
         ff.n_fast_tiles = (int)c->fast_tiles.size(); ff.tiles = c->d_tiles; ff.slots = c->d_slots; ff.fast_tiles = c->d_fast_tiles;
         ff.active = c->d_active; ff.alpha = c->d_alpha; ff.wl = c->d_wl; ff.u_la = c->d_u_la; ff.wmuh = c->d_wmuh; ff.n = c->d_n;
-        ff.gijc_T = c->d_gijc; ff.gijc_col = c->gijc_col; ff.bgchi_T = c->d_bgchi; ff.bgeta_T = c->d_bgeta;
+        ff.nsr = c->d_nsr; ff.temperature = c->d_temperature; ff.wavelength = c->d_wavelength; ff.Ncont = c->Ncont; ff.nF_max = c->nF_max;
+        ff.bgchi_T = c->d_bgchi; ff.bgeta_T = c->d_bgeta;
         ff.bgxchi_T = c->d_bgxchi; ff.bgxeta_T = c->d_bgxeta; ff.J_T = c->d_J[c->jcur ^ 1]; ff.Psi2_T = c->d_Psi2;
         ff.Gpart = c->d_Gpart; ff.colmask = c->d_colmask;
         dim3 grid((c->Nspace * c->L + 255) / 256, (unsigned)c->fast_tiles.size(), (unsigned)c->ncol);
@@ -1123,8 +1216,8 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
     }
     if (timed) HIPCHK(hipEventRecord(c->ev1, c->stream));
     if (has_fast) {
-        const int KC = std::max(1, 64 / c->L), nt = 64;
-        const size_t sm = (size_t)(2 * c->NLtot + c->Natoms + 2 * c->nF_max) * nt * sizeof(double);
+        const int nt = c->L > 64 ? 256 : 128, KC = std::max(1, nt / c->L);
+        const size_t sm = (size_t)((c->fast_generic ? 2 * c->NLtot + c->Natoms : 0) + 2 * c->nF_max) * nt * sizeof(double);
         if (sm > 64 * 1024) return fail(LSX_EUNSUPPORTED, "fast-continuum epilogue needs %zu B of LDS", sm);
         dim3 grid((c->Nspace + KC - 1) / KC, (unsigned)c->fast_tiles.size(), (unsigned)c->ncol);
         hipLaunchKernelGGL(k_fast_gamma, grid, dim3(nt), sm, c->stream, ff, KC);

@@ -1,0 +1,67 @@
+"""HIP vs oracle on made-up atoms with awkward topologies (tests/toy.py): chained continua (generic fast
+path), lines sharing levels, continuum-only atoms, 1 / 3 / 5 rays, odd depths, per-wavelength scattering.
+
+Tolerances: one formal-solution call 1e-11 relative on I, J and off-diagonal Gamma (the two sides evaluate
+exp() with different libraries); after 8 MALI iterations 1e-8 on the populations."""
+import numpy as np
+import pytest
+
+from conftest import relerr, gamma_err
+from toy import toy_problem
+from lightspinner_amd import _capi
+from lightspinner_amd.problem import Engine
+
+CASES = [
+    dict(seed=1),                                                     # 3 rays, 37 depths, chained continua
+    dict(seed=2, Nrays=1, Nspace=20, Nspect=70),                      # 64 wavelengths per wavefront
+    dict(seed=3, Nrays=5, Nspace=82, Nspect=130, sca_per_lambda=True),
+    dict(seed=4, phi_compact=True, chain=False),
+    dict(seed=5, Nrays=2, Nspace=5, Nspect=40, ncol=40),              # shortest useful column; >= 32 columns: per-class launches
+    dict(seed=6, Nrays=7, Nspace=33, Nspect=55, ncol=33),
+]
+
+
+def _run(lib, prob, block, iters):
+    e = Engine(prob, block.ncol, lib=lib)
+    e.set_columns(0, block)
+    out = []
+    for it in range(iters):
+        dJ = e.formal_sol_gamma()
+        snap = dict(dJ=dJ, I=e.get(_capi.LSX_I), J=e.get(_capi.LSX_J), G=e.get(_capi.LSX_GAMMA))
+        if it >= 2:
+            snap['dP'] = e.stat_equil()
+            snap['n'] = e.get(_capi.LSX_N)
+        out.append(snap)
+    e.close()
+    return out
+
+
+def test_toy_problems_are_well_posed_on_the_oracle(oracle_lib):
+    prob, block = toy_problem(seed=1)
+    o = _run(oracle_lib, prob, block, 6)
+    assert all(np.isfinite(s['dJ']) for s in o)
+    assert o[-1]['dJ'] < o[1]['dJ'] and o[-1]['dP'] < 0.1
+    assert (o[-1]['n'] > 0).all() and (o[-1]['J'] > 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kw', CASES, ids=lambda k: '-'.join('%s%s' % (a[:3], b) for a, b in k.items()))
+def test_toy_parity(hip_lib, oracle_lib, kw):
+    prob, block = toy_problem(**kw)
+    h = _run(hip_lib, prob, block, 8)
+    o = _run(oracle_lib, prob, block, 8)
+    # single call (identical inputs on both sides)
+    assert relerr(h[0]['I'], o[0]['I']) < 1e-11
+    assert relerr(h[0]['J'], o[0]['J']) < 1e-11
+    off, diag = gamma_err(h[0]['G'], o[0]['G'], prob)
+    assert off < 1e-10 and diag < 1e-11, (off, diag)
+    assert abs(h[0]['dJ'] - o[0]['dJ']) <= 1e-11 * abs(o[0]['dJ'])
+    # iterated
+    for a, b in zip(h, o):
+        assert abs(a['dJ'] - b['dJ']) <= 1e-7 * max(abs(b['dJ']), 1e-3)
+    # populations: relative to the largest level population of that depth (a 5-depth column can drive small levels
+    # through zero, where a per-element relative error means nothing)
+    dn = np.abs(h[-1]['n'] - o[-1]['n']) / np.abs(o[-1]['n']).max(axis=1, keepdims=True)
+    assert dn.max() < 1e-8
+    assert relerr(h[-1]['J'], o[-1]['J']) < 1e-8
+    assert abs(h[-1]['dP'] - o[-1]['dP']) <= 1e-6 * max(abs(o[-1]['dP']), 1e-3)
