@@ -662,7 +662,13 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
 #ifndef LSX_WPE1
 #define LSX_WPE1 LSX_WAVES_PER_EU
 #endif
-#define LSX_WPE(NPT) ((NPT) == 0 ? LSX_WPE0 : ((NPT) == 1 ? LSX_WPE1 : LSX_WAVES_PER_EU))
+#ifndef LSX_WPE2
+#define LSX_WPE2 LSX_WAVES_PER_EU
+#endif
+#ifndef LSX_WPE3
+#define LSX_WPE3 (LSX_WAVES_PER_EU - 1)     // three per-ray slots: 4 waves/SIMD would spill ~60 VGPRs
+#endif
+#define LSX_WPE(NPT) ((NPT) == 0 ? LSX_WPE0 : ((NPT) == 1 ? LSX_WPE1 : ((NPT) == 2 ? LSX_WPE2 : ((NPT) == 3 ? LSX_WPE3 : LSX_WAVES_PER_EU))))
 template <int NPT, int NR, bool SCAL>
 __global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(LSX_WPE(NPT))))
 lsx_sweep_kernel(const SweepParams p)
