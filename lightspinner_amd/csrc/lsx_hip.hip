@@ -939,6 +939,10 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
                 sl.base = (int)gij_run;
                 gij_run += (size_t)sl.len * Ns;
             }
+            if (tl.nP == 1 && !(sl.flags & SLOT_FAST) && (sl.flags & (SLOT_LI_CELL | SLOT_LJ_CELL | SLOT_UI_READ | SLOT_ETA_CELL))) {
+                lsx_destroy(c);     // the single-slot kernel compiles the cell logic out
+                return fail(LSX_EUNSUPPORTED, "lsx_create: internal: single per-ray slot with shared levels");
+            }
             c->slots.push_back(sl);
             c->tile_slots.push_back(t);
         }

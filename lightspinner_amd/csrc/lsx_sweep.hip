@@ -177,7 +177,8 @@ __device__ __forceinline__ double wave_max_nan(double v)
 }
 
 // lane-private LDS cell: first writer of a pass stores, later writers add (DS add, no return)
-__device__ __forceinline__ void cell_acc(double* p, double v, bool first)
+typedef __attribute__((address_space(3))) double lds_f64;   // LDS pointers carry their address space: ds_ instructions, no flat-pointer checks
+__device__ __forceinline__ void cell_acc(lds_f64* p, double v, bool first)
 {
     if (first) *p = v;
     else __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -212,7 +213,8 @@ __device__ __forceinline__ SlotS load_slot(const __attribute__((address_space(4)
 template <int NPT, int NR, bool SCAL>
 __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, const int tile_id)
 {
-    extern __shared__ double lds[];
+    extern __shared__ double lds_raw[];
+    lds_f64* const lds = (lds_f64*)lds_raw;
     constexpr bool STATIC = NPT >= 0;
     constexpr int NS = NPT > 0 ? NPT : 1;
     const int lane = threadIdx.x & (LSX_WAVE - 1);
@@ -241,17 +243,17 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
 
     // LDS rows (64 doubles each), private to this wave except the two exchange rows at the end
     const int rows = 2 * p.ncell_lev + p.ncell_atom + 1;
-    double* const wrow = lds + (size_t)dir * rows * LSX_WAVE + lane;
+    lds_f64* const wrow = lds + (size_t)dir * rows * LSX_WAVE + lane;
 #define CCHI(c) wrow[(2 * (c)) * LSX_WAVE]
 #define CU(c) wrow[(2 * (c) + 1) * LSX_WAVE]
 #define CETA(a) wrow[(2 * p.ncell_lev + (a)) * LSX_WAVE]
-    double* const xrow = lds + (size_t)dir * rows * LSX_WAVE + (size_t)(rows - 1) * LSX_WAVE; // angle sums
-    double* const xwg = lds + (size_t)2 * rows * LSX_WAVE;                                    // [2][64] cross-wave
+    lds_f64* const xrow = lds + (size_t)dir * rows * LSX_WAVE + (size_t)(rows - 1) * LSX_WAVE; // angle sums
+    lds_f64* const xwg = lds + (size_t)2 * rows * LSX_WAVE;                                    // [2][64] cross-wave
     // static path: per-depth wave-uniform operands of the tile (n_i, n_j, wphi per slot, z, sigma) are
     // staged once per workgroup as a depth-major table utab[k][TR] -> one address register, immediate
     // offsets, counted LDS waits (scalar-cache loads return out of order and serialise on lgkmcnt(0))
     constexpr int TR = STATIC ? 3 * NPT + 2 : 1;
-    double* const utab = xwg + 2 * LSX_WAVE;
+    lds_f64* const utab = xwg + 2 * LSX_WAVE;
 
     // column bases; wave-uniform reads go through the scalar cache
     const auto* n_col = LSX_CONST(double, p.n + (size_t)col * p.NLtot * Ns);
@@ -415,7 +417,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
 #pragma unroll
             for (int u = 0; u < NPT; ++u) sv[u] = n_sv[u];
             if (s + 1 < Ns) stream_loads(k + dk, n_bc, n_be, n_jd, n_sv);
-            const double* tk = utab + k * TR;
+            const lds_f64* tk = utab + k * TR;
 #pragma unroll
             for (int u = 0; u < NPT; ++u) {
                 sni[u] = tk[3 * u + 0];
@@ -445,7 +447,8 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         double spv[NS], schi[NS], sUji[NS];
         auto pass1 = [&](const SlotS& sl, double v, double ni, double nj, double alf, double& pv, double& chi,
                          double& Uji) {
-            const int fl = sl.flags;
+            // a tile with a single per-ray slot shares no level and no atom with anything (lsx_create): no cells
+            const int fl = NPT == 1 ? (sl.flags & SLOT_LINE) : sl.flags;
             if (fl & SLOT_LINE) {
                 pv = v;
                 chi = (sl.cB * (ni - sl.g * nj)) * pv;   // n_i Vij - n_j Vji, :279-280, :613
@@ -541,7 +544,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         // ---- pass 2: Gamma integrands of the per-ray transitions (rh_method.py:643-681) ----
         auto pass2 = [&](const SlotS& sl, bool a, double pv, double chi, double Uji, double Vij, double nj, double wla,
                          double& wg1, double& wg2) {
-            const int fl = sl.flags;
+            const int fl = NPT == 1 ? (sl.flags & SLOT_LINE) : sl.flags;
             const double Vji = (fl & SLOT_LINE) ? sl.Vc * pv : pv;
             const double eta = nj * Uji;
             const double etaA = (fl & SLOT_ETA_CELL) ? CETA(sl.ca) : eta;
