@@ -77,7 +77,12 @@ struct DevSlot {
     double g;              // lines: Bji/Bij                         Vji = g Vij         :280, :450
     double Vc;             // lines: g cB
     double Uc;             // lines: (Aji/Bji) g cB                  Uji = Uc phi        :281
+    // two-slot tiles keep the level bookkeeping of rh_method.py:616-627 in registers: what the OTHER per-ray slot v
+    // of the tile adds to this slot's atom.chi[i], atom.chi[j], atom.U[j], atom.U[i], atom.eta, as factors in
+    // {-1, 0, 1}:  [li_v==li] - [lj_v==li],  [li_v==lj] - [lj_v==lj],  [lj_v==lj],  [lj_v==li],  [atom_v==atom]
+    double rel[5];
 };
+enum { REL_CI = 0, REL_CJ = 1, REL_UJ = 2, REL_UI = 3, REL_EA = 4 };
 
 struct DevTile {            // L consecutive wavelengths (L = 64 / Nrays) of one column
     int32_t la0, nla;       // first global wavelength index, count (<= L)

@@ -939,6 +939,14 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
                 sl.base = (int)gij_run;
                 gij_run += (size_t)sl.len * Ns;
             }
+            if (tl.nP == 2 && !(sl.flags & SLOT_FAST)) {
+                const DevTrans& o = c->htrans[per_ray[per_ray[0] == t ? 1 : 0]];
+                sl.rel[REL_CI] = (double)(o.li == h.li) - (double)(o.lj == h.li);
+                sl.rel[REL_CJ] = (double)(o.li == h.lj) - (double)(o.lj == h.lj);
+                sl.rel[REL_UJ] = (double)(o.lj == h.lj);
+                sl.rel[REL_UI] = (double)(o.lj == h.li);
+                sl.rel[REL_EA] = (double)(o.atom == h.atom);
+            }
             if (tl.nP == 1 && !(sl.flags & SLOT_FAST) && (sl.flags & (SLOT_LI_CELL | SLOT_LJ_CELL | SLOT_UI_READ | SLOT_ETA_CELL))) {
                 lsx_destroy(c);     // the single-slot kernel compiles the cell logic out
                 return fail(LSX_EUNSUPPORTED, "lsx_create: internal: single per-ray slot with shared levels");

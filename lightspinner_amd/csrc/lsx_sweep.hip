@@ -448,7 +448,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         auto pass1 = [&](const SlotS& sl, double v, double ni, double nj, double alf, double& pv, double& chi,
                          double& Uji) {
             // a tile with a single per-ray slot shares no level and no atom with anything (lsx_create): no cells
-            const int fl = NPT == 1 ? (sl.flags & SLOT_LINE) : sl.flags;
+            const int fl = (NPT == 1 || NPT == 2) ? (sl.flags & SLOT_LINE) : sl.flags;   // NPT == 2: bookkeeping in registers (pass 2)
             if (fl & SLOT_LINE) {
                 pv = v;
                 chi = (sl.cB * (ni - sl.g * nj)) * pv;   // n_i Vij - n_j Vji, :279-280, :613
@@ -542,6 +542,16 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         STAMP(4);
 
         // ---- pass 2: Gamma integrands of the per-ray transitions (rh_method.py:643-681) ----
+        auto pass2x = [&](bool line, double Vc, bool a, double pv, double Uji, double Vij, double wla, double etaA,
+                          double chi_i, double chi_j, double U_j, double U_i, double& wg1, double& wg2) {
+            const double Vji = line ? Vc * pv : pv;
+            const double Ieff = I - Psi * etaA;                            // :652
+            const double g1 = (Uji + Vji * Ieff) - (chi_i * Psi) * U_j;    // :677
+            const double g2 = (Vij * Ieff) - (chi_j * Psi) * U_i;          // :680
+            const double wt = (a && valid) ? wq_l * wla : 0.0;             // :665
+            wg1 = wt * g1;
+            wg2 = wt * g2;
+        };
         auto pass2 = [&](const SlotS& sl, bool a, double pv, double chi, double Uji, double Vij, double nj, double wla,
                          double& wg1, double& wg2) {
             const int fl = NPT == 1 ? (sl.flags & SLOT_LINE) : sl.flags;
@@ -568,7 +578,21 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                 const SlotS sl = load_slot(slots + u, Ns);
                 const bool line = (sl.flags & SLOT_LINE) != 0;
                 const double Vij = line ? sl.cB * spv[u] : alv[u];
-                pass2(sl, (pact >> u) & 1u, spv[u], schi[u], sUji[u], Vij, snj[u], wlv[u] * swp[u], w1[u], w2v[u]); // :451, :455
+                if constexpr (NPT == 2) {
+                    // atom.chi / atom.U / atom.eta of this slot's levels from the two slots' values, in transition
+                    // order (a factor 0 drops the other slot, +-1 adds it with one rounding)
+                    const int v = 1 - u;
+                    const auto* rel = slots[u].rel;
+                    const double etaA = fma(rel[REL_EA], snj[v] * sUji[v], snj[u] * sUji[u]);
+                    const double chi_i = fma(rel[REL_CI], schi[v], schi[u]);
+                    const double chi_j = fma(rel[REL_CJ], schi[v], -schi[u]);
+                    const double U_j = fma(rel[REL_UJ], sUji[v], sUji[u]);
+                    const double U_i = rel[REL_UI] * sUji[v];
+                    pass2x(line, sl.Vc, (pact >> u) & 1u, spv[u], sUji[u], Vij, wlv[u] * swp[u], etaA, chi_i, chi_j, U_j, U_i,
+                           w1[u], w2v[u]);
+                } else {
+                    pass2(sl, (pact >> u) & 1u, spv[u], schi[u], sUji[u], Vij, snj[u], wlv[u] * swp[u], w1[u], w2v[u]); // :451, :455
+                }
             }
             if constexpr (NPT == 1) {
                 const double t = reduce_pair(w1[0], w2v[0]);
