@@ -274,19 +274,23 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     const double* __restrict__ gijc_col = p.gijc_T + (size_t)col * p.gijc_col_stride;
     double* __restrict__ gpart = p.Gpart + ((size_t)col * p.nslot_total + slot0) * 4 * Ns;
 
+    //   per slot: lines (cB (n_i - g n_j), n_j, wphi)   continua (n_i, n_j, 1);   then the half length of the
+    //   interval ABOVE depth k (0.5 |z[k-1] - z[k]|, formal_solver.py:123/129) and the scattering coefficient
     if constexpr (STATIC) {
-        const double* srcs[TR];
-#pragma unroll
-        for (int u = 0; u < NPT; ++u) {
-            srcs[3 * u + 0] = p.n + (size_t)col * p.NLtot * Ns + (size_t)slots[u].li * Ns;
-            srcs[3 * u + 1] = p.n + (size_t)col * p.NLtot * Ns + (size_t)slots[u].lj * Ns;
-            srcs[3 * u + 2] = (slots[u].flags & SLOT_LINE) ? p.wphi + (size_t)col * p.Nlines * Ns + slots[u].wphi_off : nullptr;
-        }
-        srcs[3 * NPT + 0] = p.height + (size_t)col * Ns;
-        srcs[3 * NPT + 1] = sca_l ? nullptr : p.sca + (size_t)col * Ns;
+        const double* ncolp = p.n + (size_t)col * p.NLtot * Ns;
+        const double* zc = p.height + (size_t)col * Ns;
+        if (threadIdx.x < TR) utab[Ns * TR + threadIdx.x] = 0.0;     // row Ns: the up sweep reads row k + 1
         for (int e = threadIdx.x; e < Ns; e += 2 * LSX_WAVE) {
 #pragma unroll
-            for (int r = 0; r < TR; ++r) utab[e * TR + r] = srcs[r] ? srcs[r][e] : 1.0;
+            for (int u = 0; u < NPT; ++u) {
+                const double ni = ncolp[(size_t)slots[u].li * Ns + e], nj = ncolp[(size_t)slots[u].lj * Ns + e];
+                const bool line = (slots[u].flags & SLOT_LINE) != 0;
+                utab[e * TR + 3 * u + 0] = line ? slots[u].cB * (ni - slots[u].g * nj) : ni;   // :279-280, :613
+                utab[e * TR + 3 * u + 1] = nj;
+                utab[e * TR + 3 * u + 2] = line ? p.wphi[(size_t)col * p.Nlines * Ns + slots[u].wphi_off + e] : 1.0;
+            }
+            utab[e * TR + 3 * NPT + 0] = e > 0 ? 0.5 * fabs(zc[e - 1] - zc[e]) : 0.0;
+            utab[e * TR + 3 * NPT + 1] = sca_l ? 1.0 : p.sca[(size_t)col * Ns + e];
         }
         __syncthreads();
     }
@@ -315,7 +319,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     //   idx0: element index of (depth 0, this ray, this wavelength) in phi_T (line) / gijc_T (continuum)
     //   wl: wavelength quadrature weight, al: alpha (continua)
     int idx0[NS], kstr[NS];
-    double wlv[NS], alv[NS];
+    double wlv[NS], alv[NS];    // wlv: (w_mu/2 4pi) x wavelength weight of this ray, 0 where the transition is inactive
     if constexpr (STATIC) {
 #pragma unroll
         for (int u = 0; u < NPT; ++u) {
@@ -328,7 +332,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             (void)Nlam;
             idx0[u] = slots[u].base + (line ? raysel * len : 0) + lb;
             kstr[u] = line ? kmul * len : len;
-            wlv[u] = a ? p.wl[slots[u].wl_off + l] : 0.0;
+            wlv[u] = (a && valid) ? wq_l * p.wl[slots[u].wl_off + l] : 0.0;                // :451/:455, :665
             alv[u] = (a && !line) ? p.alpha[slots[u].wl_off + l] : 0.0;
         }
     }
@@ -427,16 +431,16 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         } else {
             stream_loads(k, chiTot, be_l, jd, sv);
         }
-        double zk, scv;
+        double hdzm, scv;
         if constexpr (STATIC) {
-            zk = utab[k * TR + 3 * NPT];
+            hdzm = (utab + TR * dir)[k * TR + 3 * NPT] * zmu_l;   // the interval behind this ray: row k (down) / k + 1 (up)
             scv = sca_l ? sca[kl] : utab[k * TR + 3 * NPT + 1];
         } else {
-            zk = z[k];
+            const double zk = z[k];
             scv = sca_l ? sca[kl] : LSX_CONST(double, sca)[k];
+            hdzm = (0.5 * fabs(zprev - zk)) * zmu_l;
+            zprev = zk;
         }
-        const double hdzm = (0.5 * fabs(zprev - zk)) * zmu_l;
-        zprev = zk;
         double etaTot = be_l + scv * jd;
         STAMP(0);
 
@@ -451,7 +455,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             const int fl = (NPT == 1 || NPT == 2) ? (sl.flags & SLOT_LINE) : sl.flags;   // NPT == 2: bookkeeping in registers (pass 2)
             if (fl & SLOT_LINE) {
                 pv = v;
-                chi = (sl.cB * (ni - sl.g * nj)) * pv;   // n_i Vij - n_j Vji, :279-280, :613
+                chi = (STATIC ? ni : sl.cB * (ni - sl.g * nj)) * pv;   // n_i Vij - n_j Vji, :279-280, :613 (static: ni holds the product)
                 Uji = sl.Uc * pv;                        // :281
             } else {
                 pv = v * alf;                            // Vji = g_ij alpha, :284-285
@@ -542,17 +546,16 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         STAMP(4);
 
         // ---- pass 2: Gamma integrands of the per-ray transitions (rh_method.py:643-681) ----
-        auto pass2x = [&](bool line, double Vc, bool a, double pv, double Uji, double Vij, double wla, double etaA,
+        auto pass2x = [&](bool line, double Vc, double pv, double Uji, double Vij, double wt, double etaA,
                           double chi_i, double chi_j, double U_j, double U_i, double& wg1, double& wg2) {
             const double Vji = line ? Vc * pv : pv;
             const double Ieff = I - Psi * etaA;                            // :652
             const double g1 = (Uji + Vji * Ieff) - (chi_i * Psi) * U_j;    // :677
             const double g2 = (Vij * Ieff) - (chi_j * Psi) * U_i;          // :680
-            const double wt = (a && valid) ? wq_l * wla : 0.0;             // :665
-            wg1 = wt * g1;
+            wg1 = wt * g1;                                                 // wt: :451/:455, :665
             wg2 = wt * g2;
         };
-        auto pass2 = [&](const SlotS& sl, bool a, double pv, double chi, double Uji, double Vij, double nj, double wla,
+        auto pass2 = [&](const SlotS& sl, double pv, double chi, double Uji, double Vij, double nj, double wt,
                          double& wg1, double& wg2) {
             const int fl = NPT == 1 ? (sl.flags & SLOT_LINE) : sl.flags;
             const double Vji = (fl & SLOT_LINE) ? sl.Vc * pv : pv;
@@ -565,7 +568,6 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             const double Ieff = I - Psi * etaA;                            // :652
             const double g1 = (Uji + Vji * Ieff) - (chi_i * Psi) * U_j;    // :677
             const double g2 = (Vij * Ieff) - (chi_j * Psi) * U_i;          // :680
-            const double wt = (a && valid) ? wq_l * wla : 0.0;             // :665
             wg1 = wt * g1;
             wg2 = wt * g2;
         };
@@ -588,10 +590,10 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                     const double chi_j = fma(rel[REL_CJ], schi[v], -schi[u]);
                     const double U_j = fma(rel[REL_UJ], sUji[v], sUji[u]);
                     const double U_i = rel[REL_UI] * sUji[v];
-                    pass2x(line, sl.Vc, (pact >> u) & 1u, spv[u], sUji[u], Vij, wlv[u] * swp[u], etaA, chi_i, chi_j, U_j, U_i,
+                    pass2x(line, sl.Vc, spv[u], sUji[u], Vij, wlv[u] * swp[u], etaA, chi_i, chi_j, U_j, U_i,
                            w1[u], w2v[u]);
                 } else {
-                    pass2(sl, (pact >> u) & 1u, spv[u], schi[u], sUji[u], Vij, snj[u], wlv[u] * swp[u], w1[u], w2v[u]); // :451, :455
+                    pass2(sl, spv[u], schi[u], sUji[u], Vij, snj[u], wlv[u] * swp[u], w1[u], w2v[u]); // :451, :455
                 }
             }
             if constexpr (NPT == 1) {
@@ -632,7 +634,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                     chi = ni * Vij - nj * pv;
                 }
                 double wg1, wg2;
-                pass2(sl, a, pv, chi, Uji, Vij, nj, wla, wg1, wg2);
+                pass2(sl, pv, chi, Uji, Vij, nj, (a && valid) ? wq_l * wla : 0.0, wg1, wg2);
                 const double t = reduce_pair(wg1, wg2);
                 if (lane == 31) *gslot(u, 0) = t;
                 if (lane == 63) *gslot(u, 1) = t;
@@ -687,7 +689,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
 #define LSX_WPE0 (LSX_WAVES_PER_EU + 1)
 #endif
 #ifndef LSX_WPE1
-#define LSX_WPE1 LSX_WAVES_PER_EU
+#define LSX_WPE1 (LSX_WAVES_PER_EU + 1)     // one per-ray slot: 96 VGPRs, no spills
 #endif
 #ifndef LSX_WPE2
 #define LSX_WPE2 LSX_WAVES_PER_EU
