@@ -90,7 +90,8 @@ struct DevTile {            // L consecutive wavelengths (L = 64 / Nrays) of one
     int32_t nF;             // fast continua
     int32_t slot0;          // first entry in the slot table / first Gpart slab
     int32_t fast_simple;    // the fast continua need no level cells (k_fast_gamma)
-    int32_t pad1, pad2;
+    int32_t nL;             // lines among the per-ray slots (they come first)
+    int32_t pad2;
 };
 
 struct SweepParams {

@@ -562,6 +562,7 @@ __global__ void k_piecewise(int nray, int Ns, const double* __restrict__ z, cons
 // ------------------------------------------------------------------------------- context
 struct SweepClass {           // tiles that run the same kernel instantiation, launched on their own stream
     int npt = -1;              // compile-time per-ray slot count, -1 = generic
+    int nl = 0;                // lines among them (compile-time too)
     std::vector<int> tiles;
     int* d_tiles = nullptr;
     int ncell_lev = 1, ncell_atom = 1;
@@ -969,10 +970,12 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
             if (!simple) c->fast_generic = true;
         }
         const int npt = tl.nP <= 3 ? tl.nP : -1;
+        const int nl = npt >= 0 ? (int)lines.size() : 0;
+        tl.nL = (int)lines.size();
         SweepClass* k = nullptr;
         for (auto& q : c->classes)
-            if (q.npt == npt) k = &q;
-        if (!k) { c->classes.push_back(SweepClass()); k = &c->classes.back(); k->npt = npt; }
+            if (q.npt == npt && q.nl == nl) k = &q;
+        if (!k) { c->classes.push_back(SweepClass()); k = &c->classes.back(); k->npt = npt; k->nl = nl; }
         k->tiles.push_back((int)c->tiles.size());
         k->ncell_lev = std::max(k->ncell_lev, (int)lev_ids.size());
         k->ncell_atom = std::max(k->ncell_atom, (int)atom_ids.size());
@@ -1218,7 +1221,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
         p.ncell_lev = k.ncell_lev; p.ncell_atom = k.ncell_atom; p.nstash = 0;
         hipStream_t st = fork ? k.stream : c->stream;
         if (fork) HIPCHK(hipStreamWaitEvent(st, c->ev_fork, 0));
-        hipError_t e = lsx_launch_sweep(&p, k.npt, (int)nblocks, k.lds_bytes, st);
+        hipError_t e = lsx_launch_sweep(&p, k.npt >= 0 ? k.npt * 8 + k.nl : -1, (int)nblocks, k.lds_bytes, st);
         if (e != hipSuccess) return fail(LSX_EDEVICE, "sweep launch (per-ray slots %d): %s", k.npt, hipGetErrorString(e));
         if (fork) {
             HIPCHK(hipEventRecord(k.done, st));

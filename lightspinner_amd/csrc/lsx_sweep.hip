@@ -114,8 +114,10 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_f64(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    // `old` = the source itself: no zero has to be materialised; lanes a row mask leaves out keep their own
+    // value (their sums are never consumed, see the callers)
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_sum(double v)
@@ -210,7 +212,9 @@ __device__ __forceinline__ SlotS load_slot(const __attribute__((address_space(4)
 // NR > 0: number of rays per wavelength as a compile-time constant (angle sums unroll into independent
 // LDS reads); SCAL: the scattering coefficient may be wavelength dependent (vector load) -- otherwise
 // it is one scalar per depth.
-template <int NPT, int NR, bool SCAL>
+// NL: how many of the NPT per-ray slots are lines (they come first, lsx_create) -- the slot kind is then a
+// compile-time property of the unrolled slot index and only one of the two formula sets is emitted.
+template <int NPT, int NL, int NR, bool SCAL>
 __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, const int tile_id)
 {
     extern __shared__ double lds_raw[];
@@ -284,7 +288,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
 #pragma unroll
             for (int u = 0; u < NPT; ++u) {
                 const double ni = ncolp[(size_t)slots[u].li * Ns + e], nj = ncolp[(size_t)slots[u].lj * Ns + e];
-                const bool line = (slots[u].flags & SLOT_LINE) != 0;
+                const bool line = u < NL;
                 utab[e * TR + 3 * u + 0] = line ? slots[u].cB * (ni - slots[u].g * nj) : ni;   // :279-280, :613
                 utab[e * TR + 3 * u + 1] = nj;
                 utab[e * TR + 3 * u + 2] = line ? p.wphi[(size_t)col * p.Nlines * Ns + slots[u].wphi_off + e] : 1.0;
@@ -326,7 +330,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             const bool a = (pact >> u) & 1u;
             const int l = a ? la - slots[u].Nblue : 0;
             const int Nlam = slots[u].Nlam;
-            const bool line = (slots[u].flags & SLOT_LINE) != 0;
+            const bool line = u < NL;
             const int len = slots[u].len;
             const int lb = a ? la - slots[u].first : 0;      // position inside the (tile, transition) block
             (void)Nlam;
@@ -404,7 +408,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
 #pragma unroll
             for (int u = 0; u < NPT; ++u) {
                 const bool a = (pact >> u) & 1u;
-                const double* tab = (slots[u].flags & SLOT_LINE) ? phi_col : gijc_col;
+                const double* tab = u < NL ? phi_col : gijc_col;
                 v[u] = a ? tab[idx0[u] + kk * kstr[u]] : 0.0;
             }
         }
@@ -449,11 +453,11 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         // ---- pass 1: opacity / emissivity of the per-ray transitions (rh_method.py:601-627) ----
         //   kept for pass 2 (static path): pv = phi | Vji, chi, Uji
         double spv[NS], schi[NS], sUji[NS];
-        auto pass1 = [&](const SlotS& sl, double v, double ni, double nj, double alf, double& pv, double& chi,
+        auto pass1 = [&](const bool line, const SlotS& sl, double v, double ni, double nj, double alf, double& pv, double& chi,
                          double& Uji) {
             // a tile with a single per-ray slot shares no level and no atom with anything (lsx_create): no cells
-            const int fl = (NPT == 1 || NPT == 2) ? (sl.flags & SLOT_LINE) : sl.flags;   // NPT == 2: bookkeeping in registers (pass 2)
-            if (fl & SLOT_LINE) {
+            const int fl = (NPT == 1 || NPT == 2) ? 0 : sl.flags;   // NPT == 2: bookkeeping in registers (pass 2)
+            if (line) {
                 pv = v;
                 chi = (STATIC ? ni : sl.cB * (ni - sl.g * nj)) * pv;   // n_i Vij - n_j Vji, :279-280, :613 (static: ni holds the product)
                 Uji = sl.Uc * pv;                        // :281
@@ -476,7 +480,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
 #pragma unroll
             for (int u = 0; u < NPT; ++u) {
                 const SlotS sl = load_slot(slots + u, Ns);
-                pass1(sl, sv[u], sni[u], snj[u], alv[u], spv[u], schi[u], sUji[u]);
+                pass1(u < NL, sl, sv[u], sni[u], snj[u], alv[u], spv[u], schi[u], sUji[u]);
             }
         } else {
             for (int u = 0; u < nP; ++u) {
@@ -493,7 +497,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                     alf = a ? p.alpha[sl.wl_off + l] : 0.0;
                 }
                 double pv, chi, Uji;
-                pass1(sl, v, ni, nj, alf, pv, chi, Uji);
+                pass1((sl.flags & SLOT_LINE) != 0, sl, v, ni, nj, alf, pv, chi, Uji);
             }
         }
         STAMP(2);
@@ -530,16 +534,16 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         // ---- angle quadrature of this wavelength: J (:640) and the two ray sums of the fast path ----
         xrow[lane] = wmuh_l * I;
         __builtin_amdgcn_wave_barrier();
-        double Jsum = 0.0;
+        double Jsum = xrow[j];
 #pragma unroll
-        for (int m = 0; m < Nrays; ++m) Jsum += xrow[m * L + j];
+        for (int m = 1; m < Nrays; ++m) Jsum += xrow[m * L + j];
         if (nF > 0) {                                   // Psibar of this direction, for k_fast_gamma
             __builtin_amdgcn_wave_barrier();
             xrow[lane] = wq_l * Psi;
             __builtin_amdgcn_wave_barrier();
-            double sPsi = 0.0;
+            double sPsi = xrow[j];
 #pragma unroll
-            for (int m = 0; m < Nrays; ++m) sPsi += xrow[m * L + j];
+            for (int m = 1; m < Nrays; ++m) sPsi += xrow[m * L + j];
             if (lead) psibar[kl] = sPsi;
         }
         __builtin_amdgcn_wave_barrier();
@@ -555,10 +559,10 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             wg1 = wt * g1;                                                 // wt: :451/:455, :665
             wg2 = wt * g2;
         };
-        auto pass2 = [&](const SlotS& sl, double pv, double chi, double Uji, double Vij, double nj, double wt,
+        auto pass2 = [&](const bool line, const SlotS& sl, double pv, double chi, double Uji, double Vij, double nj, double wt,
                          double& wg1, double& wg2) {
-            const int fl = NPT == 1 ? (sl.flags & SLOT_LINE) : sl.flags;
-            const double Vji = (fl & SLOT_LINE) ? sl.Vc * pv : pv;
+            const int fl = NPT == 1 ? 0 : sl.flags;
+            const double Vji = line ? sl.Vc * pv : pv;
             const double eta = nj * Uji;
             const double etaA = (fl & SLOT_ETA_CELL) ? CETA(sl.ca) : eta;
             const double chi_i = (fl & SLOT_LI_CELL) ? CCHI(sl.ci) : chi;
@@ -578,7 +582,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
 #pragma unroll
             for (int u = 0; u < NPT; ++u) {
                 const SlotS sl = load_slot(slots + u, Ns);
-                const bool line = (sl.flags & SLOT_LINE) != 0;
+                const bool line = u < NL;
                 const double Vij = line ? sl.cB * spv[u] : alv[u];
                 if constexpr (NPT == 2) {
                     // atom.chi / atom.U / atom.eta of this slot's levels from the two slots' values, in transition
@@ -593,7 +597,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                     pass2x(line, sl.Vc, spv[u], sUji[u], Vij, wlv[u] * swp[u], etaA, chi_i, chi_j, U_j, U_i,
                            w1[u], w2v[u]);
                 } else {
-                    pass2(sl, spv[u], schi[u], sUji[u], Vij, snj[u], wlv[u] * swp[u], w1[u], w2v[u]); // :451, :455
+                    pass2(line, sl, spv[u], schi[u], sUji[u], Vij, snj[u], wlv[u] * swp[u], w1[u], w2v[u]); // :451, :455
                 }
             }
             if constexpr (NPT == 1) {
@@ -634,7 +638,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                     chi = ni * Vij - nj * pv;
                 }
                 double wg1, wg2;
-                pass2(sl, pv, chi, Uji, Vij, nj, (a && valid) ? wq_l * wla : 0.0, wg1, wg2);
+                pass2((sl.flags & SLOT_LINE) != 0, sl, pv, chi, Uji, Vij, nj, (a && valid) ? wq_l * wla : 0.0, wg1, wg2);
                 const double t = reduce_pair(wg1, wg2);
                 if (lane == 31) *gslot(u, 0) = t;
                 if (lane == 63) *gslot(u, 1) = t;
@@ -654,14 +658,14 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             if (lead && dir == 0) {
                 const double Jv = Jsum + xwg[LSX_WAVE + j];
                 Jnew[kl] = Jv;
-                dJ = nanmax(dJ, fabs(1.0 - jd / Jv));         // :705
+                dJ = nanmax(dJ, fabs(1.0 - jd * rcp(Jv)));         // :705
             }
         } else {
             if (s2 == nm1 + 1 || s2 == nm1 + 2) __syncthreads(); // the partner wave's first-half stores
             if (lead) {
                 const double Jv = Jnew[kl] + Jsum;
                 Jnew[kl] = Jv;
-                dJ = nanmax(dJ, fabs(1.0 - jd / Jv));         // :705
+                dJ = nanmax(dJ, fabs(1.0 - jd * rcp(Jv)));         // :705
             }
         }
     }
@@ -698,7 +702,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
 #define LSX_WPE3 (LSX_WAVES_PER_EU - 1)     // three per-ray slots: 4 waves/SIMD would spill ~60 VGPRs
 #endif
 #define LSX_WPE(NPT) ((NPT) == 0 ? LSX_WPE0 : ((NPT) == 1 ? LSX_WPE1 : ((NPT) == 2 ? LSX_WPE2 : ((NPT) == 3 ? LSX_WPE3 : LSX_WAVES_PER_EU))))
-template <int NPT, int NR, bool SCAL>
+template <int NPT, int NL, int NR, bool SCAL>
 __global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(LSX_WPE(NPT))))
 lsx_sweep_kernel(const SweepParams p)
 {
@@ -719,7 +723,7 @@ lsx_sweep_kernel(const SweepParams p)
         for (int e = threadIdx.x; e < p.Nspace * p.L; e += 2 * LSX_WAVE) p.Jnew_T[tb + e] = p.Jdag_T[tb + e];
         return;
     }
-    sweep_tile<NPT, NR, SCAL>(p, vb, tile_id);
+    sweep_tile<NPT, NL, NR, SCAL>(p, vb, tile_id);
 }
 
 // Small batches (a few columns) are latency bound: one launch that dispatches on the tile's class inside
@@ -736,24 +740,28 @@ lsx_sweep_kernel_all(const SweepParams p)
         for (int e = threadIdx.x; e < p.Nspace * p.L; e += 2 * LSX_WAVE) p.Jnew_T[tb + e] = p.Jdag_T[tb + e];
         return;
     }
-    const int nP = (LSX_CONST(DevTile, p.tiles) + tile_id)->nP;
-    if (nP == 0) sweep_tile<0, NR, SCAL>(p, vb, tile_id);
-    else if (nP == 1) sweep_tile<1, NR, SCAL>(p, vb, tile_id);
-    else if (nP == 2) sweep_tile<2, NR, SCAL>(p, vb, tile_id);
-    else if (nP == 3) sweep_tile<3, NR, SCAL>(p, vb, tile_id);
-    else sweep_tile<-1, NR, SCAL>(p, vb, tile_id);
+    const int nP = (LSX_CONST(DevTile, p.tiles) + tile_id)->nP, nL = (LSX_CONST(DevTile, p.tiles) + tile_id)->nL;
+    if (nP == 0) sweep_tile<0, 0, NR, SCAL>(p, vb, tile_id);
+    else if (nP == 1) sweep_tile<1, 1, NR, SCAL>(p, vb, tile_id);
+    else if (nP == 2 && nL == 2) sweep_tile<2, 2, NR, SCAL>(p, vb, tile_id);
+    else if (nP == 2 && nL == 1) sweep_tile<2, 1, NR, SCAL>(p, vb, tile_id);
+    else sweep_tile<-1, 0, NR, SCAL>(p, vb, tile_id);     // three-slot tiles take the generic path here (code size)
 }
 
 template <int NR, bool SCAL>
 static void launch_class(const SweepParams& p, int npt, dim3 g, dim3 b, size_t lds_bytes, hipStream_t st)
 {
+    // npt: -2 fused, -1 generic, else (per-ray slots) * 8 + (lines among them)
     switch (npt) {
     case -2: hipLaunchKernelGGL((lsx_sweep_kernel_all<NR, SCAL>), g, b, lds_bytes, st, p); break;
-    case 0: hipLaunchKernelGGL((lsx_sweep_kernel<0, NR, SCAL>), g, b, lds_bytes, st, p); break;
-    case 1: hipLaunchKernelGGL((lsx_sweep_kernel<1, NR, SCAL>), g, b, lds_bytes, st, p); break;
-    case 2: hipLaunchKernelGGL((lsx_sweep_kernel<2, NR, SCAL>), g, b, lds_bytes, st, p); break;
-    case 3: hipLaunchKernelGGL((lsx_sweep_kernel<3, NR, SCAL>), g, b, lds_bytes, st, p); break;
-    default: hipLaunchKernelGGL((lsx_sweep_kernel<-1, NR, SCAL>), g, b, lds_bytes, st, p); break;
+    case 0: hipLaunchKernelGGL((lsx_sweep_kernel<0, 0, NR, SCAL>), g, b, lds_bytes, st, p); break;
+    case 8 + 1: hipLaunchKernelGGL((lsx_sweep_kernel<1, 1, NR, SCAL>), g, b, lds_bytes, st, p); break;
+    case 16 + 1: hipLaunchKernelGGL((lsx_sweep_kernel<2, 1, NR, SCAL>), g, b, lds_bytes, st, p); break;
+    case 16 + 2: hipLaunchKernelGGL((lsx_sweep_kernel<2, 2, NR, SCAL>), g, b, lds_bytes, st, p); break;
+    case 24 + 1: hipLaunchKernelGGL((lsx_sweep_kernel<3, 1, NR, SCAL>), g, b, lds_bytes, st, p); break;
+    case 24 + 2: hipLaunchKernelGGL((lsx_sweep_kernel<3, 2, NR, SCAL>), g, b, lds_bytes, st, p); break;
+    case 24 + 3: hipLaunchKernelGGL((lsx_sweep_kernel<3, 3, NR, SCAL>), g, b, lds_bytes, st, p); break;
+    default: hipLaunchKernelGGL((lsx_sweep_kernel<-1, 0, NR, SCAL>), g, b, lds_bytes, st, p); break;
     }
 }
 
