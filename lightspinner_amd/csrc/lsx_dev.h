@@ -62,6 +62,8 @@ enum {
 // A tile's slots are ordered: per-ray slots first (lines, then continua of atoms that have
 // a line in the tile), then "fast" continua (atoms without a line in the tile: their
 // opacity, emissivity and level bookkeeping do not depend on the ray).
+#define LSX_EXP_TAB 128     // doubles at the start of the sweep's LDS: the exp table
+
 struct DevSlot {
     int32_t flags;
     int32_t li, lj;        // global level ids (rows of n)
@@ -137,4 +139,5 @@ struct SweepParams {
     double* dJpart;
     const uint8_t* colmask;     // per-column activity (frozen columns exit at once), or null
     double* debug;              // diagnostic builds only
+    const double* exp2_tab;     // [64][2]: 2^(j/64) as a (head, tail) pair, for the sweep's exp(-dtau)
 };

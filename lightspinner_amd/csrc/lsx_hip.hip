@@ -609,6 +609,7 @@ struct lsx_ctx {
     std::vector<int> fast_tiles;
     int* d_fast_tiles = nullptr;
     int *d_cont_li = nullptr, *d_cont_lj = nullptr;
+    double* d_exp2_tab = nullptr;
     int nF_max = 0, Ncont = 0;
     bool fast_generic = false;
     double* d_nsr = nullptr;     // [col][Ncont][k] nStar_i / nStar_j of the continua
@@ -705,7 +706,7 @@ void lsx_destroy(lsx_ctx* c)
                     c->d_tiles, c->d_slots, c->d_tile_slots, c->d_Nlevel, c->d_lev2_off, c->d_height,
                     c->d_temperature, c->d_nStar, c->d_nTotal, c->d_n, c->d_C, c->d_Gamma, c->d_wphi, c->d_bgchi,
                     c->d_bgeta, c->d_sca, c->d_phi, c->d_gijc, c->d_J[0], c->d_J[1], c->d_I, c->d_Gpart, c->d_dJpart,
-                    c->d_dJcol, c->d_dPcol, c->d_max, c->d_singular, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_nsr, c->d_cont_li, c->d_cont_lj};
+                    c->d_dJcol, c->d_dPcol, c->d_max, c->d_singular, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& k : c->classes) {
@@ -986,7 +987,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     for (auto& k : c->classes) {
         // per wave: level cells, atom cells, angle-sum row; + two cross-wave exchange rows; + the static
         // path's per-depth table of wave-uniform operands, Nspace x (3 npt + 2) doubles
-        k.lds_bytes = (size_t)(2 * (2 * k.ncell_lev + k.ncell_atom + 1) + 2) * LSX_WAVE * sizeof(double) +
+        k.lds_bytes = (size_t)LSX_EXP_TAB * sizeof(double) + (size_t)(2 * (2 * k.ncell_lev + k.ncell_atom + 1) + 2) * LSX_WAVE * sizeof(double) +
                       (size_t)(k.npt >= 0 ? (Ns + 1) * (3 * k.npt + 2) : 0) * sizeof(double);
         if (k.lds_bytes > 64 * 1024) { lsx_destroy(c); return fail(LSX_EUNSUPPORTED, "lsx_create: a tile needs %zu B of LDS", k.lds_bytes); }
         c->lds_bytes = std::max(c->lds_bytes, k.lds_bytes);
@@ -1004,6 +1005,15 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     TRY(upload(&c->d_wl, wl, c->stream));
     TRY(upload(&c->d_alpha, alpha, c->stream));
     TRY(upload(&c->d_u_la, u_la, c->stream));
+    {   // 2^(j/64) as head + tail (extended precision on the host)
+        std::vector<double> et(LSX_EXP_TAB);
+        for (int j = 0; j < 64; ++j) {
+            const long double v = exp2l((long double)j / 64.0L);
+            et[2 * j] = (double)v;
+            et[2 * j + 1] = (double)(v - (long double)et[2 * j]);
+        }
+        TRY(upload(&c->d_exp2_tab, et, c->stream));
+    }
     TRY(upload(&c->d_active, active, c->stream));
     TRY(upload(&c->d_trans, c->htrans, c->stream));
     TRY(upload(&c->d_tiles, c->tiles, c->stream));
@@ -1178,7 +1188,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
     p.height = c->d_height; p.temperature = c->d_temperature; p.n = c->d_n; p.wphi = c->d_wphi;
     p.bgchi_T = c->d_bgchi; p.bgeta_T = c->d_bgeta; p.bgxchi_T = c->d_bgxchi; p.bgxeta_T = c->d_bgxeta; p.Psi2_T = c->d_Psi2; p.sca = c->d_sca; p.phi_T = c->d_phi; p.gijc_T = c->d_gijc;
     p.Jdag_T = c->d_J[c->jcur]; p.Jnew_T = c->d_J[c->jcur ^ 1];
-    p.Iout = c->d_I; p.Gpart = c->d_Gpart; p.dJpart = c->d_dJpart; p.debug = c->d_debug; p.colmask = c->d_colmask;
+    p.Iout = c->d_I; p.Gpart = c->d_Gpart; p.dJpart = c->d_dJpart; p.debug = c->d_debug; p.colmask = c->d_colmask; p.exp2_tab = c->d_exp2_tab;
 
     FastParams ff{};
     const bool has_fast = !c->fast_tiles.empty();
@@ -1205,7 +1215,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
         for (auto& k : c->classes) { p.ncell_lev = std::max(p.ncell_lev, k.ncell_lev); p.ncell_atom = std::max(p.ncell_atom, k.ncell_atom); }
         int npt_max = -1;
         for (auto& k : c->classes) npt_max = std::max(npt_max, k.npt);
-        const size_t lds = (size_t)(2 * (2 * p.ncell_lev + p.ncell_atom + 1) + 2) * LSX_WAVE * sizeof(double) +
+        const size_t lds = (size_t)LSX_EXP_TAB * sizeof(double) + (size_t)(2 * (2 * p.ncell_lev + p.ncell_atom + 1) + 2) * LSX_WAVE * sizeof(double) +
                            (size_t)(npt_max >= 0 ? (c->Nspace + 1) * (3 * npt_max + 2) : 0) * sizeof(double);
         hipError_t e = lsx_launch_sweep(&p, -2, (int)nblocks, lds, c->stream);
         if (e != hipSuccess) return fail(LSX_EDEVICE, "sweep launch (fused): %s", hipGetErrorString(e));

@@ -62,15 +62,37 @@ __device__ __forceinline__ double rcp(double x)
     return r;
 }
 
+typedef __attribute__((address_space(3))) double lds_f64;   // LDS pointers carry their address space: ds_ instructions, no flat-pointer checks
+
+// exp(x) for the sweep (x = -dtau, -50 <= x <= -5e-4 where the value is used): x = (64 q + j) ln2/64 + r with
+// |r| <= ln2/128, exp(x) = 2^q * 2^(j/64) * exp(r).  2^(j/64) comes from a 64-entry (head, tail) table in LDS, exp(r)
+// from a degree-6 polynomial (truncation < 2e-19); about half the instructions of the library routine, and the
+// coefficients fit the scalar operand slot.  Error below 1 ulp, like the library's.  NaN propagates.
+__device__ __forceinline__ double exp_tab64(double x, const lds_f64* tab)
+{
+    const double kf = __builtin_rint(x * 0x1.71547652b82fep+6);        // 64 / ln2
+    double r = fma(kf, -0x1.62e42fef80000p-7, x);                       // ln2/64, head (18 trailing zero bits)
+    r = fma(kf, -0x1.1cf79abc9e3b4p-42, r);                             //         tail
+    const int ki = (int)kf;
+    const lds_f64* e = tab + 2 * (ki & 63);
+    const double th = e[0], tl = e[1];
+    double t = fma(r, 1.0 / 720.0, 1.0 / 120.0);
+    t = fma(r, t, 1.0 / 24.0);
+    t = fma(r, t, 1.0 / 6.0);
+    t = fma(r, t, 0.5);
+    const double m = fma(r * r, t, r);                                  // exp(r) - 1
+    return ldexp(fma(th, m, tl) + th, ki >> 6);
+}
+
 // formal_solver.py:14-44.  The three regimes are selected per lane; the exponential is skipped
 // for the whole wavefront when no lane is in the middle regime (top / bottom of the atmosphere).
-__device__ __forceinline__ void w2(double dtau, double& w0, double& w1)
+__device__ __forceinline__ void w2(double dtau, double& w0, double& w1, const lds_f64* exp2_tab)
 {
     const bool small = dtau < 5e-4;
     const bool large = dtau > 50.0;
     double a0 = 1.0, a1 = 1.0;
     if (__builtin_amdgcn_ballot_w64(!(small || large)) != 0) {
-        const double e = exp(-dtau);
+        const double e = exp_tab64(-dtau, exp2_tab);
         a0 = 1.0 - e;
         a1 = a0 - dtau * e;
     }
@@ -179,7 +201,6 @@ __device__ __forceinline__ double wave_max_nan(double v)
 }
 
 // lane-private LDS cell: first writer of a pass stores, later writers add (DS add, no return)
-typedef __attribute__((address_space(3))) double lds_f64;   // LDS pointers carry their address space: ds_ instructions, no flat-pointer checks
 __device__ __forceinline__ void cell_acc(lds_f64* p, double v, bool first)
 {
     if (first) *p = v;
@@ -218,7 +239,8 @@ template <int NPT, int NL, int NR, bool SCAL>
 __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, const int tile_id)
 {
     extern __shared__ double lds_raw[];
-    lds_f64* const lds = (lds_f64*)lds_raw;
+    lds_f64* const etab = (lds_f64*)lds_raw;            // [64][2] exp table (16-byte aligned pairs)
+    lds_f64* const lds = etab + LSX_EXP_TAB;
     constexpr bool STATIC = NPT >= 0;
     constexpr int NS = NPT > 0 ? NPT : 1;
     const int lane = threadIdx.x & (LSX_WAVE - 1);
@@ -296,8 +318,9 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             utab[e * TR + 3 * NPT + 0] = e > 0 ? 0.5 * fabs(zc[e - 1] - zc[e]) : 0.0;
             utab[e * TR + 3 * NPT + 1] = sca_l ? 1.0 : p.sca[(size_t)col * Ns + e];
         }
-        __syncthreads();
     }
+    etab[threadIdx.x] = p.exp2_tab[threadIdx.x];          // 2 x 64 threads, 64 x 2 doubles
+    __syncthreads();
 
     const double wav = p.wavelength[la];
     const double u_la = p.u_la[la];
@@ -517,7 +540,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             // S[kEnd - dk] with the fresh dS, dtau (reference behaviour, reproduced deliberately)
             const bool last = (s == Ns - 1);
             double w0, w1;
-            w2(last ? dtau_prev : dtau, w0, w1);
+            w2(last ? dtau_prev : dtau, w0, w1, etab);
             const double Sx = last ? S_prev : S;
             I = Iu * (1.0 - w0) + w0 * Sx + w1 * dS;
             Lam = w0 - w1 * rdt;
