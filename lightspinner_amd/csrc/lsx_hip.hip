@@ -1036,7 +1036,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     c->gijc_col = gij_run;
     c->til_col = c->tiles.size() * (size_t)c->L * Ns;        // one tile-major [tile][k][j] array
     c->sca_col = c->sca_per_lambda ? c->til_col : (size_t)Ns;
-    if (c->phi_col > 0x7fffffff || c->gijc_col > 0x7fffffff) { lsx_destroy(c); return fail(LSX_EUNSUPPORTED, "column too large for 32-bit offsets"); }
+    if (c->phi_col > 0x0fffffff || c->gijc_col > 0x0fffffff || c->til_col > 0x0fffffff) { lsx_destroy(c); return fail(LSX_EUNSUPPORTED, "column too large for 32-bit byte offsets"); }
     TRY(dmalloc(&c->d_height, nc * Ns));
     TRY(dmalloc(&c->d_temperature, nc * Ns));
     TRY(dmalloc(&c->d_nStar, nc * c->NLtot * Ns));

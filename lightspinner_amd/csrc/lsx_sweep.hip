@@ -138,8 +138,13 @@ __device__ __forceinline__ double dpp_f64(double v)
     int lo = __double2loint(v), hi = __double2hiint(v);
     // `old` = the source itself: no zero has to be materialised; lanes a row mask leaves out keep their own
     // value (their sums are never consumed, see the callers)
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    if constexpr (ROW_MASK == 0xf) {                // every lane is written: no `old` operand to set up
+        lo = __builtin_amdgcn_mov_dpp(lo, CTRL, ROW_MASK, 0xf, true);
+        hi = __builtin_amdgcn_mov_dpp(hi, CTRL, ROW_MASK, 0xf, true);
+    } else {
+        lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    }
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_sum(double v)
@@ -186,6 +191,17 @@ __device__ __forceinline__ double reduce_quad(double a, double b, double c, doub
     return row_sums(__hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]));
 }
 #endif
+
+// element at a 32-bit BYTE offset from a wave-uniform base: one scalar base + one 32-bit vector offset
+// (global_load ... v_off, s[base]) instead of 64-bit vector address arithmetic per access
+__device__ __forceinline__ const double& at(const double* base, unsigned byte_off)
+{
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ double& at(double* base, unsigned byte_off)
+{
+    return *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + byte_off);
+}
 
 __device__ __forceinline__ double nanmax(double a, double b)
 {
@@ -423,16 +439,16 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     double n_bc = 0.0, n_be = 0.0, n_jd = 0.0, n_sv[NS];
 
     auto stream_loads = [&](int kk, double& bc, double& be, double& jdv, double (&v)[NS]) {
-        const int kkl = kk * L + j;
-        jdv = Jdag[kkl];
-        bc = bgchi[kkl];
-        be = bgeta[kkl];
+        const unsigned kko = (unsigned)(kk * L + j) * 8u;
+        jdv = at(Jdag, kko);
+        bc = at(bgchi, kko);
+        be = at(bgeta, kko);
         if constexpr (STATIC) {
 #pragma unroll
             for (int u = 0; u < NPT; ++u) {
                 const bool a = (pact >> u) & 1u;
                 const double* tab = u < NL ? phi_col : gijc_col;
-                v[u] = a ? tab[idx0[u] + kk * kstr[u]] : 0.0;
+                v[u] = a ? at(tab, (unsigned)(idx0[u] + kk * kstr[u]) * 8u) : 0.0;
             }
         }
     };
@@ -440,7 +456,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
 
     for (int s = 0; s < Ns; ++s) {
         const int k = kS + dk * s;
-        const int kl = k * L + j;                       // position in the tile-major [k][j] streams
+        const unsigned kl = (unsigned)(k * L + j) * 8u;     // byte position in the tile-major [k][j] streams
         double jd, chiTot, be_l;
         double sv[NS], sni[NS], snj[NS], swp[NS];
         if constexpr (STATIC) {
@@ -461,10 +477,10 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         double hdzm, scv;
         if constexpr (STATIC) {
             hdzm = (utab + TR * dir)[k * TR + 3 * NPT] * zmu_l;   // the interval behind this ray: row k (down) / k + 1 (up)
-            scv = sca_l ? sca[kl] : utab[k * TR + 3 * NPT + 1];
+            scv = sca_l ? at(sca, kl) : utab[k * TR + 3 * NPT + 1];
         } else {
             const double zk = z[k];
-            scv = sca_l ? sca[kl] : LSX_CONST(double, sca)[k];
+            scv = sca_l ? at(sca, kl) : LSX_CONST(double, sca)[k];
             hdzm = (0.5 * fabs(zprev - zk)) * zmu_l;
             zprev = zk;
         }
@@ -567,7 +583,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             double sPsi = xrow[j];
 #pragma unroll
             for (int m = 1; m < Nrays; ++m) sPsi += xrow[m * L + j];
-            if (lead) psibar[kl] = sPsi;
+            if (lead) at(psibar, kl) = sPsi;
         }
         __builtin_amdgcn_wave_barrier();
         STAMP(4);
@@ -674,20 +690,20 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         // ---- J: the two directions meet at depth k at different steps ----
         const int s2 = 2 * s, nm1 = Ns - 1;
         if (s2 < nm1) {
-            if (lead) Jnew[kl] = Jsum;                        // first visitor stores its half
+            if (lead) at(Jnew, kl) = Jsum;                    // first visitor stores its half
         } else if (s2 == nm1) {                               // odd Nspace: both waves are at the same k
             if (lead) xwg[dir * LSX_WAVE + j] = Jsum;
             __syncthreads();
             if (lead && dir == 0) {
                 const double Jv = Jsum + xwg[LSX_WAVE + j];
-                Jnew[kl] = Jv;
+                at(Jnew, kl) = Jv;
                 dJ = nanmax(dJ, fabs(1.0 - jd * rcp(Jv)));         // :705
             }
         } else {
             if (s2 == nm1 + 1 || s2 == nm1 + 2) __syncthreads(); // the partner wave's first-half stores
             if (lead) {
-                const double Jv = Jnew[kl] + Jsum;
-                Jnew[kl] = Jv;
+                const double Jv = at(Jnew, kl) + Jsum;
+                at(Jnew, kl) = Jv;
                 dJ = nanmax(dJ, fabs(1.0 - jd * rcp(Jv)));         // :705
             }
         }
