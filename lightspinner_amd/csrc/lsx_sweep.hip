@@ -454,6 +454,15 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     };
     if constexpr (STATIC) stream_loads(kS, n_bc, n_be, n_jd, n_sv);
 
+    double gacc[2 * NS];
+#pragma unroll
+    for (int q = 0; q < 2 * NS; ++q) gacc[q] = 0.0;
+    // acc[lane dst] = t[lane src]  (src a constant, dst wave-uniform)
+    auto park = [](double& acc, double t, int src, int dst) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(t), src), hi = __builtin_amdgcn_readlane(__double2hiint(t), src);
+        acc = (int)(threadIdx.x & (LSX_WAVE - 1)) == dst ? __hiloint2double(hi, lo) : acc;
+    };
+
     for (int s = 0; s < Ns; ++s) {
         const int k = kS + dk * s;
         const unsigned kl = (unsigned)(k * L + j) * 8u;     // byte position in the tile-major [k][j] streams
@@ -583,7 +592,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             double sPsi = xrow[j];
 #pragma unroll
             for (int m = 1; m < Nrays; ++m) sPsi += xrow[m * L + j];
-            if (lead) at(psibar, kl) = sPsi;
+            at(psibar, kl) = sPsi;                          // every lane of a wavelength holds the same sum: no branch
         }
         __builtin_amdgcn_wave_barrier();
         STAMP(4);
@@ -614,7 +623,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             wg1 = wt * g1;
             wg2 = wt * g2;
         };
-        // store the reductions of slot u: Gpart[slot][e][dir][k], e = 0: Gamma[i][j], e = 1: Gamma[j][i]
+        // the reductions of slot u go to Gpart[slot][e][dir][k], e = 0: Gamma[i][j], e = 1: Gamma[j][i]
         auto gslot = [&](int u, int e) -> double* { return gpart + ((u * 2 + e) * 2 + dir) * Ns + k; };
         if constexpr (STATIC) {
             double w1[NS], w2v[NS];
@@ -639,20 +648,30 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                     pass2(line, sl, spv[u], schi[u], sUji[u], Vij, snj[u], wlv[u] * swp[u], w1[u], w2v[u]); // :451, :455
                 }
             }
+            // the totals of step s are parked in lane (s mod 64) of per-(slot, entry) accumulators and leave as one
+            // 64-wide store every 64 steps: no store (and no store acknowledgement to wait for) inside a step
+            const int sl64 = s & 63;
             if constexpr (NPT == 1) {
                 const double t = reduce_pair(w1[0], w2v[0]);
-                if (lane == 31) *gslot(0, 0) = t;
-                if (lane == 63) *gslot(0, 1) = t;
+                park(gacc[0], t, 31, sl64);
+                park(gacc[1], t, 63, sl64);
             } else if constexpr (NPT >= 2) {
                 const double t = reduce_quad(w1[0], w2v[0], w1[1], w2v[1]);
-                if (lane == 15) *gslot(0, 0) = t;
-                if (lane == 47) *gslot(0, 1) = t;
-                if (lane == 31) *gslot(1, 0) = t;
-                if (lane == 63) *gslot(1, 1) = t;
+                park(gacc[0], t, 15, sl64);
+                park(gacc[1], t, 47, sl64);
+                park(gacc[2], t, 31, sl64);
+                park(gacc[3], t, 63, sl64);
                 if constexpr (NPT == 3) {
                     const double t2 = reduce_pair(w1[2], w2v[2]);
-                    if (lane == 31) *gslot(2, 0) = t2;
-                    if (lane == 63) *gslot(2, 1) = t2;
+                    park(gacc[4], t2, 31, sl64);
+                    park(gacc[5], t2, 63, sl64);
+                }
+            }
+            if (sl64 == 63 || s == Ns - 1) {
+                const int ks = kS + dk * (s - sl64 + lane);         // the depth parked in this lane
+                if (lane <= sl64) {
+#pragma unroll
+                    for (int q = 0; q < 2 * NPT; ++q) gpart[(q * 2 + dir) * Ns + ks] = gacc[q];
                 }
             }
         } else {
@@ -689,8 +708,9 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
 
         // ---- J: the two directions meet at depth k at different steps ----
         const int s2 = 2 * s, nm1 = Ns - 1;
+        // (the Nrays lanes of a wavelength hold the same Jsum and write the same word: stores need no branch)
         if (s2 < nm1) {
-            if (lead) at(Jnew, kl) = Jsum;                    // first visitor stores its half
+            at(Jnew, kl) = Jsum;                              // first visitor stores its half
         } else if (s2 == nm1) {                               // odd Nspace: both waves are at the same k
             if (lead) xwg[dir * LSX_WAVE + j] = Jsum;
             __syncthreads();
@@ -701,11 +721,9 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             }
         } else {
             if (s2 == nm1 + 1 || s2 == nm1 + 2) __syncthreads(); // the partner wave's first-half stores
-            if (lead) {
-                const double Jv = at(Jnew, kl) + Jsum;
-                at(Jnew, kl) = Jv;
-                dJ = nanmax(dJ, fabs(1.0 - jd * rcp(Jv)));         // :705
-            }
+            const double Jv = at(Jnew, kl) + Jsum;
+            at(Jnew, kl) = Jv;
+            dJ = nanmax(dJ, fabs(1.0 - jd * rcp(Jv)));         // :705
         }
     }
 
