@@ -34,6 +34,7 @@
 //     (k_fast_gamma) forms it from J = sum w I and Psibar = sum w Psi*, which this kernel stores
 //     per direction for the tiles that have such continua.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "lsx_dev.h"
 
 namespace {
@@ -448,7 +449,8 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             for (int u = 0; u < NPT; ++u) {
                 const bool a = (pact >> u) & 1u;
                 const double* tab = u < NL ? phi_col : gijc_col;
-                v[u] = a ? at(tab, (unsigned)(idx0[u] + kk * kstr[u]) * 8u) : 0.0;
+                (void)a;    // inactive lanes read the block's first element; the value is dropped where it is consumed
+                v[u] = at(tab, (unsigned)(idx0[u] + kk * kstr[u]) * 8u);
             }
         }
     };
@@ -463,16 +465,27 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         acc = (int)(threadIdx.x & (LSX_WAVE - 1)) == dst ? __hiloint2double(hi, lo) : acc;
     };
 
-    for (int s = 0; s < Ns; ++s) {
+    // A sweep runs in three phases with a fixed set of memory operations each, so the compiler's wait counts are
+    // exact and neither a store acknowledgement nor the half-J read-back is waited for inside a step:
+    //   phase 0: this wave is the first visitor of its depths (stores its half of J)
+    //   phase 1: odd Nspace only, the one depth both waves visit in the same step (exchange through LDS)
+    //   phase 2: second visitor (the partner's half is requested at the top of the step, used at its end)
+    auto step = [&](const int s, auto phase_c) {
+        constexpr int PH = decltype(phase_c)::value;
         const int k = kS + dk * s;
         const unsigned kl = (unsigned)(k * L + j) * 8u;     // byte position in the tile-major [k][j] streams
         double jd, chiTot, be_l;
         double sv[NS], sni[NS], snj[NS], swp[NS];
+        double jhalf = 0.0;
+        if constexpr (PH == 2) {
+            if (2 * s == Ns || 2 * s == Ns + 1) __syncthreads();   // the partner wave's first-half stores
+        }
         if constexpr (STATIC) {
             jd = n_jd; chiTot = n_bc; be_l = n_be;
 #pragma unroll
-            for (int u = 0; u < NPT; ++u) sv[u] = n_sv[u];
+            for (int u = 0; u < NPT; ++u) sv[u] = ((pact >> u) & 1u) ? n_sv[u] : 0.0;
             if (s + 1 < Ns) stream_loads(k + dk, n_bc, n_be, n_jd, n_sv);
+            if constexpr (PH == 2) jhalf = at(Jnew, kl);
             const lds_f64* tk = utab + k * TR;
 #pragma unroll
             for (int u = 0; u < NPT; ++u) {
@@ -575,8 +588,10 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         Iu = I;
         chi_prev = chiTot;
         S_prev = S;
-        if (s == Ns - 1 && dir == 1 && valid)            // emergent intensity, :638
-            p.Iout[((size_t)col * Nspect + la) * Nrays + mu] = I;
+        if constexpr (PH == 2) {
+            if (s == Ns - 1 && dir == 1 && valid)        // emergent intensity, :638
+                p.Iout[((size_t)col * Nspect + la) * Nrays + mu] = I;
+        }
         STAMP(3);
 
         // ---- angle quadrature of this wavelength: J (:640) and the two ray sums of the fast path ----
@@ -707,11 +722,10 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         STAMP(6);
 
         // ---- J: the two directions meet at depth k at different steps ----
-        const int s2 = 2 * s, nm1 = Ns - 1;
         // (the Nrays lanes of a wavelength hold the same Jsum and write the same word: stores need no branch)
-        if (s2 < nm1) {
+        if constexpr (PH == 0) {
             at(Jnew, kl) = Jsum;                              // first visitor stores its half
-        } else if (s2 == nm1) {                               // odd Nspace: both waves are at the same k
+        } else if constexpr (PH == 1) {                       // odd Nspace: both waves are at the same k
             if (lead) xwg[dir * LSX_WAVE + j] = Jsum;
             __syncthreads();
             if (lead && dir == 0) {
@@ -720,11 +734,17 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                 dJ = nanmax(dJ, fabs(1.0 - jd * rcp(Jv)));         // :705
             }
         } else {
-            if (s2 == nm1 + 1 || s2 == nm1 + 2) __syncthreads(); // the partner wave's first-half stores
-            const double Jv = at(Jnew, kl) + Jsum;
+            if constexpr (!STATIC) jhalf = at(Jnew, kl);
+            const double Jv = jhalf + Jsum;
             at(Jnew, kl) = Jv;
             dJ = nanmax(dJ, fabs(1.0 - jd * rcp(Jv)));         // :705
         }
+    };
+    {
+        const int nA = Ns / 2;                                // depths this wave reaches first: 2 s < Nspace - 1
+        for (int s = 0; s < nA; ++s) step(s, std::integral_constant<int, 0>{});
+        if (Ns & 1) step(nA, std::integral_constant<int, 1>{});
+        for (int s = nA + (Ns & 1); s < Ns; ++s) step(s, std::integral_constant<int, 2>{});
     }
 
 #ifdef LSX_STAMPS
