@@ -132,8 +132,11 @@ def main():
     reducer = MaxReducer(device=dev)
 
     def step():
-        dJ = eng.formal_sol_gamma()
-        dP = eng.stat_equil()
+        # one MALI iteration: both calls are enqueued, the host reads (dJ, dPops) once -- what the
+        # reference's `while dJ > 2e-3 or dPops > 1e-3` loop needs per iteration (test.py:23-29)
+        eng.formal_sol_gamma_async()
+        eng.stat_equil_async()
+        dJ, dP = eng.sync()
         return reducer(dJ, dP)
 
     def barrier():
@@ -166,7 +169,7 @@ def main():
         balg = eng.algorithmic_bytes_per_column()      # SURVEY 8d formula, whole FS call
         bsweep = info(0)                               # the part of it the sweep kernel itself moves
         peak = 8000.0
-        kernel = 'lsx_sweep_kernel'
+        kernel = 'lsx_sweep_kernel<slots,lines,rays,sca> (one instance per tile class, launched side by side; duration = span)'
         traffic = None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(pmc):
@@ -184,8 +187,9 @@ def main():
                         point_updates_per_sec_kernel=prob.work_units_per_column() * ncol / (ms_sweep * 1e-3),
                         tiles_per_column=info(1), wavelengths_per_tile=info(3), lds_bytes_per_workgroup=info(2),
                         slab_bytes_per_column=info(5),
-                        note='fp64 VALU work (~150 flop per 13 algorithmic bytes, SURVEY 8d) bounds this kernel as much as '
-                             'HBM does; achieved = algorithmic bytes / HIP-event duration on the launch stream')
+                        note='achieved = algorithmic bytes / HIP-event duration on the launch stream, from before the first '
+                             'class launch to after the last class joined back (profiles/README.md). The sweep is fp64-issue '
+                             'bound (~0.6 M wave-level VALU instructions per column, profiles/r01_pmc_summary.json), not HBM bound')
 
         # ---- parity + single-column (C2) numbers in the same run -----------------------
         single = None

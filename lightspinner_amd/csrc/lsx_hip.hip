@@ -51,24 +51,6 @@ int fail(int code, const char* fmt, ...)
     } while (0)
 
 // ------------------------------------------------------------------------------- kernels
-// out[b][c][r] = in[b][r][c]
-__global__ void k_transpose(const double* __restrict__ in, double* __restrict__ out, int R, int Cc)
-{
-    __shared__ double tile[32][33];
-    const size_t b = blockIdx.z;
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-    const int tx = threadIdx.x, ty = threadIdx.y; // 32 x 8
-    for (int j = ty; j < 32; j += 8) {
-        const int r = r0 + j, c = c0 + tx;
-        if (r < R && c < Cc) tile[j][tx] = in[(b * R + r) * Cc + c];
-    }
-    __syncthreads();
-    for (int j = ty; j < 32; j += 8) {
-        const int c = c0 + j, r = r0 + tx;
-        if (r < R && c < Cc) out[(b * Cc + c) * R + r] = tile[tx][j];
-    }
-}
-
 // one (tile, line) block of the profile: in [col][lt][mu][dir][k] (rows lt0 .. lt0+len of the line)
 //   ->  out [col]{block: [dir][k][mu][l<len]}     (compact: pass Nrays = 1, ndir = 1)
 __global__ void k_pack_phi(const double* __restrict__ in, double* __restrict__ out, int lt0, int len, int Nrays, int ndir,
@@ -658,14 +640,6 @@ int ensure_stage(lsx_ctx* c, size_t doubles)
     return LSX_OK;
 }
 
-int launch_transpose(lsx_ctx* c, const double* in, double* out, int B, int R, int Cc)
-{
-    dim3 grid((Cc + 31) / 32, (R + 31) / 32, B), block(32, 8);
-    hipLaunchKernelGGL(k_transpose, grid, block, 0, c->stream, in, out, R, Cc);
-    HIPCHK(hipGetLastError());
-    return LSX_OK;
-}
-
 int launch_tiles_pack(lsx_ctx* c, const double* in, double* out, int B, bool unpack)
 {
     const int total = (int)c->til_col;
@@ -982,8 +956,10 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         k->ncell_atom = std::max(k->ncell_atom, (int)atom_ids.size());
         c->tiles.push_back(tl);
     }
-    // heaviest class first (its workgroups are enqueued first; the light classes fill the gaps)
-    std::sort(c->classes.begin(), c->classes.end(), [](const SweepClass& a, const SweepClass& b) { return a.tiles.size() > b.tiles.size(); });
+    // the class whose workgroups run longest goes first and gets the highest stream priority: its tail is the
+    // call's tail, the shorter-lived classes fill in behind it
+    auto wg_cost = [](const SweepClass& k) { return k.npt < 0 ? 100 : k.npt; };
+    std::sort(c->classes.begin(), c->classes.end(), [&](const SweepClass& a, const SweepClass& b) { return wg_cost(a) > wg_cost(b); });
     for (auto& k : c->classes) {
         // per wave: level cells, atom cells, angle-sum row; + two cross-wave exchange rows; + the static
         // path's per-depth table of wave-uniform operands, Nspace x (3 npt + 2) doubles
@@ -1023,7 +999,11 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     TRY(upload(&c->d_lev2_off, c->lev2_off, c->stream));
     for (auto& k : c->classes) {
         TRY(upload(&k.d_tiles, k.tiles, c->stream));
-        if (hipStreamCreateWithFlags(&k.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&k.done, hipEventDisableTiming) != hipSuccess) { lsx_destroy(c); return fail(LSX_EDEVICE, "class stream"); }
+        int prio_lo = 0, prio_hi = 0;       // numerically lower = higher priority
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        const int rank = (int)(&k - &c->classes[0]);
+        const int prio = getenv("LSX_NO_PRIO") ? prio_lo : std::min(prio_lo, prio_hi + rank);
+        if (hipStreamCreateWithPriority(&k.stream, hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&k.done, hipEventDisableTiming) != hipSuccess) { lsx_destroy(c); return fail(LSX_EDEVICE, "class stream"); }
     }
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { lsx_destroy(c); return fail(LSX_EDEVICE, "hipEventCreate"); }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess) { lsx_destroy(c); return fail(LSX_EDEVICE, "hipEventCreate"); }

@@ -1,33 +1,78 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 CSVs of profiles/collect.sh: per-kernel averages of every counter.
-usage: python profiles/summarize.py gpurun_out/<tag> [kernel-substring] [min_grid]"""
-import csv, glob, os, sys, collections, json
+"""Summarise the rocprofv3 CSVs written by profiles/collect.sh into one JSON (stdout).
+
+usage: python profiles/summarize.py gpurun_out/<tag> [ncol]
+
+The sweep of one formal-solution call is several kernels (`lsx_sweep_kernel<slots, lines, rays, sca>`, one per
+tile class) launched side by side on forked streams, so the figure that corresponds to bench.py's
+`roofline.avg_launch_ms` is the SPAN of those launches (first start -> last end), not one kernel's duration;
+HBM bytes are summed over the classes of a call.  FETCH_SIZE is in KiB and counts half the bytes on gfx950
+(MI355X_MICROARCH.md; factor checked by the calibration pass): bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
+"""
+import csv, glob, json, os, re, sys, collections
+
+
+def short(name):
+    m = re.search(r'(lsx_sweep_kernel(?:_all)?<[^>]*>)', name)
+    if m:
+        return m.group(1).replace(' ', '')
+    m = re.search(r'(k_\w+|__amd_\w+)', name)
+    return m.group(1) if m else name[:40]
+
 
 def main():
     tag = sys.argv[1]
-    want = sys.argv[2] if len(sys.argv) > 2 else 'lsx_sweep_kernel'
-    min_grid = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-    out = {}
-    for d in sorted(glob.glob(tag + '_pmc*')):
-        for f in glob.glob(os.path.join(d, '*counter_collection.csv')):
-            acc = collections.defaultdict(list)
-            for row in csv.DictReader(open(f)):
-                if want not in row['Kernel_Name']:
-                    continue
-                if int(row.get('Grid_Size', 0)) < min_grid:
-                    continue
-                acc[row['Counter_Name']].append(float(row['Counter_Value']))
-            for k, v in acc.items():
-                out[k] = dict(mean=sum(v) / len(v), n=len(v))
+    ncol = int(sys.argv[2]) if len(sys.argv) > 2 else None
+    out = {'tag': os.path.basename(tag)}
     kt = glob.glob(tag + '_kt/*kernel_trace.csv')
     if kt:
-        durs = []
-        for row in csv.DictReader(open(kt[0])):
-            if want in row['Kernel_Name'] and int(row.get('Grid_Size', 0)) >= min_grid:
-                durs.append(int(row['End_Timestamp']) - int(row['Start_Timestamp']))
-        if durs:
-            out['duration_ns'] = dict(mean=sum(durs) / len(durs), n=len(durs), min=min(durs), max=max(durs))
+        rows = [r for r in csv.DictReader(open(kt[0]))]
+        per = collections.defaultdict(list)
+        for r in rows:
+            per[short(r['Kernel_Name'])].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+        out['kernels_avg_us'] = {k: {'calls': len(v), 'avg_us': round(sum(v) / len(v) / 1e3, 2)} for k, v in sorted(per.items())}
+        sw = sorted([r for r in rows if 'lsx_sweep_kernel' in r['Kernel_Name']], key=lambda r: int(r['Start_Timestamp']))
+        classes = sorted({short(r['Kernel_Name']) for r in sw})
+        n = len(classes)
+        spans = []
+        for i in range(0, len(sw) - n + 1, n):
+            grp = sw[i:i + n]
+            if len({short(r['Kernel_Name']) for r in grp}) != n:
+                continue        # a call whose launches interleave with the next one is skipped
+            spans.append(max(int(r['End_Timestamp']) for r in grp) - min(int(r['Start_Timestamp']) for r in grp))
+        if spans:
+            out['sweep'] = {'classes': classes, 'calls': len(spans), 'span_avg_ms': round(sum(spans) / len(spans) / 1e6, 4),
+                            'span_min_ms': round(min(spans) / 1e6, 4), 'span_max_ms': round(max(spans) / 1e6, 4)}
+    ctr = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in sorted(glob.glob(tag + '_pmc*')):
+        for f in glob.glob(os.path.join(d, '*counter_collection.csv')):
+            for r in csv.DictReader(open(f)):
+                if 'lsx_sweep_kernel' in r['Kernel_Name']:
+                    ctr[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+    if ctr:
+        pc = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in ctr.items()}
+        out['sweep_counters_per_launch'] = {k: {c: round(v, 1) for c, v in d.items()} for k, d in sorted(pc.items())}
+        tot = collections.Counter()
+        for d in pc.values():
+            for c, v in d.items():
+                tot[c] += v
+        if 'FETCH_SIZE' in tot and 'WRITE_SIZE' in tot:
+            hbm = (2.0 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024.0
+            out['sweep_hbm_bytes_per_call'] = hbm
+            if ncol:
+                out['sweep_hbm_bytes_per_call_per_column'] = hbm / ncol
+        if 'SQ_WAVES' in tot:
+            out['sweep_per_wave'] = {k: {c.replace('SQ_INSTS_', '').replace('SQ_', ''): round(d[c] / d['SQ_WAVES'], 1)
+                                         for c in d if c != 'SQ_WAVES'} for k, d in sorted(pc.items()) if 'SQ_WAVES' in d}
+    cal = glob.glob(tag + '_calib/*counter_collection.csv')
+    log = tag + '_calib.log'
+    if cal and os.path.exists(log):
+        fetch = [float(r['Counter_Value']) for r in csv.DictReader(open(cal[0])) if 'k_calib_read' in r['Kernel_Name'] and r['Counter_Name'] == 'FETCH_SIZE']
+        byts = [float(x) for x in re.findall(r'bytes_read=(\d+)', open(log).read())]
+        if fetch and len(fetch) == len(byts):
+            out['fetch_size_calibration_factor'] = [round(b / (f * 1024.0), 4) for b, f in zip(byts, fetch)]
     print(json.dumps(out, indent=1))
+
 
 if __name__ == '__main__':
     main()
