@@ -964,7 +964,8 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         // per wave: level cells, atom cells, angle-sum row; + two cross-wave exchange rows; + the static
         // path's per-depth table of wave-uniform operands, Nspace x (3 npt + 2) doubles
         k.lds_bytes = (size_t)LSX_EXP_TAB * sizeof(double) + (size_t)(2 * (2 * k.ncell_lev + k.ncell_atom + 1) + 2) * LSX_WAVE * sizeof(double) +
-                      (size_t)(k.npt >= 0 ? (Ns + 1) * (3 * k.npt + 2) : 0) * sizeof(double);
+                      (size_t)(k.npt >= 0 ? (Ns + 1) * (3 * k.npt + 2) : 0) * sizeof(double) +
+                      (size_t)(k.npt > 0 ? 2 * 2 * k.npt * LSX_WAVE : 0) * sizeof(double);     // parked Gamma totals
         if (k.lds_bytes > 64 * 1024) { lsx_destroy(c); return fail(LSX_EUNSUPPORTED, "lsx_create: a tile needs %zu B of LDS", k.lds_bytes); }
         c->lds_bytes = std::max(c->lds_bytes, k.lds_bytes);
     }
@@ -1196,7 +1197,8 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
         int npt_max = -1;
         for (auto& k : c->classes) npt_max = std::max(npt_max, k.npt);
         const size_t lds = (size_t)LSX_EXP_TAB * sizeof(double) + (size_t)(2 * (2 * p.ncell_lev + p.ncell_atom + 1) + 2) * LSX_WAVE * sizeof(double) +
-                           (size_t)(npt_max >= 0 ? (c->Nspace + 1) * (3 * npt_max + 2) : 0) * sizeof(double);
+                           (size_t)(npt_max >= 0 ? (c->Nspace + 1) * (3 * npt_max + 2) : 0) * sizeof(double) +
+                           (size_t)(npt_max > 0 ? 2 * 2 * npt_max * LSX_WAVE : 0) * sizeof(double);
         hipError_t e = lsx_launch_sweep(&p, -2, (int)nblocks, lds, c->stream);
         if (e != hipSuccess) return fail(LSX_EDEVICE, "sweep launch (fused): %s", hipGetErrorString(e));
     } else {

@@ -456,14 +456,12 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     };
     if constexpr (STATIC) stream_loads(kS, n_bc, n_be, n_jd, n_sv);
 
-    double gacc[2 * NS];
-#pragma unroll
-    for (int q = 0; q < 2 * NS; ++q) gacc[q] = 0.0;
-    // acc[lane dst] = t[lane src]  (src a constant, dst wave-uniform)
-    auto park = [](double& acc, double t, int src, int dst) {
-        const int lo = __builtin_amdgcn_readlane(__double2loint(t), src), hi = __builtin_amdgcn_readlane(__double2hiint(t), src);
-        acc = (int)(threadIdx.x & (LSX_WAVE - 1)) == dst ? __hiloint2double(hi, lo) : acc;
-    };
+    // Gamma totals wait in LDS, one 64-entry row per (slot, entry) and wave, until 64 depths can leave in one store.
+    // The lanes that hold totals after a reduction (31 / 63, or 15 / 47 / 31 / 63) each own one row.
+    lds_f64* const gpk = utab + (STATIC ? (p.Nspace + 1) * TR : 0) + (size_t)dir * (2 * NS) * LSX_WAVE;
+    const bool own_pair = lane == 31 || lane == 63, own_quad = (lane & 15) == 15;
+    const int row_pair = (lane >> 5) * LSX_WAVE;                                   // 31 -> row 0, 63 -> row 1
+    const int row_quad = ((((lane >> 4) & 1) << 1) | (lane >> 5)) * LSX_WAVE;      // 15 -> 0, 47 -> 1, 31 -> 2, 63 -> 3
 
     // A sweep runs in three phases with a fixed set of memory operations each, so the compiler's wait counts are
     // exact and neither a store acknowledgement nor the half-J read-back is waited for inside a step:
@@ -663,30 +661,25 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                     pass2(line, sl, spv[u], schi[u], sUji[u], Vij, snj[u], wlv[u] * swp[u], w1[u], w2v[u]); // :451, :455
                 }
             }
-            // the totals of step s are parked in lane (s mod 64) of per-(slot, entry) accumulators and leave as one
+            // the totals of step s are parked in entry (s mod 64) of per-(slot, entry) LDS rows and leave as one
             // 64-wide store every 64 steps: no store (and no store acknowledgement to wait for) inside a step
             const int sl64 = s & 63;
             if constexpr (NPT == 1) {
                 const double t = reduce_pair(w1[0], w2v[0]);
-                park(gacc[0], t, 31, sl64);
-                park(gacc[1], t, 63, sl64);
+                if (own_pair) gpk[row_pair + sl64] = t;
             } else if constexpr (NPT >= 2) {
                 const double t = reduce_quad(w1[0], w2v[0], w1[1], w2v[1]);
-                park(gacc[0], t, 15, sl64);
-                park(gacc[1], t, 47, sl64);
-                park(gacc[2], t, 31, sl64);
-                park(gacc[3], t, 63, sl64);
+                if (own_quad) gpk[row_quad + sl64] = t;
                 if constexpr (NPT == 3) {
                     const double t2 = reduce_pair(w1[2], w2v[2]);
-                    park(gacc[4], t2, 31, sl64);
-                    park(gacc[5], t2, 63, sl64);
+                    if (own_pair) gpk[4 * LSX_WAVE + row_pair + sl64] = t2;
                 }
             }
             if (sl64 == 63 || s == Ns - 1) {
-                const int ks = kS + dk * (s - sl64 + lane);         // the depth parked in this lane
+                const int ks = kS + dk * (s - sl64 + lane);         // the depth parked in entry `lane` of every row
                 if (lane <= sl64) {
 #pragma unroll
-                    for (int q = 0; q < 2 * NPT; ++q) gpart[(q * 2 + dir) * Ns + ks] = gacc[q];
+                    for (int q = 0; q < 2 * NPT; ++q) gpart[(q * 2 + dir) * Ns + ks] = gpk[q * LSX_WAVE + lane];
                 }
             }
         } else {
