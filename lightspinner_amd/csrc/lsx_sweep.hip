@@ -473,7 +473,8 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         const int k = kS + dk * s;
         const unsigned kl = (unsigned)(k * L + j) * 8u;     // byte position in the tile-major [k][j] streams
         double jd, chiTot, be_l;
-        double sv[NS], sni[NS], snj[NS], swp[NS];
+        double sv[NS], sni[NS], snj[NS];
+        const lds_f64* tk = utab + k * TR;
         double jhalf = 0.0;
         if constexpr (PH == 2) {
             if (2 * s == Ns || 2 * s == Ns + 1) __syncthreads();   // the partner wave's first-half stores
@@ -484,12 +485,10 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             for (int u = 0; u < NPT; ++u) sv[u] = ((pact >> u) & 1u) ? n_sv[u] : 0.0;
             if (s + 1 < Ns) stream_loads(k + dk, n_bc, n_be, n_jd, n_sv);
             if constexpr (PH == 2) jhalf = at(Jnew, kl);
-            const lds_f64* tk = utab + k * TR;
 #pragma unroll
             for (int u = 0; u < NPT; ++u) {
                 sni[u] = tk[3 * u + 0];
                 snj[u] = tk[3 * u + 1];
-                swp[u] = tk[3 * u + 2];
             }
         } else {
             stream_loads(k, chiTot, be_l, jd, sv);
@@ -511,9 +510,9 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
 
         // ---- pass 1: opacity / emissivity of the per-ray transitions (rh_method.py:601-627) ----
         //   kept for pass 2 (static path): pv = phi | Vji, chi, Uji
-        double spv[NS], schi[NS], sUji[NS];
+        double spv[NS], schi[NS], sUji[NS], seta[NS];
         auto pass1 = [&](const bool line, const SlotS& sl, double v, double ni, double nj, double alf, double& pv, double& chi,
-                         double& Uji) {
+                         double& Uji, double& eta) {
             // a tile with a single per-ray slot shares no level and no atom with anything (lsx_create): no cells
             const int fl = (NPT == 1 || NPT == 2) ? 0 : sl.flags;   // NPT == 2: bookkeeping in registers (pass 2)
             if (line) {
@@ -525,7 +524,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                 chi = ni * alf - nj * pv;
                 Uji = u_la * pv;                         // :286
             }
-            const double eta = nj * Uji;                 // :614
+            eta = nj * Uji;                              // :614
             if (fl & SLOT_LI_CELL) cell_acc(&CCHI(sl.ci), chi, fl & SLOT_CHI_I_FIRST);
             if (fl & SLOT_LJ_CELL) {
                 cell_acc(&CCHI(sl.cj), -chi, fl & SLOT_CHI_J_FIRST);
@@ -539,7 +538,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
 #pragma unroll
             for (int u = 0; u < NPT; ++u) {
                 const SlotS sl = load_slot(slots + u, Ns);
-                pass1(u < NL, sl, sv[u], sni[u], snj[u], alv[u], spv[u], schi[u], sUji[u]);
+                pass1(u < NL, sl, sv[u], sni[u], snj[u], alv[u], spv[u], schi[u], sUji[u], seta[u]);
             }
         } else {
             for (int u = 0; u < nP; ++u) {
@@ -555,8 +554,8 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                     v = a ? gijc_col[sl.base + k * sl.len + (la - sl.first)] : 0.0;
                     alf = a ? p.alpha[sl.wl_off + l] : 0.0;
                 }
-                double pv, chi, Uji;
-                pass1((sl.flags & SLOT_LINE) != 0, sl, v, ni, nj, alf, pv, chi, Uji);
+                double pv, chi, Uji, eta;
+                pass1((sl.flags & SLOT_LINE) != 0, sl, v, ni, nj, alf, pv, chi, Uji, eta);
             }
         }
         STAMP(2);
@@ -574,7 +573,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             const double dS = (S_prev - S) * rdt;
             // formal_solver.py:138-139: the end point re-uses the PREVIOUS interval's w and
             // S[kEnd - dk] with the fresh dS, dtau (reference behaviour, reproduced deliberately)
-            const bool last = (s == Ns - 1);
+            const bool last = PH == 2 && s == Ns - 1;       // the end point lies in the second-visitor phase (Nspace >= 3)
             double w0, w1;
             w2(last ? dtau_prev : dtau, w0, w1, etab);
             const double Sx = last ? S_prev : S;
@@ -620,11 +619,10 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             wg1 = wt * g1;                                                 // wt: :451/:455, :665
             wg2 = wt * g2;
         };
-        auto pass2 = [&](const bool line, const SlotS& sl, double pv, double chi, double Uji, double Vij, double nj, double wt,
+        auto pass2 = [&](const bool line, const SlotS& sl, double pv, double chi, double Uji, double Vij, double eta, double wt,
                          double& wg1, double& wg2) {
             const int fl = NPT == 1 ? 0 : sl.flags;
             const double Vji = line ? sl.Vc * pv : pv;
-            const double eta = nj * Uji;
             const double etaA = (fl & SLOT_ETA_CELL) ? CETA(sl.ca) : eta;
             const double chi_i = (fl & SLOT_LI_CELL) ? CCHI(sl.ci) : chi;
             const double chi_j = (fl & SLOT_LJ_CELL) ? CCHI(sl.cj) : -chi;
@@ -650,15 +648,15 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                     // order (a factor 0 drops the other slot, +-1 adds it with one rounding)
                     const int v = 1 - u;
                     const auto* rel = slots[u].rel;
-                    const double etaA = fma(rel[REL_EA], snj[v] * sUji[v], snj[u] * sUji[u]);
+                    const double etaA = fma(rel[REL_EA], seta[v], seta[u]);
                     const double chi_i = fma(rel[REL_CI], schi[v], schi[u]);
                     const double chi_j = fma(rel[REL_CJ], schi[v], -schi[u]);
                     const double U_j = fma(rel[REL_UJ], sUji[v], sUji[u]);
                     const double U_i = rel[REL_UI] * sUji[v];
-                    pass2x(line, sl.Vc, spv[u], sUji[u], Vij, wlv[u] * swp[u], etaA, chi_i, chi_j, U_j, U_i,
+                    pass2x(line, sl.Vc, spv[u], sUji[u], Vij, wlv[u] * tk[3 * u + 2], etaA, chi_i, chi_j, U_j, U_i,
                            w1[u], w2v[u]);
                 } else {
-                    pass2(line, sl, spv[u], schi[u], sUji[u], Vij, snj[u], wlv[u] * swp[u], w1[u], w2v[u]); // :451, :455
+                    pass2(line, sl, spv[u], schi[u], sUji[u], Vij, seta[u], wlv[u] * tk[3 * u + 2], w1[u], w2v[u]); // :451, :455
                 }
             }
             // the totals of step s are parked in entry (s mod 64) of per-(slot, entry) LDS rows and leave as one
@@ -704,7 +702,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                     chi = ni * Vij - nj * pv;
                 }
                 double wg1, wg2;
-                pass2((sl.flags & SLOT_LINE) != 0, sl, pv, chi, Uji, Vij, nj, (a && valid) ? wq_l * wla : 0.0, wg1, wg2);
+                pass2((sl.flags & SLOT_LINE) != 0, sl, pv, chi, Uji, Vij, nj * Uji, (a && valid) ? wq_l * wla : 0.0, wg1, wg2);
                 const double t = reduce_pair(wg1, wg2);
                 if (lane == 31) *gslot(u, 0) = t;
                 if (lane == 63) *gslot(u, 1) = t;
