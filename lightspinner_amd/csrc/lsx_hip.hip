@@ -191,7 +191,7 @@ struct FastParams {
     const double* n;            // [col][NLtot][k]
     const double* nsr;          // [col][Ncont][k]  nStar_i / nStar_j of every continuum (rh_method.py:453)
     const double* temperature;  // [col][k]
-    const double* wavelength;   // [Nspect]
+    const double* hck_la;       // [Nspect]  hc / (k lambda)
     int Ncont, nF_max;
     const double* bgchi_T;
     const double* bgeta_T;
@@ -209,8 +209,13 @@ struct FastParams {
 struct FastVal { double alf, Vji, Uji, chi, eta; bool a; };
 __device__ __forceinline__ double fast_boltzmann(const FastParams& f, size_t col, int la, int k)
 {
-    const double hc_k = kHC / (kKBoltzmann * kNM_TO_M);
-    return exp(-hc_k / f.wavelength[la] / f.temperature[col * f.Nspace + k]);
+    // exp(-hc / (k lambda T)) with hc/(k lambda) tabulated per wavelength and 1/T by reciprocal + Newton (the
+    // argument differs from the divided form by an ulp or two: a relative 1e-14 on E at the shortest wavelengths)
+    const double T = f.temperature[col * f.Nspace + k];
+    double r = __builtin_amdgcn_rcp(T);
+    r = fma(fma(-T, r, 1.0), r, r);
+    r = fma(fma(-T, r, 1.0), r, r);
+    return exp(-(f.hck_la[la] * r));
 }
 __device__ __forceinline__ FastVal fast_value(const FastParams& f, const DevSlot& sl, size_t col, int la, int k, double E)
 {
@@ -592,6 +597,7 @@ struct lsx_ctx {
     int* d_fast_tiles = nullptr;
     int *d_cont_li = nullptr, *d_cont_lj = nullptr;
     double* d_exp2_tab = nullptr;
+    double* d_hck_la = nullptr;
     int nF_max = 0, Ncont = 0;
     bool fast_generic = false;
     double* d_nsr = nullptr;     // [col][Ncont][k] nStar_i / nStar_j of the continua
@@ -680,7 +686,7 @@ void lsx_destroy(lsx_ctx* c)
                     c->d_tiles, c->d_slots, c->d_tile_slots, c->d_Nlevel, c->d_lev2_off, c->d_height,
                     c->d_temperature, c->d_nStar, c->d_nTotal, c->d_n, c->d_C, c->d_Gamma, c->d_wphi, c->d_bgchi,
                     c->d_bgeta, c->d_sca, c->d_phi, c->d_gijc, c->d_J[0], c->d_J[1], c->d_I, c->d_Gpart, c->d_dJpart,
-                    c->d_dJcol, c->d_dPcol, c->d_max, c->d_singular, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab};
+                    c->d_dJcol, c->d_dPcol, c->d_max, c->d_singular, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab, c->d_hck_la};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& k : c->classes) {
@@ -982,6 +988,11 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     TRY(upload(&c->d_wl, wl, c->stream));
     TRY(upload(&c->d_alpha, alpha, c->stream));
     TRY(upload(&c->d_u_la, u_la, c->stream));
+    {
+        std::vector<double> hck(Nspect);
+        for (int la = 0; la < Nspect; ++la) hck[la] = kHC / (kKBoltzmann * kNM_TO_M) / wave[la];
+        TRY(upload(&c->d_hck_la, hck, c->stream));
+    }
     {   // 2^(j/64) as head + tail (extended precision on the host)
         std::vector<double> et(LSX_EXP_TAB);
         for (int j = 0; j < 64; ++j) {
@@ -1178,7 +1189,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
         ff.L = c->L; ff.NLtot = c->NLtot; ff.Natoms = c->Natoms; ff.nslot_total = (int)c->tile_slots.size();
         ff.n_fast_tiles = (int)c->fast_tiles.size(); ff.tiles = c->d_tiles; ff.slots = c->d_slots; ff.fast_tiles = c->d_fast_tiles;
         ff.active = c->d_active; ff.alpha = c->d_alpha; ff.wl = c->d_wl; ff.u_la = c->d_u_la; ff.wmuh = c->d_wmuh; ff.n = c->d_n;
-        ff.nsr = c->d_nsr; ff.temperature = c->d_temperature; ff.wavelength = c->d_wavelength; ff.Ncont = c->Ncont; ff.nF_max = c->nF_max;
+        ff.nsr = c->d_nsr; ff.temperature = c->d_temperature; ff.hck_la = c->d_hck_la; ff.Ncont = c->Ncont; ff.nF_max = c->nF_max;
         ff.bgchi_T = c->d_bgchi; ff.bgeta_T = c->d_bgeta;
         ff.bgxchi_T = c->d_bgxchi; ff.bgxeta_T = c->d_bgxeta; ff.J_T = c->d_J[c->jcur ^ 1]; ff.Psi2_T = c->d_Psi2;
         ff.Gpart = c->d_Gpart; ff.colmask = c->d_colmask;
