@@ -96,7 +96,9 @@ typedef struct lsx_columns {
     const double* bg_chi;       /* [ncol][Nspect][Nspace]      background.chi          */
     const double* bg_eta;       /* [ncol][Nspect][Nspace]      background.eta          */
     const double* bg_sca;       /* [ncol][Nspace] or [ncol][Nspect][Nspace]            */
-    const double* phi;          /* [ncol][SNl][Nrays][2][Nspace] or [ncol][SNl][Nspace] */
+    const double* phi;          /* [ncol][SNl][Nrays][2][Nspace] or [ncol][SNl][Nspace];
+                                   phi and wphi may both be NULL when the profiles of these
+                                   columns are set with lsx_set_line_profiles afterwards      */
     const double* wphi;         /* [ncol][Nlines][Nspace]      t.wphi                  */
 } lsx_columns;
 
@@ -114,7 +116,9 @@ enum {
     LSX_C = 7,         /* [NL2tot][Nspace]                                            */
     LSX_RIJ = 8,       /* [Ntrans][Nspace]  t.Rij, accumulated over calls exactly as the
                           reference does (rh_method.py:691; never zeroed, quirk kept)    */
-    LSX_RJI = 9        /* [Ntrans][Nspace]  t.Rji (rh_method.py:692, uses Vij: quirk kept) */
+    LSX_RJI = 9,       /* [Ntrans][Nspace]  t.Rji (rh_method.py:692, uses Vij: quirk kept) */
+    LSX_PHI = 10,      /* [SNl][Nrays][2][Nspace] (or [SNl][Nspace] when phi_compact)  t.phi  */
+    LSX_WPHI = 11      /* [Nlines][Nspace]  t.wphi                                     */
 };
 
 /* Create a context for `ncol` columns on HIP device `device` (ignored by the
@@ -127,6 +131,20 @@ void lsx_destroy(lsx_ctx* ctx);
 /* Upload (copy) inputs for columns [col0, col0+ncol).  J is reset to 0 for those
  * columns (rh_method.py:562).  Host pointers. */
 int lsx_set_columns(lsx_ctx* ctx, int32_t col0, int32_t ncol, const lsx_columns* cols);
+
+/* ComputationalTransition.compute_phi (rh_method.py:198-243) for every line of columns
+ * [col0, col0+ncol), evaluated by the library instead of being handed over:
+ *   v = (lambda - lambda0) c / (vBroad lambda0);  vk = v -+ muz vlos / vBroad  (- down, + up; :231-238)
+ *   phi = H(aDamp, vk) / (sqrt(pi) vBroad)        (:239, H = Re w(vk + i aDamp), utils.py:13-15)
+ *   wphi = 1 / sum_{lambda, mu, dir} phi wlambda (wmu/2)                      (:236-242)
+ * aDamp:  [ncol][Nlines][Nspace]  line.damping(atmos, vBroad, hGround)[0]     (:223)
+ * vBroad: [ncol][Natoms][Nspace]  atom.vBroad                                 (:409)
+ * vlos:   [ncol][Nspace] m/s, or NULL for 0.  A context created with phi_compact = 1 accepts
+ *         only vlos == NULL (the profile is then ray independent).
+ * The Voigt function is the library's own (exponentially convergent trapezoid sum with pole
+ * correction, relative error < 1e-13 against scipy.special.wofz for 1e-4 <= aDamp). */
+int lsx_set_line_profiles(lsx_ctx* ctx, int32_t col0, int32_t ncol, const double* aDamp,
+                          const double* vBroad, const double* vlos);
 
 /* One Context.formal_sol_gamma_matrices() over all columns.  *dJ_max receives the
  * maximum over columns of the reference's return value (rh_method.py:705-708). */

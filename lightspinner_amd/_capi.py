@@ -13,7 +13,7 @@ import numpy as np
 ABI_VERSION = 1
 
 # item selectors (include/lsx.h)
-LSX_I, LSX_J, LSX_N, LSX_GAMMA, LSX_DJ_COL, LSX_DPOPS_COL, LSX_NSTAR, LSX_C, LSX_RIJ, LSX_RJI = range(10)
+LSX_I, LSX_J, LSX_N, LSX_GAMMA, LSX_DJ_COL, LSX_DPOPS_COL, LSX_NSTAR, LSX_C, LSX_RIJ, LSX_RJI, LSX_PHI, LSX_WPHI = range(12)
 
 ERRORS = {1: 'LSX_EINVAL', 2: 'LSX_EDEVICE', 3: 'LSX_ESINGULAR', 4: 'LSX_ENONFINITE', 5: 'LSX_EUNSUPPORTED'}
 
@@ -48,7 +48,7 @@ REQUIRED_SYMBOLS = (
     'lsx_create', 'lsx_destroy', 'lsx_set_columns', 'lsx_formal_sol_gamma', 'lsx_stat_equil',
     'lsx_formal_sol_gamma_async', 'lsx_stat_equil_async', 'lsx_sync', 'lsx_get', 'lsx_set',
     'lsx_piecewise_linear_1d', 'lsx_time_formal_sol', 'lsx_last_error', 'lsx_backend_name',
-    'lsx_abi_version', 'lsx_algorithmic_bytes_per_column', 'lsx_set_active_columns',
+    'lsx_abi_version', 'lsx_algorithmic_bytes_per_column', 'lsx_set_active_columns', 'lsx_set_line_profiles',
 )
 
 
@@ -105,6 +105,7 @@ class LsxLibrary:
         d.lsx_piecewise_linear_1d.argtypes = [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp,
                                               C.POINTER(C.c_int32), _dp, _dp, _dp, _dp, _dp]
         d.lsx_set_active_columns.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
+        d.lsx_set_line_profiles.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp]
         d.lsx_time_formal_sol.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp]
         d.lsx_algorithmic_bytes_per_column.argtypes = [C.c_void_p]
         d.lsx_algorithmic_bytes_per_column.restype = C.c_double

@@ -40,6 +40,7 @@ struct DevTrans {           // one radiative transition, column independent (hos
     double cB;              // lines: (hc/4pi) * Bij                     rh_method.py:268,279
     double gij;             // lines: Bji / Bij                          rh_method.py:450
     double AB;              // lines: Aji / Bji                          rh_method.py:281
+    double lambda0;         // lines: rest wavelength [nm] (profile set-up, rh_method.py:234)
 };
 
 // level-bookkeeping flags of a slot inside its tile (atom.chi / atom.U / atom.eta of

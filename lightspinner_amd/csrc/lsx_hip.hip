@@ -68,6 +68,120 @@ __global__ void k_pack_phi(const double* __restrict__ in, double* __restrict__ o
     }
 }
 
+
+// inverse of k_pack_phi (lsx_get of LSX_PHI)
+__global__ void k_unpack_phi(const double* __restrict__ in, double* __restrict__ out, int lt0, int len, int Nrays, int ndir,
+                             int Ns, size_t in_col_stride, size_t out_col_stride)
+{
+    const size_t col = blockIdx.y;
+    const size_t total = (size_t)len * Nrays * ndir * Ns;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        size_t r = o;
+        const int l = r % len; r /= len;
+        const int mu = r % Nrays; r /= Nrays;
+        const int k = r % Ns; r /= Ns;
+        const int d = (int)r;
+        out[col * out_col_stride + (((size_t)(lt0 + l) * Nrays + mu) * ndir + d) * Ns + k] = in[col * in_col_stride + o];
+    }
+}
+
+// ---- Voigt function H(a, v) = Re w(v + i a), a > 0 (utils.py:13-15 calls scipy's wofz) ----
+// Trapezoid rule with step h = 1/2 on w(z) = (i/pi) int exp(-t^2)/(z - t) dt plus the residue of the pole the
+// contour crosses (Chiarella & Reichel 1968; Matta & Reichel 1971):
+//   H = (h a/pi) sum_n exp(-g_n^2) / ((v - g_n)^2 + a^2) + Re[ 2 exp(-z^2) / (1 -+ exp(-2 pi i z/h)) ]
+// on the grid g_n = n h (sign -) or (n + 1/2) h (sign +), whichever keeps v at least h/4 away from a node; error
+// ~ exp(-pi^2/h^2) = 7e-18.  Every term of the sum is positive (no cancellation in the far wings).
+// W: [2][28] = exp(-g_n^2) for n = -14 .. 13 on the two grids (host-computed).
+__device__ __forceinline__ double dev_voigt(double a, double v, const double* __restrict__ W)
+{
+    const double h = 0.5;
+    const double x = fabs(v);
+    const double t = x * 2.0, fr = t - floor(t);
+    const bool half = !(fr >= 0.25 && fr < 0.75);
+    const double shift = half ? 0.5 : 0.0;
+    const double* w = W + (half ? 28 : 0);
+    const double a2 = a * a;
+    double s = 0.0;
+#pragma unroll 4
+    for (int n = -14; n <= 13; ++n) {
+        const double d = x - ((double)n + shift) * h;
+        s += w[n + 14] / (d * d + a2);
+    }
+    double H = (h / M_PI) * a * s;
+    if (x < 27.0 && a < 2.0 * M_PI) {
+        // exp(-z^2) = exp(a^2 - x^2) (cos 2xa - i sin 2xa);  exp(-2 pi i z/h) = exp(4 pi a) (cos - i sin)(4 pi x)
+        double s1, c1, st, ct;
+        sincos(2.0 * x * a, &s1, &c1);
+        sincospi(4.0 * x, &st, &ct);
+        const double er = exp(a2 - x * x), E = exp(4.0 * M_PI * a), sg = half ? 1.0 : -1.0;
+        const double dr = 1.0 + sg * E * ct, di = -sg * E * st;
+        H += 2.0 * er * (c1 * dr - s1 * di) / (dr * dr + di * di);
+    }
+    return H;
+}
+
+struct VoigtParams {
+    int Ns, Nrays, ndir, Nlines, Natoms;
+    const double* wavelength;   // [Nspect]
+    const double* muz;          // [Nrays]
+    const double* wmu;          // [Nrays]
+    const double* W;            // [2][28]
+    const double* aDamp;        // [nb][Nlines][Ns]
+    const double* vBroad;       // [nb][Natoms][Ns]
+    const double* vlos;         // [nb][Ns] or null
+};
+
+// compute_phi (rh_method.py:228-239) straight into one (tile, line) block of phi_T: [dir][k][mu][l<len]
+__global__ void k_voigt_block(const VoigtParams q, double* __restrict__ out, size_t out_col_stride, int first, int len,
+                              int line, int atom, double lambda0)
+{
+    const size_t col = blockIdx.y;
+    const size_t total = (size_t)len * q.Nrays * q.ndir * q.Ns;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        size_t r = o;
+        const int l = r % len; r /= len;
+        const int mu = r % q.Nrays; r /= q.Nrays;
+        const int k = r % q.Ns; r /= q.Ns;
+        const int d = (int)r;
+        const double vb = q.vBroad[(col * q.Natoms + atom) * q.Ns + k];
+        const double ad = q.aDamp[(col * q.Nlines + line) * q.Ns + k];
+        const double vl = (q.vlos && q.ndir == 2) ? q.vlos[col * q.Ns + k] : 0.0;
+        const double v = (q.wavelength[first + l] - lambda0) * kCLight / (vb * lambda0);          // :234
+        const double vk = v + (d ? 1.0 : -1.0) * (q.muz[mu] * vl / vb);                            // :231, :237-238
+        out[col * out_col_stride + o] = dev_voigt(ad, vk, q.W) / (sqrt(M_PI) * vb);                // :239
+    }
+}
+
+// wphi = 1 / sum_{lambda, mu, dir} phi wlambda (wmu / 2)  (rh_method.py:236-242): one thread per (column, depth)
+__global__ void k_voigt_wphi(const VoigtParams q, double* __restrict__ wphi, int ncol, int Nblue, int Nlam, int line, int atom,
+                             double lambda0)
+{
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)ncol * q.Ns) return;
+    const size_t col = gid / q.Ns;
+    const int k = gid % q.Ns;
+    const double vb = q.vBroad[(col * q.Natoms + atom) * q.Ns + k];
+    const double ad = q.aDamp[(col * q.Nlines + line) * q.Ns + k];
+    const double vl = q.vlos ? q.vlos[col * q.Ns + k] : 0.0;
+    const double* wl = q.wavelength + Nblue;
+    double acc = 0.0;
+    for (int la = 0; la < Nlam; ++la) {
+        double wla = la == 0 ? 0.5 * (wl[1] - wl[0]) : (la == Nlam - 1 ? 0.5 * (wl[la] - wl[la - 1]) : 0.5 * (wl[la + 1] - wl[la - 1]));
+        wla *= kCLight / lambda0;                                                                   // :157-196
+        const double v = (wl[la] - lambda0) * kCLight / (vb * lambda0);
+        for (int mu = 0; mu < q.Nrays; ++mu) {
+            const double sh = q.muz[mu] * vl / vb;
+            const double wt = wla * 0.5 * q.wmu[mu];
+            for (int d = 0; d < 2; ++d) {
+                const double p = dev_voigt(ad, v + (d ? sh : -sh), q.W) / (sqrt(M_PI) * vb);
+                acc += p * wt;
+                if (vl == 0.0) { acc += p * wt; break; }        // ray independent profile: both directions are equal
+            }
+        }
+    }
+    wphi[col * q.Nlines * q.Ns + (size_t)line * q.Ns + k] = 1.0 / acc;
+}
+
 // g_ij of a continuum (rh_method.py:453-454) for one (tile, continuum) block: out[col]{[k][l<len]}
 __global__ void k_build_gijc(const double* __restrict__ nStar, const double* __restrict__ temperature,
                              const double* __restrict__ wavelength, double* __restrict__ out, int li, int lj, int first,
@@ -598,6 +712,8 @@ struct lsx_ctx {
     int *d_cont_li = nullptr, *d_cont_lj = nullptr;
     double* d_exp2_tab = nullptr;
     double* d_hck_la = nullptr;
+    double* d_voigt_w = nullptr;
+    double *d_muz = nullptr, *d_wmu = nullptr;
     int nF_max = 0, Ncont = 0;
     bool fast_generic = false;
     double* d_nsr = nullptr;     // [col][Ncont][k] nStar_i / nStar_j of the continua
@@ -686,7 +802,7 @@ void lsx_destroy(lsx_ctx* c)
                     c->d_tiles, c->d_slots, c->d_tile_slots, c->d_Nlevel, c->d_lev2_off, c->d_height,
                     c->d_temperature, c->d_nStar, c->d_nTotal, c->d_n, c->d_C, c->d_Gamma, c->d_wphi, c->d_bgchi,
                     c->d_bgeta, c->d_sca, c->d_phi, c->d_gijc, c->d_J[0], c->d_J[1], c->d_I, c->d_Gpart, c->d_dJpart,
-                    c->d_dJcol, c->d_dPcol, c->d_max, c->d_singular, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab, c->d_hck_la};
+                    c->d_dJcol, c->d_dPcol, c->d_max, c->d_singular, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab, c->d_hck_la, c->d_voigt_w, c->d_muz, c->d_wmu};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& k : c->classes) {
@@ -768,6 +884,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
             h.cB = (0.25 * kHC / M_PI) * tr.Bij; // rh_method.py:268,279
             h.gij = tr.Bji / tr.Bij;             // :450
             h.AB = tr.Aji / tr.Bji;              // :281
+            h.lambda0 = tr.lambda0;
             for (int lt = 0; lt < tr.Nlambda; ++lt) { wl.push_back(wlambda(c, wave, tr, lt) / kHC); alpha.push_back(0.0); } // :451
         } else {
             h.cont_off = c->SNc;
@@ -984,6 +1101,11 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
 #define TRY(x) do { rc = (x); if (rc) { lsx_destroy(c); return rc; } } while (0)
     TRY(upload(&c->d_wavelength, wave, c->stream));
     TRY(upload(&c->d_zmu, zmu, c->stream));
+    {
+        std::vector<double> muzv(d->muz, d->muz + c->Nrays), wmuv(d->wmu, d->wmu + c->Nrays);
+        TRY(upload(&c->d_muz, muzv, c->stream));
+        TRY(upload(&c->d_wmu, wmuv, c->stream));
+    }
     TRY(upload(&c->d_wmuh, wmuh, c->stream));
     TRY(upload(&c->d_wl, wl, c->stream));
     TRY(upload(&c->d_alpha, alpha, c->stream));
@@ -1087,8 +1209,9 @@ int lsx_set_columns(lsx_ctx* c, int32_t col0, int32_t ncol, const lsx_columns* s
 {
     if (!c || !s || col0 < 0 || ncol < 1 || col0 + ncol > c->ncol) return fail(LSX_EINVAL, "lsx_set_columns: bad range");
     if (!s->height || !s->temperature || !s->nStar || !s->nTotal || !s->n || !s->C || !s->bg_chi || !s->bg_eta || !s->bg_sca ||
-        (c->Nlines && (!s->phi || !s->wphi)))
+        (c->Nlines && ((s->phi == nullptr) != (s->wphi == nullptr))))
         return fail(LSX_EINVAL, "lsx_set_columns: null array pointer");
+    const bool have_phi = c->Nlines && s->phi;     // else: lsx_set_line_profiles follows
     HIPCHK(hipSetDevice(c->device));
     const int Ns = c->Nspace, Nspect = c->Nspect;
     const size_t o = col0;
@@ -1104,7 +1227,7 @@ int lsx_set_columns(lsx_ctx* c, int32_t col0, int32_t ncol, const lsx_columns* s
     TRY(h2d(c->d_nTotal + o * c->Natoms * Ns, s->nTotal, (size_t)c->Natoms * Ns, ncol));
     TRY(h2d(c->d_n + o * c->NLtot * Ns, s->n, (size_t)c->NLtot * Ns, ncol));
     TRY(h2d(c->d_C + o * c->NL2tot * Ns, s->C, (size_t)c->NL2tot * Ns, ncol));
-    if (c->Nlines) TRY(h2d(c->d_wphi + o * c->Nlines * Ns, s->wphi, (size_t)c->Nlines * Ns, ncol));
+    if (have_phi) TRY(h2d(c->d_wphi + o * c->Nlines * Ns, s->wphi, (size_t)c->Nlines * Ns, ncol));
 
     // arrays that change layout go through the staging buffer in sub-chunks (<= 256 MiB of staging)
     const size_t per_col_max = std::max<size_t>({(size_t)Nspect * Ns, c->phi_in_col, (size_t)1});
@@ -1125,7 +1248,7 @@ int lsx_set_columns(lsx_ctx* c, int32_t col0, int32_t ncol, const lsx_columns* s
             TRY(h2d(c->d_sca + cc * Ns, s->bg_sca + b0 * Ns, Ns, nb));
         }
         // line profiles: rows [lt][mu][dir][k] of a line -> one [k][dir][mu][l] block per (tile, line)
-        if (c->Nlines) {
+        if (have_phi) {
             TRY(h2d(c->d_stage, s->phi + b0 * c->phi_in_col, c->phi_in_col, nb));
             const int R = c->phi_compact ? 1 : c->Nrays, D = c->phi_compact ? 1 : 2;
             for (const DevSlot& sl : c->slots) {
@@ -1258,6 +1381,64 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
     return LSX_OK;
 }
 
+int lsx_set_line_profiles(lsx_ctx* c, int32_t col0, int32_t ncol, const double* aDamp, const double* vBroad, const double* vlos)
+{
+    if (!c || !aDamp || !vBroad || col0 < 0 || ncol < 1 || col0 + ncol > c->ncol)
+        return fail(LSX_EINVAL, "lsx_set_line_profiles: bad argument");
+    if (c->phi_compact && vlos) return fail(LSX_EINVAL, "lsx_set_line_profiles: a phi_compact context takes vlos == NULL");
+    if (!c->Nlines) return LSX_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const int Ns = c->Nspace;
+    if (!c->d_voigt_w) {
+        std::vector<double> W(56);
+        for (int g = 0; g < 2; ++g)
+            for (int n = -14; n <= 13; ++n) { const double x = (n + 0.5 * g) * 0.5; W[g * 28 + n + 14] = std::exp(-x * x); }
+        int rc = upload(&c->d_voigt_w, W, c->stream);
+        if (rc) return rc;
+    }
+    const size_t per = (size_t)(c->Nlines + c->Natoms + 1) * Ns;
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(ncol, ((size_t)32 << 20) / per));
+    int rc = ensure_stage(c, chunk * per);
+    if (rc) return rc;
+    for (size_t b0 = 0; b0 < (size_t)ncol; b0 += chunk) {
+        const size_t nb = std::min(chunk, (size_t)ncol - b0);
+        const size_t cc = (size_t)col0 + b0;
+        double* dA = c->d_stage;
+        double* dV = dA + nb * c->Nlines * Ns;
+        double* dL = dV + nb * c->Natoms * Ns;
+        HIPCHK(hipMemcpyAsync(dA, aDamp + b0 * c->Nlines * Ns, nb * c->Nlines * Ns * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(dV, vBroad + b0 * c->Natoms * Ns, nb * c->Natoms * Ns * 8, hipMemcpyHostToDevice, c->stream));
+        if (vlos) HIPCHK(hipMemcpyAsync(dL, vlos + b0 * Ns, nb * Ns * 8, hipMemcpyHostToDevice, c->stream));
+        VoigtParams q{};
+        q.Ns = Ns; q.Nlines = c->Nlines; q.Natoms = c->Natoms; q.wavelength = c->d_wavelength; q.muz = c->d_muz; q.wmu = c->d_wmu;
+        q.W = c->d_voigt_w; q.aDamp = dA; q.vBroad = dV; q.vlos = vlos ? dL : nullptr;
+        // the profile blocks of the sweep, one launch per (tile, line)
+        const int R = c->phi_compact ? 1 : c->Nrays, D = c->phi_compact ? 1 : 2;
+        q.Nrays = R; q.ndir = D;
+        for (const DevSlot& sl : c->slots) {
+            if (!(sl.flags & SLOT_LINE) || sl.len <= 0) continue;
+            const DevTrans& h = c->htrans[sl.trans];
+            const size_t total = (size_t)sl.len * R * D * Ns;
+            dim3 grid((unsigned)std::min<size_t>((total + 255) / 256, 256), (unsigned)nb);
+            hipLaunchKernelGGL(k_voigt_block, grid, dim3(256), 0, c->stream, q, c->d_phi + cc * c->phi_col + sl.base, c->phi_col,
+                               sl.first, sl.len, h.line_idx, h.atom, h.lambda0);
+            HIPCHK(hipGetLastError());
+        }
+        // the normalisation of every line
+        q.Nrays = c->Nrays; q.ndir = 2;
+        for (int t = 0; t < c->Ntrans; ++t) {
+            const DevTrans& h = c->htrans[t];
+            if (!h.is_line) continue;
+            const long nth = (long)nb * Ns;
+            hipLaunchKernelGGL(k_voigt_wphi, dim3((unsigned)((nth + 63) / 64)), dim3(64), 0, c->stream, q,
+                               c->d_wphi + cc * c->Nlines * Ns, (int)nb, h.Nblue, h.Nlam, h.line_idx, h.atom, h.lambda0);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));   // the staging buffer is re-used by the next sub-chunk
+    }
+    return LSX_OK;
+}
+
 int lsx_formal_sol_gamma_async(lsx_ctx* c)
 {
     if (!c) return fail(LSX_EINVAL, "null ctx");
@@ -1359,6 +1540,8 @@ int lsx_get(lsx_ctx* c, int32_t what, int32_t col0, int32_t ncol, double* dst, s
     case LSX_DPOPS_COL: base = c->d_dPcol; per = 1; break;
     case LSX_NSTAR: base = c->d_nStar; per = (size_t)c->NLtot * Ns; break;
     case LSX_C: base = c->d_C; per = (size_t)c->NL2tot * Ns; break;
+    case LSX_WPHI: base = c->d_wphi; per = (size_t)c->Nlines * Ns; break;
+    case LSX_PHI: per = c->phi_in_col; break;
     case LSX_RIJ:
     case LSX_RJI:
         return fail(LSX_EUNSUPPORTED, "lsx_get: radiative rates Rij/Rji are not produced by the HIP backend "
@@ -1366,6 +1549,28 @@ int lsx_get(lsx_ctx* c, int32_t what, int32_t col0, int32_t ncol, double* dst, s
     default: return fail(LSX_EINVAL, "lsx_get: unknown item %d", what);
     }
     if (nbytes != per * ncol * 8) return fail(LSX_EINVAL, "lsx_get: nbytes does not match the item's shape");
+    if (what == LSX_PHI) { // device holds one block per (tile, line): back to [lt][mu][dir][k]
+        if (per == 0) return LSX_OK;
+        const size_t chunk = std::max<size_t>(1, std::min<size_t>(ncol, ((size_t)32 << 20) / per));
+        int rc = ensure_stage(c, chunk * per);
+        if (rc) return rc;
+        const int R = c->phi_compact ? 1 : c->Nrays, D = c->phi_compact ? 1 : 2;
+        for (size_t b0 = 0; b0 < (size_t)ncol; b0 += chunk) {
+            const size_t nb = std::min(chunk, (size_t)ncol - b0);
+            for (const DevSlot& sl : c->slots) {
+                if (!(sl.flags & SLOT_LINE) || sl.len <= 0) continue;
+                const DevTrans& h = c->htrans[sl.trans];
+                const size_t total = (size_t)sl.len * R * D * Ns;
+                dim3 grid((unsigned)std::min<size_t>((total + 255) / 256, 256), (unsigned)nb);
+                hipLaunchKernelGGL(k_unpack_phi, grid, dim3(256), 0, c->stream, c->d_phi + (col0 + b0) * c->phi_col + sl.base,
+                                   c->d_stage + (size_t)h.phi_off * R * D * Ns, sl.first - h.Nblue, sl.len, R, D, (int)Ns, c->phi_col, c->phi_in_col);
+                HIPCHK(hipGetLastError());
+            }
+            HIPCHK(hipMemcpyAsync(dst + b0 * per, c->d_stage, nb * per * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+        return LSX_OK;
+    }
     if (what == LSX_J) { // device holds J depth-major: [k][la] -> [la][k]
         const size_t chunk = std::max<size_t>(1, std::min<size_t>(ncol, ((size_t)32 << 20) / per));
         int rc = ensure_stage(c, chunk * per);

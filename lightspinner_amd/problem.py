@@ -135,8 +135,8 @@ class ColumnBlock:
     bg_chi: np.ndarray
     bg_eta: np.ndarray
     bg_sca: np.ndarray
-    phi: np.ndarray
-    wphi: np.ndarray
+    phi: Optional[np.ndarray] = None      # None (with wphi None): Engine.set_line_profiles computes them on the device
+    wphi: Optional[np.ndarray] = None
 
     @property
     def ncol(self):
@@ -148,22 +148,27 @@ class ColumnBlock:
                       n=(nc, p.NLtot, Ns), C=(nc, p.NL2tot, Ns), bg_chi=(nc, p.Nspect, Ns),
                       bg_eta=(nc, p.Nspect, Ns), bg_sca=(nc,) + p.sca_shape(), phi=(nc,) + p.phi_shape(),
                       wphi=(nc, p.Nlines, Ns))
+        if (self.phi is None) != (self.wphi is None):
+            raise ValueError('phi and wphi must both be given or both be None')
         for k in _COLUMN_FIELDS:
-            setattr(self, k, f64(getattr(self, k), shapes[k]))
+            if getattr(self, k) is not None:
+                setattr(self, k, f64(getattr(self, k), shapes[k]))
         return self
 
     def slice(self, c0, c1):
-        return ColumnBlock(**{k: getattr(self, k)[c0:c1] for k in _COLUMN_FIELDS})
+        return ColumnBlock(**{k: (None if getattr(self, k) is None else getattr(self, k)[c0:c1]) for k in _COLUMN_FIELDS})
 
     def to_c(self):
         s = _capi.LsxColumns()
         for k in _COLUMN_FIELDS:
-            setattr(s, k, _ptr(getattr(self, k)))
+            if getattr(self, k) is not None:
+                setattr(s, k, _ptr(getattr(self, k)))
         return s
 
     @staticmethod
     def concatenate(blocks):
-        return ColumnBlock(**{k: np.concatenate([getattr(b, k) for b in blocks]) for k in _COLUMN_FIELDS})
+        return ColumnBlock(**{k: (None if getattr(blocks[0], k) is None else np.concatenate([getattr(b, k) for b in blocks]))
+                              for k in _COLUMN_FIELDS})
 
 
 class Engine:
@@ -194,6 +199,18 @@ class Engine:
         block.validate(self.problem)
         cs = block.to_c()
         self.lib.check(self.lib.dll.lsx_set_columns(self._h, int(col0), block.ncol, C.byref(cs)))
+
+    def set_line_profiles(self, col0, aDamp, vBroad, vlos=None):
+        """ComputationalTransition.compute_phi (rh_method.py:198-243) on the device, for columns
+        [col0, col0 + ncol): aDamp [ncol][Nlines][Nspace], vBroad [ncol][Natoms][Nspace], vlos [ncol][Nspace]."""
+        p = self.problem
+        aDamp = f64(aDamp)
+        ncol = aDamp.shape[0]
+        aDamp = f64(aDamp, (ncol, p.Nlines, p.Nspace))
+        vBroad = f64(vBroad, (ncol, p.Natoms, p.Nspace))
+        vl = None if vlos is None else f64(vlos, (ncol, p.Nspace))
+        self.lib.check(self.lib.dll.lsx_set_line_profiles(self._h, int(col0), ncol, _ptr(aDamp), _ptr(vBroad),
+                                                          _ptr(vl) if vl is not None else None))
 
     def set(self, what, arr, col0=0):
         arr = f64(arr)
@@ -247,7 +264,8 @@ class Engine:
                 _capi.LSX_N: (p.NLtot, p.Nspace), _capi.LSX_GAMMA: (p.NL2tot, p.Nspace),
                 _capi.LSX_DJ_COL: (), _capi.LSX_DPOPS_COL: (), _capi.LSX_NSTAR: (p.NLtot, p.Nspace),
                 _capi.LSX_C: (p.NL2tot, p.Nspace), _capi.LSX_RIJ: (p.Ntrans, p.Nspace),
-                _capi.LSX_RJI: (p.Ntrans, p.Nspace)}[what]
+                _capi.LSX_RJI: (p.Ntrans, p.Nspace), _capi.LSX_PHI: p.phi_shape(),
+                _capi.LSX_WPHI: (p.Nlines, p.Nspace)}[what]
 
     def get(self, what, col0=0, ncol=None):
         ncol = self.ncol - col0 if ncol is None else ncol

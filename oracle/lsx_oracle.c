@@ -161,12 +161,97 @@ int lsx_set_columns(lsx_ctx* c, int32_t col0, int32_t ncol, const lsx_columns* s
     CP(c->nStar, s->nStar, c->NLtot * Ns); CP(c->nTotal, s->nTotal, c->Natoms * Ns); CP(c->n, s->n, c->NLtot * Ns);
     CP(c->C, s->C, c->NL2tot * Ns); CP(c->bg_chi, s->bg_chi, c->Nspect * Ns); CP(c->bg_eta, s->bg_eta, c->Nspect * Ns);
     CP(c->bg_sca, s->bg_sca, sca_per_col(c));
-    if (c->Nlines) { CP(c->phi, s->phi, phi_per_col(c)); CP(c->wphi, s->wphi, c->Nlines * Ns); }
+    if (c->Nlines && (s->phi || s->wphi)) { CP(c->phi, s->phi, phi_per_col(c)); CP(c->wphi, s->wphi, c->Nlines * Ns); }
 #undef CP
     memset(c->J + o * c->Nspect * Ns, 0, n * c->Nspect * Ns * 8);   /* rh_method.py:562 */
     memset(c->I + o * c->Nspect * c->Nrays, 0, n * c->Nspect * c->Nrays * 8);
     memset(c->Rij + o * c->Ntrans * Ns, 0, n * c->Ntrans * Ns * 8);  /* rh_method.py:130-131 */
     memset(c->Rji + o * c->Ntrans * Ns, 0, n * c->Ntrans * Ns * 8);
+    return LSX_OK;
+}
+
+/* ---- Voigt function H(a, v) = Re w(v + i a), a > 0 (utils.py:13-15 calls scipy's wofz) ------
+ * Trapezoid rule with step h on w(z) = (i/pi) int exp(-t^2)/(z - t) dt plus the residue of the
+ * pole the contour crosses (Chiarella & Reichel 1968; Matta & Reichel 1971):
+ *   H = (h a/pi) sum_n exp(-g_n^2) / ((v - g_n)^2 + a^2) + Re[ 2 exp(-z^2) / (1 -+ exp(-2 pi i z/h)) ]
+ * on the grid g_n = n h (sign -) or (n + 1/2) h (sign +), whichever keeps v at least h/4 away from
+ * a node; error ~ exp(-pi^2/h^2) = 7e-18 for h = 1/2.  All terms of the sum are positive. */
+static double voigt_H(double a, double v)
+{
+    const double h = 0.5, pi = 3.14159265358979323846;
+    double x = fabs(v);
+    double t = x / h, fr = t - floor(t);
+    int half = !(fr >= 0.25 && fr < 0.75);
+    double shift = half ? 0.5 : 0.0;
+    double s = 0.0;
+    for (int n = -14; n <= 13; ++n) {
+        double g = (n + shift) * h;
+        double d = x - g;
+        s += exp(-g * g) / (d * d + a * a);
+    }
+    double H = h * a / pi * s;
+    if (x < 27.0 && a < pi / h) {
+        /* exp(-z^2) = exp(a^2 - x^2) (cos 2xa - i sin 2xa);  exp(-2 pi i z/h) = exp(2 pi a/h) (cos - i sin)(2 pi x/h) */
+        double er = exp(a * a - x * x), c1 = cos(2.0 * x * a), s1 = -sin(2.0 * x * a);
+        double E = exp(2.0 * pi * a / h), th = 2.0 * pi * x / h;
+        double sg = half ? 1.0 : -1.0;
+        double dr = 1.0 + sg * E * cos(th), di = -sg * E * sin(th);
+        /* Re[(c1 + i s1) / (dr + i di)] */
+        H += 2.0 * er * (c1 * dr + s1 * di) / (dr * dr + di * di);
+    }
+    return H;
+}
+
+double lsx_oracle_voigt(double a, double v) { return voigt_H(a, v); }
+
+/* rh_method.py:198-243 */
+int lsx_set_line_profiles(lsx_ctx* c, int32_t col0, int32_t ncol, const double* aDamp, const double* vBroad,
+                          const double* vlos)
+{
+    if (!c || !aDamp || !vBroad || col0 < 0 || ncol < 1 || col0 + ncol > c->ncol)
+        return fail(LSX_EINVAL, "lsx_set_line_profiles: bad argument");
+    if (c->phi_compact && vlos) return fail(LSX_EINVAL, "lsx_set_line_profiles: a phi_compact context takes vlos == NULL");
+    const double CLight = 2.99792458E+08, sqrtPi = 1.7724538509055160273;
+    const int Ns = c->Nspace, Nrays = c->Nrays;
+    for (int cc = 0; cc < ncol; ++cc) {
+        size_t col = (size_t)col0 + cc;
+        double* phi = c->phi + col * phi_per_col(c);
+        for (int kr = 0; kr < c->Ntrans; ++kr) {
+            const lsx_transition* t = &c->trans[kr];
+            if (!t->is_line) continue;
+            const int li = c->line_idx[kr];
+            const double* ad = aDamp + ((size_t)cc * c->Nlines + li) * Ns;
+            const double* vb = vBroad + ((size_t)cc * c->Natoms + t->atom) * Ns;
+            const double* wl = c->wavelength + t->Nblue;
+            double* wphi = c->wphi + (col * c->Nlines + li) * Ns;
+            for (int k = 0; k < Ns; ++k) wphi[k] = 0.0;
+            for (int la = 0; la < t->Nlambda; ++la) {
+                /* wlambda, rh_method.py:157-196 */
+                double wla = (la == 0) ? 0.5 * (wl[1] - wl[0]) : (la == t->Nlambda - 1) ? 0.5 * (wl[la] - wl[la - 1]) : 0.5 * (wl[la + 1] - wl[la - 1]);
+                wla *= CLight / t->lambda0;
+                for (int mu = 0; mu < (c->phi_compact ? 1 : Nrays); ++mu)
+                    for (int d = 0; d < (c->phi_compact ? 1 : 2); ++d) {
+                        double* ph = c->phi_compact ? phi + ((size_t)c->phi_off[kr] + la) * Ns
+                                                    : phi + ((((size_t)c->phi_off[kr] + la) * Nrays + mu) * 2 + d) * Ns;
+                        for (int k = 0; k < Ns; ++k) {
+                            double v = (wl[la] - t->lambda0) * CLight / (vb[k] * t->lambda0);
+                            double vl = vlos ? vlos[(size_t)cc * Ns + k] : 0.0;
+                            double vk = v + (d ? 1.0 : -1.0) * (c->muz[mu] * vl / vb[k]);
+                            double p = voigt_H(ad[k], vk) / (sqrtPi * vb[k]);
+                            ph[k] = p;
+                            if (!c->phi_compact) wphi[k] += p * (wla * 0.5 * c->wmu[mu]);
+                        }
+                    }
+                if (c->phi_compact) {   /* same value for every ray and direction: the weights sum over them */
+                    const double* ph = phi + ((size_t)c->phi_off[kr] + la) * Ns;
+                    for (int mu = 0; mu < Nrays; ++mu)
+                        for (int d = 0; d < 2; ++d)
+                            for (int k = 0; k < Ns; ++k) wphi[k] += ph[k] * (wla * 0.5 * c->wmu[mu]);
+                }
+            }
+            for (int k = 0; k < Ns; ++k) wphi[k] = 1.0 / wphi[k];
+        }
+    }
     return LSX_OK;
 }
 
@@ -651,6 +736,8 @@ static int locate(lsx_ctx* c, int what, double** base, size_t* per)
     case LSX_C: *base = c->C; *per = (size_t)c->NL2tot * Ns; break;
     case LSX_RIJ: *base = c->Rij; *per = (size_t)c->Ntrans * Ns; break;
     case LSX_RJI: *base = c->Rji; *per = (size_t)c->Ntrans * Ns; break;
+    case LSX_PHI: *base = c->phi; *per = phi_per_col(c); break;
+    case LSX_WPHI: *base = c->wphi; *per = (size_t)c->Nlines * Ns; break;
     default: return 1;
     }
     return 0;
