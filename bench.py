@@ -24,27 +24,44 @@ import numpy as np  # noqa: E402
 
 
 def _gen_chunk(args):
-    path, first, n, seed, vlos_sigma, compact = args
+    path, first, n, seed, vlos_sigma, compact, device_profiles = args
     from lightspinner_amd import fixtures, synth
     prob, block, raw = fixtures.load_problem_npz(path, phi_compact=compact)
-    return synth.perturbed_columns(prob, block, raw, ncol=n, seed=seed, first=first, vlos_sigma=vlos_sigma)
+    return synth.perturbed_columns(prob, block, raw, ncol=n, seed=seed, first=first, vlos_sigma=vlos_sigma,
+                                   device_profiles=device_profiles)
 
 
-def generate_columns(path, first, ncol, compact, nproc, seed=1234, chunk=25):
-    """synthetic ensemble columns [first, first+ncol) (before the GPU is touched: fork is safe)"""
+def generate_columns(path, first, ncol, compact, nproc, seed=1234, chunk=25, device_profiles=True):
+    """synthetic ensemble columns [first, first+ncol) (before the GPU is touched: fork is safe).
+    -> (ColumnBlock, profile inputs or None)"""
+    import numpy as np
     from lightspinner_amd.problem import ColumnBlock
-    jobs = [(path, first + c0, min(chunk, ncol - c0), seed, 0.0 if compact else 2.0e3, compact)
+    jobs = [(path, first + c0, min(chunk, ncol - c0), seed, 0.0 if compact else 2.0e3, compact, device_profiles)
             for c0 in range(0, ncol, chunk)]
-    if nproc > 1 and len(jobs) > 1:
+    if nproc > 1 and len(jobs) > 1 and not device_profiles:
         import multiprocessing as mp
         with mp.get_context('fork').Pool(min(nproc, len(jobs))) as pool:
             blocks = pool.map(_gen_chunk, jobs)
     else:
         blocks = [_gen_chunk(j) for j in jobs]
-    return ColumnBlock.concatenate(blocks)
+    if not device_profiles:
+        return ColumnBlock.concatenate(blocks), None
+    prof = [b[1] for b in blocks]
+    vl = None if prof[0][2] is None else np.concatenate([p[2] for p in prof])
+    return ColumnBlock.concatenate([b[0] for b in blocks]), (np.concatenate([p[0] for p in prof]),
+                                                             np.concatenate([p[1] for p in prof]), vl)
 
 
-def cpu_baseline(prob, batch, seconds_target=12.0):
+def load_columns(eng, batch, prof, c0=0, step=100):
+    """inputs -> engine: arrays by lsx_set_columns, line profiles by lsx_set_line_profiles when they were not built on the host"""
+    for a in range(0, batch.ncol, step):
+        b = min(batch.ncol, a + step)
+        eng.set_columns(c0 + a, batch.slice(a, b))
+        if prof is not None:
+            eng.set_line_profiles(c0 + a, prof[0][a:b], prof[1][a:b], None if prof[2] is None else prof[2][a:b])
+
+
+def cpu_baseline(prob, batch, prof, seconds_target=12.0):
     """The oracle (C restatement, kind 'port') on a bounded sample of the same workload, on this
     host's cores, OpenMP over columns.  Checker/baseline only -- never the product path."""
     import oracle
@@ -54,7 +71,7 @@ def cpu_baseline(prob, batch, seconds_target=12.0):
     cores = min(os.cpu_count() or 1, int(os.environ.get('LSX_CPU_THREADS', '16')))
     nsample = min(batch.ncol, 4 * cores)
     eng = Engine(prob, nsample, lib=lib)
-    eng.set_columns(0, batch.slice(0, nsample))
+    load_columns(eng, batch.slice(0, nsample), None if prof is None else tuple(None if p is None else p[:nsample] for p in prof))
     out = {}
     for label, nthreads in (('1thread', 1), ('allcores', cores)):
         lib.check(lib.dll.lsx_oracle_set_threads(eng._h, nthreads))
@@ -86,6 +103,7 @@ def main():
     ap.add_argument('--columns', type=int, default=None, help='columns per GPU (default 1000 / 1 / 1250)')
     ap.add_argument('--compact-phi', action='store_true', help='vlos == 0: ray independent profiles (P = 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--host-profiles', action='store_true', help='build the line profiles on the host (scipy) and upload them')
     ap.add_argument('--kernel-reps', type=int, default=10)
     ap.add_argument('--no-single-column', action='store_true',
                     help='skip the FALC single-column section (used for rocprofv3 runs so that every sweep launch has the workload size)')
@@ -107,12 +125,13 @@ def main():
     prob, base, raw = fixtures.load_problem_npz(fixture, phi_compact=compact)
     t0 = time.time()
     nproc = max(1, min(os.cpu_count() or 1, 16 * max(1, world)) // max(1, world))
-    batch = generate_columns(fixture, rank * ncol, ncol, compact, nproc) if ncol > 1 else base
+    devprof = not args.host_profiles
+    batch, prof = generate_columns(fixture, rank * ncol, ncol, compact, nproc, device_profiles=devprof) if ncol > 1 else (base, None)
     t_gen = time.time() - t0
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(prob, batch)
+        cpu = cpu_baseline(prob, batch, prof)
 
     # ---- GPU ---------------------------------------------------------------------------
     import torch
@@ -125,10 +144,11 @@ def main():
     lib = _capi.load_hip_library()
     eng = Engine(prob, ncol, device=local_rank, stream=stream or None, lib=lib)
     t0 = time.time()
-    for c0 in range(0, ncol, 100):
-        eng.set_columns(c0, batch.slice(c0, min(ncol, c0 + 100)))
+    load_columns(eng, batch, prof)
     t_up = time.time() - t0
-    upload_bytes = sum(getattr(batch, k).nbytes for k in ('phi', 'bg_chi', 'bg_eta', 'C', 'n', 'nStar'))
+    upload_bytes = sum(getattr(batch, k).nbytes for k in ('phi', 'bg_chi', 'bg_eta', 'C', 'n', 'nStar') if getattr(batch, k) is not None)
+    if prof is not None:
+        upload_bytes += sum(p.nbytes for p in prof if p is not None)
     reducer = MaxReducer(device=dev)
 
     def step():
@@ -227,7 +247,8 @@ def main():
                       roofline=roofline, cpu_baseline=cpu, falc_single_column=single,
                       max_dn_over_n_vs_ref=single['max_dn_over_n_vs_ref'] if single else None,
                       setup=dict(generate_s=t_gen, upload_s=t_up, upload_GB=upload_bytes / 1e9,
-                                 note='PCIe-inclusive upload is outside the timed region (inputs resident in HBM)'))
+                                 line_profiles='built on the device (lsx_set_line_profiles)' if prof is not None else 'built on the host and uploaded',
+                                 note='PCIe-inclusive upload (and the device-side profile build) is outside the timed region (inputs resident in HBM)'))
     eng.close()
     if world > 1:
         dist.barrier()

@@ -21,14 +21,18 @@ def _smooth_field(rng, Ns, corr):
 
 
 def perturbed_columns(prob: Problem, base: ColumnBlock, raw: dict, ncol: int, seed: int = 1234, sigma: float = 0.05,
-                      corr: int = 8, vlos_sigma: float = 2.0e3, first: int = 0) -> ColumnBlock:
-    """columns [first, first + ncol) of the synthetic ensemble (deterministic per absolute index)."""
+                      corr: int = 8, vlos_sigma: float = 2.0e3, first: int = 0, device_profiles: bool = False):
+    """columns [first, first + ncol) of the synthetic ensemble (deterministic per absolute index).
+
+    device_profiles=True: the line profiles are not built here; returns (block with phi = wphi = None,
+    (aDamp [ncol][Nlines][Nspace], vBroad [ncol][Natoms][Nspace], vlos [ncol][Nspace] or None)) for
+    Engine.set_line_profiles -- compute_phi then runs on the device (rh_method.py:198-243)."""
     Ns = prob.Nspace
     f = lambda a: np.repeat(np.asarray(a), ncol, axis=0).copy()
     out = {k: f(getattr(base, k)) for k in ('height', 'temperature', 'nStar', 'nTotal', 'n', 'C', 'bg_chi', 'bg_eta',
                                             'bg_sca', 'wphi')}
     use_vlos = vlos_sigma > 0 and not prob.phi_compact and prob.Nlines > 0
-    phi = np.empty((ncol,) + prob.phi_shape())
+    phi = None if device_profiles else np.empty((ncol,) + prob.phi_shape())
     vlos = np.zeros((ncol, Ns))
     for q in range(ncol):
         c = first + q
@@ -45,6 +49,12 @@ def perturbed_columns(prob: Problem, base: ColumnBlock, raw: dict, ncol: int, se
         out['C'][q] *= fc
         if use_vlos:
             vlos[q] = vlos_sigma * _smooth_field(rng, Ns, corr)
+    if device_profiles:
+        lines = [kr for kr, t in enumerate(prob.trans) if t.is_line]
+        aD = np.repeat(np.stack([raw['t%d_aDamp' % kr] for kr in lines])[None], ncol, axis=0)
+        vB = np.repeat(np.stack([raw['a%d_vBroad' % a] for a in range(prob.Natoms)])[None], ncol, axis=0)
+        out['wphi'] = None
+        return ColumnBlock(phi=None, **out).validate(prob), (aD, vB, vlos if use_vlos else None)
     if use_vlos:
         o, li = 0, 0
         for kr, t in enumerate(prob.trans):
