@@ -306,7 +306,7 @@ struct FastParams {
     const double* nsr;          // [col][Ncont][k]  nStar_i / nStar_j of every continuum (rh_method.py:453)
     const double* temperature;  // [col][k]
     const double* hck_la;       // [Nspect]  hc / (k lambda)
-    int Ncont, nF_max;
+    int Ncont, nF_max, generic;
     const double* bgchi_T;
     const double* bgeta_T;
     double* bgxchi_T;
@@ -392,14 +392,32 @@ __global__ void k_fast_gamma(const FastParams f, int KC)
     const DevTile tl = f.tiles[t];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int kc = tid / f.L, j = tid - kc * f.L;
-    const int k = blockIdx.x * KC + kc;
+    const int k0 = blockIdx.x * KC, k = k0 + kc;
     const bool on = kc < KC && k < f.Nspace && j < tl.nla;
     double* red = sm;                                       // red[(q*2 + e) * nt + tid]
     const DevSlot* fs = f.slots + tl.slot0 + tl.nP;
     const int la = tl.la0 + (j < tl.nla ? j : 0);
+    // operands of the block's (slot, depth) and (slot, wavelength) pairs, staged once:
+    //   sN[(q*KC + kc)*3 + {0,1,2}] = n_i, n_j, nStar_i/nStar_j      sA[(q*L + j)*3 + {0,1,2}] = active, alpha, wlambda
+    double* sN = sm + (size_t)(2 * f.nF_max + (f.generic ? 2 * f.NLtot + f.Natoms : 0)) * nt;
+    double* sA = sN + (size_t)3 * f.nF_max * KC;
+    for (int e = tid; e < tl.nF * KC; e += nt) {
+        const int q = e / KC, kk = min(k0 + e % KC, f.Nspace - 1);
+        sN[e * 3 + 0] = f.n[(col * f.NLtot + fs[q].li) * f.Nspace + kk];
+        sN[e * 3 + 1] = f.n[(col * f.NLtot + fs[q].lj) * f.Nspace + kk];
+        sN[e * 3 + 2] = f.nsr[col * f.Ncont * f.Nspace + fs[q].base + kk];
+    }
+    for (int e = tid; e < tl.nF * f.L; e += nt) {
+        const int q = e / f.L, jj = e % f.L, lq = tl.la0 + min(jj, tl.nla - 1), lt = lq - fs[q].Nblue;
+        const bool a = jj < tl.nla && lt >= 0 && lt < fs[q].Nlam && f.active[(size_t)fs[q].trans * f.Nspect + lq] != 0;
+        sA[e * 3 + 0] = a ? 1.0 : 0.0;
+        sA[e * 3 + 1] = a ? f.alpha[fs[q].wl_off + lt] : 0.0;
+        sA[e * 3 + 2] = a ? f.wl[fs[q].wl_off + lt] : 0.0;
+    }
     double sW = 0.0;
     for (int m = 0; m < f.Nrays; ++m) sW += 2.0 * f.wmuh[m] * (4.0 * M_PI);   // both directions
     double sI = 0.0, sPsi = 0.0, E = 0.0;
+    const double ula = f.u_la[la];
     if (on) {
         const size_t o = ((col * f.ntile + t) * f.Nspace + k) * f.L + j;
         const size_t dstride = (size_t)f.ncol * f.ntile * f.Nspace * f.L;
@@ -407,6 +425,23 @@ __global__ void k_fast_gamma(const FastParams f, int KC)
         sPsi = f.Psi2_T[o] + f.Psi2_T[dstride + o];
         E = fast_boltzmann(f, col, la, k);
     }
+    __syncthreads();
+    // fast_value() from the staged operands (same arithmetic)
+    auto value = [&](int q) {
+        FastVal v;
+        const double* A = sA + (size_t)(q * f.L + j) * 3;
+        const double* N = sN + (size_t)(q * KC + (kc < KC ? kc : 0)) * 3;
+        v.a = A[0] != 0.0;
+        v.alf = v.Vji = v.Uji = v.chi = v.eta = 0.0;
+        if (v.a) {
+            v.alf = A[1];
+            v.Vji = (N[2] * E) * v.alf;
+            v.Uji = ula * v.Vji;
+            v.chi = N[0] * v.alf - N[1] * v.Vji;
+            v.eta = N[1] * v.Uji;
+        }
+        return v;
+    };
     if (tl.fast_simple) {
         for (int q0 = 0; q0 < tl.nF;) {                     // one atom at a time
             const int atom = fs[q0].atom;
@@ -414,7 +449,7 @@ __global__ void k_fast_gamma(const FastParams f, int KC)
             double chi_j = 0.0, U_j = 0.0, etaA = 0.0;      // atom.chi[j], atom.U[j], atom.eta of rh_method.py:616-627
             for (; q1 < tl.nF && fs[q1].atom == atom; ++q1) {
                 if (on) {
-                    const FastVal v = fast_value(f, fs[q1], col, la, k, E);
+                    const FastVal v = value(q1);
                     chi_j -= v.chi;
                     U_j += v.Uji;
                     etaA += v.eta;
@@ -423,11 +458,11 @@ __global__ void k_fast_gamma(const FastParams f, int KC)
             for (int q = q0; q < q1; ++q) {
                 double g1 = 0.0, g2 = 0.0;
                 if (on) {
-                    const FastVal v = fast_value(f, fs[q], col, la, k, E);
+                    const FastVal v = value(q);
                     if (v.a) {
                         const double chi_i = 0.0 + v.chi, U_i = 0.0;
                         const double sIe = sI - etaA * sPsi;
-                        const double wla = f.wl[fs[q].wl_off + (la - fs[q].Nblue)];
+                        const double wla = sA[(size_t)(q * f.L + j) * 3 + 2];
                         g1 = wla * ((v.Uji * sW + v.Vji * sIe) - (chi_i * U_j) * sPsi);
                         g2 = wla * ((v.alf * sIe) - (chi_j * U_i) * sPsi);
                     }
@@ -443,7 +478,7 @@ __global__ void k_fast_gamma(const FastParams f, int KC)
         for (int c = 0; c < ncell; ++c) cell[c * nt] = 0.0;
         if (on) {
             for (int q = 0; q < tl.nF; ++q) {
-                const FastVal v = fast_value(f, fs[q], col, la, k, E);
+                const FastVal v = value(q);
                 cell[fs[q].li * nt] += v.chi;
                 cell[fs[q].lj * nt] -= v.chi;
                 cell[(f.NLtot + fs[q].lj) * nt] += v.Uji;
@@ -453,13 +488,13 @@ __global__ void k_fast_gamma(const FastParams f, int KC)
         for (int q = 0; q < tl.nF; ++q) {
             double g1 = 0.0, g2 = 0.0;
             if (on) {
-                const FastVal v = fast_value(f, fs[q], col, la, k, E);
+                const FastVal v = value(q);
                 if (v.a) {
                     const double etaA = cell[(2 * f.NLtot + fs[q].atom) * nt];
                     const double chi_i = cell[fs[q].li * nt], chi_j = cell[fs[q].lj * nt];
                     const double U_i = cell[(f.NLtot + fs[q].li) * nt], U_j = cell[(f.NLtot + fs[q].lj) * nt];
                     const double sIe = sI - etaA * sPsi;
-                    const double wla = f.wl[fs[q].wl_off + (la - fs[q].Nblue)];
+                    const double wla = sA[(size_t)(q * f.L + j) * 3 + 2];
                     g1 = wla * ((v.Uji * sW + v.Vji * sIe) - (chi_i * U_j) * sPsi);
                     g2 = wla * ((v.alf * sIe) - (chi_j * U_i) * sPsi);
                 }
@@ -1312,7 +1347,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
         ff.L = c->L; ff.NLtot = c->NLtot; ff.Natoms = c->Natoms; ff.nslot_total = (int)c->tile_slots.size();
         ff.n_fast_tiles = (int)c->fast_tiles.size(); ff.tiles = c->d_tiles; ff.slots = c->d_slots; ff.fast_tiles = c->d_fast_tiles;
         ff.active = c->d_active; ff.alpha = c->d_alpha; ff.wl = c->d_wl; ff.u_la = c->d_u_la; ff.wmuh = c->d_wmuh; ff.n = c->d_n;
-        ff.nsr = c->d_nsr; ff.temperature = c->d_temperature; ff.hck_la = c->d_hck_la; ff.Ncont = c->Ncont; ff.nF_max = c->nF_max;
+        ff.nsr = c->d_nsr; ff.temperature = c->d_temperature; ff.hck_la = c->d_hck_la; ff.Ncont = c->Ncont; ff.nF_max = c->nF_max; ff.generic = c->fast_generic ? 1 : 0;
         ff.bgchi_T = c->d_bgchi; ff.bgeta_T = c->d_bgeta;
         ff.bgxchi_T = c->d_bgxchi; ff.bgxeta_T = c->d_bgxeta; ff.J_T = c->d_J[c->jcur ^ 1]; ff.Psi2_T = c->d_Psi2;
         ff.Gpart = c->d_Gpart; ff.colmask = c->d_colmask;
@@ -1358,7 +1393,8 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
     if (timed) HIPCHK(hipEventRecord(c->ev1, c->stream));
     if (has_fast) {
         const int nt = c->L > 64 ? 256 : 128, KC = std::max(1, nt / c->L);
-        const size_t sm = (size_t)((c->fast_generic ? 2 * c->NLtot + c->Natoms : 0) + 2 * c->nF_max) * nt * sizeof(double);
+        const size_t sm = ((size_t)((c->fast_generic ? 2 * c->NLtot + c->Natoms : 0) + 2 * c->nF_max) * nt +
+                           (size_t)3 * c->nF_max * (KC + c->L)) * sizeof(double);
         if (sm > 64 * 1024) return fail(LSX_EUNSUPPORTED, "fast-continuum epilogue needs %zu B of LDS", sm);
         dim3 grid((c->Nspace + KC - 1) / KC, (unsigned)c->fast_tiles.size(), (unsigned)c->ncol);
         hipLaunchKernelGGL(k_fast_gamma, grid, dim3(nt), sm, c->stream, ff, KC);
