@@ -140,5 +140,6 @@ struct SweepParams {
     double* dJpart;
     const uint8_t* colmask;     // per-column activity (frozen columns exit at once), or null
     double* debug;              // diagnostic builds only
+    int32_t static_max;         // fused launch: tiles with more per-ray slots than this take the generic path
     const double* exp2_tab;     // [64][2]: 2^(j/64) as a (head, tail) pair, for the sweep's exp(-dtau)
 };

@@ -749,7 +749,7 @@ struct lsx_ctx {
     double* d_hck_la = nullptr;
     double* d_voigt_w = nullptr;
     double *d_muz = nullptr, *d_wmu = nullptr;
-    int nF_max = 0, Ncont = 0;
+    int nF_max = 0, Ncont = 0, static_max = -1;
     bool fast_generic = false;
     double* d_nsr = nullptr;     // [col][Ncont][k] nStar_i / nStar_j of the continua
     std::vector<int> cont_li, cont_lj;
@@ -1102,7 +1102,11 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
             tl.fast_simple = simple ? 1 : 0;
             if (!simple) c->fast_generic = true;
         }
-        const int npt = tl.nP <= 3 ? tl.nP : -1;
+        // a compile-time slot count needs the per-depth operand table in LDS; very deep columns fall back to the
+        // generic instance (runtime slot loops, operands through the scalar cache)
+        const bool table_fits = (size_t)(Ns + 1) * (3 * tl.nP + 2) * sizeof(double) <= 32 * 1024;
+        const int npt = (tl.nP <= 3 && table_fits) ? tl.nP : -1;
+        if (npt >= 0) c->static_max = std::max(c->static_max, npt);
         const int nl = npt >= 0 ? (int)lines.size() : 0;
         tl.nL = (int)lines.size();
         SweepClass* k = nullptr;
@@ -1338,7 +1342,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
     p.height = c->d_height; p.temperature = c->d_temperature; p.n = c->d_n; p.wphi = c->d_wphi;
     p.bgchi_T = c->d_bgchi; p.bgeta_T = c->d_bgeta; p.bgxchi_T = c->d_bgxchi; p.bgxeta_T = c->d_bgxeta; p.Psi2_T = c->d_Psi2; p.sca = c->d_sca; p.phi_T = c->d_phi; p.gijc_T = c->d_gijc;
     p.Jdag_T = c->d_J[c->jcur]; p.Jnew_T = c->d_J[c->jcur ^ 1];
-    p.Iout = c->d_I; p.Gpart = c->d_Gpart; p.dJpart = c->d_dJpart; p.debug = c->d_debug; p.colmask = c->d_colmask; p.exp2_tab = c->d_exp2_tab;
+    p.Iout = c->d_I; p.Gpart = c->d_Gpart; p.dJpart = c->d_dJpart; p.debug = c->d_debug; p.colmask = c->d_colmask; p.exp2_tab = c->d_exp2_tab; p.static_max = c->static_max;
 
     FastParams ff{};
     const bool has_fast = !c->fast_tiles.empty();

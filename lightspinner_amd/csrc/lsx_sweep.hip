@@ -809,7 +809,8 @@ lsx_sweep_kernel_all(const SweepParams p)
         return;
     }
     const int nP = (LSX_CONST(DevTile, p.tiles) + tile_id)->nP, nL = (LSX_CONST(DevTile, p.tiles) + tile_id)->nL;
-    if (nP == 0) sweep_tile<0, 0, NR, SCAL>(p, vb, tile_id);
+    if (nP > p.static_max) sweep_tile<-1, 0, NR, SCAL>(p, vb, tile_id);
+    else if (nP == 0) sweep_tile<0, 0, NR, SCAL>(p, vb, tile_id);
     else if (nP == 1) sweep_tile<1, 1, NR, SCAL>(p, vb, tile_id);
     else if (nP == 2 && nL == 2) sweep_tile<2, 2, NR, SCAL>(p, vb, tile_id);
     else if (nP == 2 && nL == 1) sweep_tile<2, 1, NR, SCAL>(p, vb, tile_id);

@@ -18,6 +18,9 @@ CASES = [
     dict(seed=4, phi_compact=True, chain=False),
     dict(seed=5, Nrays=2, Nspace=5, Nspect=40, ncol=40),              # shortest useful column; >= 32 columns: per-class launches
     dict(seed=6, Nrays=7, Nspace=33, Nspect=55, ncol=33),
+    dict(seed=7, Nrays=8, Nspace=21, Nspect=48, ncol=2),              # 8 wavelengths per wavefront, all 64 lanes used
+    dict(seed=8, Nrays=3, Nspace=700, Nspect=30, ncol=33),            # deep column: the operand table no longer fits LDS -> generic instance
+    dict(seed=9, Nrays=3, Nspace=700, Nspect=30, ncol=2),             # same through the fused small-batch launch
 ]
 
 
