@@ -245,42 +245,46 @@ struct FinishParams {
 // diagonal (rh_method.py:587-590, 698-703).  One thread per (column, depth).
 __global__ void k_gamma_finish(const FinishParams f)
 {
+    extern __shared__ double sm[];
     const int Ns = f.Nspace;
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const long gid = (long)blockIdx.x * nt + tid;
     if (gid >= (long)f.ncol * Ns) return;
     const int col = gid / Ns, k = gid % Ns;
     if (f.colmask && !f.colmask[col]) {
         if (k == 0) f.dJcol[col] = 0.0;
         return;
     }
-    double* G = f.Gamma + (size_t)col * f.NL2tot * Ns + k;
+    double* G = sm + tid;                                   // thread-private Gamma: G[e * nt]
     const double* Cm = f.C + (size_t)col * f.NL2tot * Ns + k;
-    for (int e = 0; e < f.NL2tot; ++e) G[(size_t)e * Ns] = 0.0 + Cm[(size_t)e * Ns];
+    for (int e = 0; e < f.NL2tot; ++e) G[e * nt] = 0.0 + Cm[(size_t)e * Ns];     // Gamma = C, :587-590
     const double* P = f.Gpart + (size_t)col * f.nslot_total * 4 * Ns + k;
     for (int t = 0; t < f.ntile; ++t) {
         const DevTile tl = f.tiles[t];
         for (int u = 0; u < tl.nP + tl.nF; ++u) {
             const DevTrans& tr = f.trans[f.tile_slots[tl.slot0 + u]];
             const double* q = P + (size_t)(tl.slot0 + u) * 4 * Ns;
-            double gij = G[(size_t)tr.gam_ij * Ns], gji = G[(size_t)tr.gam_ji * Ns];
+            double gij = G[tr.gam_ij * nt], gji = G[tr.gam_ji * nt];
             gij += q[0];
             gij += q[(size_t)Ns];
             gji += q[(size_t)2 * Ns];
             gji += q[(size_t)3 * Ns];
-            G[(size_t)tr.gam_ij * Ns] = gij;
-            G[(size_t)tr.gam_ji * Ns] = gji;
+            G[tr.gam_ij * nt] = gij;
+            G[tr.gam_ji * nt] = gji;
         }
     }
+    double* Gout = f.Gamma + (size_t)col * f.NL2tot * Ns + k;
     for (int a = 0; a < f.Natoms; ++a) {
         const int Nl = f.Nlevel[a];
-        double* Ga = G + (size_t)f.lev2_off[a] * Ns;
-        for (int i = 0; i < Nl; ++i) Ga[(size_t)(i * Nl + i) * Ns] = 0.0;
-        for (int i = 0; i < Nl; ++i) {
+        double* Ga = G + f.lev2_off[a] * nt;
+        for (int i = 0; i < Nl; ++i) Ga[(i * Nl + i) * nt] = 0.0;
+        for (int i = 0; i < Nl; ++i) {                       // Gamma_ii = -sum_{l != i} Gamma_li, :698-703
             double s = 0.0;
-            for (int l = 0; l < Nl; ++l) s += Ga[(size_t)(l * Nl + i) * Ns];
-            Ga[(size_t)(i * Nl + i) * Ns] = -s;
+            for (int l = 0; l < Nl; ++l) s += Ga[(l * Nl + i) * nt];
+            Ga[(i * Nl + i) * nt] = -s;
         }
     }
+    for (int e = 0; e < f.NL2tot; ++e) Gout[(size_t)e * Ns] = G[e * nt];
     if (k == 0) { // per-column dJ: max over the column's tiles, NaN propagating (rh_method.py:705-706)
         double m = 0.0;
         for (int t = 0; t < 2 * f.ntile; ++t) {
@@ -1411,7 +1415,13 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
     f.tile_slots = c->d_tile_slots; f.trans = c->d_trans; f.C = c->d_C; f.Gpart = c->d_Gpart; f.dJpart = c->d_dJpart;
     f.Gamma = c->d_Gamma; f.dJcol = c->d_dJcol; f.colmask = c->d_colmask;
     const long nthreads = (long)c->ncol * c->Nspace;
-    hipLaunchKernelGGL(k_gamma_finish, dim3((unsigned)((nthreads + 127) / 128)), dim3(128), 0, c->stream, f);
+    {
+        int nt = 128;
+        while (nt > 32 && (size_t)c->NL2tot * nt * sizeof(double) > 48 * 1024) nt >>= 1;
+        const size_t smf = (size_t)c->NL2tot * nt * sizeof(double);
+        if (smf > 64 * 1024) return fail(LSX_EUNSUPPORTED, "gamma epilogue needs %zu B of LDS", smf);
+        hipLaunchKernelGGL(k_gamma_finish, dim3((unsigned)((nthreads + nt - 1) / nt)), dim3(nt), smf, c->stream, f);
+    }
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, c->stream, c->d_dJcol, c->ncol, c->d_max);
     HIPCHK(hipGetLastError());
