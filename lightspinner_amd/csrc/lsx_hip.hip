@@ -335,25 +335,6 @@ __device__ __forceinline__ double fast_boltzmann(const FastParams& f, size_t col
     r = fma(fma(-T, r, 1.0), r, r);
     return exp(-(f.hck_la[la] * r));
 }
-__device__ __forceinline__ FastVal fast_value(const FastParams& f, const DevSlot& sl, size_t col, int la, int k, double E)
-{
-    FastVal v;
-    const int lt = la - sl.Nblue;
-    v.a = lt >= 0 && lt < sl.Nlam && f.active[(size_t)sl.trans * f.Nspect + la] != 0;
-    v.alf = v.Vji = v.Uji = v.chi = v.eta = 0.0;
-    if (v.a) {
-        const double ni = f.n[(col * f.NLtot + sl.li) * f.Nspace + k];
-        const double nj = f.n[(col * f.NLtot + sl.lj) * f.Nspace + k];
-        const double g = f.nsr[col * f.Ncont * f.Nspace + sl.base + k] * E;
-        v.alf = f.alpha[sl.wl_off + lt];
-        v.Vji = g * v.alf;
-        v.Uji = f.u_la[la] * v.Vji;
-        v.chi = ni * v.alf - nj * v.Vji;
-        v.eta = nj * v.Uji;
-    }
-    return v;
-}
-
 // effective background of the tiles that have fast continua: bgx = bg + sum over the tile's fast continua
 __global__ void k_fast_prepass(const FastParams f)
 {
@@ -361,18 +342,44 @@ __global__ void k_fast_prepass(const FastParams f)
     if (f.colmask && !f.colmask[col]) return;
     const int t = f.fast_tiles[blockIdx.y];
     const DevTile tl = f.tiles[t];
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;       // (k, j)
+    extern __shared__ double sm[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int e = blockIdx.x * nt + tid;                        // (k, j)
+    const DevSlot* fs = f.slots + tl.slot0 + tl.nP;
+    // operands of the block's (slot, depth) and (slot, wavelength) pairs, staged once (as in k_fast_gamma)
+    const int k_lo = (blockIdx.x * nt) / f.L, KR = nt / f.L + 2;
+    double* sN = sm;
+    double* sA = sN + (size_t)3 * f.nF_max * KR;
+    for (int x = tid; x < tl.nF * KR; x += nt) {
+        const int q = x / KR, kk = min(k_lo + x % KR, f.Nspace - 1);
+        sN[x * 3 + 0] = f.n[(col * f.NLtot + fs[q].li) * f.Nspace + kk];
+        sN[x * 3 + 1] = f.n[(col * f.NLtot + fs[q].lj) * f.Nspace + kk];
+        sN[x * 3 + 2] = f.nsr[col * f.Ncont * f.Nspace + fs[q].base + kk];
+    }
+    for (int x = tid; x < tl.nF * f.L; x += nt) {
+        const int q = x / f.L, jj = x % f.L, lq = tl.la0 + min(jj, tl.nla - 1), lt = lq - fs[q].Nblue;
+        const bool a = jj < tl.nla && lt >= 0 && lt < fs[q].Nlam && f.active[(size_t)fs[q].trans * f.Nspect + lq] != 0;
+        sA[x * 3 + 0] = a ? 1.0 : 0.0;
+        sA[x * 3 + 1] = a ? f.alpha[fs[q].wl_off + lt] : 0.0;
+    }
+    __syncthreads();
     if (e >= f.Nspace * f.L) return;
     const int k = e / f.L, j = e - k * f.L;
     const size_t o = ((col * f.ntile + t) * f.Nspace) * f.L + e;
     double chi = f.bgchi_T[o], eta = f.bgeta_T[o];
     if (j < tl.nla) {
         const int la = tl.la0 + j;
-        const double E = fast_boltzmann(f, col, la, k);
+        const double E = fast_boltzmann(f, col, la, k), ula = f.u_la[la];
         for (int q = 0; q < tl.nF; ++q) {
-            const FastVal v = fast_value(f, f.slots[tl.slot0 + tl.nP + q], col, la, k, E);
-            chi += v.chi;
-            eta += v.eta;
+            const double* A = sA + (size_t)(q * f.L + j) * 3;
+            const double* N = sN + (size_t)(q * KR + (k - k_lo)) * 3;
+            if (A[0] != 0.0) {                                   // fast_value(), same arithmetic
+                const double alf = A[1];
+                const double Vji = (N[2] * E) * alf;
+                const double Uji = ula * Vji;
+                chi += N[0] * alf - N[1] * Vji;
+                eta += N[1] * Uji;
+            }
         }
     }
     f.bgxchi_T[o] = chi;
@@ -1360,7 +1367,8 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
         ff.bgxchi_T = c->d_bgxchi; ff.bgxeta_T = c->d_bgxeta; ff.J_T = c->d_J[c->jcur ^ 1]; ff.Psi2_T = c->d_Psi2;
         ff.Gpart = c->d_Gpart; ff.colmask = c->d_colmask;
         dim3 grid((c->Nspace * c->L + 255) / 256, (unsigned)c->fast_tiles.size(), (unsigned)c->ncol);
-        hipLaunchKernelGGL(k_fast_prepass, grid, dim3(256), 0, c->stream, ff);
+        const size_t smp = (size_t)3 * c->nF_max * (256 / c->L + 2 + c->L) * sizeof(double);
+        hipLaunchKernelGGL(k_fast_prepass, grid, dim3(256), smp, c->stream, ff);
         HIPCHK(hipGetLastError());
     }
     if (timed) HIPCHK(hipEventRecord(c->ev0, c->stream));
