@@ -130,7 +130,7 @@ def main():
     t_gen = time.time() - t0
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # CPU baseline: rank 0 at N = 1 only
         cpu = cpu_baseline(prob, batch, prof)
 
     # ---- GPU ---------------------------------------------------------------------------

@@ -967,8 +967,10 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
             return np;
         };
         auto cost = [](int np) {
-            static const double C[] = {2500.0, 3900.0, 6600.0, 12800.0};
-            return np <= 3 ? C[np] : 14600.0 + 2500.0 * (np - 4);
+            // SIMD time of one wavefront (wave cycles / resident waves per SIMD), PMC-measured on MI355X for the
+            // classes with 0 .. 4 compile-time slots (profiles/); more slots run the generic instance
+            static const double C[] = {2500.0, 2950.0, 3550.0, 6600.0, 9600.0};
+            return np <= 4 ? C[np] : 14600.0 + 2500.0 * (np - 5);
         };
         const char* env = getenv("LSX_TILER");
         const bool natural = env && std::string(env) == "natural";
@@ -1116,7 +1118,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         // a compile-time slot count needs the per-depth operand table in LDS; very deep columns fall back to the
         // generic instance (runtime slot loops, operands through the scalar cache)
         const bool table_fits = (size_t)(Ns + 1) * (3 * tl.nP + 2) * sizeof(double) <= 32 * 1024;
-        const int npt = (tl.nP <= 3 && table_fits) ? tl.nP : -1;
+        const int npt = (tl.nP <= 4 && table_fits) ? tl.nP : -1;
         if (npt >= 0) c->static_max = std::max(c->static_max, npt);
         const int nl = npt >= 0 ? (int)lines.size() : 0;
         tl.nL = (int)lines.size();

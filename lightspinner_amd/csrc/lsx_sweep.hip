@@ -672,6 +672,10 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                     const double t2 = reduce_pair(w1[2], w2v[2]);
                     if (own_pair) gpk[4 * LSX_WAVE + row_pair + sl64] = t2;
                 }
+                if constexpr (NPT == 4) {
+                    const double t2 = reduce_quad(w1[2], w2v[2], w1[3], w2v[3]);
+                    if (own_quad) gpk[4 * LSX_WAVE + row_quad + sl64] = t2;
+                }
             }
             if (sl64 == 63 || s == Ns - 1) {
                 const int ks = kS + dk * (s - sl64 + lane);         // the depth parked in entry `lane` of every row
@@ -769,7 +773,10 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
 #ifndef LSX_WPE3
 #define LSX_WPE3 (LSX_WAVES_PER_EU - 1)     // three per-ray slots: 4 waves/SIMD would spill ~60 VGPRs
 #endif
-#define LSX_WPE(NPT) ((NPT) == 0 ? LSX_WPE0 : ((NPT) == 1 ? LSX_WPE1 : ((NPT) == 2 ? LSX_WPE2 : ((NPT) == 3 ? LSX_WPE3 : LSX_WAVES_PER_EU))))
+#ifndef LSX_WPE4
+#define LSX_WPE4 (LSX_WAVES_PER_EU - 1)
+#endif
+#define LSX_WPE(NPT) ((NPT) == 0 ? LSX_WPE0 : ((NPT) == 1 ? LSX_WPE1 : ((NPT) == 2 ? LSX_WPE2 : ((NPT) == 3 ? LSX_WPE3 : ((NPT) == 4 ? LSX_WPE4 : LSX_WAVES_PER_EU)))))
 template <int NPT, int NL, int NR, bool SCAL>
 __global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(LSX_WPE(NPT))))
 lsx_sweep_kernel(const SweepParams p)
@@ -830,6 +837,10 @@ static void launch_class(const SweepParams& p, int npt, dim3 g, dim3 b, size_t l
     case 24 + 1: hipLaunchKernelGGL((lsx_sweep_kernel<3, 1, NR, SCAL>), g, b, lds_bytes, st, p); break;
     case 24 + 2: hipLaunchKernelGGL((lsx_sweep_kernel<3, 2, NR, SCAL>), g, b, lds_bytes, st, p); break;
     case 24 + 3: hipLaunchKernelGGL((lsx_sweep_kernel<3, 3, NR, SCAL>), g, b, lds_bytes, st, p); break;
+    case 32 + 1: hipLaunchKernelGGL((lsx_sweep_kernel<4, 1, NR, SCAL>), g, b, lds_bytes, st, p); break;
+    case 32 + 2: hipLaunchKernelGGL((lsx_sweep_kernel<4, 2, NR, SCAL>), g, b, lds_bytes, st, p); break;
+    case 32 + 3: hipLaunchKernelGGL((lsx_sweep_kernel<4, 3, NR, SCAL>), g, b, lds_bytes, st, p); break;
+    case 32 + 4: hipLaunchKernelGGL((lsx_sweep_kernel<4, 4, NR, SCAL>), g, b, lds_bytes, st, p); break;
     default: hipLaunchKernelGGL((lsx_sweep_kernel<-1, 0, NR, SCAL>), g, b, lds_bytes, st, p); break;
     }
 }
