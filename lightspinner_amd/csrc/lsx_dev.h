@@ -80,10 +80,13 @@ struct DevSlot {
     double g;              // lines: Bji/Bij                         Vji = g Vij         :280, :450
     double Vc;             // lines: g cB
     double Uc;             // lines: (Aji/Bji) g cB                  Uji = Uc phi        :281
-    // two-slot tiles keep the level bookkeeping of rh_method.py:616-627 in registers: what the OTHER per-ray slot v
-    // of the tile adds to this slot's atom.chi[i], atom.chi[j], atom.U[j], atom.U[i], atom.eta, as factors in
-    // {-1, 0, 1}:  [li_v==li] - [lj_v==li],  [li_v==lj] - [lj_v==lj],  [lj_v==lj],  [lj_v==li],  [atom_v==atom]
-    double rel[5];
+    // tiles with a compile-time slot count keep the level bookkeeping of rh_method.py:616-627 in registers: what
+    // every OTHER per-ray slot v of the tile (ascending, o = 0, 1, 2) adds to this slot's atom.chi[i], atom.chi[j],
+    // atom.U[j], atom.U[i], atom.eta, as factors in {-1, 0, 1}:
+    //   [li_v==li] - [lj_v==li],  [li_v==lj] - [lj_v==lj],  [lj_v==lj],  [lj_v==li],  [atom_v==atom]
+    double rel[3][5];
+    uint32_t relmask;      // bit o: rel[o] has a non-zero factor
+    int32_t pad_rel;
 };
 enum { REL_CI = 0, REL_CJ = 1, REL_UJ = 2, REL_UI = 3, REL_EA = 4 };
 

@@ -1086,13 +1086,20 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
                 sl.base = (int)gij_run;
                 gij_run += (size_t)sl.len * Ns;
             }
-            if (tl.nP == 2 && !(sl.flags & SLOT_FAST)) {
-                const DevTrans& o = c->htrans[per_ray[per_ray[0] == t ? 1 : 0]];
-                sl.rel[REL_CI] = (double)(o.li == h.li) - (double)(o.lj == h.li);
-                sl.rel[REL_CJ] = (double)(o.li == h.lj) - (double)(o.lj == h.lj);
-                sl.rel[REL_UJ] = (double)(o.lj == h.lj);
-                sl.rel[REL_UI] = (double)(o.lj == h.li);
-                sl.rel[REL_EA] = (double)(o.atom == h.atom);
+            if (tl.nP >= 2 && tl.nP <= 4 && !(sl.flags & SLOT_FAST)) {
+                int o = 0;
+                for (int tv : per_ray) {
+                    if (tv == t) continue;
+                    const DevTrans& x = c->htrans[tv];
+                    sl.rel[o][REL_CI] = (double)(x.li == h.li) - (double)(x.lj == h.li);
+                    sl.rel[o][REL_CJ] = (double)(x.li == h.lj) - (double)(x.lj == h.lj);
+                    sl.rel[o][REL_UJ] = (double)(x.lj == h.lj);
+                    sl.rel[o][REL_UI] = (double)(x.lj == h.li);
+                    sl.rel[o][REL_EA] = (double)(x.atom == h.atom);
+                    for (int q = 0; q < 5; ++q)
+                        if (sl.rel[o][q] != 0.0) sl.relmask |= 1u << o;
+                    ++o;
+                }
             }
             if (tl.nP == 1 && !(sl.flags & SLOT_FAST) && (sl.flags & (SLOT_LI_CELL | SLOT_LJ_CELL | SLOT_UI_READ | SLOT_ETA_CELL))) {
                 lsx_destroy(c);     // the single-slot kernel compiles the cell logic out
@@ -1138,9 +1145,12 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     for (auto& k : c->classes) {
         // per wave: level cells, atom cells, angle-sum row; + two cross-wave exchange rows; + the static
         // path's per-depth table of wave-uniform operands, Nspace x (3 npt + 2) doubles
-        k.lds_bytes = (size_t)LSX_EXP_TAB * sizeof(double) + (size_t)(2 * (2 * k.ncell_lev + k.ncell_atom + 1) + 2) * LSX_WAVE * sizeof(double) +
+        // (level / atom cells exist only in the generic instance; compile-time classes keep that bookkeeping in registers)
+        const int cl = k.npt >= 0 ? 0 : k.ncell_lev, ca = k.npt >= 0 ? 0 : k.ncell_atom;
+        k.lds_bytes = (size_t)LSX_EXP_TAB * sizeof(double) + (size_t)(2 * (2 * cl + ca + 1) + 2) * LSX_WAVE * sizeof(double) +
                       (size_t)(k.npt >= 0 ? (Ns + 1) * (3 * k.npt + 2) : 0) * sizeof(double) +
-                      (size_t)(k.npt > 0 ? 2 * 2 * k.npt * LSX_WAVE : 0) * sizeof(double);     // parked Gamma totals
+                      (size_t)(k.npt > 0 ? 2 * 2 * k.npt * LSX_WAVE : 0) * sizeof(double) +    // parked Gamma totals
+                      (size_t)(k.npt >= 3 ? k.npt * (k.npt - 1) * 5 : 0) * sizeof(double);    // slot-pair factors
         if (k.lds_bytes > 64 * 1024) { lsx_destroy(c); return fail(LSX_EUNSUPPORTED, "lsx_create: a tile needs %zu B of LDS", k.lds_bytes); }
         c->lds_bytes = std::max(c->lds_bytes, k.lds_bytes);
     }
@@ -1385,7 +1395,8 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
         for (auto& k : c->classes) npt_max = std::max(npt_max, k.npt);
         const size_t lds = (size_t)LSX_EXP_TAB * sizeof(double) + (size_t)(2 * (2 * p.ncell_lev + p.ncell_atom + 1) + 2) * LSX_WAVE * sizeof(double) +
                            (size_t)(npt_max >= 0 ? (c->Nspace + 1) * (3 * npt_max + 2) : 0) * sizeof(double) +
-                           (size_t)(npt_max > 0 ? 2 * 2 * npt_max * LSX_WAVE : 0) * sizeof(double);
+                           (size_t)(npt_max > 0 ? 2 * 2 * npt_max * LSX_WAVE : 0) * sizeof(double) +
+                           (size_t)(npt_max >= 3 ? npt_max * (npt_max - 1) * 5 : 0) * sizeof(double);
         hipError_t e = lsx_launch_sweep(&p, -2, (int)nblocks, lds, c->stream);
         if (e != hipSuccess) return fail(LSX_EDEVICE, "sweep launch (fused): %s", hipGetErrorString(e));
     } else {
@@ -1397,7 +1408,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
         if (nblocks > 0x7fffffffL) return fail(LSX_EUNSUPPORTED, "grid too large");
         p.class_tiles = k.d_tiles;
         p.n_class_tiles = (int)k.tiles.size();
-        p.ncell_lev = k.ncell_lev; p.ncell_atom = k.ncell_atom; p.nstash = 0;
+        p.ncell_lev = k.npt >= 0 ? 0 : k.ncell_lev; p.ncell_atom = k.npt >= 0 ? 0 : k.ncell_atom; p.nstash = 0;
         hipStream_t st = fork ? k.stream : c->stream;
         if (fork) HIPCHK(hipStreamWaitEvent(st, c->ev_fork, 0));
         hipError_t e = lsx_launch_sweep(&p, k.npt >= 0 ? k.npt * 8 + k.nl : -1, (int)nblocks, k.lds_bytes, st);

@@ -337,6 +337,14 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         }
     }
     etab[threadIdx.x] = p.exp2_tab[threadIdx.x];          // 2 x 64 threads, 64 x 2 doubles
+    // three- and four-slot tiles: the slot-pair factors of the level bookkeeping, [u][other o][5]
+    lds_f64* const ctab = utab + (STATIC ? (p.Nspace + 1) * TR : 0) + (size_t)2 * (2 * NS) * LSX_WAVE;
+    if constexpr (NPT >= 3) {
+        if (threadIdx.x < NPT * (NPT - 1) * 5) {
+            const int u = threadIdx.x / ((NPT - 1) * 5), r = threadIdx.x % ((NPT - 1) * 5);
+            ctab[threadIdx.x] = p.slots[slot0 + u].rel[r / 5][r % 5];
+        }
+    }
     __syncthreads();
 
     const double wav = p.wavelength[la];
@@ -514,7 +522,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         auto pass1 = [&](const bool line, const SlotS& sl, double v, double ni, double nj, double alf, double& pv, double& chi,
                          double& Uji, double& eta) {
             // a tile with a single per-ray slot shares no level and no atom with anything (lsx_create): no cells
-            const int fl = (NPT == 1 || NPT == 2) ? 0 : sl.flags;   // NPT == 2: bookkeeping in registers (pass 2)
+            const int fl = STATIC ? 0 : sl.flags;   // compile-time slot counts: bookkeeping in registers (pass 2)
             if (line) {
                 pv = v;
                 chi = (STATIC ? ni : sl.cB * (ni - sl.g * nj)) * pv;   // n_i Vij - n_j Vji, :279-280, :613 (static: ni holds the product)
@@ -643,11 +651,37 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                 const SlotS sl = load_slot(slots + u, Ns);
                 const bool line = u < NL;
                 const double Vij = line ? sl.cB * spv[u] : alv[u];
-                if constexpr (NPT == 2) {
+                if constexpr (NPT >= 3) {
+                    // atom.chi / atom.U / atom.eta of this slot's levels, accumulated in transition order; another slot
+                    // enters through five factors in {-1, 0, 1} (one fma each), and only if any of them is non-zero
+                    const unsigned mask = slots[u].relmask;
+                    double etaA = 0.0, chi_i = 0.0, chi_j = 0.0, U_j = 0.0, U_i = 0.0;
+#pragma unroll
+                    for (int v = 0; v < NPT; ++v) {
+                        if (v == u) {
+                            chi_i += schi[u];
+                            chi_j -= schi[u];
+                            U_j += sUji[u];
+                            etaA += seta[u];
+                        } else {
+                            const int o = v < u ? v : v - 1;
+                            if ((mask >> o) & 1u) {
+                                const lds_f64* r = ctab + (u * (NPT - 1) + o) * 5;
+                                chi_i = fma(r[REL_CI], schi[v], chi_i);
+                                chi_j = fma(r[REL_CJ], schi[v], chi_j);
+                                U_j = fma(r[REL_UJ], sUji[v], U_j);
+                                U_i = fma(r[REL_UI], sUji[v], U_i);
+                                etaA = fma(r[REL_EA], seta[v], etaA);
+                            }
+                        }
+                    }
+                    pass2x(line, sl.Vc, spv[u], sUji[u], Vij, wlv[u] * tk[3 * u + 2], etaA, chi_i, chi_j, U_j, U_i,
+                           w1[u], w2v[u]);
+                } else if constexpr (NPT == 2) {
                     // atom.chi / atom.U / atom.eta of this slot's levels from the two slots' values, in transition
                     // order (a factor 0 drops the other slot, +-1 adds it with one rounding)
                     const int v = 1 - u;
-                    const auto* rel = slots[u].rel;
+                    const auto* rel = slots[u].rel[0];
                     const double etaA = fma(rel[REL_EA], seta[v], seta[u]);
                     const double chi_i = fma(rel[REL_CI], schi[v], schi[u]);
                     const double chi_j = fma(rel[REL_CJ], schi[v], -schi[u]);
