@@ -259,19 +259,19 @@ __global__ void k_gamma_finish(const FinishParams f)
     const double* Cm = f.C + (size_t)col * f.NL2tot * Ns + k;
     for (int e = 0; e < f.NL2tot; ++e) G[e * nt] = 0.0 + Cm[(size_t)e * Ns];     // Gamma = C, :587-590
     const double* P = f.Gpart + (size_t)col * f.nslot_total * 4 * Ns + k;
-    for (int t = 0; t < f.ntile; ++t) {
-        const DevTile tl = f.tiles[t];
-        for (int u = 0; u < tl.nP + tl.nF; ++u) {
-            const DevTrans& tr = f.trans[f.tile_slots[tl.slot0 + u]];
-            const double* q = P + (size_t)(tl.slot0 + u) * 4 * Ns;
-            double gij = G[tr.gam_ij * nt], gji = G[tr.gam_ji * nt];
-            gij += q[0];
-            gij += q[(size_t)Ns];
-            gji += q[(size_t)2 * Ns];
-            gji += q[(size_t)3 * Ns];
-            G[tr.gam_ij * nt] = gij;
-            G[tr.gam_ji * nt] = gji;
-        }
+    // slabs in (tile, slot, entry, direction) order = slot-table order; the loads of several slots are in flight at once
+#pragma unroll 4
+    for (int u = 0; u < f.nslot_total; ++u) {
+        const DevTrans& tr = f.trans[f.tile_slots[u]];
+        const double* q = P + (size_t)u * 4 * Ns;
+        const double q0 = q[0], q1 = q[(size_t)Ns], q2 = q[(size_t)2 * Ns], q3 = q[(size_t)3 * Ns];
+        double gij = G[tr.gam_ij * nt], gji = G[tr.gam_ji * nt];
+        gij += q0;
+        gij += q1;
+        gji += q2;
+        gji += q3;
+        G[tr.gam_ij * nt] = gij;
+        G[tr.gam_ji * nt] = gji;
     }
     double* Gout = f.Gamma + (size_t)col * f.NL2tot * Ns + k;
     for (int a = 0; a < f.Natoms; ++a) {
