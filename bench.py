@@ -57,8 +57,8 @@ def load_columns(eng, batch, prof, c0=0, step=100):
     for a in range(0, batch.ncol, step):
         b = min(batch.ncol, a + step)
         eng.set_columns(c0 + a, batch.slice(a, b))
-        if prof is not None:
-            eng.set_line_profiles(c0 + a, prof[0][a:b], prof[1][a:b], None if prof[2] is None else prof[2][a:b])
+    if prof is not None:        # small inputs: all columns in one call keeps the profile kernels wide
+        eng.set_line_profiles(c0, prof[0], prof[1], prof[2])
 
 
 def cpu_baseline(prob, batch, prof, seconds_target=12.0):
