@@ -608,6 +608,95 @@ __global__ void k_stat_equil(const double* __restrict__ Gamma, const double* __r
     atomic_max_nonneg(&dPcol[col], mx);
 }
 
+// The same elimination with the system in registers: NL is a compile-time constant, every loop is unrolled and the
+// data-dependent row choices (the eliminated row, the pivot) become predicated selects.  Same operations in the same
+// order as k_stat_equil => identical results; used for the small atoms (NL <= 8) that stellar problems have.
+template <int NL>
+__global__ void __launch_bounds__(64)
+k_stat_equil_reg(const double* __restrict__ Gamma, const double* __restrict__ nTotal, double* __restrict__ n,
+                 double* __restrict__ dPcol, int* __restrict__ singular, int lev_off, int lev2_off, int atom, int Natoms,
+                 int NLtot, int NL2tot, int Ns, int ncol, const uint8_t* __restrict__ colmask)
+{
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)ncol * Ns) return;
+    const int col = gid / Ns, k = gid % Ns;
+    if (colmask && !colmask[col]) return;
+    double* nk = n + ((size_t)col * NLtot + lev_off) * Ns + k;
+    const double* G = Gamma + ((size_t)col * NL2tot + lev2_off) * Ns + k;
+    double a[NL][NL], b[NL], nOld[NL];           // a[i][j]: row i, column j
+
+    int iE = 0;
+    double nmax = nk[0];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        nOld[l] = nk[(size_t)l * Ns];
+        if (nOld[l] > nmax) { nmax = nOld[l]; iE = l; }      // np.argmax: first maximum
+    }
+    const double ntot = nTotal[((size_t)col * Natoms + atom) * Ns + k];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const double g = G[(size_t)(i * NL + j) * Ns];
+            a[i][j] = (i == iE) ? 1.0 : g;
+        }
+        b[i] = (i == iE) ? ntot : 0.0;
+    }
+    bool sing = false;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        int pv = j;
+        double amax = fabs(a[j][j]), apv = a[j][j];
+#pragma unroll
+        for (int i = j + 1; i < NL; ++i) {
+            const double v = fabs(a[i][j]);
+            if (v > amax) { amax = v; pv = i; apv = a[i][j]; }
+        }
+        if (!sing && (apv == 0.0 || amax != amax)) sing = true;
+#pragma unroll
+        for (int r = j + 1; r < NL; ++r) {
+            const bool sw = r == pv;
+#pragma unroll
+            for (int q = 0; q < NL; ++q) {
+                const double t = a[j][q];
+                a[j][q] = sw ? a[r][q] : t;
+                a[r][q] = sw ? t : a[r][q];
+            }
+            const double t = b[j];
+            b[j] = sw ? b[r] : t;
+            b[r] = sw ? t : b[r];
+        }
+        const double rr = 1.0 / a[j][j];
+#pragma unroll
+        for (int i = j + 1; i < NL; ++i) a[i][j] *= rr;
+#pragma unroll
+        for (int q = j + 1; q < NL; ++q) {
+            const double ajq = a[j][q];
+#pragma unroll
+            for (int i = j + 1; i < NL; ++i) a[i][q] -= a[i][j] * ajq;
+        }
+    }
+    if (sing) { atomicOr(singular, 1); return; }
+#pragma unroll
+    for (int j = 0; j < NL; ++j)
+#pragma unroll
+        for (int i = j + 1; i < NL; ++i) b[i] -= a[i][j] * b[j];
+#pragma unroll
+    for (int j = NL - 1; j >= 0; --j) {
+        b[j] /= a[j][j];
+#pragma unroll
+        for (int i = 0; i < j; ++i) b[i] -= a[i][j] * b[j];
+    }
+    double mx = 0.0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const double ch = fabs(1.0 - nOld[i] / b[i]);
+        mx = (ch != ch || mx != mx) ? __builtin_nan("") : fmax(mx, ch);
+        nk[(size_t)i * Ns] = b[i];
+    }
+    atomic_max_nonneg(&dPcol[col], mx);
+}
+
 // out[0] = NaN-propagating max of v[0..n)
 __global__ void k_reduce_max(const double* __restrict__ v, int n, double* __restrict__ out)
 {
@@ -1556,11 +1645,21 @@ int lsx_stat_equil_async(lsx_ctx* c)
     for (int a = 0; a < c->Natoms; ++a) {
         const int Nl = c->Nlevel[a];
         const int nt = 64;
-        const size_t sm = (size_t)(Nl * Nl + 2 * Nl) * nt * sizeof(double);
-        if (sm > 160 * 1024) return fail(LSX_EUNSUPPORTED, "stat_equil: Nlevel = %d needs %zu B of LDS", Nl, sm);
-        hipLaunchKernelGGL(k_stat_equil, dim3((unsigned)((nthreads + nt - 1) / nt)), dim3(nt), sm, c->stream, c->d_Gamma,
-                           c->d_nTotal, c->d_n, c->d_dPcol, c->d_singular, Nl, c->lev_off[a], c->lev2_off[a], a, c->Natoms,
-                           c->NLtot, c->NL2tot, c->Nspace, c->ncol, c->d_colmask);
+        const dim3 grid((unsigned)((nthreads + nt - 1) / nt));
+#define SE_REG(NLC) case NLC: hipLaunchKernelGGL((k_stat_equil_reg<NLC>), grid, dim3(nt), 0, c->stream, c->d_Gamma, c->d_nTotal, c->d_n, \
+                              c->d_dPcol, c->d_singular, c->lev_off[a], c->lev2_off[a], a, c->Natoms, c->NLtot, c->NL2tot,      \
+                              c->Nspace, c->ncol, c->d_colmask); break;
+        switch (getenv("LSX_SE_LDS") ? 0 : Nl) {
+        SE_REG(2) SE_REG(3) SE_REG(4) SE_REG(5) SE_REG(6) SE_REG(7) SE_REG(8)
+        default: {
+            const size_t sm = (size_t)(Nl * Nl + 2 * Nl) * nt * sizeof(double);
+            if (sm > 160 * 1024) return fail(LSX_EUNSUPPORTED, "stat_equil: Nlevel = %d needs %zu B of LDS", Nl, sm);
+            hipLaunchKernelGGL(k_stat_equil, grid, dim3(nt), sm, c->stream, c->d_Gamma, c->d_nTotal, c->d_n, c->d_dPcol,
+                               c->d_singular, Nl, c->lev_off[a], c->lev2_off[a], a, c->Natoms, c->NLtot, c->NL2tot, c->Nspace,
+                               c->ncol, c->d_colmask);
+        }
+        }
+#undef SE_REG
         HIPCHK(hipGetLastError());
     }
     hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, c->stream, c->d_dPcol, c->ncol, c->d_max + 1);
