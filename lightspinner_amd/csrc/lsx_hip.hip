@@ -1296,7 +1296,8 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         // workgroups that need many registers (three or more slots, generic) find room only while the machine is not
         // yet full of small ones: they go first; the light classes fill in behind them
-        const int want = (k.npt < 0 || k.npt >= 3) ? 0 : (k.npt == 2 ? 1 : 2);
+        // ... and so does a class that carries a pre-pass -> sweep -> epilogue chain: a serial chain must not start last
+        const int want = (k.npt < 0 || k.npt >= 3) ? 0 : ((k.npt == 2 || !k.fast_tiles.empty()) ? 1 : 2);
         const int prio = getenv("LSX_NO_PRIO") ? prio_lo : std::min(prio_lo, prio_hi + want);
         if (getenv("LSX_TRACE_CLASSES")) fprintf(stderr, "class npt=%d nl=%d: stream priority %d (range %d .. %d)\n", k.npt, k.nl, prio, prio_hi, prio_lo);
         if (hipStreamCreateWithPriority(&k.stream, hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&k.done, hipEventDisableTiming) != hipSuccess) { lsx_destroy(c); return fail(LSX_EDEVICE, "class stream"); }
