@@ -1237,7 +1237,17 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     // the class whose workgroups run longest goes first and gets the highest stream priority: its tail is the
     // call's tail, the shorter-lived classes fill in behind it
     auto wg_cost = [](const SweepClass& k) { return k.npt < 0 ? 100 : k.npt; };
-    std::sort(c->classes.begin(), c->classes.end(), [&](const SweepClass& a, const SweepClass& b) { return wg_cost(a) > wg_cost(b); });
+    // launch order: by workgroup cost; where most tiles carry a pre-pass -> sweep -> epilogue chain (Ca+H: hydrogen
+    // continua nearly everywhere) the chain classes go first, because a serial chain queued behind the other classes'
+    // workgroups would become the call's tail.  Measured both ways on MI355X (C3: cost order, C4: chains first).
+    size_t chain_tiles = 0;
+    for (auto& k : c->classes)
+        if (!k.fast_tiles.empty()) chain_tiles += k.tiles.size();
+    const bool chains_first = 2 * chain_tiles > c->tiles.size();
+    std::stable_sort(c->classes.begin(), c->classes.end(), [&](const SweepClass& a, const SweepClass& b) {
+        if (chains_first && a.fast_tiles.empty() != b.fast_tiles.empty()) return !a.fast_tiles.empty();
+        return wg_cost(a) > wg_cost(b);
+    });
     for (auto& k : c->classes) {
         // per wave: level cells, atom cells, angle-sum row; + two cross-wave exchange rows; + the static
         // path's per-depth table of wave-uniform operands, Nspace x (3 npt + 2) doubles
