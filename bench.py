@@ -61,6 +61,46 @@ def load_columns(eng, batch, prof, c0=0, step=100):
         eng.set_line_profiles(c0, prof[0], prof[1], prof[2])
 
 
+def run_c5(args):
+    """C5 (response_fn.py): T[k] +- 25 K at every depth -> 164 perturbed FALC CaII columns, warm started from the
+    converged base column, every column iterated to ITS OWN convergence; rf = (I+ - I-) / I_base.  Single GPU.
+    Inputs: tests/golden/rf_ca_inputs.npz (all depths, written by make_golden.py rf_inputs); the three depths of
+    rf_ca.npz carry the reference's converged intensities and pin the result."""
+    import numpy as np
+    from lightspinner_amd import fixtures, response, _capi
+    gold = os.path.join(ROOT, 'tests', 'golden')
+    prob, base, raw = fixtures.load_problem_npz(os.path.join(gold, 'falc_ca.npz'))
+    fx = dict(np.load(os.path.join(gold, 'rf_ca_inputs.npz')))
+    ks = list(range(int(fx['Nspace'])))
+    lib = _capi.load_hip_library()
+    response.run_response_function(prob, base, fx, ks[:2], lib=lib)          # warm-up (library load, first launches)
+    t0 = time.perf_counter()
+    out = response.run_response_function(prob, base, fx, ks, lib=lib)      # ends with a blocking read-back of I
+    dt = time.perf_counter() - t0
+    ref = dict(np.load(os.path.join(gold, 'rf_ca.npz')))
+    err = 0.0
+    for k in [int(k) for k in ref['ks']]:
+        r = (ref['k%dp_I' % k][:, -1] - ref['k%dm_I' % k][:, -1]) / ref['base_I'][:, -1]
+        err = max(err, float(np.max(np.abs(out['rf'][:, k] - r)) / np.max(np.abs(r))))
+    col_iters = int(out['n_iter'].sum()) + out['n_iter_base']
+    units = prob.work_units_per_column() * col_iters
+    steps = int(out['n_iter'].max()) + out['n_iter_base']
+    print(json.dumps(dict(
+        metric='depth_points_x_wavelengths_x_rays_per_sec', value=units / dt, unit='point-updates/s', n_gpus=1, steps=steps,
+        warmup=0, ms_per_step=dt / steps * 1e3, higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64',
+        data='FALC CaII + reference-generated temperature perturbations (tests/golden/rf_ca_inputs.npz)',
+        config=dict(workload='C5: CaII temperature response function, %d perturbed columns (T[k] +- 25 K at %d depths) + base, '
+                             'per-column convergence' % (2 * len(ks), len(ks)), columns_total=2 * len(ks) + 1,
+                    Nspace=prob.Nspace, Nspect=prob.Nspect, Nrays=prob.Nrays, parallelism='single GPU'),
+        response_function=dict(seconds_total=dt, base_iterations=out['n_iter_base'],
+                               perturbed_iterations_min=int(out['n_iter'].min()), perturbed_iterations_max=int(out['n_iter'].max()),
+                               column_iterations=col_iters, rf_shape=list(out['rf'].shape),
+                               max_abs_err_vs_reference_rf_over_max=err,
+                               reference_depths_checked=[int(k) for k in ref['ks']],
+                               note='the reference runs these 165 MALI solves one after the other in pure Python (~2 h here)'),
+        roofline=None, cpu_baseline=None)))
+
+
 def cpu_baseline(prob, batch, prof, seconds_target=12.0):
     """The oracle (C restatement, kind 'port') on a bounded sample of the same workload, on this
     host's cores, OpenMP over columns.  Checker/baseline only -- never the product path."""
@@ -99,7 +139,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='c3', choices=['c2', 'c3', 'c4'])
+    ap.add_argument('--workload', default='c3', choices=['c2', 'c3', 'c4', 'c5'])
     ap.add_argument('--columns', type=int, default=None, help='columns per GPU (default 1000 / 1 / 1250)')
     ap.add_argument('--compact-phi', action='store_true', help='vlos == 0: ray independent profiles (P = 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -115,6 +155,10 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+    if args.workload == 'c5':
+        if world > 1:
+            raise SystemExit('--workload c5 runs on one GPU')
+        return run_c5(args)
     fixture = os.path.join(ROOT, 'tests', 'golden', 'falc_cah.npz' if args.workload == 'c4' else 'falc_ca.npz')
     ncol = args.columns or {'c2': 1, 'c3': 1000, 'c4': 1250}[args.workload]
     compact = args.compact_phi or args.workload == 'c2'

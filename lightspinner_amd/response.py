@@ -65,3 +65,40 @@ def apply_delta(prob: Problem, base: ColumnBlock, delta: dict, k: int, start_n=N
     if start_n is not None:
         out['n'][0] = start_n
     return ColumnBlock(**out).validate(prob)
+
+
+_RESULT_KEYS = ('I', 'n', 'niter', 'traj_dJ', 'traj_dPops')
+
+
+def deltas_of(fixture: dict, k: int, tag: str) -> dict:
+    """the delta of one perturbed run ('p': T[k] + dT/2, 'm': T[k] - dT/2) out of a fixture written by
+    tests/golden/make_golden.py (gen_rf / gen_rf_inputs)"""
+    pre = 'k%d%s_' % (k, tag)
+    return {key[len(pre):]: v for key, v in fixture.items() if key.startswith(pre) and key[len(pre):] not in _RESULT_KEYS}
+
+
+def run_response_function(prob: Problem, base: ColumnBlock, fixture: dict, ks, lib=None, device=0, mu_index=-1, log=None):
+    """response_fn.py:11-74 as two batched solves: (1) the base column to convergence (test.py:20-29 loop, per-column
+    stopping rule), (2) the 2 x len(ks) perturbed columns, warm started from the base populations
+    (response_fn.py:33), every column with its own stopping rule, then rf[la, k] = (I+ - I-) / I_base at `mu_index`
+    (response_fn.py:59-67).  -> dict(rf [Nspect][len(ks)], I_base, n_base, n_iter_base, n_iter [2 len(ks)], I [...])."""
+    from . import _capi, drivers
+    from .problem import Engine
+    e0 = Engine(prob, 1, device=device, lib=lib)
+    e0.set_columns(0, base.slice(0, 1))
+    it0 = drivers.iterate_mali_columns(e0, log=log)
+    I_base, n_base = e0.get(_capi.LSX_I)[0], e0.get(_capi.LSX_N)[0]
+    e0.close()
+    cols = []
+    for k in ks:
+        for tag in ('p', 'm'):
+            cols.append(apply_delta(prob, base, deltas_of(fixture, int(k), tag), int(k), start_n=n_base))
+    batch = ColumnBlock.concatenate(cols)
+    eng = Engine(prob, batch.ncol, device=device, lib=lib)
+    for a in range(0, batch.ncol, 64):
+        eng.set_columns(a, batch.slice(a, min(batch.ncol, a + 64)))
+    n_iter = drivers.iterate_mali_columns(eng, log=log)
+    I = eng.get(_capi.LSX_I)
+    eng.close()
+    rf = drivers.response_function(I[0::2], I[1::2], I_base, mu_index=mu_index)
+    return dict(rf=rf, I_base=I_base, n_base=n_base, n_iter_base=int(it0[0]), n_iter=n_iter, I=I)

@@ -12,7 +12,7 @@ under /root/reference is touched:
     arrays (numpy<1.25 semantics; only used for list membership in setup).
 (np.bool, used at rh_method.py:124, exists again in numpy 2.x.)
 
-Usage:  python tests/golden/make_golden.py [units] [falc_ca] [falc_cah] [falc_ca_vlos] [rf] [all]
+Usage:  python tests/golden/make_golden.py [units] [falc_ca] [falc_cah] [falc_ca_vlos] [rf] [rf_inputs] [all]
 """
 import os
 import sys
@@ -340,6 +340,39 @@ def gen_rf(ks=(20, 48, 70)):
     save('rf_ca.npz', out)
 
 
+def gen_rf_inputs(out_name='rf_ca_inputs.npz'):
+    """response_fn.py:23-57, the INPUTS of all 2 x Nspace perturbed runs (T[k] +- 25 K), delta-encoded against the
+    unperturbed column like gen_rf (only depth-k entries differ).  No converged reference outputs: running the
+    reference's 164 MALI loops is hours of pure Python; parity of the response function is pinned on gen_rf's three
+    depths, this file feeds the whole-workload run (bench.py --workload c5)."""
+    base = build_ctx(['Ca'])
+    dbase = dump_inputs(base)
+    Ns = base.atmos.Nspace
+    out = {'tempPert': np.float64(50.0), 'Nspace': np.int32(Ns)}
+    t0 = time.time()
+    for k in range(Ns):
+        for sgn, tag in ((+1, 'p'), (-1, 'm')):
+            ctx = build_ctx(['Ca'], temp_pert=(k, sgn * 25.0))
+            dp = dump_inputs(ctx)
+            for key, v in dp.items():
+                b = dbase[key]
+                if v.dtype.kind in 'USib':
+                    assert np.array_equal(v, b), key
+                    continue
+                if key.endswith('_n0') or np.array_equal(v, b):
+                    continue
+                if key == 'height':
+                    assert np.array_equal(np.diff(v), np.diff(b)), 'height diff changed'
+                    continue
+                diff = (v != b)
+                where_k = np.zeros_like(diff)
+                where_k[..., k] = True
+                assert not np.any(diff & ~where_k), 'non-local change in %s' % key
+                out['k%d%s_%s' % (k, tag, key)] = v[..., k].copy()
+        print('rf inputs: depth %d / %d  (%.0f s)' % (k + 1, Ns, time.time() - t0), flush=True)
+    save(out_name, out)
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['all']
     if 'all' in what:
@@ -347,5 +380,5 @@ if __name__ == '__main__':
     for w in what:
         t0 = time.time()
         {'units': gen_units, 'falc_ca': gen_falc_ca, 'falc_cah': gen_falc_cah,
-         'falc_ca_vlos': gen_falc_ca_vlos, 'rf': gen_rf}[w]()
+         'falc_ca_vlos': gen_falc_ca_vlos, 'rf': gen_rf, 'rf_inputs': gen_rf_inputs}[w]()
         print('%s done in %.1fs' % (w, time.time() - t0), flush=True)

@@ -77,3 +77,46 @@ def test_freeze_columns_oracle(oracle_lib):
 @pytest.mark.gpu
 def test_freeze_columns_gpu(hip_lib):
     _freeze_case(hip_lib)
+
+
+def _all_depths_fixture():
+    import os
+    p = golden('rf_ca_inputs.npz')
+    if not os.path.exists(p):
+        pytest.skip('rf_ca_inputs.npz not generated')
+    return dict(np.load(p))
+
+
+def test_all_depth_inputs_agree_with_the_three_depth_fixture():
+    """the two generators of make_golden.py (gen_rf: 3 depths with reference outputs, gen_rf_inputs: all depths, inputs
+    only) describe the same perturbed atmospheres"""
+    fx, rf = _all_depths_fixture(), dict(np.load(golden('rf_ca.npz')))
+    assert int(fx['Nspace']) == 82
+    for k in [int(k) for k in rf['ks']]:
+        for tag in ('p', 'm'):
+            a, b = response.deltas_of(fx, k, tag), response.deltas_of(rf, k, tag)
+            assert set(a) == set(b)
+            for key in a:
+                assert np.array_equal(a[key], b[key]), (k, tag, key)
+
+
+def _rf_all_depths(lib):
+    prob, base, raw = fixtures.load_problem_npz(golden('falc_ca.npz'))
+    fx, rf = _all_depths_fixture(), dict(np.load(golden('rf_ca.npz')))
+    out = response.run_response_function(prob, base, fx, range(82), lib=lib)
+    assert out['n_iter_base'] == 46 and out['rf'].shape == (prob.Nspect, 82)
+    assert out['n_iter'].min() >= 1 and out['n_iter'].max() < 46        # warm started: a handful of iterations each
+    for k in [int(k) for k in rf['ks']]:
+        ref = (rf['k%dp_I' % k][:, -1] - rf['k%dm_I' % k][:, -1]) / rf['base_I'][:, -1]
+        assert np.allclose(out['rf'][:, k], ref, rtol=0, atol=2e-6 * np.max(np.abs(ref)))
+        assert out['n_iter'][2 * k] == int(rf['k%dp_niter' % k]) and out['n_iter'][2 * k + 1] == int(rf['k%dm_niter' % k])
+    assert np.all(np.isfinite(out['rf']))
+
+
+def test_response_function_all_depths_oracle(oracle_lib):
+    _rf_all_depths(oracle_lib)
+
+
+@pytest.mark.gpu
+def test_response_function_all_depths_gpu(hip_lib):
+    _rf_all_depths(hip_lib)
