@@ -272,7 +272,8 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     const int Ns = p.Nspace;
     const int Nspect = p.Nspect;
     const int Nrays = NR > 0 ? NR : p.Nrays;
-    const int L = NR > 0 ? LSX_WAVE / NR : p.L;
+    constexpr int NRD = NR > 0 ? NR : 1;
+    const int L = NR > 0 ? LSX_WAVE / NRD : p.L;
 
     // lane -> ray.  Lanes without a ray shadow a real one (finite arithmetic) and are masked out of
     // every store and reduction.
