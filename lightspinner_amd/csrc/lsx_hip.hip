@@ -697,27 +697,6 @@ k_stat_equil_reg(const double* __restrict__ Gamma, const double* __restrict__ nT
     atomic_max_nonneg(&dPcol[col], mx);
 }
 
-// out[0] = NaN-propagating max of v[0..n)
-__global__ void k_reduce_max(const double* __restrict__ v, int n, double* __restrict__ out)
-{
-    __shared__ double sh[256];
-    double m = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const double x = v[i];
-        m = (x != x || m != m) ? __builtin_nan("") : fmax(m, x);
-    }
-    sh[threadIdx.x] = m;
-    __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            const double a = sh[threadIdx.x], b = sh[threadIdx.x + s];
-            sh[threadIdx.x] = (a != a || b != b) ? __builtin_nan("") : fmax(a, b);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = sh[0];
-}
-
 // FETCH_SIZE calibration (profiles/calibrate.py): read `rows` x `seg` doubles exactly once in the sweep
 // kernel's access shape -- one wave-instruction = 64/seg segments of `seg` consecutive doubles (8 B per
 // lane), the segments `stride` doubles apart -- and fold them into one value per wave.
@@ -842,7 +821,7 @@ struct lsx_ctx {
     double *d_height = nullptr, *d_temperature = nullptr, *d_nStar = nullptr, *d_nTotal = nullptr, *d_n = nullptr,
            *d_C = nullptr, *d_Gamma = nullptr, *d_wphi = nullptr, *d_bgchi = nullptr, *d_bgeta = nullptr,
            *d_sca = nullptr, *d_phi = nullptr, *d_gijc = nullptr, *d_J[2] = {nullptr, nullptr}, *d_I = nullptr,
-           *d_Gpart = nullptr, *d_dJpart = nullptr, *d_dJcol = nullptr, *d_dPcol = nullptr, *d_max = nullptr;
+           *d_Gpart = nullptr, *d_dJpart = nullptr, *d_dJcol = nullptr, *d_dPcol = nullptr, *d_res = nullptr;
     int* d_singular = nullptr;
     uint8_t* d_colmask = nullptr; // per-column activity, nullptr = all active
     double *d_bgxchi = nullptr, *d_bgxeta = nullptr, *d_Psi2 = nullptr; // fast-continuum side arrays
@@ -863,7 +842,7 @@ struct lsx_ctx {
     // staging
     double* d_stage = nullptr;
     size_t stage_doubles = 0;
-    double* h_pinned = nullptr; // [0] dJ max, [1] dPops max, [2] singular flag (as double bits of an int)
+    double* h_pinned = nullptr; // host mirror of d_res
     double last_dJ = 0.0, last_dP = 0.0;
     bool fs_pending = false, se_pending = false;
     hipEvent_t evA = nullptr, evB = nullptr;
@@ -941,7 +920,7 @@ void lsx_destroy(lsx_ctx* c)
                     c->d_tiles, c->d_slots, c->d_tile_slots, c->d_Nlevel, c->d_lev2_off, c->d_height,
                     c->d_temperature, c->d_nStar, c->d_nTotal, c->d_n, c->d_C, c->d_Gamma, c->d_wphi, c->d_bgchi,
                     c->d_bgeta, c->d_sca, c->d_phi, c->d_gijc, c->d_J[0], c->d_J[1], c->d_I, c->d_Gpart, c->d_dJpart,
-                    c->d_dJcol, c->d_dPcol, c->d_max, c->d_singular, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab, c->d_hck_la, c->d_voigt_w, c->d_muz, c->d_wmu};
+                    c->d_res, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab, c->d_hck_la, c->d_voigt_w, c->d_muz, c->d_wmu};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& k : c->classes) {
@@ -1342,10 +1321,12 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     TRY(dmalloc(&c->d_I, nc * Nspect * c->Nrays));
     TRY(dmalloc(&c->d_Gpart, nc * c->tile_slots.size() * 4 * Ns));
     TRY(dmalloc(&c->d_dJpart, nc * 2 * c->tiles.size()));
-    TRY(dmalloc(&c->d_dJcol, nc));
-    TRY(dmalloc(&c->d_dPcol, nc));
-    TRY(dmalloc(&c->d_max, 4));
-    TRY(dmalloc(&c->d_singular, 1));
+    // per-column convergence monitors and the singular flag in one block [dJcol | dPcol | flag]: lsx_sync brings
+    // it back with one copy and takes the maxima on the host (no reduction kernels on the stream)
+    TRY(dmalloc(&c->d_res, 2 * nc + 1));
+    c->d_dJcol = c->d_res;
+    c->d_dPcol = c->d_res + nc;
+    c->d_singular = reinterpret_cast<int*>(c->d_res + 2 * nc);
     TRY(dmalloc(&c->d_debug, 64 * 16));
     if (!c->fast_tiles.empty()) {
         TRY(upload(&c->d_fast_tiles, c->fast_tiles, c->stream));
@@ -1361,7 +1342,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     }
     (void)hipMemsetAsync(c->d_debug, 0, 64 * 16 * 8, c->stream);
 #undef TRY
-    if (hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), 4 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), (2 * nc + 1) * sizeof(double), hipHostMallocDefault) != hipSuccess) {
         lsx_destroy(c);
         return fail(LSX_EDEVICE, "hipHostMalloc failed");
     }
@@ -1369,10 +1350,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     (void)hipMemsetAsync(c->d_J[1], 0, nc * c->til_col * 8, c->stream);
     (void)hipMemsetAsync(c->d_I, 0, nc * Nspect * c->Nrays * 8, c->stream);
     (void)hipMemsetAsync(c->d_Gamma, 0, nc * c->NL2tot * Ns * 8, c->stream);
-    (void)hipMemsetAsync(c->d_dJcol, 0, nc * 8, c->stream);
-    (void)hipMemsetAsync(c->d_dPcol, 0, nc * 8, c->stream);
-    (void)hipMemsetAsync(c->d_max, 0, 4 * 8, c->stream);
-    (void)hipMemsetAsync(c->d_singular, 0, sizeof(int), c->stream);
+    (void)hipMemsetAsync(c->d_res, 0, (2 * nc + 1) * 8, c->stream);
     HIPCHK(hipStreamSynchronize(c->stream));
     *out = c;
     return LSX_OK;
@@ -1574,8 +1552,6 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
         hipLaunchKernelGGL(k_gamma_finish, dim3((unsigned)((nthreads + nt - 1) / nt)), dim3(nt), smf, c->stream, f);
     }
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, c->stream, c->d_dJcol, c->ncol, c->d_max);
-    HIPCHK(hipGetLastError());
     if (timed) HIPCHK(hipEventRecord(c->ev2, c->stream));
     c->jcur ^= 1;
     c->fs_pending = true;
@@ -1650,8 +1626,7 @@ int lsx_stat_equil_async(lsx_ctx* c)
 {
     if (!c) return fail(LSX_EINVAL, "null ctx");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemsetAsync(c->d_dPcol, 0, (size_t)c->ncol * 8, c->stream));
-    HIPCHK(hipMemsetAsync(c->d_singular, 0, sizeof(int), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_dPcol, 0, ((size_t)c->ncol + 1) * 8, c->stream));     // dPcol and the singular flag behind it
     const long nthreads = (long)c->ncol * c->Nspace;
     for (int a = 0; a < c->Natoms; ++a) {
         const int Nl = c->Nlevel[a];
@@ -1673,8 +1648,6 @@ int lsx_stat_equil_async(lsx_ctx* c)
 #undef SE_REG
         HIPCHK(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, c->stream, c->d_dPcol, c->ncol, c->d_max + 1);
-    HIPCHK(hipGetLastError());
     c->se_pending = true;
     return LSX_OK;
 }
@@ -1703,13 +1676,20 @@ int lsx_sync(lsx_ctx* c, double* dJ, double* dP)
     HIPCHK(hipSetDevice(c->device));
     int sing = 0;
     if (c->fs_pending || c->se_pending) {
-        HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_max, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(c->h_pinned + 2, c->d_singular, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        const size_t nc = (size_t)c->ncol;
+        HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_res, (2 * nc + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (c->fs_pending) c->last_dJ = c->h_pinned[0];
+        auto nanmax = [](const double* v, size_t n) {       // numpy max semantics: NaN wins (rh_method.py:706, :741)
+            double m = 0.0;
+            for (size_t i = 0; i < n; ++i)
+                if (v[i] != v[i]) return v[i];
+                else if (v[i] > m) m = v[i];
+            return m;
+        };
+        if (c->fs_pending) c->last_dJ = nanmax(c->h_pinned, nc);
         if (c->se_pending) {
-            c->last_dP = c->h_pinned[1];
-            memcpy(&sing, c->h_pinned + 2, sizeof(int));
+            c->last_dP = nanmax(c->h_pinned + nc, nc);
+            memcpy(&sing, c->h_pinned + 2 * nc, sizeof(int));
         }
         c->fs_pending = c->se_pending = false;
     } else {
