@@ -134,3 +134,25 @@ def test_response_function_formula():
     rf = drivers.response_function(Ip, Im, Ib)
     assert rf.shape == (10, 82)
     assert rf[3, 40] == pytest.approx((Ip[40, 3, 4] - Im[40, 3, 4]) / Ib[3, 4])
+
+
+def test_columns_without_profiles_and_device_profile_inputs():
+    """ColumnBlock may leave phi / wphi to lsx_set_line_profiles; synth hands over the profile inputs instead"""
+    prob, block, raw = fixtures.load_problem_npz(golden('falc_ca.npz'), phi_compact=False)
+    blk, (aD, vB, vlos) = synth.perturbed_columns(prob, block, raw, ncol=4, seed=7, device_profiles=True)
+    assert blk.phi is None and blk.wphi is None and blk.ncol == 4
+    assert aD.shape == (4, prob.Nlines, prob.Nspace) and vB.shape == (4, prob.Natoms, prob.Nspace) and vlos.shape == (4, prob.Nspace)
+    assert np.all(vlos[0] == 0.0) and np.any(vlos[1] != 0.0)            # column 0 is the unperturbed FALC column
+    host = synth.perturbed_columns(prob, block, raw, ncol=4, seed=7)      # same ensemble with host-built profiles
+    for k in ('bg_chi', 'n', 'C', 'nStar'):
+        assert np.array_equal(getattr(blk, k), getattr(host, k))
+    part = blk.slice(1, 3)
+    assert part.phi is None and part.ncol == 2
+    s = part.to_c()
+    assert not s.phi and not s.wphi                                       # NULL pointers in lsx_columns
+    both = type(blk).concatenate([part, part])
+    assert both.phi is None and both.ncol == 4
+    bad = blk.slice(0, 1)
+    bad.wphi = np.zeros((1, prob.Nlines, prob.Nspace))
+    with pytest.raises(ValueError):
+        bad.validate(prob)
