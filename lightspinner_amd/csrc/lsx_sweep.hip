@@ -655,16 +655,13 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                 if constexpr (NPT >= 3) {
                     // atom.chi / atom.U / atom.eta of this slot's levels, accumulated in transition order; another slot
                     // enters through five factors in {-1, 0, 1} (one fma each), and only if any of them is non-zero
+                    // (the slot's own terms first, then the related slots in transition order: for three and more terms the
+                    // sums are associated differently from the reference's running sums -- last-bit differences)
                     const unsigned mask = slots[u].relmask;
-                    double etaA = 0.0, chi_i = 0.0, chi_j = 0.0, U_j = 0.0, U_i = 0.0;
+                    double etaA = seta[u], chi_i = schi[u], chi_j = -schi[u], U_j = sUji[u], U_i = 0.0;
 #pragma unroll
                     for (int v = 0; v < NPT; ++v) {
-                        if (v == u) {
-                            chi_i += schi[u];
-                            chi_j -= schi[u];
-                            U_j += sUji[u];
-                            etaA += seta[u];
-                        } else {
+                        if (v != u) {
                             const int o = v < u ? v : v - 1;
                             if ((mask >> o) & 1u) {
                                 const lds_f64* r = ctab + (u * (NPT - 1) + o) * 5;
