@@ -180,10 +180,18 @@ def main():
     # ---- GPU ---------------------------------------------------------------------------
     import torch
     import torch.distributed as dist
+    # rehearsal hook: LSX_BENCH_REHEARSE=1 runs the N > 1 flow with every rank on GPU 0 and gloo instead of RCCL
+    # (RCCL refuses two ranks on one device), to exercise the multi-rank code path on a one-GPU box
+    rehearse = os.environ.get('LSX_BENCH_REHEARSE') == '1'
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    dev = torch.device('cuda', local_rank)
+        if rehearse:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    dev = torch.device('cpu') if rehearse else torch.device('cuda', local_rank)
     stream = torch.cuda.current_stream().cuda_stream
     lib = _capi.load_hip_library()
     eng = Engine(prob, ncol, device=local_rank, stream=stream or None, lib=lib)
