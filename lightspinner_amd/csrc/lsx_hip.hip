@@ -943,6 +943,7 @@ void lsx_destroy(lsx_ctx* c)
 int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream, lsx_ctx** out)
 {
     if (!d || !out || ncol < 1) return fail(LSX_EINVAL, "lsx_create: null argument or ncol < 1");
+    if (ncol > 65535) return fail(LSX_EUNSUPPORTED, "lsx_create: at most 65535 columns per context (the column is a grid dimension); use several contexts");
     if (d->abi_version != LSX_ABI_VERSION) return fail(LSX_EINVAL, "lsx_create: ABI version mismatch");
     if (d->Nspace < 3) return fail(LSX_EINVAL, "lsx_create: Nspace must be >= 3 (formal_solver.py:120-139)");
     if (d->Nrays < 1 || d->Nspect < 1 || d->Natoms < 1 || d->Ntrans < 0) return fail(LSX_EINVAL, "lsx_create: bad dimensions");
