@@ -123,7 +123,8 @@ enum {
 
 /* Create a context for `ncol` columns on HIP device `device` (ignored by the
  * oracle).  `stream` is a hipStream_t to launch on (e.g. torch's current stream),
- * or NULL for a stream owned by the context. */
+ * or NULL for a stream owned by the context.  The HIP backend takes at most 65535 columns per
+ * context (LSX_EUNSUPPORTED beyond; use several contexts). */
 int lsx_create(const lsx_problem* desc, int32_t ncol, int32_t device, void* stream,
                lsx_ctx** out);
 void lsx_destroy(lsx_ctx* ctx);
