@@ -72,3 +72,30 @@ def test_two_rank_sharding_equals_single_process(tmp_path, oracle_lib):
         assert np.array_equal(d['dJ'], np.array(h.dJ)) and np.array_equal(d['dP'][3:], np.array(h.dPops)[3:])
         seen += cnt
     assert seen == ncol_total
+
+
+@pytest.mark.gpu
+def test_max_reducer_over_rccl_single_rank():
+    """the RCCL path of the convergence reduction (device tensor, ReduceOp.MAX, NaN flag) on a one-rank communicator --
+    what the multi-GPU bench uses per iteration; more ranks need more GPUs than the test box has"""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from lightspinner_amd.parallel import MaxReducer
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        r = MaxReducer(device=torch.device('cuda', 0))
+        assert not r.active                      # one rank: the reduction is the identity and is skipped
+        r.active = True                          # force the collective path
+        assert r(0.25, 1.5e-3) == (0.25, 1.5e-3)
+        a, b = r(float('nan'), 1.0)
+        assert np.isnan(a) and np.isnan(b)       # NaN wins, like ndarray.max (rh_method.py:706)
+        assert r(3.0, 0.0) == (3.0, 0.0)
+    finally:
+        dist.destroy_process_group()
