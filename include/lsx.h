@@ -41,7 +41,8 @@ enum {
     LSX_EDEVICE = 2,     /* HIP runtime error (message carries hipGetErrorString)    */
     LSX_ESINGULAR = 3,   /* singular statistical-equilibrium system (cf. LinAlgError,
                             rh_method.py:739); populations of that (col,k) untouched */
-    LSX_ENONFINITE = 4,  /* reserved                                                 */
+    /* 4 is unused: non-finite values are not an error, they propagate through dJ exactly as in
+       the reference (numpy max, rh_method.py:705-706)                                            */
     LSX_EUNSUPPORTED = 5 /* valid request this build cannot run (e.g. Nrays > 8)     */
 };
 
@@ -183,6 +184,17 @@ int lsx_piecewise_linear_1d(int32_t device, int32_t nray, int32_t Nspace,
                             const double* height, const double* temperature,
                             const double* mu, const int32_t* to_obs, const double* wav,
                             const double* chi, const double* S, double* I, double* PsiStar);
+
+/* formal_solver.piecewise_1d_impl (formal_solver.py:46-142) for `nray` independent rays sharing one
+ * depth grid: the short-characteristics recurrence itself, with the incident intensity handed over
+ * (Istart: [nray]) instead of derived from the boundary condition.  Same arrays as above. */
+int lsx_piecewise_1d_impl(int32_t device, int32_t nray, int32_t Nspace, const double* height,
+                          const double* mu, const int32_t* to_obs, const double* Istart,
+                          const double* chi, const double* S, double* I, double* PsiStar);
+
+/* formal_solver.w2 (formal_solver.py:14-44) for n optical-depth steps, evaluated by the same
+ * device function the sweep kernel uses.  w0w1: [n][2]. */
+int lsx_w2(int32_t device, int32_t n, const double* dtau, double* w0w1);
 
 /* Measurement hooks (bench.py): time `reps` back-to-back FS calls with device events
  * on the context's stream.  ms_total = whole FS call (all kernels), ms_sweep = the

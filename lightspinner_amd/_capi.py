@@ -15,7 +15,7 @@ ABI_VERSION = 1
 # item selectors (include/lsx.h)
 LSX_I, LSX_J, LSX_N, LSX_GAMMA, LSX_DJ_COL, LSX_DPOPS_COL, LSX_NSTAR, LSX_C, LSX_RIJ, LSX_RJI, LSX_PHI, LSX_WPHI = range(12)
 
-ERRORS = {1: 'LSX_EINVAL', 2: 'LSX_EDEVICE', 3: 'LSX_ESINGULAR', 4: 'LSX_ENONFINITE', 5: 'LSX_EUNSUPPORTED'}
+ERRORS = {1: 'LSX_EINVAL', 2: 'LSX_EDEVICE', 3: 'LSX_ESINGULAR', 5: 'LSX_EUNSUPPORTED'}
 
 _dp = C.POINTER(C.c_double)
 
@@ -49,6 +49,7 @@ REQUIRED_SYMBOLS = (
     'lsx_formal_sol_gamma_async', 'lsx_stat_equil_async', 'lsx_sync', 'lsx_get', 'lsx_set',
     'lsx_piecewise_linear_1d', 'lsx_time_formal_sol', 'lsx_last_error', 'lsx_backend_name',
     'lsx_abi_version', 'lsx_algorithmic_bytes_per_column', 'lsx_set_active_columns', 'lsx_set_line_profiles',
+    'lsx_piecewise_1d_impl', 'lsx_w2',
 )
 
 
@@ -104,6 +105,9 @@ class LsxLibrary:
         d.lsx_set.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp, C.c_size_t]
         d.lsx_piecewise_linear_1d.argtypes = [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp,
                                               C.POINTER(C.c_int32), _dp, _dp, _dp, _dp, _dp]
+        d.lsx_piecewise_1d_impl.argtypes = [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.POINTER(C.c_int32), _dp, _dp, _dp,
+                                            _dp, _dp]
+        d.lsx_w2.argtypes = [C.c_int32, C.c_int32, _dp, _dp]
         d.lsx_set_active_columns.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
         d.lsx_set_line_profiles.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp]
         d.lsx_time_formal_sol.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp]
@@ -143,11 +147,58 @@ class LsxLibrary:
         return I, Psi
 
 
+    def piecewise_1d_impl(self, height, mu, to_obs, Istart, chi, S, device=0):
+        """Batched formal_solver.piecewise_1d_impl (formal_solver.py:46-142): incident intensity handed over."""
+        chi = f64(chi)
+        S = f64(S, chi.shape)
+        if chi.ndim != 2:
+            raise ValueError('chi, S must be [nray, Nspace]')
+        nray, ns = chi.shape
+        height = f64(height, (ns,))
+        mu = f64(mu, (nray,))
+        Istart = f64(Istart, (nray,))
+        to_obs = np.ascontiguousarray(to_obs, dtype=np.int32)
+        if to_obs.shape != (nray,):
+            raise ValueError('to_obs must be [nray]')
+        I = np.empty_like(chi)
+        Psi = np.empty_like(chi)
+        self.check(self.dll.lsx_piecewise_1d_impl(device, nray, ns, _ptr(height), _ptr(mu),
+                                                  to_obs.ctypes.data_as(C.POINTER(C.c_int32)), _ptr(Istart),
+                                                  _ptr(chi), _ptr(S), _ptr(I), _ptr(Psi)))
+        return I, Psi
+
+    def w2(self, dtau, device=0):
+        """formal_solver.w2 (formal_solver.py:14-44) on an array -> [n][2] (w0, w1)."""
+        dtau = f64(dtau).reshape(-1)
+        out = np.empty((dtau.shape[0], 2))
+        self.check(self.dll.lsx_w2(device, dtau.shape[0], _ptr(dtau), _ptr(out)))
+        return out
+
+
 _HIP_LIB = None
 
 
 def hip_library_path():
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'liblsx_hip.so')
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so and ask
+    for them by the unversioned name, which the loader does not match against an already loaded /opt/rocm
+    libamdhip64.so.7: if this library came first, a later `import torch` in the same process (torch.distributed,
+    streams) would bring up a second runtime that finds no GPU.  Loading torch's copy first makes both sides resolve
+    to it (same SONAME), whichever is imported first.  Without PyTorch the system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    rt = os.path.join(os.path.dirname(spec.origin), 'lib', 'libamdhip64.so')
+    if not os.path.exists(rt):
+        return None
+    return C.CDLL(rt, mode=getattr(os, 'RTLD_GLOBAL', 0x100) | getattr(os, 'RTLD_NOW', 2))
 
 
 def load_hip_library():
@@ -159,6 +210,7 @@ def load_hip_library():
             raise ImportError(
                 'lightspinner_amd: HIP extension %s not built (run `python -c "import __graft_entry__ as g; '
                 'g.build()"` or `make -C lightspinner_amd/csrc`). There is no CPU fallback.' % path)
+        _share_hip_runtime_with_torch()
         _HIP_LIB = LsxLibrary(path)
         if not _HIP_LIB.backend.startswith('hip'):
             raise ImportError('%s is not the HIP backend (%s)' % (path, _HIP_LIB.backend))

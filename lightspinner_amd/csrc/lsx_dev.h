@@ -146,3 +146,57 @@ struct SweepParams {
     int32_t static_max;         // fused launch: tiles with more per-ray slots than this take the generic path
     const double* exp2_tab;     // [64][2]: 2^(j/64) as a (head, tail) pair, for the sweep's exp(-dtau)
 };
+
+// ---- device functions shared by the sweep kernel and the stand-alone formal solver -------------------------
+#ifdef __HIPCC__
+// 1/x: v_rcp_f64 seed + two Newton steps (~1 ulp; 5 instructions instead of the ~12 of an
+// IEEE division).  The reference divides; the difference is at the last-bit level.
+static __device__ __forceinline__ double rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+typedef __attribute__((address_space(3))) double lds_f64;   // LDS pointers carry their address space: ds_ instructions, no flat-pointer checks
+
+// exp(x) for the sweep (x = -dtau, -50 <= x <= -5e-4 where the value is used): x = (64 q + j) ln2/64 + r with
+// |r| <= ln2/128, exp(x) = 2^q * 2^(j/64) * exp(r).  2^(j/64) comes from a 64-entry (head, tail) table in LDS, exp(r)
+// from a degree-6 polynomial (truncation < 2e-19); about half the instructions of the library routine, and the
+// coefficients fit the scalar operand slot.  Error below 1 ulp, like the library's.  NaN propagates.
+static __device__ __forceinline__ double exp_tab64(double x, const lds_f64* tab)
+{
+    const double kf = __builtin_rint(x * 0x1.71547652b82fep+6);        // 64 / ln2
+    double r = fma(kf, -0x1.62e42fef80000p-7, x);                       // ln2/64, head (18 trailing zero bits)
+    r = fma(kf, -0x1.1cf79abc9e3b4p-42, r);                             //         tail
+    const int ki = (int)kf;
+    const lds_f64* e = tab + 2 * (ki & 63);
+    const double th = e[0], tl = e[1];
+    double t = fma(r, 1.0 / 720.0, 1.0 / 120.0);
+    t = fma(r, t, 1.0 / 24.0);
+    t = fma(r, t, 1.0 / 6.0);
+    t = fma(r, t, 0.5);
+    const double m = fma(r * r, t, r);                                  // exp(r) - 1
+    return ldexp(fma(th, m, tl) + th, ki >> 6);
+}
+
+// formal_solver.py:14-44.  The three regimes are selected per lane; the exponential is skipped
+// for the whole wavefront when no lane is in the middle regime (top / bottom of the atmosphere).
+static __device__ __forceinline__ void w2(double dtau, double& w0, double& w1, const lds_f64* exp2_tab)
+{
+    const bool small = dtau < 5e-4;
+    const bool large = dtau > 50.0;
+    double a0 = 1.0, a1 = 1.0;
+    if (__builtin_amdgcn_ballot_w64(!(small || large)) != 0) {
+        const double e = exp_tab64(-dtau, exp2_tab);
+        a0 = 1.0 - e;
+        a1 = a0 - dtau * e;
+    }
+    const double t0 = dtau * (1.0 - 0.5 * dtau);
+    const double t1 = (dtau * dtau) * (0.5 - dtau * (1.0 / 3.0));
+    w0 = small ? t0 : (large ? 1.0 : a0);
+    w1 = small ? t1 : (large ? 1.0 : a1);
+}
+
+#endif // __HIPCC__

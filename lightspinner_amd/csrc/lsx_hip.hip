@@ -14,6 +14,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -529,9 +530,17 @@ __global__ void k_fast_gamma(const FastParams f, int KC)
     }
 }
 
+// singular system at (column, depth) = gid, atom: the flag keeps the FIRST one in (column, depth, atom) order --
+// one order-independent 64-bit atomicMax of (2^48 - key), 0 = none -- for lsx_last_error (cf. LinAlgError, rh_method.py:739)
+#define LSX_SING_BASE (1ull << 48)
+__device__ __forceinline__ void flag_singular(unsigned long long* flag, long gid, int atom)
+{
+    atomicMax(flag, LSX_SING_BASE - (((unsigned long long)gid << 8) | (unsigned)atom));
+}
+
 __device__ __forceinline__ void atomic_max_nonneg(double* addr, double v)
 {
-    // for non-negative doubles (and +NaN) the IEEE bit pattern orders like the value; NaN wins
+    // for non-negative doubles the IEEE bit pattern orders like the value
     atomicMax(reinterpret_cast<unsigned long long*>(addr),
               static_cast<unsigned long long>(__double_as_longlong(fabs(v))));
 }
@@ -540,7 +549,7 @@ __device__ __forceinline__ void atomic_max_nonneg(double* addr, double v)
 // each thread lives in a thread-private LDS column (A[e][tid]) -- dense LU with partial
 // pivoting in the operation order of LAPACK dgetf2/dgetrs.
 __global__ void k_stat_equil(const double* __restrict__ Gamma, const double* __restrict__ nTotal, double* __restrict__ n,
-                             double* __restrict__ dPcol, int* __restrict__ singular, int Nl, int lev_off, int lev2_off,
+                             double* __restrict__ dPcol, unsigned long long* __restrict__ singular, int Nl, int lev_off, int lev2_off,
                              int atom, int Natoms, int NLtot, int NL2tot, int Ns, int ncol, const uint8_t* __restrict__ colmask)
 {
     extern __shared__ double sm[];
@@ -591,7 +600,7 @@ __global__ void k_stat_equil(const double* __restrict__ Gamma, const double* __r
             for (int i = j + 1; i < Nl; ++i) A[(i + q * Nl) * nt] -= A[(i + j * Nl) * nt] * ajq;
         }
     }
-    if (sing) { atomicOr(singular, 1); return; }
+    if (sing) { flag_singular(singular, gid, atom); return; }
     for (int j = 0; j < Nl; ++j)
         for (int i = j + 1; i < Nl; ++i) b[i * nt] -= A[(i + j * Nl) * nt] * b[j * nt];
     for (int j = Nl - 1; j >= 0; --j) {
@@ -602,10 +611,12 @@ __global__ void k_stat_equil(const double* __restrict__ Gamma, const double* __r
     for (int i = 0; i < Nl; ++i) {
         const double nn = b[i * nt];
         const double ch = fabs(1.0 - nOld[i * nt] / nn);
-        mx = (ch != ch || mx != mx) ? __builtin_nan("") : fmax(mx, ch);
+        mx = (ch != ch || mx != mx) ? __builtin_nan("") : fmax(mx, ch);   // change.max(): NaN wins inside one depth
         nk[(size_t)i * Ns] = nn;
     }
-    atomic_max_nonneg(&dPcol[col], mx);
+    // maxRelChange = max(maxRelChange, change.max()) with Python's builtin max (rh_method.py:741): a NaN never
+    // replaces the running maximum, so a depth whose change is NaN drops out
+    if (mx == mx) atomic_max_nonneg(&dPcol[col], mx);
 }
 
 // The same elimination with the system in registers: NL is a compile-time constant, every loop is unrolled and the
@@ -614,7 +625,7 @@ __global__ void k_stat_equil(const double* __restrict__ Gamma, const double* __r
 template <int NL>
 __global__ void __launch_bounds__(64)
 k_stat_equil_reg(const double* __restrict__ Gamma, const double* __restrict__ nTotal, double* __restrict__ n,
-                 double* __restrict__ dPcol, int* __restrict__ singular, int lev_off, int lev2_off, int atom, int Natoms,
+                 double* __restrict__ dPcol, unsigned long long* __restrict__ singular, int lev_off, int lev2_off, int atom, int Natoms,
                  int NLtot, int NL2tot, int Ns, int ncol, const uint8_t* __restrict__ colmask)
 {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -676,7 +687,7 @@ k_stat_equil_reg(const double* __restrict__ Gamma, const double* __restrict__ nT
             for (int i = j + 1; i < NL; ++i) a[i][q] -= a[i][j] * ajq;
         }
     }
-    if (sing) { atomicOr(singular, 1); return; }
+    if (sing) { flag_singular(singular, gid, atom); return; }
 #pragma unroll
     for (int j = 0; j < NL; ++j)
 #pragma unroll
@@ -691,10 +702,10 @@ k_stat_equil_reg(const double* __restrict__ Gamma, const double* __restrict__ nT
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         const double ch = fabs(1.0 - nOld[i] / b[i]);
-        mx = (ch != ch || mx != mx) ? __builtin_nan("") : fmax(mx, ch);
+        mx = (ch != ch || mx != mx) ? __builtin_nan("") : fmax(mx, ch);   // change.max(): NaN wins inside one depth
         nk[(size_t)i * Ns] = b[i];
     }
-    atomic_max_nonneg(&dPcol[col], mx);
+    if (mx == mx) atomic_max_nonneg(&dPcol[col], mx);          // builtin max over depths drops NaN (rh_method.py:741)
 }
 
 // FETCH_SIZE calibration (profiles/calibrate.py): read `rows` x `seg` doubles exactly once in the sweep
@@ -712,32 +723,26 @@ __global__ void k_calib_read(const double* __restrict__ buf, double* __restrict_
     if (acc == 1.2345e300) out[wave] = acc; // keep the loads alive
 }
 
-// formal_solver.py:14-212 for independent rays (one ray per thread, [ray][k] layout)
-__device__ __forceinline__ void dev_w2(double dtau, double& w0, double& w1)
-{
-    if (dtau < 5e-4) {
-        w0 = dtau * (1.0 - 0.5 * dtau);
-        w1 = (dtau * dtau) * (0.5 - dtau / 3.0);
-    } else if (dtau > 50.0) {
-        w0 = 1.0;
-        w1 = 1.0;
-    } else {
-        const double e = exp(-dtau);
-        w0 = 1.0 - e;
-        w1 = w0 - dtau * e;
-    }
-}
+// formal_solver.py:14-212 for independent rays (one ray per thread, [ray][k] layout).  w2 is the sweep kernel's own
+// device function (lsx_dev.h: table-driven exp); the divisions are IEEE here (this entry point is not hot).
 __device__ __forceinline__ double dev_planck(double temp, double wav)
 {
     const double hc_Tkla = kHC / (kKBoltzmann * kNM_TO_M * wav) / temp;
     const double x = kNM_TO_M * wav;
     return (2.0 * kHC) / (x * x * x) / (exp(hc_Tkla) - 1.0);
 }
-__global__ void k_piecewise(int nray, int Ns, const double* __restrict__ z, const double* __restrict__ T,
-                            const double* __restrict__ mu, const int* __restrict__ to_obs, const double* __restrict__ wav,
-                            const double* __restrict__ chi, const double* __restrict__ S, double* __restrict__ I,
-                            double* __restrict__ Psi)
+// Istart == nullptr: boundary condition of piecewise_linear_1d (formal_solver.py:203-209, needs T and wav);
+// otherwise piecewise_1d_impl with the incident intensity handed over (formal_solver.py:46-142)
+__global__ void __launch_bounds__(64)
+k_piecewise(int nray, int Ns, const double* __restrict__ z, const double* __restrict__ T, const double* __restrict__ mu,
+            const int* __restrict__ to_obs, const double* __restrict__ wav, const double* __restrict__ Istart,
+            const double* __restrict__ chi, const double* __restrict__ S, double* __restrict__ I, double* __restrict__ Psi,
+            const double* __restrict__ exp2_tab)
 {
+    __shared__ double etab_s[LSX_EXP_TAB];
+    for (int e = threadIdx.x; e < LSX_EXP_TAB; e += blockDim.x) etab_s[e] = exp2_tab[e];
+    __syncthreads();
+    const lds_f64* etab = (const lds_f64*)etab_s;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nray) return;
     const double* c = chi + (size_t)r * Ns;
@@ -749,7 +754,9 @@ __global__ void k_piecewise(int nray, int Ns, const double* __restrict__ z, cons
     const int dk = up ? -1 : 1, kS = up ? Ns - 1 : 0, kE = up ? 0 : Ns - 1;
     double dtau = 0.5 * (c[kS] + c[kS + dk]) * zmu * fabs(z[kS] - z[kS + dk]);
     double Iu = 0.0;
-    if (up) {
+    if (Istart) {
+        Iu = Istart[r];
+    } else if (up) {
         const double dt0 = zmu * (c[kS] + c[kS + dk]) * 0.5 * fabs(z[kS] - z[kS + dk]);
         const double B0 = dev_planck(T[Ns - 2], wav[r]), B1 = dev_planck(T[Ns - 1], wav[r]);
         Iu = B1 - (B0 - B1) / dt0;
@@ -759,7 +766,7 @@ __global__ void k_piecewise(int nray, int Ns, const double* __restrict__ z, cons
     Po[kS] = 0.0;
     double w0 = 0.0, w1 = 0.0;
     for (int k = kS + dk; k != kE; k += dk) {
-        dev_w2(dtau, w0, w1);
+        w2(dtau, w0, w1, etab);
         const double Ik = Iu * (1.0 - w0) + w0 * s[k] + w1 * dS;
         Io[k] = Ik;
         Po[k] = (w0 - w1 / dtau) / c[k];
@@ -772,11 +779,38 @@ __global__ void k_piecewise(int nray, int Ns, const double* __restrict__ z, cons
     Po[kE] = (w0 - w1 / dtau) / c[kE];
 }
 
+// formal_solver.py:14-44 on an array: the sweep's w2, one value per lane
+__global__ void __launch_bounds__(64)
+k_w2(int n, const double* __restrict__ dtau, double* __restrict__ out, const double* __restrict__ exp2_tab)
+{
+    __shared__ double etab_s[LSX_EXP_TAB];
+    for (int e = threadIdx.x; e < LSX_EXP_TAB; e += blockDim.x) etab_s[e] = exp2_tab[e];
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const double x = dtau[i < n ? i : n - 1];
+    double w0, w1;
+    w2(x, w0, w1, (const lds_f64*)etab_s);
+    if (i < n) { out[2 * i] = w0; out[2 * i + 1] = w1; }
+}
+
+// 2^(j/64) as head + tail (extended precision on the host): the table exp_tab64 (lsx_dev.h) reads
+std::vector<double> make_exp2_table()
+{
+    std::vector<double> et(LSX_EXP_TAB);
+    for (int j = 0; j < 64; ++j) {
+        const long double v = exp2l((long double)j / 64.0L);
+        et[2 * j] = (double)v;
+        et[2 * j + 1] = (double)(v - (long double)et[2 * j]);
+    }
+    return et;
+}
+
 } // namespace
 
 // ------------------------------------------------------------------------------- context
 struct SweepClass {           // tiles that run the same kernel instantiation, launched on their own stream
     int npt = -1;              // compile-time per-ray slot count, -1 = generic
+    long launches = 0;         // how often this class's kernel has been launched (introspection for the tests)
     int nl = 0;                // lines among them (compile-time too)
     bool has_fast = false;     // some tile of the class has fast continua: the class reads the pre-pass output
     hipEvent_t tdone = nullptr; // timed runs: end of this class's launch
@@ -822,7 +856,11 @@ struct lsx_ctx {
            *d_C = nullptr, *d_Gamma = nullptr, *d_wphi = nullptr, *d_bgchi = nullptr, *d_bgeta = nullptr,
            *d_sca = nullptr, *d_phi = nullptr, *d_gijc = nullptr, *d_J[2] = {nullptr, nullptr}, *d_I = nullptr,
            *d_Gpart = nullptr, *d_dJpart = nullptr, *d_dJcol = nullptr, *d_dPcol = nullptr, *d_res = nullptr;
-    int* d_singular = nullptr;
+    unsigned long long* d_singular = nullptr;
+    std::vector<uint8_t> phi_set;    // per column: line profiles have been handed over or built
+    size_t n_phi_set = 0;
+    bool opt_se_lds = false, opt_trace_classes = false;   // LSX_SE_LDS / LSX_TRACE_CLASSES, read once in lsx_create
+    long fused_launches = 0;
     uint8_t* d_colmask = nullptr; // per-column activity, nullptr = all active
     double *d_bgxchi = nullptr, *d_bgxeta = nullptr, *d_Psi2 = nullptr; // fast-continuum side arrays
     std::vector<int> fast_tiles;
@@ -969,6 +1007,8 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     c->sca_per_lambda = d->sca_per_lambda ? 1 : 0;
     c->phi_compact = d->phi_compact ? 1 : 0;
     c->L = LSX_WAVE / d->Nrays;
+    c->opt_se_lds = getenv("LSX_SE_LDS") != nullptr;              // diagnostics; the environment is read here only
+    c->opt_trace_classes = getenv("LSX_TRACE_CLASSES") != nullptr;
     const int Ns = c->Nspace, Nspect = c->Nspect;
     for (int a = 0; a < c->Natoms; ++a) {
         if (d->Nlevel[a] < 2) { lsx_destroy(c); return fail(LSX_EINVAL, "lsx_create: Nlevel < 2"); }
@@ -1263,15 +1303,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         for (int la = 0; la < Nspect; ++la) hck[la] = kHC / (kKBoltzmann * kNM_TO_M) / wave[la];
         TRY(upload(&c->d_hck_la, hck, c->stream));
     }
-    {   // 2^(j/64) as head + tail (extended precision on the host)
-        std::vector<double> et(LSX_EXP_TAB);
-        for (int j = 0; j < 64; ++j) {
-            const long double v = exp2l((long double)j / 64.0L);
-            et[2 * j] = (double)v;
-            et[2 * j + 1] = (double)(v - (long double)et[2 * j]);
-        }
-        TRY(upload(&c->d_exp2_tab, et, c->stream));
-    }
+    TRY(upload(&c->d_exp2_tab, make_exp2_table(), c->stream));
     TRY(upload(&c->d_active, active, c->stream));
     TRY(upload(&c->d_trans, c->htrans, c->stream));
     TRY(upload(&c->d_tiles, c->tiles, c->stream));
@@ -1289,7 +1321,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         // ... and so does a class that carries a pre-pass -> sweep -> epilogue chain: a serial chain must not start last
         const int want = (k.npt < 0 || k.npt >= 3) ? 0 : ((k.npt == 2 || !k.fast_tiles.empty()) ? 1 : 2);
         const int prio = getenv("LSX_NO_PRIO") ? prio_lo : std::min(prio_lo, prio_hi + want);
-        if (getenv("LSX_TRACE_CLASSES")) fprintf(stderr, "class npt=%d nl=%d: stream priority %d (range %d .. %d)\n", k.npt, k.nl, prio, prio_hi, prio_lo);
+        if (c->opt_trace_classes) fprintf(stderr, "class npt=%d nl=%d: stream priority %d (range %d .. %d)\n", k.npt, k.nl, prio, prio_hi, prio_lo);
         if (hipStreamCreateWithPriority(&k.stream, hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&k.done, hipEventDisableTiming) != hipSuccess) { lsx_destroy(c); return fail(LSX_EDEVICE, "class stream"); }
     }
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { lsx_destroy(c); return fail(LSX_EDEVICE, "hipEventCreate"); }
@@ -1327,7 +1359,8 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     TRY(dmalloc(&c->d_res, 2 * nc + 1));
     c->d_dJcol = c->d_res;
     c->d_dPcol = c->d_res + nc;
-    c->d_singular = reinterpret_cast<int*>(c->d_res + 2 * nc);
+    c->d_singular = reinterpret_cast<unsigned long long*>(c->d_res + 2 * nc);
+    c->phi_set.assign(nc, 0);
     TRY(dmalloc(&c->d_debug, 64 * 16));
     if (!c->fast_tiles.empty()) {
         TRY(upload(&c->d_fast_tiles, c->fast_tiles, c->stream));
@@ -1432,6 +1465,11 @@ int lsx_set_columns(lsx_ctx* c, int32_t col0, int32_t ncol, const lsx_columns* s
         HIPCHK(hipStreamSynchronize(c->stream)); // the staging buffer is re-used by the next sub-chunk
     }
 #undef TRY
+    for (int q = 0; q < ncol; ++q) {       // profiles of these columns: handed over, or still to come (lsx_set_line_profiles)
+        const uint8_t v = (have_phi || !c->Nlines) ? 1 : 0;
+        c->n_phi_set += (size_t)v - c->phi_set[o + q];
+        c->phi_set[o + q] = v;
+    }
     // J starts at 0 (rh_method.py:562); so do I and the convergence monitors of these columns
     HIPCHK(hipMemsetAsync(c->d_J[c->jcur] + o * c->til_col, 0, (size_t)ncol * c->til_col * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->d_I + o * Nspect * c->Nrays, 0, (size_t)ncol * Nspect * c->Nrays * 8, c->stream));
@@ -1442,6 +1480,12 @@ int lsx_set_columns(lsx_ctx* c, int32_t col0, int32_t ncol, const lsx_columns* s
 
 static int enqueue_fs(lsx_ctx* c, bool timed)
 {
+    if (c->n_phi_set != (size_t)c->ncol) {
+        size_t q = 0;
+        while (q < (size_t)c->ncol && c->phi_set[q]) ++q;
+        return fail(LSX_EINVAL, "formal_sol_gamma: column %zu has no line profiles (lsx_set_columns with phi == NULL "
+                                "must be followed by lsx_set_line_profiles)", q);
+    }
     HIPCHK(hipSetDevice(c->device));
     SweepParams p{};
     p.Nspace = c->Nspace; p.Nrays = c->Nrays; p.Nspect = c->Nspect; p.Natoms = c->Natoms; p.Ntrans = c->Ntrans;
@@ -1506,6 +1550,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
                            (size_t)(npt_max >= 0 ? (c->Nspace + 1) * (3 * npt_max + 2) : 0) * sizeof(double) +
                            (size_t)(npt_max > 0 ? 2 * 2 * npt_max * LSX_WAVE : 0) * sizeof(double) +
                            (size_t)(npt_max >= 3 ? npt_max * (npt_max - 1) * 5 : 0) * sizeof(double);
+        c->fused_launches++;
         hipError_t e = lsx_launch_sweep(&p, -2, (int)nblocks, lds, c->stream);
         if (e != hipSuccess) return fail(LSX_EDEVICE, "sweep launch (fused): %s", hipGetErrorString(e));
         if (has_fast && (rc2 = launch_fast_gamma(c->stream, c->d_fast_tiles, c->fast_tiles.size()))) return rc2;
@@ -1524,6 +1569,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
             p.class_tiles = k.d_tiles;
             p.n_class_tiles = (int)k.tiles.size();
             p.ncell_lev = k.npt >= 0 ? 0 : k.ncell_lev; p.ncell_atom = k.npt >= 0 ? 0 : k.ncell_atom; p.nstash = 0;
+            k.launches++;
             hipError_t e = lsx_launch_sweep(&p, k.npt >= 0 ? k.npt * 8 + k.nl : -1, (int)nblocks, k.lds_bytes, st);
             if (e != hipSuccess) return fail(LSX_EDEVICE, "sweep launch (per-ray slots %d): %s", k.npt, hipGetErrorString(e));
             if (timed) {
@@ -1614,6 +1660,10 @@ int lsx_set_line_profiles(lsx_ctx* c, int32_t col0, int32_t ncol, const double* 
         }
         HIPCHK(hipStreamSynchronize(c->stream));   // the staging buffer is re-used by the next sub-chunk
     }
+    for (int q = 0; q < ncol; ++q) {
+        c->n_phi_set += (size_t)1 - c->phi_set[(size_t)col0 + q];
+        c->phi_set[(size_t)col0 + q] = 1;
+    }
     return LSX_OK;
 }
 
@@ -1636,7 +1686,7 @@ int lsx_stat_equil_async(lsx_ctx* c)
 #define SE_REG(NLC) case NLC: hipLaunchKernelGGL((k_stat_equil_reg<NLC>), grid, dim3(nt), 0, c->stream, c->d_Gamma, c->d_nTotal, c->d_n, \
                               c->d_dPcol, c->d_singular, c->lev_off[a], c->lev2_off[a], a, c->Natoms, c->NLtot, c->NL2tot,      \
                               c->Nspace, c->ncol, c->d_colmask); break;
-        switch (getenv("LSX_SE_LDS") ? 0 : Nl) {
+        switch (c->opt_se_lds ? 0 : Nl) {
         SE_REG(2) SE_REG(3) SE_REG(4) SE_REG(5) SE_REG(6) SE_REG(7) SE_REG(8)
         default: {
             const size_t sm = (size_t)(Nl * Nl + 2 * Nl) * nt * sizeof(double);
@@ -1675,12 +1725,12 @@ int lsx_sync(lsx_ctx* c, double* dJ, double* dP)
 {
     if (!c) return fail(LSX_EINVAL, "null ctx");
     HIPCHK(hipSetDevice(c->device));
-    int sing = 0;
+    unsigned long long sing = 0;
     if (c->fs_pending || c->se_pending) {
         const size_t nc = (size_t)c->ncol;
         HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_res, (2 * nc + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        auto nanmax = [](const double* v, size_t n) {       // numpy max semantics: NaN wins (rh_method.py:706, :741)
+        auto nanmax = [](const double* v, size_t n) {       // numpy max semantics: NaN wins (rh_method.py:706)
             double m = 0.0;
             for (size_t i = 0; i < n; ++i)
                 if (v[i] != v[i]) return v[i];
@@ -1689,8 +1739,8 @@ int lsx_sync(lsx_ctx* c, double* dJ, double* dP)
         };
         if (c->fs_pending) c->last_dJ = nanmax(c->h_pinned, nc);
         if (c->se_pending) {
-            c->last_dP = nanmax(c->h_pinned + nc, nc);
-            memcpy(&sing, c->h_pinned + 2 * nc, sizeof(int));
+            c->last_dP = nanmax(c->h_pinned + nc, nc);      // the per-column values are never NaN (k_stat_equil)
+            memcpy(&sing, c->h_pinned + 2 * nc, sizeof sing);
         }
         c->fs_pending = c->se_pending = false;
     } else {
@@ -1698,7 +1748,13 @@ int lsx_sync(lsx_ctx* c, double* dJ, double* dP)
     }
     if (dJ) *dJ = c->last_dJ;
     if (dP) *dP = c->last_dP;
-    if (sing) return fail(LSX_ESINGULAR, "stat_equil: singular matrix (cf. LinAlgError at rh_method.py:739)");
+    if (sing) {
+        const unsigned long long key = LSX_SING_BASE - sing;
+        const long gid = (long)(key >> 8);
+        return fail(LSX_ESINGULAR, "stat_equil: singular matrix at column %ld, depth %ld, atom %d (the first such system; cf. "
+                                   "LinAlgError at rh_method.py:739); its populations are left untouched",
+                    gid / c->Nspace, gid % c->Nspace, (int)(key & 0xff));
+    }
     return LSX_OK;
 }
 
@@ -1807,39 +1863,123 @@ int lsx_set(lsx_ctx* c, int32_t what, int32_t col0, int32_t ncol, const double* 
     return LSX_OK;
 }
 
+// Stand-alone formal solver entry points: per-device scratch (a stream, one growing device buffer, the exp table) that
+// lives for the life of the library, so a call costs copies + one launch, not nine hipMalloc/hipFree pairs.
+namespace {
+struct PwScratch {
+    hipStream_t stream = nullptr;
+    char* buf = nullptr;
+    size_t cap = 0;
+    double* exp_tab = nullptr;
+};
+std::mutex g_pw_mutex;
+PwScratch g_pw[64];
+
+int pw_scratch(int device, size_t bytes, PwScratch** out)
+{
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(LSX_EDEVICE, "no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev || device >= 64) return fail(LSX_EINVAL, "bad device %d (%d visible)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    PwScratch& q = g_pw[device];
+    if (!q.stream) HIPCHK(hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking));
+    if (!q.exp_tab) {
+        const std::vector<double> et = make_exp2_table();
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&q.exp_tab), et.size() * sizeof(double)));
+        HIPCHK(hipMemcpy(q.exp_tab, et.data(), et.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (bytes > q.cap) {
+        if (q.buf) HIPCHK(hipFree(q.buf));
+        q.buf = nullptr;
+        q.cap = 0;
+        const size_t want = std::max<size_t>(bytes + bytes / 4, (size_t)1 << 20);
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&q.buf), want));
+        q.cap = want;
+    }
+    *out = &q;
+    return LSX_OK;
+}
+
+int run_piecewise(int32_t device, int32_t nray, int32_t Nspace, const double* height, const double* temperature,
+                  const double* mu, const int32_t* to_obs, const double* wav, const double* Istart, const double* chi,
+                  const double* S, double* I, double* PsiStar, const char* who)
+{
+    if (nray < 0 || Nspace < 3) return fail(LSX_EINVAL, "%s: need Nspace >= 3 (formal_solver.py:120-139)", who);
+    if (nray == 0) return LSX_OK;
+    if (!height || !mu || !to_obs || !chi || !S || !I || !PsiStar || (!Istart && (!temperature || !wav)))
+        return fail(LSX_EINVAL, "%s: null array pointer", who);
+    std::lock_guard<std::mutex> lock(g_pw_mutex);
+    const size_t Ns = Nspace, nr = nray;
+    const size_t rnd = 32;   // keep every array 256-B aligned
+    auto al = [&](size_t n) { return (n + rnd - 1) / rnd * rnd; };
+    const size_t doubles = 2 * al(Ns) + 3 * al(nr) + 4 * al(nr * Ns) + al((nr + 1) / 2);
+    PwScratch* q = nullptr;
+    int rc = pw_scratch(device, doubles * sizeof(double), &q);
+    if (rc) return rc;
+    double* p = reinterpret_cast<double*>(q->buf);
+    double* dz = p; p += al(Ns);
+    double* dT = p; p += al(Ns);
+    double* dmu = p; p += al(nr);
+    double* dwav = p; p += al(nr);
+    double* dI0 = p; p += al(nr);
+    double* dchi = p; p += al(nr * Ns);
+    double* dS = p; p += al(nr * Ns);
+    double* dI = p; p += al(nr * Ns);
+    double* dP = p; p += al(nr * Ns);
+    int* dto = reinterpret_cast<int*>(p);
+    hipStream_t st = q->stream;
+    HIPCHK(hipMemcpyAsync(dz, height, Ns * 8, hipMemcpyHostToDevice, st));
+    if (temperature) HIPCHK(hipMemcpyAsync(dT, temperature, Ns * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dmu, mu, nr * 8, hipMemcpyHostToDevice, st));
+    if (wav) HIPCHK(hipMemcpyAsync(dwav, wav, nr * 8, hipMemcpyHostToDevice, st));
+    if (Istart) HIPCHK(hipMemcpyAsync(dI0, Istart, nr * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dto, to_obs, nr * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dchi, chi, nr * Ns * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dS, S, nr * Ns * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_piecewise, dim3((nray + 63) / 64), dim3(64), 0, st, nray, Nspace, dz, dT, dmu, dto, dwav,
+                       Istart ? dI0 : nullptr, dchi, dS, dI, dP, q->exp_tab);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(I, dI, nr * Ns * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(PsiStar, dP, nr * Ns * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return LSX_OK;
+}
+} // namespace
+
 int lsx_piecewise_linear_1d(int32_t device, int32_t nray, int32_t Nspace, const double* height, const double* temperature,
                             const double* mu, const int32_t* to_obs, const double* wav, const double* chi, const double* S,
                             double* I, double* PsiStar)
 {
-    if (nray < 0 || Nspace < 3) return fail(LSX_EINVAL, "lsx_piecewise_linear_1d: need Nspace >= 3");
-    if (nray == 0) return LSX_OK;
-    int ndev = 0;
-    HIPCHK(hipGetDeviceCount(&ndev));
-    if (device < 0 || device >= ndev) return fail(LSX_EINVAL, "lsx_piecewise_linear_1d: bad device");
-    HIPCHK(hipSetDevice(device));
-    const size_t Ns = Nspace, nr = nray;
-    double *dz = nullptr, *dT = nullptr, *dmu = nullptr, *dwav = nullptr, *dchi = nullptr, *dS = nullptr, *dI = nullptr, *dP = nullptr;
-    int* dto = nullptr;
-    int rc = LSX_OK;
-    auto cleanup = [&]() { for (void* q : {(void*)dz, (void*)dT, (void*)dmu, (void*)dwav, (void*)dchi, (void*)dS, (void*)dI, (void*)dP, (void*)dto}) if (q) (void)hipFree(q); };
-#define TRYC(x) do { rc = (x); if (rc) { cleanup(); return rc; } } while (0)
-#define HIPC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(LSX_EDEVICE, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
-    TRYC(dmalloc(&dz, Ns)); TRYC(dmalloc(&dT, Ns)); TRYC(dmalloc(&dmu, nr)); TRYC(dmalloc(&dwav, nr)); TRYC(dmalloc(&dto, nr));
-    TRYC(dmalloc(&dchi, nr * Ns)); TRYC(dmalloc(&dS, nr * Ns)); TRYC(dmalloc(&dI, nr * Ns)); TRYC(dmalloc(&dP, nr * Ns));
-    HIPC(hipMemcpy(dz, height, Ns * 8, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(dT, temperature, Ns * 8, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(dmu, mu, nr * 8, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(dwav, wav, nr * 8, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(dto, to_obs, nr * 4, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(dchi, chi, nr * Ns * 8, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(dS, S, nr * Ns * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_piecewise, dim3((nray + 63) / 64), dim3(64), 0, 0, nray, Nspace, dz, dT, dmu, dto, dwav, dchi, dS, dI, dP);
-    HIPC(hipGetLastError());
-    HIPC(hipMemcpy(I, dI, nr * Ns * 8, hipMemcpyDeviceToHost));
-    HIPC(hipMemcpy(PsiStar, dP, nr * Ns * 8, hipMemcpyDeviceToHost));
-#undef TRYC
-#undef HIPC
-    cleanup();
+    if (nray > 0 && (!temperature || !wav)) return fail(LSX_EINVAL, "lsx_piecewise_linear_1d: null array pointer");
+    return run_piecewise(device, nray, Nspace, height, temperature, mu, to_obs, wav, nullptr, chi, S, I, PsiStar,
+                         "lsx_piecewise_linear_1d");
+}
+
+int lsx_piecewise_1d_impl(int32_t device, int32_t nray, int32_t Nspace, const double* height, const double* mu,
+                          const int32_t* to_obs, const double* Istart, const double* chi, const double* S, double* I,
+                          double* PsiStar)
+{
+    if (nray > 0 && !Istart) return fail(LSX_EINVAL, "lsx_piecewise_1d_impl: null array pointer");
+    return run_piecewise(device, nray, Nspace, height, nullptr, mu, to_obs, nullptr, Istart, chi, S, I, PsiStar,
+                         "lsx_piecewise_1d_impl");
+}
+
+int lsx_w2(int32_t device, int32_t n, const double* dtau, double* w0w1)
+{
+    if (n < 0 || (n > 0 && (!dtau || !w0w1))) return fail(LSX_EINVAL, "lsx_w2: bad argument");
+    if (n == 0) return LSX_OK;
+    std::lock_guard<std::mutex> lock(g_pw_mutex);
+    PwScratch* q = nullptr;
+    int rc = pw_scratch(device, (size_t)n * 3 * sizeof(double), &q);
+    if (rc) return rc;
+    double* din = reinterpret_cast<double*>(q->buf);
+    double* dout = din + n;
+    HIPCHK(hipMemcpyAsync(din, dtau, (size_t)n * 8, hipMemcpyHostToDevice, q->stream));
+    hipLaunchKernelGGL(k_w2, dim3((n + 63) / 64), dim3(64), 0, q->stream, n, din, dout, q->exp_tab);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(w0w1, dout, (size_t)n * 16, hipMemcpyDeviceToHost, q->stream));
+    HIPCHK(hipStreamSynchronize(q->stream));
     return LSX_OK;
 }
 
@@ -1869,7 +2009,7 @@ int lsx_time_formal_sol(lsx_ctx* c, int32_t warmup, int32_t reps, double* ms_tot
                 if (k.tdone) {
                     float t = 0.f;
                     HIPCHK(hipEventElapsedTime(&t, c->ev0, k.tdone));
-                    if (getenv("LSX_TRACE_CLASSES") && i == reps - 1) fprintf(stderr, "class npt=%d nl=%d fast=%d tiles=%zu: done at %.3f ms\n", k.npt, k.nl, (int)k.has_fast, k.tiles.size(), t);
+                    if (c->opt_trace_classes && i == reps - 1) fprintf(stderr, "class npt=%d nl=%d fast=%d tiles=%zu: done at %.3f ms\n", k.npt, k.nl, (int)k.has_fast, k.tiles.size(), t);
                     mx = std::max(mx, t);
                 }
             if (mx > 0.f) ms = mx;
@@ -1901,6 +2041,20 @@ double lsx_hip_info(const lsx_ctx* c, int32_t what)
     case 5: return 8.0 * c->Nspace * 4.0 * (double)c->tile_slots.size();
     default: return 0.0;
     }
+}
+
+// HIP-only introspection for the tests: which sweep instantiations a context launches.  Returns the number of tile
+// classes; for 0 <= idx < that number out[0..3] = per-ray slots (compile time, -1 generic), lines among them, tiles per
+// column, launches so far.  idx == -1: out[0] = launches of the fused small-batch kernel.
+int32_t lsx_hip_class_info(const lsx_ctx* c, int32_t idx, int64_t* out)
+{
+    if (!c) return 0;
+    if (out && idx == -1) out[0] = c->fused_launches;
+    if (out && idx >= 0 && idx < (int)c->classes.size()) {
+        const SweepClass& k = c->classes[idx];
+        out[0] = k.npt; out[1] = k.nl; out[2] = (int64_t)k.tiles.size(); out[3] = k.launches;
+    }
+    return (int32_t)c->classes.size();
 }
 
 // diagnostic: stream `gib` GiB once in the sweep's access shape (see k_calib_read); returns the bytes read

@@ -14,6 +14,7 @@ class MaliHistory:
     dJ: List[float] = field(default_factory=list)
     dPops: List[float] = field(default_factory=list)   # nan while only J is iterated
     converged: bool = False
+    nonfinite: bool = False     # some monitor was NaN / inf on the way (the reference carries on silently)
 
     @property
     def n_iter(self):
@@ -41,7 +42,9 @@ def iterate_mali(ctx, dJ_tol=2e-3, dPops_tol=1e-3, n_lambda_only=3, max_iter=500
         h.dPops.append(dPops if i > n_lambda_only else float('nan'))
         if log:
             log('Iteration %.3d: dJ: %.2e, dPops: %s' % (i, dJ, 'Just iterating Jbar' if i <= n_lambda_only else '%.2e' % dPops))
-        if i >= max_iter or not (np.isfinite(dJ) and np.isfinite(dPops)):
+        if not (np.isfinite(dJ) and np.isfinite(dPops)):
+            h.nonfinite = True          # the loop condition decides, exactly as in the reference: NaN > tol is False
+        if i >= max_iter:
             break
     h.converged = (dJ <= dJ_tol and dPops <= dPops_tol)
     return h
@@ -56,18 +59,25 @@ def response_function(I_plus, I_minus, I_base, mu_index=-1):
     return (Ip - Im) / np.asarray(I_base)[:, mu_index][:, None]
 
 
-def iterate_mali_columns(engine, dJ_tol=2e-3, dPops_tol=1e-3, n_lambda_only=3, max_iter=500, all_done=None, log=None):
+def iterate_mali_columns(engine, dJ_tol=2e-3, dPops_tol=1e-3, n_lambda_only=3, max_iter=500, all_done=None, log=None,
+                         report=None):
     """Many independent columns, each with the reference's own stopping rule: a column is frozen
     (lsx_set_active_columns) as soon as ITS dJ <= 2e-3 and dPops <= 1e-3, so it performs exactly the
     iterations a single-column reference Context would (test.py:20-29, response_fn.py:11-21).
 
     engine: problem.Engine.  all_done(bool) -> bool: hook for the multi-GPU driver (logical AND over
-    ranks).  Returns the number of iterations each column took ([ncol] int array)."""
+    ranks).  Returns the number of iterations each column took ([ncol] int array).
+
+    A column whose monitors turn NaN is treated as the reference's `while dJ > 2e-3 or dPops > 1e-3` treats it: the
+    comparisons with NaN are False, so the column stops as soon as its other monitor is below its threshold (it does
+    not keep the batch iterating to max_iter).  report (a dict, optional) receives 'nonfinite': the indices of the
+    columns that ever showed a non-finite monitor."""
     from . import _capi
     ncol = engine.ncol
     active = np.ones(ncol, dtype=bool)
     dP = np.ones(ncol)
     n_iter = np.zeros(ncol, dtype=np.int64)
+    bad = np.zeros(ncol, dtype=bool)
     i = 0
     engine.set_active_columns(None)
     while True:
@@ -78,8 +88,10 @@ def iterate_mali_columns(engine, dJ_tol=2e-3, dPops_tol=1e-3, n_lambda_only=3, m
             engine.stat_equil()
             dP = np.where(active, engine.get(_capi.LSX_DPOPS_COL), dP)
         n_iter[active] = i
-        still = (dJ > dJ_tol) | (dP > dPops_tol)
-        active &= still | ~np.isfinite(dJ) | ~np.isfinite(dP)
+        bad |= active & ~(np.isfinite(dJ) & np.isfinite(dP))
+        with np.errstate(invalid='ignore'):
+            still = (dJ > dJ_tol) | (dP > dPops_tol)      # NaN compares False (test.py:23)
+        active &= still
         if i >= max_iter:
             active[:] = False
         done = not active.any()
@@ -91,4 +103,6 @@ def iterate_mali_columns(engine, dJ_tol=2e-3, dPops_tol=1e-3, n_lambda_only=3, m
             break
         engine.set_active_columns(active)
     engine.set_active_columns(None)
+    if report is not None:
+        report['nonfinite'] = np.flatnonzero(bad)
     return n_iter

@@ -58,6 +58,7 @@ struct lsx_ctx {
     /* per column, reference layouts */
     double *height, *temperature, *nStar, *nTotal, *n, *C, *bg_chi, *bg_eta, *bg_sca, *phi, *wphi;
     double *J, *I, *Gamma, *Rij, *Rji, *dJcol, *dPcol;
+    long* sing_col; /* per column: (depth << 8 | atom) of its first singular system in the last stat_equil, or -1 */
     int nthreads;
     uint8_t* colmask; /* NULL = all active */
     double last_dJ, last_dP;
@@ -127,6 +128,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     c->Rij = (double*)calloc(nc * (c->Ntrans ? c->Ntrans : 1) * Ns, 8);
     c->Rji = (double*)calloc(nc * (c->Ntrans ? c->Ntrans : 1) * Ns, 8);
     c->dJcol = (double*)calloc(nc, 8); c->dPcol = (double*)calloc(nc, 8);
+    c->sing_col = (long*)calloc(nc, sizeof(long));
     c->nthreads = 1;
     *out = c;
     return LSX_OK;
@@ -140,7 +142,7 @@ void lsx_destroy(lsx_ctx* c)
     free(c->height); free(c->temperature); free(c->nStar); free(c->nTotal); free(c->n); free(c->C);
     free(c->bg_chi); free(c->bg_eta); free(c->bg_sca); free(c->phi); free(c->wphi);
     free(c->colmask);
-    free(c->J); free(c->I); free(c->Gamma); free(c->Rij); free(c->Rji); free(c->dJcol); free(c->dPcol);
+    free(c->J); free(c->I); free(c->Gamma); free(c->Rij); free(c->Rji); free(c->dJcol); free(c->dPcol); free(c->sing_col);
     free(c);
 }
 
@@ -338,6 +340,27 @@ int lsx_piecewise_linear_1d(int32_t device, int32_t nray, int32_t Nspace, const 
     for (int r = 0; r < nray; ++r)
         piecewise_linear_1d(Nspace, height, temperature, mu[r], to_obs[r], wav[r], chi + (size_t)r * Nspace,
                             S + (size_t)r * Nspace, I + (size_t)r * Nspace, PsiStar + (size_t)r * Nspace);
+    return LSX_OK;
+}
+
+/* formal_solver.py:46-142 / 14-44 behind the ABI names (include/lsx.h) */
+int lsx_piecewise_1d_impl(int32_t device, int32_t nray, int32_t Nspace, const double* height, const double* mu,
+                          const int32_t* to_obs, const double* Istart, const double* chi, const double* S, double* I,
+                          double* PsiStar)
+{
+    (void)device;
+    if (nray < 0 || Nspace < 3) return fail(LSX_EINVAL, "lsx_piecewise_1d_impl: need Nspace >= 3");
+    for (int r = 0; r < nray; ++r)
+        piecewise_1d_impl(mu[r], to_obs[r], Istart[r], Nspace, height, chi + (size_t)r * Nspace, S + (size_t)r * Nspace,
+                          I + (size_t)r * Nspace, PsiStar + (size_t)r * Nspace);
+    return LSX_OK;
+}
+
+int lsx_w2(int32_t device, int32_t n, const double* dtau, double* w0w1)
+{
+    (void)device;
+    if (n < 0) return fail(LSX_EINVAL, "lsx_w2: bad argument");
+    for (int i = 0; i < n; ++i) w2(dtau[i], w0w1 + 2 * (size_t)i);
     return LSX_OK;
 }
 
@@ -648,7 +671,7 @@ static int stat_equil_column(lsx_ctx* c, int col)
 {
     const int Ns = c->Nspace;
     double maxRel = 0.0;
-    int nan = 0, singular = 0;
+    int singular = 0;
     double A[32 * 32], b[32], nOld[32];
     for (int a = 0; a < c->Natoms; ++a) {
         const int Nl = c->Nlevel[a];
@@ -663,16 +686,25 @@ static int stat_equil_column(lsx_ctx* c, int col)
                 for (int j = 0; j < Nl; ++j) A[i + j * Nl] = (i == iE) ? 1.0 : G[((size_t)i * Nl + j) * Ns + k];
             for (int i = 0; i < Nl; ++i) { b[i] = 0.0; nOld[i] = n[(size_t)i * Ns + k]; }
             b[iE] = nTot[k];
-            if (gesv(Nl, A, b)) { singular = 1; continue; }
+            if (gesv(Nl, A, b)) {
+                if (!singular) { singular = 1; c->sing_col[col] = ((long)k << 8) | a; }
+                continue;
+            }
+            /* change.max() is numpy's max: NaN wins among the levels of this depth; the running
+             * maxRelChange = max(maxRelChange, change.max()) is Python's builtin max, which keeps
+             * maxRelChange when the new value is NaN (rh_method.py:740-741) */
+            double chmax = 0.0;
+            int nan = 0;
             for (int i = 0; i < Nl; ++i) {
                 double ch = fabs(1.0 - nOld[i] / b[i]);
                 if (ch != ch) nan = 1;
-                else if (ch > maxRel) maxRel = ch;
+                else if (ch > chmax) chmax = ch;
                 n[(size_t)i * Ns + k] = b[i];
             }
+            if (!nan && chmax > maxRel) maxRel = chmax;
         }
     }
-    c->dPcol[col] = nan ? NAN : maxRel;
+    c->dPcol[col] = maxRel;
     return singular;
 }
 
@@ -686,11 +718,19 @@ int lsx_stat_equil_async(lsx_ctx* c)
 #pragma omp parallel for num_threads(c->nthreads) reduction(| : sing)
 #endif
     for (int col = 0; col < c->ncol; ++col) {
+        c->sing_col[col] = -1;
         if (c->colmask && !c->colmask[col]) { c->dPcol[col] = 0.0; continue; }
         sing |= stat_equil_column(c, col);
     }
     c->last_dP = colmax(c->dPcol, c->ncol);
-    if (sing) return fail(LSX_ESINGULAR, "stat_equil: singular system");
+    if (sing) {
+        char msg[256];
+        int col = 0;
+        while (col < c->ncol && c->sing_col[col] < 0) ++col;
+        snprintf(msg, sizeof msg, "stat_equil: singular matrix at column %d, depth %ld, atom %ld (the first such system; cf. "
+                                  "LinAlgError at rh_method.py:739)", col, c->sing_col[col] >> 8, c->sing_col[col] & 0xff);
+        return fail(LSX_ESINGULAR, msg);
+    }
     return LSX_OK;
 }
 

@@ -1,0 +1,159 @@
+"""Bodies of the drop-in boundary tests (rh_method.Context / formal_solver.piecewise_linear_1d of lightspinner_amd),
+shared by the CPU run (oracle bound as the checker, tests/test_host_logic.py) and the GPU run (the product library,
+tests/test_context_hip.py).  `lib=None` means the product default: the HIP library."""
+import numpy as np
+import pytest
+
+from conftest import golden, relerr, gamma_err
+from helpers import build_fakes
+from lightspinner_amd.rh_method import Context
+
+
+_ONE_ATOM_6 = type('P', (), dict(Natoms=1, Nlevel=[6], lev2_off=[0], Nspace=82))
+
+
+def context_dropin_matches_reference_golden(lib):
+    d = dict(np.load(golden('falc_ca.npz')))
+    atmos, spect, eq, bg = build_fakes(d)
+    ctx = Context(atmos, spect, eq, bg, lib=lib)
+    assert atmos.nondim_calls == 1                                   # rh_method.py:553
+    assert ctx.problem.phi_compact and not ctx.problem.sca_per_lambda
+    atom = ctx.activeAtoms[0]
+    assert atom.n is eq['CA'].pops                                   # aliasing contract, rh_method.py:412-416
+    assert relerr(atom.trans[0].phi[:, 0, 0, :], d['t0_phi']) < 1e-13 and relerr(atom.trans[0].wphi, d['t0_wphi']) < 1e-13
+    for it in range(1, 6):
+        dJ = ctx.formal_sol_gamma_matrices()
+        assert dJ == pytest.approx(float(d['fs%d_dJ' % it]), rel=1e-8)
+        assert relerr(ctx.I, d['fs%d_I' % it]) < (1e-12 if it < 5 else 1e-8)
+        assert relerr(ctx.J, d['fs%d_J' % it]) < (1e-12 if it < 5 else 1e-8)
+        assert atom.Gamma.shape == d['fs%d_Gamma_a0' % it].shape
+        off, diag = gamma_err(atom.Gamma.reshape(-1, 82), d['fs%d_Gamma_a0' % it].reshape(-1, 82), _ONE_ATOM_6)
+        assert off < (1e-11 if it < 5 else 1e-7) and diag < (1e-12 if it < 5 else 1e-8), (it, off, diag)
+        if it > 3:
+            n_before = atom.n
+            dP = ctx.stat_equil()
+            assert dP == pytest.approx(float(d['se%d_dPops' % it]), rel=1e-7)
+            assert atom.n is n_before and eq['CA'].n is atom.n       # updated in place
+            assert relerr(atom.n, d['se%d_n_a0' % it]) < 1e-7
+    with pytest.raises(AttributeError):
+        atom.trans[0].Rij
+
+
+def context_warm_start_and_host_edits(lib):
+    d = dict(np.load(golden('falc_ca.npz')))
+    atmos, spect, eq, bg = build_fakes(d, start_pops=[d['conv_n_a0']])
+    ctx = Context(atmos, spect, eq, bg, lib=lib)
+    assert np.array_equal(ctx.activeAtoms[0].n, d['conv_n_a0'])      # response_fn.py:33
+    ctx.J[...] = d['conv_J']                                         # caller edits are honoured
+    dJ = ctx.formal_sol_gamma_matrices()
+    assert dJ < 2e-3
+    ctx.activeAtoms[0].n[...] = d['a0_nStar']                        # back to LTE in place
+    ctx.formal_sol_gamma_matrices()
+    dP = ctx.stat_equil()
+    assert dP > 0.1
+
+
+def context_two_active_atoms_order_and_shapes(lib):
+    d = dict(np.load(golden('falc_cah.npz')))
+    atmos, spect, eq, bg = build_fakes(d)
+    ctx = Context(atmos, spect, eq, bg, lib=lib)
+    assert [a.atomicModel.name for a in ctx.activeAtoms] == ['H', 'CA']   # ascending atomic weight
+    assert ctx.problem.Ntrans == 25 and ctx.problem.Nspect == 777
+    dJ = ctx.formal_sol_gamma_matrices()
+    assert dJ == 1.0
+    assert relerr(ctx.I, d['fs1_I']) < 3e-11
+    for a in range(2):
+        off, diag = gamma_err(ctx.activeAtoms[a].Gamma.reshape(-1, 82), d['fs1_Gamma_a%d' % a].reshape(-1, 82),
+                              _ONE_ATOM_6)
+        assert off < 3e-10 and diag < 3e-11
+
+
+class _Atmos:
+    """what formal_solver.piecewise_linear_1d reads from an Atmosphere (formal_solver.py:144-212)"""
+    def __init__(self, d):
+        self.height, self.temperature, self.muz = d['pl_height'], d['pl_temperature'], d['pl_muz']
+        self.Nspace = self.height.shape[0]
+
+
+def piecewise_linear_1d_dropin(lib):
+    """lightspinner_amd.formal_solver.piecewise_linear_1d(atmos, mu, toFrom, wav, chi, S) -> IPsi, the reference's own
+    signature (formal_solver.py:144), against the reference's outputs for 16 rays (boundary conditions of both
+    directions, formal_solver.py:203-209)"""
+    from lightspinner_amd.formal_solver import piecewise_linear_1d, IPsi
+    d = np.load(golden('units.npz'))
+    atmos = _Atmos(d)
+    for wi in range(4):
+        for mu in range(2):
+            for tf in (False, True):
+                r = piecewise_linear_1d(atmos, mu, tf, float(d['pl_wav'][wi]), d['pl_chi'], d['pl_S'], lib=lib)
+                assert isinstance(r, IPsi) and r.I.shape == r.PsiStar.shape == (atmos.Nspace,)
+                tag = '%d_%d_%d' % (wi, mu, int(tf))
+                assert relerr(r.I, d['pl_I_' + tag], floor=1e-300) < 5e-12
+                assert np.allclose(r.PsiStar, d['pl_Psi_' + tag], rtol=5e-12, atol=0)
+                assert r.PsiStar[-1 if tf else 0] == 0.0
+
+
+def golden_w2_and_piecewise_1d_impl(lib):
+    """the reference's unit vectors for w2 (407 optical depths over the three branches and both thresholds,
+    formal_solver.py:14-44) and piecewise_1d_impl (10 grids, N = 3 ... 200, both directions, formal_solver.py:46-142)
+    through the C ABI (lsx_w2 / lsx_piecewise_1d_impl)"""
+    d = np.load(golden('units.npz'))
+    w = lib.w2(d['w2_dtau'])
+    # exp() implementations differ by an ulp of exp(-dtau) <= 1; w0 = 1 - e and w1 = w0 - dtau e inherit that as an
+    # ABSOLUTE error (the formulas cancel) -- same bar as the oracle's own test
+    assert np.allclose(w, d['w2_out'], rtol=4e-16, atol=5e-16)
+    small, large = d['w2_dtau'] < 5e-4, d['w2_dtau'] > 50.0
+    assert small.any() and large.any() and (~small & ~large).any()
+    assert np.array_equal(w[large], np.ones((int(large.sum()), 2)))          # saturated branch is exact
+    assert np.allclose(w[small], d['w2_out'][small], rtol=3e-16, atol=0)      # Taylor branch: no exp involved
+    for c, N in enumerate(d['pw_N']):
+        for tf in (0, 1):
+            tag = 'pw%d_%d' % (c, tf)
+            I, Psi = lib.piecewise_1d_impl(d[tag + '_z'], [float(d[tag + '_mu'])], [tf], [float(d[tag + '_Istart'])],
+                                           d[tag + '_chi'][None], d[tag + '_S'][None])
+            assert relerr(I[0], d[tag + '_I']) < 2e-12, tag
+            assert np.allclose(Psi[0], d[tag + '_Psi'], rtol=2e-12, atol=1e-30), tag
+            assert Psi[0][N - 1 if tf else 0] == 0.0
+    # many rays of one grid in one call (ragged batch sizes around the 64-lane launch width)
+    tag = 'pw4_1'
+    for nray in (1, 63, 64, 65, 130):
+        I, Psi = lib.piecewise_1d_impl(d[tag + '_z'], [float(d[tag + '_mu'])] * nray, [1] * nray, [float(d[tag + '_Istart'])] * nray,
+                                       np.tile(d[tag + '_chi'], (nray, 1)), np.tile(d[tag + '_S'], (nray, 1)))
+        assert np.array_equal(I, np.tile(I[0], (nray, 1))) and relerr(I[-1], d[tag + '_I']) < 2e-12
+    # empty input
+    I, Psi = lib.piecewise_1d_impl(d[tag + '_z'], [], [], [], np.zeros((0, 82)), np.zeros((0, 82)))
+    assert I.shape == (0, 82)
+    assert lib.w2([]).shape == (0, 2)
+
+
+def dead_level_nan_is_dropped_from_dpops(lib):
+    """A level that nothing populates: the first stat_equil drives it to exactly 0 (relative change inf, which the
+    reference reports: abs(1 - nOld/0)), the second sees 0/0 = NaN for it.  rh_method.py:741 takes the depth's
+    change.max() (NaN, numpy) into Python's builtin max(maxRelChange, .), which keeps maxRelChange: that depth drops
+    out and the call returns the largest finite change of the other depths / atoms -- never NaN."""
+    from toy import toy_problem
+    from lightspinner_amd.problem import Engine
+    from lightspinner_amd import _capi, drivers
+    prob, block = toy_problem(seed=11, ncol=3, dead_level=True)
+    e = Engine(prob, block.ncol, lib=lib)
+    e.set_columns(0, block)
+    for _ in range(3):
+        e.formal_sol_gamma()
+    assert e.stat_equil() == float('inf')
+    n = e.get(_capi.LSX_N)
+    assert np.all(n[:, prob.NLtot - 1, :] == 0.0)
+    e.formal_sol_gamma()
+    dP = e.stat_equil()
+    assert np.isfinite(dP) and dP > 0.0
+    per_col = e.get(_capi.LSX_DPOPS_COL)
+    assert np.all(np.isfinite(per_col)) and per_col.max() == dP
+    # the level stays at 0 and the other levels keep converging
+    e.formal_sol_gamma()
+    assert e.stat_equil() < dP
+    assert np.all(e.get(_capi.LSX_N)[:, prob.NLtot - 1, :] == 0.0)
+    # per-column driver: a column stops by the reference's own comparisons; none is kept alive by a NaN
+    rep = {}
+    it = drivers.iterate_mali_columns(e, max_iter=60, report=rep)
+    assert it.max() < 60
+    e.close()
+    return dP

@@ -1,0 +1,36 @@
+"""The drop-in boundary on the PRODUCT library (GPU): lightspinner_amd.rh_method.Context and
+lightspinner_amd.formal_solver.piecewise_linear_1d with their default backend (lib=None -> liblsx_hip.so), on the
+reference-shaped stand-in objects of tests/helpers.py, against the reference's golden vectors; the reference's unit
+vectors for w2 / piecewise_1d_impl through the HIP C ABI.  Same bodies as the CPU run (tests/context_cases.py)."""
+import numpy as np
+import pytest
+
+import context_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def test_context_on_hip_matches_reference_golden(hip_lib):
+    context_cases.context_dropin_matches_reference_golden(None)        # None: the product default, i.e. HIP
+
+
+def test_context_on_hip_warm_start_and_host_edits(hip_lib):
+    context_cases.context_warm_start_and_host_edits(None)
+
+
+def test_context_on_hip_two_active_atoms(hip_lib):
+    context_cases.context_two_active_atoms_order_and_shapes(None)
+
+
+def test_piecewise_linear_1d_dropin_on_hip(hip_lib):
+    context_cases.piecewise_linear_1d_dropin(None)
+
+
+def test_golden_w2_and_piecewise_1d_impl_on_hip(hip_lib):
+    context_cases.golden_w2_and_piecewise_1d_impl(hip_lib)
+
+
+def test_dead_level_nan_is_dropped_from_dpops_on_hip(hip_lib, oracle_lib):
+    a = context_cases.dead_level_nan_is_dropped_from_dpops(hip_lib)
+    b = context_cases.dead_level_nan_is_dropped_from_dpops(oracle_lib)
+    assert a == pytest.approx(b, rel=1e-6)

@@ -9,6 +9,7 @@ import pytest
 
 from conftest import golden, relerr, gamma_err, ROOT
 from helpers import build_fakes
+import context_cases
 from lightspinner_amd import _capi, fixtures, synth, drivers
 from lightspinner_amd.parallel import shard_columns
 from lightspinner_amd.rh_method import Context
@@ -52,57 +53,27 @@ def test_hip_engine_fails_loudly_without_a_gpu():
 
 
 def test_context_dropin_matches_reference_golden(oracle_lib):
-    d = dict(np.load(golden('falc_ca.npz')))
-    atmos, spect, eq, bg = build_fakes(d)
-    ctx = Context(atmos, spect, eq, bg, lib=oracle_lib)
-    assert atmos.nondim_calls == 1                                   # rh_method.py:553
-    assert ctx.problem.phi_compact and not ctx.problem.sca_per_lambda
-    atom = ctx.activeAtoms[0]
-    assert atom.n is eq['CA'].pops                                   # aliasing contract, rh_method.py:412-416
-    assert relerr(atom.trans[0].phi[:, 0, 0, :], d['t0_phi']) < 1e-13 and relerr(atom.trans[0].wphi, d['t0_wphi']) < 1e-13
-    for it in range(1, 6):
-        dJ = ctx.formal_sol_gamma_matrices()
-        assert dJ == pytest.approx(float(d['fs%d_dJ' % it]), rel=1e-8)
-        assert relerr(ctx.I, d['fs%d_I' % it]) < (1e-12 if it < 5 else 1e-8)
-        assert relerr(ctx.J, d['fs%d_J' % it]) < (1e-12 if it < 5 else 1e-8)
-        assert atom.Gamma.shape == d['fs%d_Gamma_a0' % it].shape
-        if it > 3:
-            n_before = atom.n
-            dP = ctx.stat_equil()
-            assert dP == pytest.approx(float(d['se%d_dPops' % it]), rel=1e-7)
-            assert atom.n is n_before and eq['CA'].n is atom.n       # updated in place
-            assert relerr(atom.n, d['se%d_n_a0' % it]) < 1e-7
-    with pytest.raises(AttributeError):
-        atom.trans[0].Rij
+    context_cases.context_dropin_matches_reference_golden(oracle_lib)
 
 
 def test_context_warm_start_and_host_edits(oracle_lib):
-    d = dict(np.load(golden('falc_ca.npz')))
-    atmos, spect, eq, bg = build_fakes(d, start_pops=[d['conv_n_a0']])
-    ctx = Context(atmos, spect, eq, bg, lib=oracle_lib)
-    assert np.array_equal(ctx.activeAtoms[0].n, d['conv_n_a0'])      # response_fn.py:33
-    ctx.J[...] = d['conv_J']                                         # caller edits are honoured
-    dJ = ctx.formal_sol_gamma_matrices()
-    assert dJ < 2e-3
-    ctx.activeAtoms[0].n[...] = d['a0_nStar']                        # back to LTE in place
-    ctx.formal_sol_gamma_matrices()
-    dP = ctx.stat_equil()
-    assert dP > 0.1
+    context_cases.context_warm_start_and_host_edits(oracle_lib)
 
 
 def test_context_two_active_atoms_order_and_shapes(oracle_lib):
-    d = dict(np.load(golden('falc_cah.npz')))
-    atmos, spect, eq, bg = build_fakes(d)
-    ctx = Context(atmos, spect, eq, bg, lib=oracle_lib)
-    assert [a.atomicModel.name for a in ctx.activeAtoms] == ['H', 'CA']   # ascending atomic weight
-    assert ctx.problem.Ntrans == 25 and ctx.problem.Nspect == 777
-    dJ = ctx.formal_sol_gamma_matrices()
-    assert dJ == 1.0
-    assert relerr(ctx.I, d['fs1_I']) < 3e-11
-    for a in range(2):
-        off, diag = gamma_err(ctx.activeAtoms[a].Gamma.reshape(-1, 82), d['fs1_Gamma_a%d' % a].reshape(-1, 82),
-                              type('P', (), dict(Natoms=1, Nlevel=[6], lev2_off=[0], Nspace=82)))
-        assert off < 3e-10 and diag < 3e-11
+    context_cases.context_two_active_atoms_order_and_shapes(oracle_lib)
+
+
+def test_piecewise_linear_1d_dropin(oracle_lib):
+    context_cases.piecewise_linear_1d_dropin(oracle_lib)
+
+
+def test_golden_w2_and_piecewise_1d_impl_through_the_abi(oracle_lib):
+    context_cases.golden_w2_and_piecewise_1d_impl(oracle_lib)
+
+
+def test_dead_level_nan_is_dropped_from_dpops(oracle_lib):
+    context_cases.dead_level_nan_is_dropped_from_dpops(oracle_lib)
 
 
 def test_shard_columns_partitions_exactly():

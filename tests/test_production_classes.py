@@ -1,0 +1,119 @@
+"""GPU parity at the PRODUCTION launch path and workloads (BASELINE configs C3 / C4): >= 32 columns take one kernel
+instantiation per tile class on forked streams (lsx_hip.hip: enqueue_fs), not the fused small-batch kernel the
+single-column tests reach.  C4's tiles with three and four per-ray slots (`lsx_sweep_kernel<3|4, *, 5, false>`) meet
+the oracle here.
+
+Inputs: synth.perturbed_columns(..., device_profiles=True) -- FALC-perturbed columns with a smooth line-of-sight
+velocity (2 km/s), so the line profiles are ray dependent and are built by each library's own lsx_set_line_profiles
+(the two Voigt functions agree to 3e-14, tests/test_line_profiles.py).
+
+Tolerances: first formal-solution call J, I <= tol relative, off-diagonal Gamma <= 10 tol, diagonal <= tol of
+its column's largest entry; tol = 1e-12 (CaII), 3e-11 (Ca+H: DESIGN 2, the w2 cancellation next to the Taylor switch);
+after 8 MALI iterations (5 of them with stat_equil) populations <= 1e-8."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import golden, relerr, gamma_err
+from lightspinner_amd import fixtures, synth, Engine, _capi
+
+pytestmark = pytest.mark.gpu
+
+
+def class_table(lib, eng):
+    """-> ({(per-ray slots, lines): (tiles, launches)}, fused launches)"""
+    f = lib.dll.lsx_hip_class_info
+    f.restype = C.c_int32
+    f.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
+    out = (C.c_int64 * 4)()
+    n = f(eng._h, -1, out)
+    fused = int(out[0])
+    table = {}
+    for i in range(n):
+        f(eng._h, i, out)
+        table[(int(out[0]), int(out[1]))] = (int(out[2]), int(out[3]))
+    return table, fused
+
+
+def _run_pair(hip_lib, oracle_lib, name, ncol, seed, tol, expect_classes):
+    prob, base, raw = fixtures.load_problem_npz(golden(name), phi_compact=False)
+    blk, (aD, vB, vlos) = synth.perturbed_columns(prob, base, raw, ncol=ncol, seed=seed, vlos_sigma=2.0e3,
+                                                  device_profiles=True)
+    assert vlos is not None and np.any(vlos[1] != 0.0)
+    engs = []
+    for lib in (hip_lib, oracle_lib):
+        e = Engine(prob, ncol, lib=lib)
+        e.set_columns(0, blk)
+        e.set_line_profiles(0, aD, vB, vlos)
+        engs.append(e)
+    hip, ora = engs
+    oracle_lib.dll.lsx_oracle_set_threads(ora._h, 8)
+    # ---- first call: identical inputs on both sides
+    dJ, dJo = hip.formal_sol_gamma(), ora.formal_sol_gamma()
+    assert dJ == dJo == 1.0
+    assert relerr(hip.get(_capi.LSX_J), ora.get(_capi.LSX_J)) < tol
+    assert relerr(hip.get(_capi.LSX_I), ora.get(_capi.LSX_I)) < tol
+    off, diag = gamma_err(hip.get(_capi.LSX_GAMMA), ora.get(_capi.LSX_GAMMA), prob)
+    assert off < 10 * tol and diag < tol, (off, diag)
+    # per-column monitors agree column by column
+    assert np.allclose(hip.get(_capi.LSX_DJ_COL), ora.get(_capi.LSX_DJ_COL), rtol=1e-9)
+    # ---- 8 MALI iterations (test.py:20-29: the first three update J only)
+    for it in range(2, 9):
+        dJ, dJo = hip.formal_sol_gamma(), ora.formal_sol_gamma()
+        assert dJ == pytest.approx(dJo, rel=1e-6)
+        if it > 3:
+            dP, dPo = hip.stat_equil(), ora.stat_equil()
+            assert dP == pytest.approx(dPo, rel=1e-6)
+    assert relerr(hip.get(_capi.LSX_N), ora.get(_capi.LSX_N)) < 1e-8
+    assert relerr(hip.get(_capi.LSX_J), ora.get(_capi.LSX_J)) < 1e-8
+    assert relerr(hip.get(_capi.LSX_I), ora.get(_capi.LSX_I)) < 1e-8
+    # ---- the production instantiations are what ran
+    table, fused = class_table(hip_lib, hip)
+    assert fused == 0, 'the fused small-batch kernel must not be what this test measures'
+    for key in expect_classes:
+        assert key in table and table[key][1] == 8, (key, table)
+    assert all(launches == 8 for _, launches in table.values())
+    for e in engs:
+        e.close()
+    return table
+
+
+def test_c3_caii_columns_per_class_path(hip_lib, oracle_lib):
+    """C3: CaII, 64 columns, ray-dependent device-built profiles; tile classes 0, 1 (one line), 2 (H & K overlap)"""
+    table = _run_pair(hip_lib, oracle_lib, 'falc_ca.npz', 64, 1234, 1e-12, [(0, 0), (1, 1), (2, 2)])
+    assert sum(t for t, _ in table.values()) == 25          # 25 tiles for FALC CaII
+
+
+def test_c4_cah_columns_three_and_four_slot_instances(hip_lib, oracle_lib):
+    """C4: Ca+H, 40 columns: the first time lsx_sweep_kernel<3, {1,2}, 5, false> and <4, {1,2}, 5, false> meet the oracle"""
+    table = _run_pair(hip_lib, oracle_lib, 'falc_cah.npz', 40, 4321, 3e-11, [(1, 1), (2, 1), (2, 2), (3, 1), (3, 2), (4, 1), (4, 2)])
+    assert -1 not in [k[0] for k in table]                  # no tile falls back to the generic instance
+
+
+def test_single_column_reaches_the_fused_kernel(hip_lib):
+    """the counterpart: fewer than 32 columns take ONE fused launch (what the golden single-column tests exercise)"""
+    prob, base, raw = fixtures.load_problem_npz(golden('falc_ca.npz'))
+    e = Engine(prob, 1, lib=hip_lib)
+    e.set_columns(0, base)
+    e.formal_sol_gamma()
+    table, fused = class_table(hip_lib, e)
+    assert fused == 1 and all(launches == 0 for _, launches in table.values())
+    e.close()
+
+
+def test_profiles_must_be_set_before_a_formal_solution(hip_lib):
+    """lsx_set_columns with phi == NULL leaves the profiles to lsx_set_line_profiles; a formal solution in between is
+    refused instead of reading uninitialised memory"""
+    prob, base, raw = fixtures.load_problem_npz(golden('falc_ca.npz'), phi_compact=False)
+    blk, (aD, vB, vlos) = synth.perturbed_columns(prob, base, raw, ncol=2, seed=5, device_profiles=True)
+    e = Engine(prob, 2, lib=hip_lib)
+    e.set_columns(0, blk)
+    with pytest.raises(_capi.LsxError, match='no line profiles'):
+        e.formal_sol_gamma()
+    e.set_line_profiles(0, aD[:1], vB[:1], vlos[:1])
+    with pytest.raises(_capi.LsxError, match='column 1'):
+        e.formal_sol_gamma()
+    e.set_line_profiles(1, aD[1:], vB[1:], vlos[1:])
+    assert e.formal_sol_gamma() == 1.0
+    e.close()

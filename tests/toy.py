@@ -22,7 +22,11 @@ def _gl(n):
     return 0.5 * x + 0.5, 0.5 * w
 
 
-def toy_problem(seed=0, Nspace=37, Nrays=3, Nspect=90, ncol=3, sca_per_lambda=False, phi_compact=False, chain=True):
+def toy_problem(seed=0, Nspace=37, Nrays=3, Nspect=90, ncol=3, sca_per_lambda=False, phi_compact=False, chain=True,
+                dead_level=False):
+    """dead_level: atom 1 gets a fourth level that no radiative transition touches and no collision populates
+    (only collisions out of it): statistical equilibrium drives it to exactly 0, so the next stat_equil sees
+    0/0 = NaN in its relative change (the case rh_method.py:741's builtin max drops)."""
     rng = np.random.default_rng(seed)
     wavelength = np.sort(rng.uniform(90.0, 900.0, Nspect))
     wavelength[1:] += np.arange(1, Nspect) * 1e-3          # strictly increasing
@@ -42,7 +46,7 @@ def toy_problem(seed=0, Nspace=37, Nrays=3, Nspect=90, ncol=3, sca_per_lambda=Fa
         specs0.append(('c', 0, 1, 0.00, 0.28))
     # atom 1: continua only, 3 levels
     specs1 = [('c', 0, 2, 0.00, 0.35), ('c', 1, 2, 0.10, 0.75)]
-    Nlevel = [5, 3]
+    Nlevel = [5, 4 if dead_level else 3]
     for atom, specs in enumerate((specs0, specs1)):
         for kind, i, j, lo, hi in specs:
             Nblue, Nlam = rng_range(lo, hi)
@@ -94,6 +98,8 @@ def toy_problem(seed=0, Nspace=37, Nrays=3, Nspect=90, ncol=3, sca_per_lambda=Fa
             Ca = 10.0 ** rng.uniform(1.0, 4.0, (nl, nl, Ns)) * (ntot / ntot[-1]) ** 0.5
             for l in range(nl):
                 Ca[l, l] = 0.0
+            if dead_level and a == 1:
+                Ca[nl - 1, :] = 0.0                         # C[to][from]: nothing goes INTO the last level
             C[o:o + nl * nl] = Ca.reshape(nl * nl, Ns)
             o += nl * nl
         bg_chi = 1e-9 * np.exp(11.0 * depth)[None, :] * rng.uniform(0.5, 2.0, (Nspect, 1)) * (1 + 0.1 * rng.uniform(-1, 1, (Nspect, Ns)))
