@@ -7,7 +7,9 @@ over every atmosphere column resident on the GPU.  Workload (config.workload):
                 (BASELINE.json configs[2]; weak scaling: columns per GPU fixed)
   c2            the single FALC CaII column (configs[1]; 45 wavefronts -- latency bound by
                 construction, reported inside every run as `falc_single_column`)
-  c4            FALC-perturbed Ca+H columns (configs[3] per-GPU share, 1250 columns)
+  c4            FALC-perturbed Ca+H columns (configs[3] per-GPU share, 1250 columns); its one-GPU share is
+                also measured inside every default run (`c4_share`)
+  c5            the CaII temperature response function (configs[4]): 164 perturbed columns, sharded over the ranks
 value = depth-points x wavelengths x rays updated per second, whole job.
 Inputs are resident in HBM before the timed region.  One JSON line on stdout (rank 0).
 """
@@ -22,6 +24,10 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
+HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
+N_SIMD, CLOCK_HZ = 1024, 2.4e9    # 256 CUs x 4 SIMD-32, max clock
+VALU_PEAK = N_SIMD * CLOCK_HZ / 4.0   # wave64 fp64 VALU instructions per second (4 cycles each)
+
 
 def _gen_chunk(args):
     path, first, n, seed, vlos_sigma, compact, device_profiles = args
@@ -34,7 +40,6 @@ def _gen_chunk(args):
 def generate_columns(path, first, ncol, compact, nproc, seed=1234, chunk=25, device_profiles=True):
     """synthetic ensemble columns [first, first+ncol) (before the GPU is touched: fork is safe).
     -> (ColumnBlock, profile inputs or None)"""
-    import numpy as np
     from lightspinner_amd.problem import ColumnBlock
     jobs = [(path, first + c0, min(chunk, ncol - c0), seed, 0.0 if compact else 2.0e3, compact, device_profiles)
             for c0 in range(0, ncol, chunk)]
@@ -61,44 +66,107 @@ def load_columns(eng, batch, prof, c0=0, step=100):
         eng.set_line_profiles(c0, prof[0], prof[1], prof[2])
 
 
-def run_c5(args):
+def stats_ms(times):
+    t = np.asarray(times) * 1e3
+    return dict(min=float(t.min()), median=float(np.median(t)), max=float(t.max()), p10=float(np.percentile(t, 10)),
+                p90=float(np.percentile(t, 90)), n=int(t.size))
+
+
+def dist_env():
+    return int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+
+
+def init_gpu(local_rank, world):
+    """-> (torch, dist, device for collectives, rehearsal info or None).  LSX_BENCH_REHEARSE=1 runs the N > 1 flow with
+    every rank on GPU 0 and gloo instead of RCCL (RCCL refuses two ranks on one device): a rehearsal of the multi-rank code
+    path on a one-GPU box, labelled as such in the output -- never a multi-GPU measurement."""
+    import torch
+    import torch.distributed as dist
+    rehearse = os.environ.get('LSX_BENCH_REHEARSE') == '1'
+    if rehearse:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        if rehearse:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    dev = torch.device('cpu') if rehearse else torch.device('cuda', local_rank)
+    info = dict(rehearsal=True, backend='gloo', gpus_physical=1,
+                note='all ranks share ONE GPU and exchange over gloo: exercises the multi-rank code path only; the value is '
+                     'NOT a multi-GPU measurement') if rehearse else None
+    return torch, dist, dev, local_rank, info
+
+
+def parallelism_text(world, rehearsal):
+    if world == 1:
+        return 'one GPU (columns are independent 1-D problems; no collective)'
+    if rehearsal:
+        return 'REHEARSAL: %d ranks on one GPU, gloo all-reduce(MAX) of the convergence monitors per iteration' % world
+    return 'columns sharded over %d GPUs, no data-path collective; RCCL all-reduce(MAX) of (dJ, dPops, flags) per iteration' % world
+
+
+def run_c5(args, rank, local_rank, world):
     """C5 (response_fn.py): T[k] +- 25 K at every depth -> 164 perturbed FALC CaII columns, warm started from the
-    converged base column, every column iterated to ITS OWN convergence; rf = (I+ - I-) / I_base.  Single GPU.
-    Inputs: tests/golden/rf_ca_inputs.npz (all depths, written by make_golden.py rf_inputs); the three depths of
-    rf_ca.npz carry the reference's converged intensities and pin the result."""
-    import numpy as np
+    converged base column, every column iterated to ITS OWN convergence; rf = (I+ - I-) / I_base.  Over several ranks
+    the perturbed columns are block partitioned (164 -> 21 / 20 per GPU at 8), all_done = AND over ranks, the
+    intensities are gathered at the end.  Inputs: tests/golden/rf_ca_inputs.npz (all depths, written by make_golden.py
+    rf_inputs); the three depths of rf_ca.npz carry the reference's converged intensities and pin the result."""
     from lightspinner_amd import fixtures, response, _capi
+    from lightspinner_amd.parallel import AllDone
     gold = os.path.join(ROOT, 'tests', 'golden')
     prob, base, raw = fixtures.load_problem_npz(os.path.join(gold, 'falc_ca.npz'))
     fx = dict(np.load(os.path.join(gold, 'rf_ca_inputs.npz')))
     ks = list(range(int(fx['Nspace'])))
+    torch, dist, dev, local_rank, rehearsal = init_gpu(local_rank, world)
     lib = _capi.load_hip_library()
-    response.run_response_function(prob, base, fx, ks[:2], lib=lib)          # warm-up (library load, first launches)
+    kw = dict(lib=lib, device=local_rank, rank=rank, world=world)
+    if world > 1:
+        kw.update(all_done=AllDone(), gather=response.gather_over_ranks())
+    response.run_response_function(prob, base, fx, ks[:2 * world], **kw)          # warm-up (library load, first launches)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = response.run_response_function(prob, base, fx, ks, lib=lib)      # ends with a blocking read-back of I
+    out = response.run_response_function(prob, base, fx, ks, **kw)      # ends with a blocking read-back / gather of I
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
     ref = dict(np.load(os.path.join(gold, 'rf_ca.npz')))
     err = 0.0
     for k in [int(k) for k in ref['ks']]:
         r = (ref['k%dp_I' % k][:, -1] - ref['k%dm_I' % k][:, -1]) / ref['base_I'][:, -1]
         err = max(err, float(np.max(np.abs(out['rf'][:, k] - r)) / np.max(np.abs(r))))
-    col_iters = int(out['n_iter'].sum()) + out['n_iter_base']
+    col_iters = int(out['n_iter'].sum()) + out['n_iter_base'] * world     # every rank solves the base column itself
     units = prob.work_units_per_column() * col_iters
     steps = int(out['n_iter'].max()) + out['n_iter_base']
-    print(json.dumps(dict(
-        metric='depth_points_x_wavelengths_x_rays_per_sec', value=units / dt, unit='point-updates/s', n_gpus=1, steps=steps,
-        warmup=0, ms_per_step=dt / steps * 1e3, higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64',
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    result = dict(
+        metric='depth_points_x_wavelengths_x_rays_per_sec', value=units / dt, unit='point-updates/s', n_gpus=world, steps=steps,
+        warmup=0, ms_per_step=dt / steps * 1e3, higher_is_better=True, scaling='strong', vs_baseline=None, dtype='f64',
         data='FALC CaII + reference-generated temperature perturbations (tests/golden/rf_ca_inputs.npz)',
         config=dict(workload='C5: CaII temperature response function, %d perturbed columns (T[k] +- 25 K at %d depths) + base, '
                              'per-column convergence' % (2 * len(ks), len(ks)), columns_total=2 * len(ks) + 1,
-                    Nspace=prob.Nspace, Nspect=prob.Nspect, Nrays=prob.Nrays, parallelism='single GPU'),
+                    Nspace=prob.Nspace, Nspect=prob.Nspect, Nrays=prob.Nrays, parallelism=parallelism_text(world, rehearsal)),
         response_function=dict(seconds_total=dt, base_iterations=out['n_iter_base'],
                                perturbed_iterations_min=int(out['n_iter'].min()), perturbed_iterations_max=int(out['n_iter'].max()),
                                column_iterations=col_iters, rf_shape=list(out['rf'].shape),
                                max_abs_err_vs_reference_rf_over_max=err,
                                reference_depths_checked=[int(k) for k in ref['ks']],
                                note='the reference runs these 165 MALI solves one after the other in pure Python (~2 h here)'),
-        roofline=None, cpu_baseline=None)))
+        roofline=None, cpu_baseline=None)
+    if rehearsal:
+        result.update(rehearsal)
+    print(json.dumps(result))
 
 
 def cpu_baseline(prob, batch, prof, seconds_target=12.0):
@@ -134,31 +202,123 @@ def cpu_baseline(prob, batch, prof, seconds_target=12.0):
                 value_1thread=out['1thread']['value'])
 
 
+def profile_figures(workload):
+    """counter-derived figures of an EARLIER, builder-run rocprofv3 collection (profiles/pmc_figures.json, written by
+    profiles/summarize.py): HBM bytes and VALU work per column per formal-solution call.  Static: labelled as such."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_figures.json')
+    try:
+        return json.load(open(path)).get(workload), 'profiles/pmc_figures.json'
+    except Exception:
+        return None, None
+
+
+def roofline_block(eng, lib, prob, ncol, workload, kernel_reps):
+    """roofline of the dominant kernel, measured live with HIP events on the kernels' own streams (lsx_time_formal_sol)"""
+    import ctypes as C
+    ms_total, ms_sweep = eng.time_formal_sol(2, kernel_reps)
+    lib.dll.lsx_hip_info.argtypes = [C.c_void_p, C.c_int32]
+    lib.dll.lsx_hip_info.restype = C.c_double
+    info = lambda w: float(lib.dll.lsx_hip_info(eng._h, w))
+    balg = eng.algorithmic_bytes_per_column()      # SURVEY 8d formula, whole FS call
+    bsweep = info(0)                               # the part of it the sweep kernel itself moves
+    ach = bsweep * ncol / (ms_sweep * 1e-3) / 1e9
+    fig, src = profile_figures(workload)
+    traffic = valu = None
+    bound = 'hbm'
+    if fig:
+        if fig.get('hbm_bytes_per_call_per_column') is not None:
+            traffic = fig['hbm_bytes_per_call_per_column'] * ncol
+        if fig.get('valu_insts_per_call_per_column') is not None:
+            rate = fig['valu_insts_per_call_per_column'] * ncol / (ms_sweep * 1e-3)
+            valu = dict(achieved=rate, peak=VALU_PEAK, unit='wave64 VALU instructions/s', frac=rate / VALU_PEAK,
+                        peak_definition='1024 SIMDs x 2.4 GHz / 4 cycles: the issue rate of fp64 VALU instructions (wave64 on a '
+                                        'SIMD-32 at half rate); 32-bit VALU instructions take 2 cycles, so frac slightly '
+                                        'overstates the pipe share of a mixed stream -- pmc_busy_frac is the counter ratio',
+                        pmc_busy_frac=fig.get('valu_busy_frac'), f64_share_of_valu_insts=fig.get('f64_share_of_valu_insts'),
+                        insts_per_launch=fig['valu_insts_per_call_per_column'] * ncol,
+                        source='%s (instruction counts from a builder-run rocprofv3 --pmc pass of this command, per column; '
+                               'divided by the LIVE duration)' % src)
+            if valu['frac'] > ach / HBM_PEAK_GBPS:
+                bound = 'valu'
+    return dict(bound=bound, kernel='lsx_sweep_kernel<slots,lines,rays,sca> (one instance per tile class, launched side by side; '
+                                    'duration = span)',
+                achieved=ach, peak=HBM_PEAK_GBPS, unit='GB/s', frac=ach / HBM_PEAK_GBPS, traffic=traffic,
+                traffic_source=('%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a builder run, (2*FETCH_SIZE + WRITE_SIZE)'
+                                '*1024 per call per column x columns; not measured in this run' % src) if traffic is not None else None,
+                valu=valu, alg_bytes_per_launch=bsweep * ncol, avg_launch_ms=ms_sweep,
+                fs_call=dict(ms=ms_total, ms_sweep_kernel=ms_sweep, ms_epilogue_kernels=info(4), alg_bytes=balg * ncol,
+                             achieved_GBps=balg * ncol / (ms_total * 1e-3) / 1e9,
+                             frac=balg * ncol / (ms_total * 1e-3) / 1e9 / HBM_PEAK_GBPS),
+                point_updates_per_sec_kernel=prob.work_units_per_column() * ncol / (ms_sweep * 1e-3),
+                tiles_per_column=info(1), wavelengths_per_tile=info(3), lds_bytes_per_workgroup=info(2),
+                slab_bytes_per_column=info(5),
+                note='achieved/peak/frac = algorithmic bytes against the HBM peak (HIP-event duration on the launch streams, from '
+                     'before the first class launch to after the last class joined back; profiles/README.md). `bound` names the '
+                     'resource with the larger fraction: the sweep issues ~150 fp64-rate VALU instructions per 13 algorithmic '
+                     'bytes, so vector issue, not HBM, is what it runs against (valu.frac, valu.pmc_busy_frac)')
+
+
+def timed_steps(eng, reducer, nsteps, warmup, barrier):
+    from lightspinner_amd import drivers
+    for _ in range(warmup):
+        drivers.mali_step(eng, True, reducer)
+    barrier()
+    per = []
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        ta = time.perf_counter()
+        dJ, dP = drivers.mali_step(eng, True, reducer)
+        per.append(time.perf_counter() - ta)
+    barrier()
+    return time.perf_counter() - t0, per, dJ, dP
+
+
+def measure_share(workload, ncol, local_rank, lib, torch, steps=40, warmup=3, kernel_reps=10):
+    """one GPU's share of another configuration, measured in the same run (used for C4: the north-star workload's
+    per-GPU share of 1250 Ca+H columns) -> dict"""
+    from lightspinner_amd import fixtures, Engine
+    fixture = os.path.join(ROOT, 'tests', 'golden', 'falc_cah.npz' if workload == 'c4' else 'falc_ca.npz')
+    prob, base, raw = fixtures.load_problem_npz(fixture, phi_compact=False)
+    t0 = time.time()
+    batch, prof = generate_columns(fixture, 0, ncol, False, 1)
+    t_gen = time.time() - t0
+    ts = torch.cuda.Stream()
+    eng = Engine(prob, ncol, device=local_rank, stream=ts.cuda_stream, lib=lib)
+    load_columns(eng, batch, prof)
+    del batch
+    dt, per, dJ, dP = timed_steps(eng, None, steps, warmup, torch.cuda.synchronize)
+    units = prob.work_units_per_column() * ncol * steps
+    roof = roofline_block(eng, lib, prob, ncol, workload, kernel_reps)
+    eng.close()
+    return dict(workload='C4 share: %d FALC-perturbed Ca+H columns on one GPU (10 000 / 8), 82 depth x %d wavelengths x 5 rays x 2'
+                         % (ncol, prob.Nspect),
+                columns=ncol, steps=steps, value=units / dt, unit='point-updates/s', ms_per_step=dt / steps * 1e3,
+                step_ms=stats_ms(per), last_dJ=dJ, last_dPops=dP, sweep_span_ms=roof['avg_launch_ms'], roofline=roof,
+                generate_s=t_gen)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='c3', choices=['c2', 'c3', 'c4', 'c5'])
     ap.add_argument('--columns', type=int, default=None, help='columns per GPU (default 1000 / 1 / 1250)')
     ap.add_argument('--compact-phi', action='store_true', help='vlos == 0: ray independent profiles (P = 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host-profiles', action='store_true', help='build the line profiles on the host (scipy) and upload them')
-    ap.add_argument('--kernel-reps', type=int, default=10)
+    ap.add_argument('--kernel-reps', type=int, default=20)
     ap.add_argument('--no-single-column', action='store_true',
                     help='skip the FALC single-column section (used for rocprofv3 runs so that every sweep launch has the workload size)')
+    ap.add_argument('--no-c4-share', action='store_true', help='skip the C4 per-GPU share measured beside the default workload')
     args = ap.parse_args()
 
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank, local_rank, world = dist_env()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
     if args.workload == 'c5':
-        if world > 1:
-            raise SystemExit('--workload c5 runs on one GPU')
-        return run_c5(args)
+        return run_c5(args, rank, local_rank, world)
     fixture = os.path.join(ROOT, 'tests', 'golden', 'falc_cah.npz' if args.workload == 'c4' else 'falc_ca.npz')
     ncol = args.columns or {'c2': 1, 'c3': 1000, 'c4': 1250}[args.workload]
     compact = args.compact_phi or args.workload == 'c2'
@@ -178,52 +338,27 @@ def main():
         cpu = cpu_baseline(prob, batch, prof)
 
     # ---- GPU ---------------------------------------------------------------------------
-    import torch
-    import torch.distributed as dist
-    # rehearsal hook: LSX_BENCH_REHEARSE=1 runs the N > 1 flow with every rank on GPU 0 and gloo instead of RCCL
-    # (RCCL refuses two ranks on one device), to exercise the multi-rank code path on a one-GPU box
-    rehearse = os.environ.get('LSX_BENCH_REHEARSE') == '1'
-    if rehearse:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        if rehearse:
-            dist.init_process_group('gloo')
-        else:
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    dev = torch.device('cpu') if rehearse else torch.device('cuda', local_rank)
-    stream = torch.cuda.current_stream().cuda_stream
+    torch, dist, dev, local_rank, rehearsal = init_gpu(local_rank, world)
     lib = _capi.load_hip_library()
-    eng = Engine(prob, ncol, device=local_rank, stream=stream or None, lib=lib)
+    ts = torch.cuda.Stream()                      # the engine launches on this stream; so does the collective (MaxReducer)
+    eng = Engine(prob, ncol, device=local_rank, stream=ts.cuda_stream, lib=lib)
     t0 = time.time()
     load_columns(eng, batch, prof)
     t_up = time.time() - t0
     upload_bytes = sum(getattr(batch, k).nbytes for k in ('phi', 'bg_chi', 'bg_eta', 'C', 'n', 'nStar') if getattr(batch, k) is not None)
     if prof is not None:
         upload_bytes += sum(p.nbytes for p in prof if p is not None)
-    reducer = MaxReducer(device=dev)
-
-    def step():
-        # one MALI iteration: both calls are enqueued, the host reads (dJ, dPops) once -- what the
-        # reference's `while dJ > 2e-3 or dPops > 1e-3` loop needs per iteration (test.py:23-29)
-        eng.formal_sol_gamma_async()
-        eng.stat_equil_async()
-        dJ, dP = eng.sync()
-        return reducer(dJ, dP)
+    # one MALI iteration: both calls are enqueued, the monitors are read once -- what the reference's
+    # `while dJ > 2e-3 or dPops > 1e-3` loop needs per iteration (test.py:23-29).  Over several ranks the monitors stay
+    # on the device until RCCL has reduced them (parallel.MaxReducer.engine)
+    reducer = MaxReducer(device=dev, stream=ts) if world > 1 else None
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        dJ, dP = step()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt, per_step, dJ, dP = timed_steps(eng, reducer, args.steps, args.warmup, barrier)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -232,49 +367,16 @@ def main():
     units = prob.work_units_per_column() * ncol * world * args.steps
     result = None
     if rank == 0:
-        # ---- roofline of the dominant kernel, HIP events on the kernel's own stream ----
-        ms_total, ms_sweep = eng.time_formal_sol(2, args.kernel_reps)
-        import ctypes as C
-        lib.dll.lsx_hip_info.argtypes = [C.c_void_p, C.c_int32]
-        lib.dll.lsx_hip_info.restype = C.c_double
-        info = lambda w: float(lib.dll.lsx_hip_info(eng._h, w))
-        balg = eng.algorithmic_bytes_per_column()      # SURVEY 8d formula, whole FS call
-        bsweep = info(0)                               # the part of it the sweep kernel itself moves
-        peak = 8000.0
-        kernel = 'lsx_sweep_kernel<slots,lines,rays,sca> (one instance per tile class, launched side by side; duration = span)'
-        traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(args.workload, {}).get('hbm_bytes_per_launch_per_column')
-                traffic = traffic * ncol if traffic is not None else None
-            except Exception:
-                traffic = None
-        ach = bsweep * ncol / (ms_sweep * 1e-3) / 1e9
-        roofline = dict(bound='hbm', kernel=kernel, achieved=ach, peak=peak, unit='GB/s', frac=ach / peak, traffic=traffic,
-                        alg_bytes_per_launch=bsweep * ncol, avg_launch_ms=ms_sweep,
-                        fs_call=dict(ms=ms_total, ms_sweep_kernel=ms_sweep, ms_epilogue_kernels=info(4), alg_bytes=balg * ncol,
-                                     achieved_GBps=balg * ncol / (ms_total * 1e-3) / 1e9,
-                                     frac=balg * ncol / (ms_total * 1e-3) / 1e9 / peak),
-                        point_updates_per_sec_kernel=prob.work_units_per_column() * ncol / (ms_sweep * 1e-3),
-                        tiles_per_column=info(1), wavelengths_per_tile=info(3), lds_bytes_per_workgroup=info(2),
-                        slab_bytes_per_column=info(5),
-                        note='achieved = algorithmic bytes / HIP-event duration on the launch stream, from before the first '
-                             'class launch to after the last class joined back (profiles/README.md). The sweep is fp64-issue '
-                             'bound (~0.6 M wave-level VALU instructions per column, profiles/r01_pmc_summary.json), not HBM bound')
+        roofline = roofline_block(eng, lib, prob, ncol, args.workload, args.kernel_reps)
 
         # ---- parity + single-column (C2) numbers in the same run -----------------------
         single = None
         if not args.no_single_column:
             p1, b1, r1 = fixtures.load_problem_npz(os.path.join(ROOT, 'tests', 'golden', 'falc_ca.npz'))
-            e1 = Engine(p1, 1, device=local_rank, stream=stream or None, lib=lib)
+            e1 = Engine(p1, 1, device=local_rank, stream=ts.cuda_stream, lib=lib)
             e1.set_columns(0, b1)
-
-            class A:
-                def formal_sol_gamma_matrices(self): return e1.formal_sol_gamma()
-                def stat_equil(self): return e1.stat_equil()
             t0 = time.perf_counter()
-            h = drivers.iterate_mali(A())
+            h = drivers.iterate_mali_engine(e1)
             t_c2 = time.perf_counter() - t0
             nref = fixtures.pops_from_raw(r1, 'conv', p1)
             n1 = e1.get(_capi.LSX_N)[0]
@@ -293,7 +395,8 @@ def main():
                                             'c4': 'C4 share: %d FALC-perturbed Ca+H columns per GPU, 82 depth x 777 wavelengths x 5 rays x 2' % ncol}[args.workload],
                                   columns_per_gpu=ncol, columns_total=ncol * world, Nspace=prob.Nspace, Nspect=prob.Nspect,
                                   Nrays=prob.Nrays, profiles='compact (vlos=0)' if compact else 'ray dependent (vlos!=0)',
-                                  parallelism='columns sharded over %d GPU(s); RCCL all-reduce(MAX) of (dJ, dPops) per iteration' % world),
+                                  parallelism=parallelism_text(world, rehearsal)),
+                      step_ms=dict(stats_ms(per_step), note='host clock around each step on rank 0 (a step ends with the read-back of the monitors)'),
                       mali_iters_per_sec=args.steps / dt, column_iters_per_sec=args.steps * ncol * world / dt,
                       last_dJ=dJ, last_dPops=dP,
                       roofline=roofline, cpu_baseline=cpu, falc_single_column=single,
@@ -301,7 +404,12 @@ def main():
                       setup=dict(generate_s=t_gen, upload_s=t_up, upload_GB=upload_bytes / 1e9,
                                  line_profiles='built on the device (lsx_set_line_profiles)' if prof is not None else 'built on the host and uploaded',
                                  note='PCIe-inclusive upload (and the device-side profile build) is outside the timed region (inputs resident in HBM)'))
+        if rehearsal:
+            result.update(rehearsal)
     eng.close()
+    del batch
+    if rank == 0 and world == 1 and args.workload == 'c3' and not args.no_c4_share:
+        result['c4_share'] = measure_share('c4', 1250, local_rank, lib, torch)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

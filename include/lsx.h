@@ -162,6 +162,15 @@ int lsx_formal_sol_gamma_async(lsx_ctx* ctx);
 int lsx_stat_equil_async(lsx_ctx* ctx);
 int lsx_sync(lsx_ctx* ctx, double* dJ_max, double* dPops_max);
 
+/* The convergence monitors of the most recent (enqueued) calls, reduced over this context's columns and left where the
+ * caller's collective can take them without a host round trip: dst[0] = max dJ, dst[1] = max dPops, dst[2] = 1 if dJ is
+ * NaN anywhere else 0 (MAX collectives do not order NaN; with the flag set dst[0] holds the maximum of the other
+ * columns), dst[3] = 1 if a statistical-equilibrium system was singular else 0.  For the HIP library dst is a DEVICE
+ * pointer to 4 doubles and the reduction is enqueued on the context's stream (hand dst to the all-reduce on that stream,
+ * read it once afterwards); for the oracle it is host memory.  This is the per-iteration exchange of a multi-GPU MALI
+ * loop (test.py:23 over all ranks: one all-reduce(MAX) of these four numbers). */
+int lsx_monitors(lsx_ctx* ctx, double* dst);
+
 /* Copy results for columns [col0, col0+ncol) to host memory (reference layouts). */
 int lsx_get(lsx_ctx* ctx, int32_t what, int32_t col0, int32_t ncol, double* dst,
             size_t nbytes);

@@ -49,7 +49,7 @@ REQUIRED_SYMBOLS = (
     'lsx_formal_sol_gamma_async', 'lsx_stat_equil_async', 'lsx_sync', 'lsx_get', 'lsx_set',
     'lsx_piecewise_linear_1d', 'lsx_time_formal_sol', 'lsx_last_error', 'lsx_backend_name',
     'lsx_abi_version', 'lsx_algorithmic_bytes_per_column', 'lsx_set_active_columns', 'lsx_set_line_profiles',
-    'lsx_piecewise_1d_impl', 'lsx_w2',
+    'lsx_piecewise_1d_impl', 'lsx_w2', 'lsx_monitors',
 )
 
 
@@ -108,6 +108,7 @@ class LsxLibrary:
         d.lsx_piecewise_1d_impl.argtypes = [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.POINTER(C.c_int32), _dp, _dp, _dp,
                                             _dp, _dp]
         d.lsx_w2.argtypes = [C.c_int32, C.c_int32, _dp, _dp]
+        d.lsx_monitors.argtypes = [C.c_void_p, C.c_void_p]
         d.lsx_set_active_columns.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
         d.lsx_set_line_profiles.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp]
         d.lsx_time_formal_sol.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp]

@@ -18,8 +18,33 @@
 #include <string>
 #include <vector>
 
-#include "../../include/lsx.h"
-#include "lsx_dev.h"
+#include "lsx_ctx.h"
+
+namespace lsxd {
+thread_local std::string g_err;
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+int ensure_stage(lsx_ctx* c, size_t doubles)
+{
+    if (doubles <= c->stage_doubles) return LSX_OK;
+    if (c->d_stage) HIPCHK(hipFree(c->d_stage));
+    c->d_stage = nullptr;
+    c->stage_doubles = 0;
+    int rc = dmalloc(&c->d_stage, doubles);
+    if (rc) return rc;
+    c->stage_doubles = doubles;
+    return LSX_OK;
+}
+} // namespace lsxd
+using namespace lsxd;
 
 // launcher defined in lsx_sweep.hip
 extern "C" hipError_t lsx_launch_sweep(const SweepParams*, int, int, size_t, hipStream_t);
@@ -32,24 +57,6 @@ constexpr double kKBoltzmann = 1.380658E-23;
 constexpr double kNM_TO_M = 1.0E-09;
 constexpr double kHC = kHPlanck * kCLight;
 
-thread_local std::string g_err;
-
-int fail(int code, const char* fmt, ...)
-{
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    g_err = buf;
-    return code;
-}
-
-#define HIPCHK(expr)                                                                             \
-    do {                                                                                         \
-        hipError_t e_ = (expr);                                                                  \
-        if (e_ != hipSuccess) return fail(LSX_EDEVICE, "%s: %s", #expr, hipGetErrorString(e_));  \
-    } while (0)
 
 // ------------------------------------------------------------------------------- kernels
 // one (tile, line) block of the profile: in [col][lt][mu][dir][k] (rows lt0 .. lt0+len of the line)
@@ -619,6 +626,37 @@ __global__ void k_stat_equil(const double* __restrict__ Gamma, const double* __r
     if (mx == mx) atomic_max_nonneg(&dPcol[col], mx);
 }
 
+// max over the context's columns of the per-column monitors (lsx_monitors): one block, fixed order
+__global__ void __launch_bounds__(256)
+k_monitors(const double* __restrict__ res, int ncol, double* __restrict__ dst)
+{
+    __shared__ double sj[256], sp[256];
+    __shared__ int sn[256];
+    double mj = 0.0, mp = 0.0;
+    int nan = 0;
+    for (int c = threadIdx.x; c < ncol; c += 256) {
+        const double a = res[c], b = res[ncol + c];
+        if (a != a) nan = 1; else mj = fmax(mj, a);
+        mp = fmax(mp, b);                       // per-column dPops is never NaN (k_stat_equil)
+    }
+    sj[threadIdx.x] = mj; sp[threadIdx.x] = mp; sn[threadIdx.x] = nan;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) {
+            sj[threadIdx.x] = fmax(sj[threadIdx.x], sj[threadIdx.x + h]);
+            sp[threadIdx.x] = fmax(sp[threadIdx.x], sp[threadIdx.x + h]);
+            sn[threadIdx.x] |= sn[threadIdx.x + h];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        dst[0] = sj[0];
+        dst[1] = sp[0];
+        dst[2] = sn[0] ? 1.0 : 0.0;
+        dst[3] = reinterpret_cast<const unsigned long long*>(res)[2 * (size_t)ncol] ? 1.0 : 0.0;
+    }
+}
+
 // The same elimination with the system in registers: NL is a compile-time constant, every loop is unrolled and the
 // data-dependent row choices (the eliminated row, the pivot) become predicated selects.  Same operations in the same
 // order as k_stat_equil => identical results; used for the small atoms (NL <= 8) that stellar problems have.
@@ -808,115 +846,7 @@ std::vector<double> make_exp2_table()
 } // namespace
 
 // ------------------------------------------------------------------------------- context
-struct SweepClass {           // tiles that run the same kernel instantiation, launched on their own stream
-    int npt = -1;              // compile-time per-ray slot count, -1 = generic
-    long launches = 0;         // how often this class's kernel has been launched (introspection for the tests)
-    int nl = 0;                // lines among them (compile-time too)
-    bool has_fast = false;     // some tile of the class has fast continua: the class reads the pre-pass output
-    hipEvent_t tdone = nullptr; // timed runs: end of this class's launch
-    std::vector<int> fast_tiles; // the class's tiles that have fast continua
-    int* d_fast_tiles = nullptr;
-    std::vector<int> tiles;
-    int* d_tiles = nullptr;
-    int ncell_lev = 1, ncell_atom = 1;
-    size_t lds_bytes = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t done = nullptr;
-};
-
-struct lsx_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    int Nspace = 0, Nrays = 0, Nspect = 0, Natoms = 0, Ntrans = 0, ncol = 0;
-    int NLtot = 0, NL2tot = 0, Nlines = 0, SNl = 0, SNc = 0;
-    int sca_per_lambda = 0, phi_compact = 0;
-    std::vector<int> Nlevel, lev_off, lev2_off;
-    std::vector<lsx_transition> trans;
-    std::vector<DevTrans> htrans;
-    std::vector<DevTile> tiles;
-    std::vector<int> tile_slots;
-    std::vector<DevSlot> slots;
-    DevSlot* d_slots = nullptr;
-    int L = 0;
-    std::vector<SweepClass> classes;
-    hipEvent_t ev_fork = nullptr;
-    double ms_sweep = 0.0, ms_finish = 0.0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
-    size_t lds_bytes = 0;
-    // device: column independent
-    double *d_wavelength = nullptr, *d_zmu = nullptr, *d_wmuh = nullptr, *d_wl = nullptr, *d_alpha = nullptr,
-           *d_u_la = nullptr;
-    uint8_t* d_active = nullptr;
-    DevTrans* d_trans = nullptr;
-    DevTile* d_tiles = nullptr;
-    int *d_tile_slots = nullptr, *d_Nlevel = nullptr, *d_lev2_off = nullptr;
-    // device: per column
-    double *d_height = nullptr, *d_temperature = nullptr, *d_nStar = nullptr, *d_nTotal = nullptr, *d_n = nullptr,
-           *d_C = nullptr, *d_Gamma = nullptr, *d_wphi = nullptr, *d_bgchi = nullptr, *d_bgeta = nullptr,
-           *d_sca = nullptr, *d_phi = nullptr, *d_gijc = nullptr, *d_J[2] = {nullptr, nullptr}, *d_I = nullptr,
-           *d_Gpart = nullptr, *d_dJpart = nullptr, *d_dJcol = nullptr, *d_dPcol = nullptr, *d_res = nullptr;
-    unsigned long long* d_singular = nullptr;
-    std::vector<uint8_t> phi_set;    // per column: line profiles have been handed over or built
-    size_t n_phi_set = 0;
-    bool opt_se_lds = false, opt_trace_classes = false;   // LSX_SE_LDS / LSX_TRACE_CLASSES, read once in lsx_create
-    long fused_launches = 0;
-    uint8_t* d_colmask = nullptr; // per-column activity, nullptr = all active
-    double *d_bgxchi = nullptr, *d_bgxeta = nullptr, *d_Psi2 = nullptr; // fast-continuum side arrays
-    std::vector<int> fast_tiles;
-    int* d_fast_tiles = nullptr;
-    int *d_cont_li = nullptr, *d_cont_lj = nullptr;
-    double* d_exp2_tab = nullptr;
-    double* d_hck_la = nullptr;
-    double* d_voigt_w = nullptr;
-    double *d_muz = nullptr, *d_wmu = nullptr;
-    int nF_max = 0, Ncont = 0, static_max = -1;
-    bool fast_generic = false;
-    double* d_nsr = nullptr;     // [col][Ncont][k] nStar_i / nStar_j of the continua
-    std::vector<int> cont_li, cont_lj;
-    double* d_debug = nullptr;   // 64 x 16 x 8 B, diagnostic builds of the sweep kernel write stamps here
-    int jcur = 0; // d_J[jcur] holds the current J (Jdag of the next call)
-    size_t phi_col = 0, phi_in_col = 0, gijc_col = 0, sca_col = 0, til_col = 0;
-    // staging
-    double* d_stage = nullptr;
-    size_t stage_doubles = 0;
-    double* h_pinned = nullptr; // host mirror of d_res
-    double last_dJ = 0.0, last_dP = 0.0;
-    bool fs_pending = false, se_pending = false;
-    hipEvent_t evA = nullptr, evB = nullptr;
-};
-
 namespace {
-
-template <typename T>
-int dmalloc(T** p, size_t count)
-{
-    if (count == 0) count = 1;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
-    if (e != hipSuccess) return fail(LSX_EDEVICE, "hipMalloc(%zu bytes): %s", count * sizeof(T), hipGetErrorString(e));
-    return LSX_OK;
-}
-
-template <typename T>
-int upload(T** dptr, const std::vector<T>& v, hipStream_t st)
-{
-    int rc = dmalloc(dptr, v.size());
-    if (rc) return rc;
-    if (!v.empty()) HIPCHK(hipMemcpyAsync(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
-    return LSX_OK;
-}
-
-int ensure_stage(lsx_ctx* c, size_t doubles)
-{
-    if (doubles <= c->stage_doubles) return LSX_OK;
-    if (c->d_stage) HIPCHK(hipFree(c->d_stage));
-    c->d_stage = nullptr;
-    c->stage_doubles = 0;
-    int rc = dmalloc(&c->d_stage, doubles);
-    if (rc) return rc;
-    c->stage_doubles = doubles;
-    return LSX_OK;
-}
 
 int launch_tiles_pack(lsx_ctx* c, const double* in, double* out, int B, bool unpack)
 {
@@ -943,9 +873,83 @@ double wlambda(const lsx_ctx* c, const std::vector<double>& wave, const lsx_tran
 
 } // namespace
 
+namespace lsxd {
+
+// what depends on (nStar, temperature) of columns [cc, cc + nb): the continuum g_ij tables (rh_method.py:453-454), one
+// block per (tile, per-ray continuum), and the nStar ratios the fast continua use.  Enqueued on the context's stream.
+int rebuild_derived(lsx_ctx* c, size_t cc, size_t nb)
+{
+    const int Ns = c->Nspace;
+    for (const DevSlot& sl : c->slots) {
+        if ((sl.flags & (SLOT_LINE | SLOT_FAST)) || sl.len <= 0) continue;
+        dim3 grid((sl.len * Ns + 255) / 256, (unsigned)nb);
+        hipLaunchKernelGGL(k_build_gijc, grid, dim3(256), 0, c->stream, c->d_nStar + cc * c->NLtot * Ns,
+                           c->d_temperature + cc * Ns, c->d_wavelength, c->d_gijc + cc * c->gijc_col + sl.base, sl.li, sl.lj,
+                           sl.first, sl.len, Ns, c->NLtot, c->gijc_col);
+        HIPCHK(hipGetLastError());
+    }
+    if (c->d_nsr) {
+        dim3 grid((c->Ncont * Ns + 255) / 256, (unsigned)nb);
+        hipLaunchKernelGGL(k_build_nsr, grid, dim3(256), 0, c->stream, c->d_nStar + cc * c->NLtot * Ns,
+                           c->d_nsr + cc * c->Ncont * Ns, c->d_cont_li, c->d_cont_lj, c->Ncont, (int)Ns, c->NLtot);
+        HIPCHK(hipGetLastError());
+    }
+    return LSX_OK;
+}
+
+// compute_phi (rh_method.py:198-243) for columns [cc, cc + nb) from DEVICE arrays dA [nb][Nlines][Ns], dV [nb][Natoms][Ns],
+// dL [nb][Ns] or null: the sweep's (tile, line) profile blocks and the normalisation wphi.  Enqueued on the context's stream.
+int profiles_from_device(lsx_ctx* c, size_t cc, size_t nb, const double* dA, const double* dV, const double* dL)
+{
+    const int Ns = c->Nspace;
+    if (!c->d_voigt_w) {
+        std::vector<double> W(56);
+        for (int g = 0; g < 2; ++g)
+            for (int n = -14; n <= 13; ++n) { const double x = (n + 0.5 * g) * 0.5; W[g * 28 + n + 14] = std::exp(-x * x); }
+        int rc = upload(&c->d_voigt_w, W, c->stream);
+        if (rc) return rc;
+    }
+    VoigtParams q{};
+    q.Ns = Ns; q.Nlines = c->Nlines; q.Natoms = c->Natoms; q.wavelength = c->d_wavelength; q.muz = c->d_muz; q.wmu = c->d_wmu;
+    q.W = c->d_voigt_w; q.aDamp = dA; q.vBroad = dV; q.vlos = dL;
+    // the profile blocks of the sweep, one launch per (tile, line)
+    const int R = c->phi_compact ? 1 : c->Nrays, D = c->phi_compact ? 1 : 2;
+    q.Nrays = R; q.ndir = D;
+    for (const DevSlot& sl : c->slots) {
+        if (!(sl.flags & SLOT_LINE) || sl.len <= 0) continue;
+        const DevTrans& h = c->htrans[sl.trans];
+        const size_t total = (size_t)sl.len * R * D * Ns;
+        dim3 grid((unsigned)std::min<size_t>((total + 255) / 256, 256), (unsigned)nb);
+        hipLaunchKernelGGL(k_voigt_block, grid, dim3(256), 0, c->stream, q, c->d_phi + cc * c->phi_col + sl.base, c->phi_col,
+                           sl.first, sl.len, h.line_idx, h.atom, h.lambda0);
+        HIPCHK(hipGetLastError());
+    }
+    // the normalisation of every line
+    q.Nrays = c->Nrays; q.ndir = 2;
+    for (int t = 0; t < c->Ntrans; ++t) {
+        const DevTrans& h = c->htrans[t];
+        if (!h.is_line) continue;
+        const long nth = (long)nb * Ns;
+        hipLaunchKernelGGL(k_voigt_wphi, dim3((unsigned)((nth + 63) / 64)), dim3(64), 0, c->stream, q,
+                           c->d_wphi + cc * c->Nlines * Ns, (int)nb, h.Nblue, h.Nlam, h.line_idx, h.atom, h.lambda0);
+        HIPCHK(hipGetLastError());
+    }
+    return LSX_OK;
+}
+
+void mark_profiles_set(lsx_ctx* c, size_t col0, size_t ncol)
+{
+    for (size_t q = 0; q < ncol; ++q) {
+        c->n_phi_set += (size_t)1 - c->phi_set[col0 + q];
+        c->phi_set[col0 + q] = 1;
+    }
+}
+
+} // namespace lsxd
+
 extern "C" {
 
-const char* lsx_last_error(void) { return g_err.c_str(); }
+const char* lsx_last_error(void) { return lsxd::g_err.c_str(); }
 const char* lsx_backend_name(void) { return "hip-gfx950"; }
 int32_t lsx_abi_version(void) { return LSX_ABI_VERSION; }
 
@@ -1447,21 +1451,7 @@ int lsx_set_columns(lsx_ctx* c, int32_t col0, int32_t ncol, const lsx_columns* s
                 HIPCHK(hipGetLastError());
             }
         }
-        // continuum g_ij tables, one block per (tile, continuum)
-        for (const DevSlot& sl : c->slots) {
-            if ((sl.flags & (SLOT_LINE | SLOT_FAST)) || sl.len <= 0) continue;
-            dim3 grid((sl.len * Ns + 255) / 256, (unsigned)nb);
-            hipLaunchKernelGGL(k_build_gijc, grid, dim3(256), 0, c->stream, c->d_nStar + cc * c->NLtot * Ns,
-                               c->d_temperature + cc * Ns, c->d_wavelength, c->d_gijc + cc * c->gijc_col + sl.base, sl.li, sl.lj,
-                               sl.first, sl.len, Ns, c->NLtot, c->gijc_col);
-            HIPCHK(hipGetLastError());
-        }
-        if (c->d_nsr) {
-            dim3 grid((c->Ncont * Ns + 255) / 256, (unsigned)nb);
-            hipLaunchKernelGGL(k_build_nsr, grid, dim3(256), 0, c->stream, c->d_nStar + cc * c->NLtot * Ns,
-                               c->d_nsr + cc * c->Ncont * Ns, c->d_cont_li, c->d_cont_lj, c->Ncont, (int)Ns, c->NLtot);
-            HIPCHK(hipGetLastError());
-        }
+        TRY(rebuild_derived(c, cc, nb));            // continuum g_ij tables and nStar ratios of these columns
         HIPCHK(hipStreamSynchronize(c->stream)); // the staging buffer is re-used by the next sub-chunk
     }
 #undef TRY
@@ -1613,13 +1603,6 @@ int lsx_set_line_profiles(lsx_ctx* c, int32_t col0, int32_t ncol, const double* 
     if (!c->Nlines) return LSX_OK;
     HIPCHK(hipSetDevice(c->device));
     const int Ns = c->Nspace;
-    if (!c->d_voigt_w) {
-        std::vector<double> W(56);
-        for (int g = 0; g < 2; ++g)
-            for (int n = -14; n <= 13; ++n) { const double x = (n + 0.5 * g) * 0.5; W[g * 28 + n + 14] = std::exp(-x * x); }
-        int rc = upload(&c->d_voigt_w, W, c->stream);
-        if (rc) return rc;
-    }
     const size_t per = (size_t)(c->Nlines + c->Natoms + 1) * Ns;
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(ncol, ((size_t)32 << 20) / per));
     int rc = ensure_stage(c, chunk * per);
@@ -1633,37 +1616,10 @@ int lsx_set_line_profiles(lsx_ctx* c, int32_t col0, int32_t ncol, const double* 
         HIPCHK(hipMemcpyAsync(dA, aDamp + b0 * c->Nlines * Ns, nb * c->Nlines * Ns * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(dV, vBroad + b0 * c->Natoms * Ns, nb * c->Natoms * Ns * 8, hipMemcpyHostToDevice, c->stream));
         if (vlos) HIPCHK(hipMemcpyAsync(dL, vlos + b0 * Ns, nb * Ns * 8, hipMemcpyHostToDevice, c->stream));
-        VoigtParams q{};
-        q.Ns = Ns; q.Nlines = c->Nlines; q.Natoms = c->Natoms; q.wavelength = c->d_wavelength; q.muz = c->d_muz; q.wmu = c->d_wmu;
-        q.W = c->d_voigt_w; q.aDamp = dA; q.vBroad = dV; q.vlos = vlos ? dL : nullptr;
-        // the profile blocks of the sweep, one launch per (tile, line)
-        const int R = c->phi_compact ? 1 : c->Nrays, D = c->phi_compact ? 1 : 2;
-        q.Nrays = R; q.ndir = D;
-        for (const DevSlot& sl : c->slots) {
-            if (!(sl.flags & SLOT_LINE) || sl.len <= 0) continue;
-            const DevTrans& h = c->htrans[sl.trans];
-            const size_t total = (size_t)sl.len * R * D * Ns;
-            dim3 grid((unsigned)std::min<size_t>((total + 255) / 256, 256), (unsigned)nb);
-            hipLaunchKernelGGL(k_voigt_block, grid, dim3(256), 0, c->stream, q, c->d_phi + cc * c->phi_col + sl.base, c->phi_col,
-                               sl.first, sl.len, h.line_idx, h.atom, h.lambda0);
-            HIPCHK(hipGetLastError());
-        }
-        // the normalisation of every line
-        q.Nrays = c->Nrays; q.ndir = 2;
-        for (int t = 0; t < c->Ntrans; ++t) {
-            const DevTrans& h = c->htrans[t];
-            if (!h.is_line) continue;
-            const long nth = (long)nb * Ns;
-            hipLaunchKernelGGL(k_voigt_wphi, dim3((unsigned)((nth + 63) / 64)), dim3(64), 0, c->stream, q,
-                               c->d_wphi + cc * c->Nlines * Ns, (int)nb, h.Nblue, h.Nlam, h.line_idx, h.atom, h.lambda0);
-            HIPCHK(hipGetLastError());
-        }
+        if ((rc = profiles_from_device(c, cc, nb, dA, dV, vlos ? dL : nullptr))) return rc;
         HIPCHK(hipStreamSynchronize(c->stream));   // the staging buffer is re-used by the next sub-chunk
     }
-    for (int q = 0; q < ncol; ++q) {
-        c->n_phi_set += (size_t)1 - c->phi_set[(size_t)col0 + q];
-        c->phi_set[(size_t)col0 + q] = 1;
-    }
+    mark_profiles_set(c, (size_t)col0, (size_t)ncol);
     return LSX_OK;
 }
 
@@ -1755,6 +1711,15 @@ int lsx_sync(lsx_ctx* c, double* dJ, double* dP)
                                    "LinAlgError at rh_method.py:739); its populations are left untouched",
                     gid / c->Nspace, gid % c->Nspace, (int)(key & 0xff));
     }
+    return LSX_OK;
+}
+
+int lsx_monitors(lsx_ctx* c, double* dst)
+{
+    if (!c || !dst) return fail(LSX_EINVAL, "lsx_monitors: null argument");
+    HIPCHK(hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_monitors, dim3(1), dim3(256), 0, c->stream, c->d_res, c->ncol, dst);
+    HIPCHK(hipGetLastError());
     return LSX_OK;
 }
 

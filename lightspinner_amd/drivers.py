@@ -50,6 +50,42 @@ def iterate_mali(ctx, dJ_tol=2e-3, dPops_tol=1e-3, n_lambda_only=3, max_iter=500
     return h
 
 
+def mali_step(engine, with_stat_equil=True, reducer=None):
+    """One MALI iteration over every column of `engine` (problem.Engine): both calls are enqueued, then the
+    convergence monitors are read ONCE -- lsx_sync on one rank, or reducer.engine(engine) over several (parallel.
+    MaxReducer: the monitors stay on the device until the all-reduce has run).  -> (dJ, dPops or None)"""
+    engine.formal_sol_gamma_async()
+    if with_stat_equil:
+        engine.stat_equil_async()
+    if reducer is not None:
+        dJ, dP = reducer.engine(engine)
+    else:
+        dJ, dP = engine.sync()
+    return dJ, (dP if with_stat_equil else None)
+
+
+def iterate_mali_engine(engine, reducer=None, dJ_tol=2e-3, dPops_tol=1e-3, n_lambda_only=3, max_iter=500, log=None) -> MaliHistory:
+    """iterate_mali (test.py:20-29) on an Engine with many columns, globally converged: the loop runs until the maxima
+    over all columns (and, with a reducer, over all ranks) are below the thresholds."""
+    h = MaliHistory()
+    dJ, dPops, i = 1.0, 1.0, 0
+    while dJ > dJ_tol or dPops > dPops_tol:
+        i += 1
+        dJ, dP = mali_step(engine, i > n_lambda_only, reducer)
+        if dP is not None:
+            dPops = dP
+        h.dJ.append(dJ)
+        h.dPops.append(dPops if i > n_lambda_only else float('nan'))
+        if log:
+            log('Iteration %.3d: dJ: %.2e, dPops: %s' % (i, dJ, 'Just iterating Jbar' if i <= n_lambda_only else '%.2e' % dPops))
+        if not (np.isfinite(dJ) and np.isfinite(dPops)):
+            h.nonfinite = True
+        if i >= max_iter:
+            break
+    h.converged = (dJ <= dJ_tol and dPops <= dPops_tol)
+    return h
+
+
 def response_function(I_plus, I_minus, I_base, mu_index=-1):
     """response_fn.py:59-67: rf[la, k] = (I+[la, mu] - I-[la, mu]) / I_base[la, mu].
     I_plus / I_minus: [Nspace][Nspect][Nrays] (one converged run per perturbed depth),

@@ -25,25 +25,93 @@ def env_rank_world():
 
 
 class MaxReducer:
-    """all-reduce(MAX) of (dJ, dPops).  NaN must win like in the single-process max
-    (numpy max semantics, rh_method.py:706): MAX collectives do not define NaN ordering, so a
-    NaN flag travels as a third element."""
+    """all-reduce(MAX) of the convergence monitors (dJ, dPops) over the ranks -- the one exchange of the sharded MALI
+    loop.  NaN must win like in the single-process max (numpy max semantics, rh_method.py:706): MAX collectives do not
+    define NaN ordering, so a NaN flag travels as a third element (and a singular-system flag as a fourth).
 
-    def __init__(self, device=None, group=None):
+    Two entry points:
+      reducer(dJ, dPops)        host values in, host values out (what the CPU tests and single-rank runs use)
+      reducer.engine(engine)    the monitors never visit the host before the collective: lsx_monitors leaves them in a
+                                device buffer on the engine's stream, RCCL reduces that buffer in place on the same
+                                stream, and ONE device-to-host copy brings the result back (per MALI iteration)."""
+
+    def __init__(self, device=None, group=None, stream=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
         self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-        self.buf = torch.zeros(3, dtype=torch.float64, device=device if device is not None else 'cpu')
+        self.device = torch.device(device) if device is not None else torch.device('cpu')
+        self.stream = stream            # torch.cuda.Stream the engine launches on (its handle went to lsx_create)
+        self.buf = torch.zeros(4, dtype=torch.float64, device=self.device)
+        self._dev_scratch = None
 
     def __call__(self, dJ: float, dPops: float):
         if not self.active:
             return dJ, dPops
         nan = float(np.isnan(dJ) or np.isnan(dPops))
-        vals = [0.0 if np.isnan(dJ) else dJ, 0.0 if np.isnan(dPops) else dPops, nan]
+        vals = [0.0 if np.isnan(dJ) else dJ, 0.0 if np.isnan(dPops) else dPops, nan, 0.0]
         self.buf.copy_(self.torch.tensor(vals, dtype=self.torch.float64))
         self.dist.all_reduce(self.buf, op=self.dist.ReduceOp.MAX, group=self.group)
         out = self.buf.tolist()
         if out[2] > 0:
             return float('nan'), float('nan')
         return out[0], out[1]
+
+    def engine(self, eng):
+        """-> (dJ, dPops) over all columns of all ranks for the calls enqueued on `eng` (problem.Engine).
+        Raises LsxSingularError on every rank if any rank met a singular system."""
+        torch = self.torch
+        on_device = eng.lib.backend.startswith('hip')
+        if on_device and self.buf.is_cuda:
+            ctx = torch.cuda.stream(self.stream) if self.stream is not None else _null_context()
+            with ctx:
+                eng.monitors_to(self.buf.data_ptr())
+                if self.stream is None:
+                    eng.sync()          # the engine owns its stream: order the collective behind it from the host
+                if self.active:
+                    self.dist.all_reduce(self.buf, op=self.dist.ReduceOp.MAX, group=self.group)
+                out = self.buf.tolist()             # the one device-to-host copy of the iteration
+        else:
+            if on_device:               # HIP engine, CPU collective (gloo rehearsal): stage through a device scratch
+                if self._dev_scratch is None:
+                    self._dev_scratch = torch.zeros(4, dtype=torch.float64, device='cuda')
+                eng.monitors_to(self._dev_scratch.data_ptr())
+                eng.sync()
+                self.buf.copy_(self._dev_scratch)
+            else:                       # the oracle writes host memory
+                host = np.zeros(4)
+                eng.monitors_to(host.ctypes.data)
+                self.buf.copy_(torch.from_numpy(host))
+            if self.active:
+                self.dist.all_reduce(self.buf, op=self.dist.ReduceOp.MAX, group=self.group)
+            out = self.buf.tolist()
+        if out[3] > 0:
+            from ._capi import LsxSingularError
+            raise LsxSingularError(3, 'stat_equil: singular matrix on some rank (cf. LinAlgError at rh_method.py:739)')
+        dJ = float('nan') if out[2] > 0 else out[0]
+        return dJ, out[1]
+
+
+class _null_context:
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+
+
+class AllDone:
+    """logical AND over ranks of "every column of my shard has converged" (the per-column driver's stop test,
+    drivers.iterate_mali_columns(all_done=...))"""
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        dev = 'cuda' if self.active and dist.get_backend(group) == 'nccl' else 'cpu'
+        self.buf = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def __call__(self, done: bool) -> bool:
+        if not self.active:
+            return done
+        self.buf.fill_(1 if done else 0)
+        self.dist.all_reduce(self.buf, op=self.dist.ReduceOp.MIN, group=self.group)
+        return bool(self.buf.item())

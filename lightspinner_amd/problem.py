@@ -249,6 +249,11 @@ class Engine:
         self.lib.check(self.lib.dll.lsx_sync(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def monitors_to(self, ptr):
+        """lsx_monitors: (max dJ, max dPops, NaN flag, singular flag) of the enqueued calls -> 4 doubles at `ptr`
+        (an int address: device memory for the HIP library -- e.g. tensor.data_ptr() -- host memory for the oracle)"""
+        self.lib.check(self.lib.dll.lsx_monitors(self._h, C.c_void_p(int(ptr))))
+
     def time_formal_sol(self, warmup, reps):
         a, b = C.c_double(), C.c_double()
         self.lib.check(self.lib.dll.lsx_time_formal_sol(self._h, int(warmup), int(reps), C.byref(a), C.byref(b)))

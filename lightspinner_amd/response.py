@@ -77,28 +77,59 @@ def deltas_of(fixture: dict, k: int, tag: str) -> dict:
     return {key[len(pre):]: v for key, v in fixture.items() if key.startswith(pre) and key[len(pre):] not in _RESULT_KEYS}
 
 
-def run_response_function(prob: Problem, base: ColumnBlock, fixture: dict, ks, lib=None, device=0, mu_index=-1, log=None):
+def run_response_function(prob: Problem, base: ColumnBlock, fixture: dict, ks, lib=None, device=0, mu_index=-1, log=None,
+                          rank=0, world=1, all_done=None, gather=None, stream=None):
     """response_fn.py:11-74 as two batched solves: (1) the base column to convergence (test.py:20-29 loop, per-column
     stopping rule), (2) the 2 x len(ks) perturbed columns, warm started from the base populations
     (response_fn.py:33), every column with its own stopping rule, then rf[la, k] = (I+ - I-) / I_base at `mu_index`
-    (response_fn.py:59-67).  -> dict(rf [Nspect][len(ks)], I_base, n_base, n_iter_base, n_iter [2 len(ks)], I [...])."""
+    (response_fn.py:59-67).  -> dict(rf [Nspect][len(ks)], I_base, n_base, n_iter_base, n_iter [2 len(ks)], I [...]).
+
+    Over several ranks (165 columns -> 21 / 20 per GPU): the perturbed columns are block partitioned
+    (parallel.shard_columns); every rank solves the (tiny) base column itself -- bit-identical everywhere, so no
+    broadcast of the warm-start populations is needed -- and iterates its shard until ALL ranks are done
+    (all_done = parallel.AllDone(): logical AND, the per-column stopping rule needs no other exchange);
+    gather(I_local [n_local][Nspect][Nrays], n_iter_local) -> (I of all columns, n_iter of all columns) on every rank
+    (e.g. torch.distributed.all_gather_object).  A rank with an empty shard still takes part in the collectives."""
     from . import _capi, drivers
+    from .parallel import shard_columns
     from .problem import Engine
-    e0 = Engine(prob, 1, device=device, lib=lib)
+    e0 = Engine(prob, 1, device=device, lib=lib, stream=stream)
     e0.set_columns(0, base.slice(0, 1))
     it0 = drivers.iterate_mali_columns(e0, log=log)
     I_base, n_base = e0.get(_capi.LSX_I)[0], e0.get(_capi.LSX_N)[0]
     e0.close()
-    cols = []
-    for k in ks:
-        for tag in ('p', 'm'):
-            cols.append(apply_delta(prob, base, deltas_of(fixture, int(k), tag), int(k), start_n=n_base))
-    batch = ColumnBlock.concatenate(cols)
-    eng = Engine(prob, batch.ncol, device=device, lib=lib)
-    for a in range(0, batch.ncol, 64):
-        eng.set_columns(a, batch.slice(a, min(batch.ncol, a + 64)))
-    n_iter = drivers.iterate_mali_columns(eng, log=log)
-    I = eng.get(_capi.LSX_I)
-    eng.close()
+    jobs = [(int(k), tag) for k in ks for tag in ('p', 'm')]
+    first, count = shard_columns(len(jobs), rank, world)
+    cols = [apply_delta(prob, base, deltas_of(fixture, k, tag), k, start_n=n_base) for k, tag in jobs[first:first + count]]
+    if cols:
+        batch = ColumnBlock.concatenate(cols)
+        eng = Engine(prob, batch.ncol, device=device, lib=lib, stream=stream)
+        for a in range(0, batch.ncol, 64):
+            eng.set_columns(a, batch.slice(a, min(batch.ncol, a + 64)))
+        n_iter = drivers.iterate_mali_columns(eng, log=log, all_done=all_done)
+        I = eng.get(_capi.LSX_I)
+        eng.close()
+    else:                                   # more ranks than columns: keep the collectives matched
+        n_iter = np.zeros(0, dtype=np.int64)
+        I = np.zeros((0, prob.Nspect, prob.Nrays))
+        if all_done is not None:
+            while not all_done(True):
+                pass
+    if world > 1:
+        if gather is None:
+            raise ValueError('run_response_function over several ranks needs gather=')
+        I, n_iter = gather(I, n_iter)
     rf = drivers.response_function(I[0::2], I[1::2], I_base, mu_index=mu_index)
-    return dict(rf=rf, I_base=I_base, n_base=n_base, n_iter_base=int(it0[0]), n_iter=n_iter, I=I)
+    return dict(rf=rf, I_base=I_base, n_base=n_base, n_iter_base=int(it0[0]), n_iter=n_iter, I=I, shard=(first, count))
+
+
+def gather_over_ranks(group=None):
+    """gather= for run_response_function: concatenates every rank's (I, n_iter) in rank order on every rank.  The
+    payload is small (165 x Nspect x Nrays doubles for C5 = 1.9 MB in total): an object all-gather is enough."""
+    import torch.distributed as dist
+
+    def gather(I, n_iter):
+        parts = [None] * dist.get_world_size(group)
+        dist.all_gather_object(parts, (I, n_iter), group=group)
+        return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+    return gather

@@ -129,6 +129,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     c->Rji = (double*)calloc(nc * (c->Ntrans ? c->Ntrans : 1) * Ns, 8);
     c->dJcol = (double*)calloc(nc, 8); c->dPcol = (double*)calloc(nc, 8);
     c->sing_col = (long*)calloc(nc, sizeof(long));
+    for (size_t q = 0; q < nc; ++q) c->sing_col[q] = -1;
     c->nthreads = 1;
     *out = c;
     return LSX_OK;
@@ -759,6 +760,20 @@ int lsx_sync(lsx_ctx* c, double* dJ, double* dP)
     if (!c) return fail(LSX_EINVAL, "null ctx");
     if (dJ) *dJ = c->last_dJ;
     if (dP) *dP = c->last_dP;
+    return LSX_OK;
+}
+
+int lsx_monitors(lsx_ctx* c, double* dst)
+{
+    if (!c || !dst) return fail(LSX_EINVAL, "lsx_monitors: null argument");
+    double mj = 0.0, mp = 0.0, nan = 0.0, sing = 0.0;
+    for (int col = 0; col < c->ncol; ++col) {
+        if (c->dJcol[col] != c->dJcol[col]) nan = 1.0;
+        else if (c->dJcol[col] > mj) mj = c->dJcol[col];
+        if (c->dPcol[col] > mp) mp = c->dPcol[col];
+        if (c->sing_col[col] >= 0) sing = 1.0;
+    }
+    dst[0] = mj; dst[1] = mp; dst[2] = nan; dst[3] = sing;
     return LSX_OK;
 }
 

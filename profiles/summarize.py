@@ -64,6 +64,51 @@ def main():
         if 'SQ_WAVES' in tot:
             out['sweep_per_wave'] = {k: {c.replace('SQ_INSTS_', '').replace('SQ_', ''): round(d[c] / d['SQ_WAVES'], 1)
                                          for c in d if c != 'SQ_WAVES'} for k, d in sorted(pc.items()) if 'SQ_WAVES' in d}
+    if ctr:
+        # ---- what binds the sweep: VALU issue against memory, from the counters alone (per class; the PMC passes serialise
+        # the classes, so each ratio is that class alone on the machine)
+        #   VALU busy   = SQ_ACTIVE_INST_VALU * 4 / (SIMDs * cycles)        (quad-cycles, MI355X_MICROARCH.md; = rocprofv3's VALUBusy)
+        #   cycles      = GRBM_GUI_ACTIVE / 8                               (the counter is summed over the 8 XCDs)
+        #   f64 share   = (FMA + ADD + MUL + TRANS)_F64 / SQ_INSTS_VALU
+        nsimd = 1024.0
+        bind = {}
+        for k, d in sorted(pc.items()):
+            b = {}
+            cyc = d.get('GRBM_GUI_ACTIVE', 0.0) / 8.0
+            if cyc and 'SQ_ACTIVE_INST_VALU' in d:
+                b['kernel_cycles'] = round(cyc)
+                b['valu_busy_frac'] = round(d['SQ_ACTIVE_INST_VALU'] * 4.0 / (nsimd * cyc), 4)
+                for nm in ('SQ_ACTIVE_INST_SCA', 'SQ_ACTIVE_INST_LDS', 'SQ_ACTIVE_INST_VMEM', 'SQ_ACTIVE_INST_ANY'):
+                    if nm in d:
+                        b[nm[3:].lower() + '_frac_of_simd_cycles'] = round(d[nm] * 4.0 / (nsimd * cyc), 4)
+            if 'SQ_WAVE_CYCLES' in d:
+                for nm in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_ACTIVE_INST_VALU'):
+                    if nm in d:
+                        b[nm[3:].lower() + '_share_of_wave_cycles'] = round(d[nm] / d['SQ_WAVE_CYCLES'], 4)
+            f64 = sum(d.get('SQ_INSTS_VALU_%s_F64' % x, 0.0) for x in ('FMA', 'ADD', 'MUL', 'TRANS'))
+            if f64 and d.get('SQ_INSTS_VALU'):
+                b['f64_insts'] = round(f64)
+                b['f64_share_of_valu_insts'] = round(f64 / d['SQ_INSTS_VALU'], 4)
+                b['valu_pipe_cycles_est'] = round(4.0 * f64 + 2.0 * (d['SQ_INSTS_VALU'] - f64))
+                if cyc:
+                    b['valu_pipe_frac_est'] = round(b['valu_pipe_cycles_est'] / (nsimd * cyc), 4)
+            if b:
+                bind[k] = b
+        if bind:
+            out['sweep_binding_resource'] = bind
+        fig = {}
+        if 'sweep_hbm_bytes_per_call_per_column' in out:
+            fig['hbm_bytes_per_call_per_column'] = out['sweep_hbm_bytes_per_call_per_column']
+        if ncol and 'SQ_INSTS_VALU' in tot:
+            fig['valu_insts_per_call_per_column'] = tot['SQ_INSTS_VALU'] / ncol
+            f64 = sum(tot.get('SQ_INSTS_VALU_%s_F64' % x, 0.0) for x in ('FMA', 'ADD', 'MUL', 'TRANS'))
+            if f64:
+                fig['f64_share_of_valu_insts'] = f64 / tot['SQ_INSTS_VALU']
+        if 'SQ_ACTIVE_INST_VALU' in tot and tot.get('GRBM_GUI_ACTIVE'):
+            # all classes together: busy quad-cycles of every class over the cycles of every class (serialised passes)
+            fig['valu_busy_frac'] = tot['SQ_ACTIVE_INST_VALU'] * 4.0 / (nsimd * tot['GRBM_GUI_ACTIVE'] / 8.0)
+        if fig:
+            out['figures'] = fig
     cal = glob.glob(tag + '_calib/*counter_collection.csv')
     log = tag + '_calib.log'
     if cal and os.path.exists(log):
@@ -72,6 +117,16 @@ def main():
         if fetch and len(fetch) == len(byts):
             out['fetch_size_calibration_factor'] = [round(b / (f * 1024.0), 4) for b, f in zip(byts, fetch)]
     print(json.dumps(out, indent=1))
+    # `python profiles/summarize.py gpurun_out/<tag> <ncol> <workload>` also records the per-column figures bench.py quotes
+    if len(sys.argv) > 3 and out.get('figures'):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'pmc_figures.json')
+        try:
+            allfig = json.load(open(path))
+        except Exception:
+            allfig = {}
+        allfig[sys.argv[3]] = dict(out['figures'], source='rocprofv3 --pmc passes of `bench.py --workload %s` (profiles/collect.sh %s), '
+                                   'summed over the sweep classes of a call' % (sys.argv[3], os.path.basename(tag)))
+        json.dump(allfig, open(path, 'w'), indent=1)
 
 
 if __name__ == '__main__':

@@ -12,7 +12,7 @@ under /root/reference is touched:
     arrays (numpy<1.25 semantics; only used for list membership in setup).
 (np.bool, used at rh_method.py:124, exists again in numpy 2.x.)
 
-Usage:  python tests/golden/make_golden.py [units] [falc_ca] [falc_cah] [falc_ca_vlos] [rf] [rf_inputs] [all]
+Usage:  python tests/golden/make_golden.py [units] [falc_ca] [falc_cah] [falc_ca_vlos] [rf] [rf_inputs] [setup] [all]
 """
 import os
 import sys
@@ -373,6 +373,129 @@ def gen_rf_inputs(out_name='rf_ca_inputs.npz'):
     save(out_name, out)
 
 
+def _atom_data(model, d, pre, fresh):
+    """numeric content of one AtomicModel (rh_atoms.py data, atomic_model.py derived constants) as flat arrays.
+    `fresh` is an identical model on which compute_wavelength_grid has NOT run: its transitions still carry the local
+    wavelength grids the merge starts from (atomic_model.py:347-380, 585-597, 645-660)."""
+    import collisional_rates as cr
+    from atomic_model import VdwUnsold, ExplicitContinuum, HydrogenicContinuum
+    tab = model.atomicTable
+    d[pre + 'weight'] = np.float64(tab[model.name].weight)
+    d[pre + 'abundance'] = np.float64(tab[model.name].abundance)
+    d[pre + 'lev_E_SI'] = np.array([l.E_SI for l in model.levels])
+    d[pre + 'lev_g'] = np.array([l.g for l in model.levels])
+    d[pre + 'lev_stage'] = np.array([l.stage for l in model.levels], dtype=np.int32)
+    L = model.lines
+    d[pre + 'line_i'] = np.array([l.i for l in L], dtype=np.int32)
+    d[pre + 'line_j'] = np.array([l.j for l in L], dtype=np.int32)
+    for key in ('f', 'gRad', 'stark', 'lambda0', 'Aji', 'Bji', 'Bij', 'qCore', 'qWing'):
+        d[pre + 'line_' + key] = np.array([getattr(l, key) for l in L], dtype=np.float64)
+    d[pre + 'line_NlambdaGen'] = np.array([l.NlambdaGen for l in L], dtype=np.int32)
+    d[pre + 'line_vdw_unsold'] = np.array([1 if isinstance(l.vdw, VdwUnsold) else 0 for l in L], dtype=np.int32)
+    d[pre + 'line_vdw_vals'] = np.array([list(l.vdw.vals)[:2] for l in L], dtype=np.float64).reshape(len(L), 2)
+    d[pre + 'line_vdw_cross'] = np.array([getattr(l.vdw, 'cross', 0.0) for l in L], dtype=np.float64)
+    for q, l in enumerate(fresh.lines):
+        d[pre + 'line%d_grid0' % q] = np.array(l.wavelength)
+    Cn = model.continua
+    d[pre + 'cont_i'] = np.array([c.i for c in Cn], dtype=np.int32)
+    d[pre + 'cont_j'] = np.array([c.j for c in Cn], dtype=np.int32)
+    d[pre + 'cont_edge'] = np.array([c.lambdaEdge for c in Cn])
+    d[pre + 'cont_minLambda'] = np.array([c.minLambda for c in Cn])
+    d[pre + 'cont_hydrogenic'] = np.array([1 if isinstance(c, HydrogenicContinuum) else 0 for c in Cn], dtype=np.int32)
+    d[pre + 'cont_alpha0'] = np.array([getattr(c, 'alpha0', 0.0) for c in Cn])
+    for q, c in enumerate(fresh.continua):
+        d[pre + 'cont%d_grid0' % q] = np.array(c.wavelength)
+        d[pre + 'cont%d_alpha_grid0' % q] = np.array(c.alpha)
+    for q, c in enumerate(Cn):
+        d[pre + 'cont%d_alpha' % q] = np.array(c.alpha)             # on the merged grid (compute_alpha)
+        d[pre + 'cont%d_wavelength' % q] = np.array(c.wavelength)
+    kinds = {cr.Omega: 0, cr.CI: 1, cr.CE: 2}
+    K = model.collisions
+    d[pre + 'col_kind'] = np.array([kinds[type(c)] for c in K], dtype=np.int32)
+    d[pre + 'col_i'] = np.array([c.i for c in K], dtype=np.int32)
+    d[pre + 'col_j'] = np.array([c.j for c in K], dtype=np.int32)
+    nt = max(len(c.temperature) for c in K)
+    d[pre + 'col_nT'] = np.array([len(c.temperature) for c in K], dtype=np.int32)
+    T = np.zeros((len(K), nt)); R = np.zeros((len(K), nt))
+    for q, c in enumerate(K):
+        T[q, :len(c.temperature)] = c.temperature
+        R[q, :len(c.rates)] = c.rates
+    d[pre + 'col_T'] = T
+    d[pre + 'col_rates'] = R
+
+
+def gen_setup():
+    """Set-up chain that defines the hot-path inputs: atomic data of the two models of
+    test.py, the wavelength-grid merge (atomic_set.py:377-455) and, for FALC and for a perturbed atmosphere, the
+    reference's v_broad (atomic_model.py:66-69), damping (:491-502: radiative + Unsold van der Waals :166-198 + Stark
+    :300-345), collisional rates (collisional_rates.py:10-96 with scipy's cubic interp1d) and LTE populations
+    (atomic_set.py:105-145)."""
+    d = {}
+    variants = []
+    k = np.arange(82)
+    for tag, dT, fv, fne in (('atm0', None, 1.0, 1.0),
+                             ('atm1', 600.0 * np.sin(2 * np.pi * k / 30.0) * np.exp(-((k - 40.0) / 30.0) ** 2) + 150.0, 1.7, 0.6)):
+        ac = Falc82()
+        ac.quadrature(5)
+        if dT is not None:
+            ac.temperature[:] = ac.temperature + dT * ac.temperature.unit
+            ac.vturb[:] = ac.vturb * fv
+            ac.ne[:] = ac.ne * fne
+        atmos = ac.convert_scales()
+        aSet = RadiativeSet([CaII_atom(), H_6_atom()])
+        aSet.set_active('Ca', 'H')
+        fresh = {m.name: m for m in RadiativeSet([CaII_atom(), H_6_atom()]).atoms}
+        spect = aSet.compute_wavelength_grid()
+        eqPops = aSet.compute_eq_pops(atmos)
+        background = Background(atmos, spect)
+        ctx = Context(atmos, spect, eqPops, background)
+        for key in ('temperature', 'ne', 'vturb', 'nHTot'):
+            d['%s_%s' % (tag, key)] = np.array(getattr(atmos, key), dtype=np.float64)
+        d['%s_hGround' % tag] = np.array(eqPops['H'].n[0])
+        for a, atom in enumerate(ctx.activeAtoms):
+            pre = '%s_a%d_' % (tag, a)
+            atom.compute_collisions()
+            d[pre + 'vBroad'] = np.array(atom.vBroad)
+            d[pre + 'nStar'] = np.array(atom.nStar)
+            d[pre + 'nTotal'] = np.array(atom.nTotal)
+            d[pre + 'C'] = np.array(atom.C)
+            lines = [t for t in atom.trans if t.isLine]
+            aD, Qe = [], []
+            for t in lines:
+                a_, q_ = t.transModel.damping(atmos, atom.vBroad, atom.hPops.n[0])
+                aD.append(a_); Qe.append(q_)
+            d[pre + 'aDamp'] = np.array(aD)
+            d[pre + 'Qelast'] = np.array(Qe)
+        if tag == 'atm0':
+            d['atom_names'] = np.array([a.atomicModel.name for a in ctx.activeAtoms])
+            tabH, tabHe = ctx.activeAtoms[0].atomicTable['H'], ctx.activeAtoms[0].atomicTable['He']
+            d['weight_H'] = np.float64(tabH.weight); d['weight_He'] = np.float64(tabHe.weight)
+            d['abundance_He'] = np.float64(tabHe.abundance)
+            for a, atom in enumerate(ctx.activeAtoms):
+                _atom_data(atom.atomicModel, d, 'm%d_' % a, fresh[atom.atomicModel.name])
+            # the merge itself: inputs are the *_grid0 arrays + continuum edges + lambdaReference; outputs:
+            d['grid_lambdaReference'] = np.float64(500.0)
+            d['grid_wavelength'] = np.array(spect.wavelength)
+            # spect.transitions order = iteration order of a Python set of models: record which (atom, kind, index) each is
+            order = []
+            for t in spect.transitions:
+                a = [x.atomicModel for x in ctx.activeAtoms].index(t.atom)
+                m = ctx.activeAtoms[a].atomicModel
+                isline = isinstance(t, AtomicLine)
+                q = [id(x) for x in (m.lines if isline else m.continua)].index(id(t))
+                order.append((a, 1 if isline else 0, q))
+            d['grid_trans_order'] = np.array(order, dtype=np.int32)
+            d['grid_blueIdx'] = np.array([int(b) for b in spect.blueIdx], dtype=np.int32)
+            d['grid_Nlambda'] = np.array([t.wavelength.shape[0] for t in spect.transitions], dtype=np.int32)
+            act = np.zeros((len(spect.transitions), spect.wavelength.shape[0]), dtype=np.bool_)
+            ids = [id(t) for t in spect.transitions]
+            for la, sset in enumerate(spect.activeSet):
+                for t in sset:
+                    act[ids.index(id(t)), la] = True
+            d['grid_active'] = act
+    save('setup_falc.npz', d)
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['all']
     if 'all' in what:
@@ -380,5 +503,5 @@ if __name__ == '__main__':
     for w in what:
         t0 = time.time()
         {'units': gen_units, 'falc_ca': gen_falc_ca, 'falc_cah': gen_falc_cah,
-         'falc_ca_vlos': gen_falc_ca_vlos, 'rf': gen_rf, 'rf_inputs': gen_rf_inputs}[w]()
+         'falc_ca_vlos': gen_falc_ca_vlos, 'rf': gen_rf, 'rf_inputs': gen_rf_inputs, 'setup': gen_setup}[w]()
         print('%s done in %.1fs' % (w, time.time() - t0), flush=True)

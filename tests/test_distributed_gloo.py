@@ -74,6 +74,99 @@ def test_two_rank_sharding_equals_single_process(tmp_path, oracle_lib):
     assert seen == ncol_total
 
 
+def _worker_engine_path(rank, world, port, ncol_total, out_dir):
+    """the same sharded loop through drivers.iterate_mali_engine + MaxReducer.engine (lsx_monitors -> all-reduce ->
+    one read-back), which is what bench.py runs per step on several GPUs"""
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import oracle
+    from lightspinner_amd import fixtures, synth, Engine, _capi, drivers
+    from lightspinner_amd.parallel import shard_columns, MaxReducer
+    lib = oracle.load()
+    prob, base, raw = fixtures.load_problem_npz(golden('falc_ca.npz'), phi_compact=False)
+    first, n = shard_columns(ncol_total, rank, world)
+    batch = synth.perturbed_columns(prob, base, raw, ncol=n, seed=99, first=first)
+    eng = Engine(prob, n, lib=lib)
+    eng.set_columns(0, batch)
+    h = drivers.iterate_mali_engine(eng, reducer=MaxReducer(), max_iter=7)
+    np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), first=first, n=eng.get(_capi.LSX_N), J=eng.get(_capi.LSX_J),
+             dJ=np.array(h.dJ), dP=np.array(h.dPops))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_rank_uneven_shards_engine_monitor_path(tmp_path, oracle_lib):
+    import torch.multiprocessing as mp
+    ncol_total, world = 6, 4            # shards of 2, 2, 1, 1 columns
+    port = _free_port()
+    mp.start_processes(_worker_engine_path, args=(world, port, ncol_total, str(tmp_path)), nprocs=world, join=True, start_method='spawn')
+    from lightspinner_amd import fixtures, synth, Engine, _capi, drivers
+    prob, base, raw = fixtures.load_problem_npz(golden('falc_ca.npz'), phi_compact=False)
+    eng = Engine(prob, ncol_total, lib=oracle_lib)
+    eng.set_columns(0, synth.perturbed_columns(prob, base, raw, ncol=ncol_total, seed=99))
+    h = drivers.iterate_mali_engine(eng, max_iter=7)
+    n, J = eng.get(_capi.LSX_N), eng.get(_capi.LSX_J)
+    sizes = []
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r))
+        f, cnt = int(d['first']), d['n'].shape[0]
+        sizes.append(cnt)
+        assert np.array_equal(d['n'], n[f:f + cnt]) and np.array_equal(d['J'], J[f:f + cnt])
+        assert np.array_equal(d['dJ'], np.array(h.dJ)) and np.array_equal(d['dP'][3:], np.array(h.dPops)[3:])
+    assert sizes == [2, 2, 1, 1]
+
+
+def _worker_rf(rank, world, port, out_dir):
+    """C5 over ranks: response.run_response_function with the perturbed columns block partitioned, per-column
+    convergence, all_done = AND over ranks, results gathered on every rank"""
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import oracle
+    from lightspinner_amd import fixtures, response
+    from lightspinner_amd.parallel import AllDone
+    lib = oracle.load()
+    prob, base, raw = fixtures.load_problem_npz(golden('falc_ca.npz'))
+    rf = dict(np.load(golden('rf_ca.npz')))
+    ks = [int(k) for k in rf['ks']]
+    out = response.run_response_function(prob, base, rf, ks, lib=lib, rank=rank, world=world, all_done=AllDone(),
+                                         gather=response.gather_over_ranks())
+    np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), rf=out['rf'], n_iter=out['n_iter'], I=out['I'], shard=np.array(out['shard']))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [4, 8])
+def test_response_function_sharded_over_ranks(tmp_path, oracle_lib, world):
+    """6 perturbed columns (3 depths x +-) over 4 ranks (2, 2, 1, 1) and over 8 ranks (six with one column, two with
+    none): every rank ends with the full response function, bit-identical to the single-process run, and every column
+    took exactly the iterations the reference's own loop took for it"""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.start_processes(_worker_rf, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method='spawn')
+    from lightspinner_amd import fixtures, response
+    prob, base, raw = fixtures.load_problem_npz(golden('falc_ca.npz'))
+    rf = dict(np.load(golden('rf_ca.npz')))
+    ks = [int(k) for k in rf['ks']]
+    one = response.run_response_function(prob, base, rf, ks, lib=oracle_lib)
+    ref_iters = [int(rf['k%d%s_niter' % (k, t)]) for k in ks for t in ('p', 'm')]
+    assert list(one['n_iter']) == ref_iters
+    shards = []
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r))
+        assert np.array_equal(d['rf'], one['rf']) and np.array_equal(d['I'], one['I'])
+        assert list(d['n_iter']) == ref_iters
+        shards.append(int(d['shard'][1]))
+    assert sum(shards) == 6 and max(shards) - min(shards) <= 1 and (world != 8 or shards.count(0) == 2)
+
+
 @pytest.mark.gpu
 def test_max_reducer_over_rccl_single_rank():
     """the RCCL path of the convergence reduction (device tensor, ReduceOp.MAX, NaN flag) on a one-rank communicator --
@@ -97,5 +190,27 @@ def test_max_reducer_over_rccl_single_rank():
         a, b = r(float('nan'), 1.0)
         assert np.isnan(a) and np.isnan(b)       # NaN wins, like ndarray.max (rh_method.py:706)
         assert r(3.0, 0.0) == (3.0, 0.0)
+        # the per-iteration exchange of the multi-GPU bench: lsx_monitors leaves (dJ, dPops, NaN flag, singular flag) in a
+        # device buffer on the engine's stream, RCCL reduces it in place, one read-back (MaxReducer.engine)
+        from lightspinner_amd import fixtures, synth, Engine, _capi, drivers
+        prob, base, raw = fixtures.load_problem_npz(golden('falc_ca.npz'))
+        batch = synth.perturbed_columns(prob, base, raw, ncol=5, seed=3, vlos_sigma=0.0)
+        ts = torch.cuda.Stream()
+        e1 = Engine(prob, 5, stream=ts.cuda_stream)
+        e2 = Engine(prob, 5)
+        for e in (e1, e2):
+            e.set_columns(0, batch)
+        red = MaxReducer(device=torch.device('cuda', 0), stream=ts)
+        red.active = True
+        for it in range(1, 6):
+            a = drivers.mali_step(e1, it > 3, reducer=red)
+            b = drivers.mali_step(e2, it > 3)
+            assert a == b, (it, a, b)
+        assert np.array_equal(e1.get(_capi.LSX_N), e2.get(_capi.LSX_N))
+        e3 = Engine(prob, 1, stream=ts.cuda_stream)            # singular system (Gamma still zero) -> LinAlgError on every rank
+        e3.set_columns(0, base)
+        e3.stat_equil_async()
+        with pytest.raises(np.linalg.LinAlgError):
+            red.engine(e3)
     finally:
         dist.destroy_process_group()

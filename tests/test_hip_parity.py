@@ -51,7 +51,11 @@ def test_piecewise_linear_1d_units(hip_lib, oracle_lib):
         a = (z, T, rng.uniform(0.05, 1, 6), [0, 1, 0, 1, 1, 0], rng.uniform(30, 2000, 6), chi, S)
         I, Psi = hip_lib.piecewise_linear_1d(*a)
         Io, Po = oracle_lib.piecewise_linear_1d(*a)
-        assert relerr(I, Io, floor=1e-300) < 1e-11 and np.allclose(Psi, Po, rtol=1e-11, atol=0)
+        assert relerr(I, Io, floor=1e-300) < 1e-11
+        # Psi* chi = w0 - w1/dtau.  w1 = (1 - e) - dtau e carries an ABSOLUTE error of an ulp of 1 (2.2e-16) wherever two
+        # exp() implementations differ in the last bit (the sweep's table-driven exp against libm), so just above the
+        # Taylor switch (dtau >= 5e-4) the quotient moves by up to 2.2e-16 / 5e-4 = 4.4e-13 absolute
+        assert np.all(np.abs(Psi - Po) * chi <= 1e-11 * np.abs(Po) * chi + 1e-12)
 
 
 @pytest.mark.parametrize('name,compact,tol', [('falc_ca.npz', True, 1e-12), ('falc_ca.npz', False, 1e-12),
