@@ -155,8 +155,22 @@ static __device__ __forceinline__ double rcp(double x)
 {
     double r = __builtin_amdgcn_rcp(x);
     r = fma(fma(-x, r, 1.0), r, r);
+#ifndef LSX_NEWTON1
     r = fma(fma(-x, r, 1.0), r, r);
+#endif
     return r;
+}
+// d = a * b + c as the three-address VOP3 form.  The compiler prefers v_fmac (d += a * b), which costs an extra
+// v_mov_b64 whenever c must survive (polynomial coefficients, running sums that are read again).
+static __device__ __forceinline__ double fma3(double a, double b, double c)
+{
+#ifdef LSX_FMA3
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+#else
+    return fma(a, b, c);
+#endif
 }
 
 typedef __attribute__((address_space(3))) double lds_f64;   // LDS pointers carry their address space: ds_ instructions, no flat-pointer checks
@@ -173,9 +187,9 @@ static __device__ __forceinline__ double exp_tab64(double x, const lds_f64* tab)
     const int ki = (int)kf;
     const lds_f64* e = tab + 2 * (ki & 63);
     const double th = e[0], tl = e[1];
-    double t = fma(r, 1.0 / 720.0, 1.0 / 120.0);
-    t = fma(r, t, 1.0 / 24.0);
-    t = fma(r, t, 1.0 / 6.0);
+    double t = fma3(r, 1.0 / 720.0, 1.0 / 120.0);
+    t = fma3(r, t, 1.0 / 24.0);
+    t = fma3(r, t, 1.0 / 6.0);
     t = fma(r, t, 0.5);
     const double m = fma(r * r, t, r);                                  // exp(r) - 1
     return ldexp(fma(th, m, tl) + th, ki >> 6);
@@ -189,14 +203,18 @@ static __device__ __forceinline__ void w2(double dtau, double& w0, double& w1, c
     const bool large = dtau > 50.0;
     double a0 = 1.0, a1 = 1.0;
     if (__builtin_amdgcn_ballot_w64(!(small || large)) != 0) {
-        const double e = exp_tab64(-dtau, exp2_tab);
+        // The saturated regime needs no select of its own: for dtau > 50 the middle formulae give exactly (1, 1) --
+        // e = exp(-dtau) < 2e-22 is below half an ulp of 1, and so is dtau e (< 1e-17 up to dtau ~ 4e4; beyond that e
+        // the product only shrinks).  The argument is clamped so that the table index stays in range for any dtau.
+        const double dc = fmin(dtau, 700.0);
+        const double e = exp_tab64(-dc, exp2_tab);
         a0 = 1.0 - e;
-        a1 = a0 - dtau * e;
+        a1 = a0 - dc * e;
     }
     const double t0 = dtau * (1.0 - 0.5 * dtau);
     const double t1 = (dtau * dtau) * (0.5 - dtau * (1.0 / 3.0));
-    w0 = small ? t0 : (large ? 1.0 : a0);
-    w1 = small ? t1 : (large ? 1.0 : a1);
+    w0 = small ? t0 : a0;     // lanes of a wave that skipped the exponential are all small or saturated: a0 = a1 = 1
+    w1 = small ? t1 : a1;
 }
 
 #endif // __HIPCC__

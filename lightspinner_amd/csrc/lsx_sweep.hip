@@ -831,7 +831,11 @@ extern "C" hipError_t lsx_launch_sweep(const SweepParams* p, int npt, int nblock
 {
     const dim3 g(nblocks), b(2 * LSX_WAVE);
     if (!p->sca_per_lambda && p->Nrays == 5) launch_class<5, false>(*p, npt, g, b, lds_bytes, st);
+#ifndef LSX_ONLY_NR5    // diagnostic builds (profiles/ab.sh variants) compile the 5-ray instances only
     else if (!p->sca_per_lambda && p->Nrays == 3) launch_class<3, false>(*p, npt, g, b, lds_bytes, st);
     else launch_class<0, true>(*p, npt, g, b, lds_bytes, st);
+#else
+    else return hipErrorNotSupported;
+#endif
     return hipGetLastError();
 }
