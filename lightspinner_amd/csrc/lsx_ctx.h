@@ -26,6 +26,7 @@ struct SweepClass {           // tiles that run the same kernel instantiation, l
     int npt = -1;              // compile-time per-ray slot count, -1 = generic
     long launches = 0;         // how often this class's kernel has been launched (introspection for the tests)
     int nl = 0;                // lines among them (compile-time too)
+    bool linked = false;       // the class's tiles have linked continua (compile-time too)
     bool has_fast = false;     // some tile of the class has fast continua: the class reads the pre-pass output
     hipEvent_t tdone = nullptr; // timed runs: end of this class's launch
     std::vector<int> fast_tiles; // the class's tiles that have fast continua
@@ -68,12 +69,12 @@ struct lsx_ctx {
     // device: per column
     double *d_height = nullptr, *d_temperature = nullptr, *d_nStar = nullptr, *d_nTotal = nullptr, *d_n = nullptr,
            *d_C = nullptr, *d_Gamma = nullptr, *d_wphi = nullptr, *d_bgchi = nullptr, *d_bgeta = nullptr,
-           *d_sca = nullptr, *d_phi = nullptr, *d_gijc = nullptr, *d_J[2] = {nullptr, nullptr}, *d_I = nullptr,
+           *d_sca = nullptr, *d_phi = nullptr, *d_E = nullptr, *d_corr = nullptr, *d_Psi3 = nullptr, *d_J[2] = {nullptr, nullptr}, *d_I = nullptr,
            *d_Gpart = nullptr, *d_dJpart = nullptr, *d_dJcol = nullptr, *d_dPcol = nullptr, *d_res = nullptr;
     unsigned long long* d_singular = nullptr;
     std::vector<uint8_t> phi_set;    // per column: line profiles have been handed over or built
     size_t n_phi_set = 0;
-    bool opt_se_lds = false, opt_trace_classes = false;   // LSX_SE_LDS / LSX_TRACE_CLASSES, read once in lsx_create
+    bool opt_se_lds = false, opt_trace_classes = false, opt_serial = false;   // LSX_SE_LDS / LSX_TRACE_CLASSES, read once in lsx_create
     long fused_launches = 0;
     uint8_t* d_colmask = nullptr; // per-column activity, nullptr = all active
     double *d_bgxchi = nullptr, *d_bgxeta = nullptr, *d_Psi2 = nullptr; // fast-continuum side arrays
@@ -81,7 +82,6 @@ struct lsx_ctx {
     int* d_fast_tiles = nullptr;
     int *d_cont_li = nullptr, *d_cont_lj = nullptr;
     double* d_exp2_tab = nullptr;
-    double* d_hck_la = nullptr;
     double* d_voigt_w = nullptr;
     double *d_muz = nullptr, *d_wmu = nullptr;
     int nF_max = 0, Ncont = 0, static_max = -1;
@@ -90,7 +90,8 @@ struct lsx_ctx {
     std::vector<int> cont_li, cont_lj;
     double* d_debug = nullptr;   // 64 x 16 x 8 B, diagnostic builds of the sweep kernel write stamps here
     int jcur = 0; // d_J[jcur] holds the current J (Jdag of the next call)
-    size_t phi_col = 0, phi_in_col = 0, gijc_col = 0, sca_col = 0, til_col = 0;
+    size_t phi_col = 0, phi_in_col = 0, corr_col = 0, pp_col = 0, sca_col = 0, til_col = 0;
+    bool any_cont = false;      // some tile has a continuum: E_T is kept
     // staging
     double* d_stage = nullptr;
     size_t stage_doubles = 0;

@@ -9,7 +9,10 @@
 //     J_T[2]             [col][tile][k][j<L]      ping-pong: Jdag <- previous call
 //     sca                [col][k]  (or [col][tile][k][j] when sca_per_lambda)
 //     phi_T              [col] { per (tile, line slot): [dir][k][mu][l<len] }   (compact: [k][l])
-//     gijc_T             [col] { per (tile, continuum slot): [k][l<len] }  g_ij of (26) in [U01], built at upload
+//     E_T                [col][tile][k][j<L]      exp(-hc / (k lambda T)): the Boltzmann factor of every continuum's g_ij
+//                                                 (rh_method.py:453-454), built at upload (constant while T is fixed)
+//     corr_T             [col] { per tile with linked continua: [line slot][EC, XCi, XCj][k][j<L] }  (k_fast_prepass)
+//     Psi3_T             [dir][col] { per tile with linked continua: [line slot][k][j<L] }  sum_mu w Psi* phi  (sweep)
 //   where the slot's block covers the len wavelengths of the tile inside the transition's range
 //   per column, reference layout (level-major; the sweep reads them with wave-uniform
 //   addresses through the scalar cache):
@@ -56,7 +59,9 @@ enum {
     SLOT_CHI_J_FIRST = 64,
     SLOT_U_J_FIRST = 128,
     SLOT_ETA_FIRST = 256,
-    SLOT_FAST = 512        // fast continuum: handled by k_fast_prepass / k_fast_gamma, not by the sweep
+    SLOT_FAST = 512,       // fast continuum: handled by k_fast_prepass / k_fast_gamma, not by the sweep
+    SLOT_LINKED = 1024     // a fast continuum whose atom HAS a line in the tile ("linked"): the line enters its Gamma
+                           // integrand through sum_mu w Psi* phi, and it enters the line's through three ray-independent sums
 };
 
 // One transition as one tile sees it ("slot"); wave-uniform, read through the scalar cache.
@@ -71,7 +76,7 @@ struct DevSlot {
     int32_t ci, cj, ca;    // tile-local LDS cell ids: level cells of i and j, atom cell
     int32_t atom;          // active-atom index
     int32_t Nblue, Nlam;
-    int32_t base;          // element offset of this (tile, transition) block inside the column's phi_T / gijc_T
+    int32_t base;          // lines: element offset of this (tile, line) block inside the column's phi_T; fast continua: row of nsr
     int32_t first, len;    // global index of the block's first wavelength, number of wavelengths in the block
     int32_t wl_off;        // into wl / alpha
     int32_t trans;         // row of the `active` table
@@ -86,7 +91,8 @@ struct DevSlot {
     //   [li_v==li] - [lj_v==li],  [li_v==lj] - [lj_v==lj],  [lj_v==lj],  [lj_v==li],  [atom_v==atom]
     double rel[3][5];
     uint32_t relmask;      // bit o: rel[o] has a non-zero factor
-    int32_t pad_rel;
+    uint32_t lkbits;       // linked continuum: for line slot u of the tile (u < 4) bits 8u + {0, 1, 2} = the line belongs to the
+                           // continuum's atom, the continuum's LOWER level is the line's lower level, ... the line's upper level
 };
 enum { REL_CI = 0, REL_CJ = 1, REL_UJ = 2, REL_UI = 3, REL_EA = 4 };
 
@@ -97,7 +103,9 @@ struct DevTile {            // L consecutive wavelengths (L = 64 / Nrays) of one
     int32_t slot0;          // first entry in the slot table / first Gpart slab
     int32_t fast_simple;    // the fast continua need no level cells (k_fast_gamma)
     int32_t nL;             // lines among the per-ray slots (they come first)
-    int32_t pad2;
+    int32_t nK;             // linked continua among the nF fast ones
+    int32_t corr_off;       // nK > 0: element offset of the tile's [nL][3][Nspace][L] block inside a column of corr_T
+    int32_t pp_off;         // nK > 0: element offset of the tile's [nL][Nspace][L] block inside a column of Psi3_T
 };
 
 struct SweepParams {
@@ -122,7 +130,7 @@ struct SweepParams {
     const DevSlot* slots;       // per (tile, slot) parameters
     const int32_t* class_tiles; // tile ids of the launched class
     // per-column strides (in doubles)
-    int64_t phi_col_stride, gijc_col_stride;
+    int64_t phi_col_stride, corr_col_stride, pp_col_stride;
     // per-column arrays
     const double* height;       // [col][k]
     const double* temperature;  // [col][k]
@@ -135,7 +143,11 @@ struct SweepParams {
     double* Psi2_T;             // [dir][col][tile][k][j]  sum_mu w Psi* per direction (tiles with fast continua)
     const double* sca;
     const double* phi_T;
-    const double* gijc_T;
+    const double* nsr;          // [col][Ncont][k] nStar_i / nStar_j of every continuum
+    int32_t Ncont, pad_nc;
+    const double* E_T;          // [col][tile][k][j]
+    const double* corr_T;       // corrections of the line slots for linked continua (k_fast_prepass)
+    double* Psi3_T;             // [dir] x pp_col_stride * ncol: sum_mu w Psi* phi per line slot of tiles with linked continua
     const double* Jdag_T;
     double* Jnew_T;
     double* Iout;
@@ -217,4 +229,39 @@ static __device__ __forceinline__ void w2(double dtau, double& w0, double& w1, c
     w1 = small ? t1 : a1;
 }
 
+// DPP (VALU cross-lane moves, no LDS crossbar traffic).  The total of the 64 lanes ends up in
+// lane 63 (the lane that stores it).
+template <int CTRL, int ROW_MASK>
+static __device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    // `old` = the source itself: no zero has to be materialised; lanes a row mask leaves out keep their own
+    // value (their sums are never consumed, see the callers)
+    if constexpr (ROW_MASK == 0xf) {                // every lane is written: no `old` operand to set up
+        lo = __builtin_amdgcn_mov_dpp(lo, CTRL, ROW_MASK, 0xf, true);
+        hi = __builtin_amdgcn_mov_dpp(hi, CTRL, ROW_MASK, 0xf, true);
+    } else {
+        lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    }
+    return __hiloint2double(hi, lo);
+}
+static __device__ __forceinline__ double wave_sum(double v)
+{
+    v += dpp_f64<0xB1, 0xf>(v);  // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E, 0xf>(v);  // quad_perm [2,3,0,1]: every lane of a quad holds the quad sum
+    v += dpp_f64<0x141, 0xf>(v); // row_half_mirror: 8-lane sums
+    v += dpp_f64<0x140, 0xf>(v); // row_mirror: 16-lane (row) sums in every lane of the row
+    v += dpp_f64<0x142, 0xa>(v); // row_bcast15 into rows 1 and 3: lane 31 = rows 0+1, lane 63 = rows 2+3
+    v += dpp_f64<0x143, 0xc>(v); // row_bcast31 into rows 2 and 3: lane 63 = all four rows
+    return v;
+}
+static __device__ __forceinline__ double row_sums(double v)   // every lane of a 16-lane row gets the row's sum
+{
+    v += dpp_f64<0xB1, 0xf>(v);
+    v += dpp_f64<0x4E, 0xf>(v);
+    v += dpp_f64<0x141, 0xf>(v);
+    v += dpp_f64<0x140, 0xf>(v);
+    return v;
+}
 #endif // __HIPCC__

@@ -5,7 +5,7 @@
 // Reference lines restated here:
 //   rh_method.py:587-590, 698-708  Gamma = C prologue, diagonal fix-up, dJ      (k_gamma_finish)
 //   rh_method.py:710-745           stat_equil                                   (k_stat_equil)
-//   rh_method.py:453-454           continuum g_ij table                          (k_build_gijc)
+//   rh_method.py:453-454           Boltzmann factor of the continuum g_ij        (k_build_E)
 //   formal_solver.py:46-212        stand-alone piecewise_linear_1d               (k_piecewise)
 #include <hip/hip_runtime.h>
 
@@ -190,20 +190,18 @@ __global__ void k_voigt_wphi(const VoigtParams q, double* __restrict__ wphi, int
     wphi[col * q.Nlines * q.Ns + (size_t)line * q.Ns + k] = 1.0 / acc;
 }
 
-// g_ij of a continuum (rh_method.py:453-454) for one (tile, continuum) block: out[col]{[k][l<len]}
-__global__ void k_build_gijc(const double* __restrict__ nStar, const double* __restrict__ temperature,
-                             const double* __restrict__ wavelength, double* __restrict__ out, int li, int lj, int first,
-                             int len, int Ns, int NLtot, size_t out_col_stride)
+// Boltzmann factor of the continuum g_ij (rh_method.py:453-454: g_ij = nStar_i / nStar_j * exp(-hc / (k lambda T))),
+// tile-major like the background streams: E_T[col][tile][k][j].  Depends on the temperature only: built at upload.
+__global__ void k_build_E(const double* __restrict__ temperature, const double* __restrict__ wavelength,
+                          double* __restrict__ out, const DevTile* __restrict__ tiles, int ntile, int L, int Ns)
 {
     const size_t col = blockIdx.y;
     const double hc_k = kHC / (kKBoltzmann * kNM_TO_M);
-    const int total = len * Ns;
+    const int total = ntile * Ns * L;
     for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gridDim.x * blockDim.x) {
-        const int l = o % len, k = o / len;
-        const double nsi = nStar[(col * NLtot + li) * Ns + k];
-        const double nsj = nStar[(col * NLtot + lj) * Ns + k];
-        const double T = temperature[col * Ns + k];
-        out[col * out_col_stride + o] = nsi / nsj * exp(-hc_k / wavelength[first + l] / T);
+        const int j = o % L, k = (o / L) % Ns, t = o / (L * Ns);
+        const int la = tiles[t].la0 + (j < tiles[t].nla ? j : tiles[t].nla - 1);
+        out[col * (size_t)total + o] = exp(-hc_k / wavelength[la] / temperature[col * Ns + k]);
     }
 }
 
@@ -303,7 +301,11 @@ __global__ void k_gamma_finish(const FinishParams f)
     }
 }
 
-// ---- fast continua (atoms with no line in the tile): ray independent, handled outside the sweep ----
+// ---- fast continua: handled outside the sweep -----------------------------------------------------------------------
+// A continuum whose Gamma integrand is affine in the ray quantities with ray-independent coefficients never enters the
+// sweep (lsx_create, roles_of): "fast" = its atom has no line in the tile; "linked" = it has, but no line touches the
+// continuum's upper level.  Per (wavelength, depth) and summed over the rays of one direction the sweep hands over
+//   J (-> sI = 4 pi J over both directions),  Psibar = sum_mu w Psi*,  and per line of the tile  PsiPhi = sum_mu w Psi* phi.
 struct FastParams {
     int Nspace, Nspect, Nrays, ncol, ntile, L, NLtot, Natoms, nslot_total, n_fast_tiles;
     const DevTile* tiles;
@@ -316,224 +318,348 @@ struct FastParams {
     const double* wmuh;
     const double* n;            // [col][NLtot][k]
     const double* nsr;          // [col][Ncont][k]  nStar_i / nStar_j of every continuum (rh_method.py:453)
-    const double* temperature;  // [col][k]
-    const double* hck_la;       // [Nspect]  hc / (k lambda)
+    const double* E_T;          // [col][tile][k][j] exp(-hc / (k lambda T))
     int Ncont, nF_max, generic;
+    int seg_depths;             // depths staged in LDS at a time: a multiple of the rows per block, >= Nspace where that fits
     const double* bgchi_T;
     const double* bgeta_T;
     double* bgxchi_T;
     double* bgxeta_T;
+    double* corr_T;             // [col]{tile: [line][EC, XCi, XCj][k][j]}
+    int64_t corr_col_stride, pp_col_stride;
     const double* J_T;          // the NEW J (after the sweep), tile-major
     const double* Psi2_T;       // [dir][col][tile][k][j]
+    const double* Psi3_T;       // [dir][col]{tile: [line][k][j]}
     double* Gpart;
     const uint8_t* colmask;
 };
 
-// one fast continuum at (lambda, depth): rh_method.py:284-286, 453-455, 613-614.  g_ij is formed here from the
-// column's nStar ratio and the Boltzmann factor E of this (lambda, depth) -- (nStar_i / nStar_j) * exp(-hc / (k lambda T)),
-// the value k_build_gijc tabulates for the per-ray continua -- so fast continua cost no g_ij stream in HBM.
+// one fast continuum at (lambda, depth): rh_method.py:284-286, 453-455, 613-614, with g_ij = (nStar_i / nStar_j) E
 struct FastVal { double alf, Vji, Uji, chi, eta; bool a; };
-__device__ __forceinline__ double fast_boltzmann(const FastParams& f, size_t col, int la, int k)
+#define LSX_MAX_TILE_LINES 4
+// effective background of the tiles that have fast continua: bgx = bg + sum over the tile's fast continua; for the
+// lines of a tile with linked continua also the three sums the line's own Gamma integrand needs from them
+// (rh_method.py:616-627: atom.eta, atom.chi[i_line], atom.chi[j_line], continuum part)
+// One block per (tile, column), 256 threads = (depth in chunk, wavelength) with LP = 16 / 32 / 64 lanes per depth row;
+// the block walks the column's depth chunks with the next chunk's loads in flight (the kernel is latency bound otherwise:
+// a staging phase, a barrier and one dependent load per thread for a few dozen instructions of arithmetic).
+template <int LP>
+__global__ void __launch_bounds__(256) k_fast_prepass(const FastParams f)
 {
-    // exp(-hc / (k lambda T)) with hc/(k lambda) tabulated per wavelength and 1/T by reciprocal + Newton (the
-    // argument differs from the divided form by an ulp or two: a relative 1e-14 on E at the shortest wavelengths)
-    const double T = f.temperature[col * f.Nspace + k];
-    double r = __builtin_amdgcn_rcp(T);
-    r = fma(fma(-T, r, 1.0), r, r);
-    r = fma(fma(-T, r, 1.0), r, r);
-    return exp(-(f.hck_la[la] * r));
-}
-// effective background of the tiles that have fast continua: bgx = bg + sum over the tile's fast continua
-__global__ void k_fast_prepass(const FastParams f)
-{
-    const size_t col = blockIdx.z;
+    constexpr int KR = 256 / LP;                                // depths per chunk
+    const size_t col = blockIdx.y;
     if (f.colmask && !f.colmask[col]) return;
-    const int t = f.fast_tiles[blockIdx.y];
+    const int t = f.fast_tiles[blockIdx.x];
     const DevTile tl = f.tiles[t];
     extern __shared__ double sm[];
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int e = blockIdx.x * nt + tid;                        // (k, j)
+    const int tid = threadIdx.x;
+    const int kc = tid / LP, j = tid % LP;
+    const int Ns = f.Nspace;
     const DevSlot* fs = f.slots + tl.slot0 + tl.nP;
-    // operands of the block's (slot, depth) and (slot, wavelength) pairs, staged once (as in k_fast_gamma)
-    const int k_lo = (blockIdx.x * nt) / f.L, KR = nt / f.L + 2;
+    const bool lane_on = j < f.L;
+    const size_t tb = (col * f.ntile + t) * (size_t)Ns * f.L;
+    auto load3 = [&](int k, double& a, double& b, double& c) {
+        const bool on = lane_on && k < Ns;
+        const size_t o = tb + (size_t)(on ? k : 0) * f.L + (lane_on ? j : 0);
+        a = f.bgchi_T[o]; b = f.bgeta_T[o]; c = f.E_T[o];
+    };
+    double n_chi, n_eta, n_E;
+    load3(kc, n_chi, n_eta, n_E);                               // first chunk's streams: in flight during the staging
+    // operands of the (slot, depth) and (slot, wavelength) pairs, staged per depth segment of KS depths (the whole column
+    // where it fits): sN[q][k - ks0] = {n_i, n_j, nStar_i/nStar_j, -}, sA[q][j] = alpha where the continuum is active, else 0
+    const int KS = f.seg_depths;
     double* sN = sm;
-    double* sA = sN + (size_t)3 * f.nF_max * KR;
-    for (int x = tid; x < tl.nF * KR; x += nt) {
-        const int q = x / KR, kk = min(k_lo + x % KR, f.Nspace - 1);
-        sN[x * 3 + 0] = f.n[(col * f.NLtot + fs[q].li) * f.Nspace + kk];
-        sN[x * 3 + 1] = f.n[(col * f.NLtot + fs[q].lj) * f.Nspace + kk];
-        sN[x * 3 + 2] = f.nsr[col * f.Ncont * f.Nspace + fs[q].base + kk];
-    }
-    for (int x = tid; x < tl.nF * f.L; x += nt) {
-        const int q = x / f.L, jj = x % f.L, lq = tl.la0 + min(jj, tl.nla - 1), lt = lq - fs[q].Nblue;
+    double* sA = sN + (size_t)4 * f.nF_max * KS;
+    auto stage = [&](int ks0) {
+        for (int x = tid; x < tl.nF * KS; x += 256) {
+            const int q = x / KS, kk = min(ks0 + (x - q * KS), Ns - 1);
+            sN[x * 4 + 0] = f.n[(col * f.NLtot + fs[q].li) * Ns + kk];
+            sN[x * 4 + 1] = f.n[(col * f.NLtot + fs[q].lj) * Ns + kk];
+            sN[x * 4 + 2] = f.nsr[col * f.Ncont * Ns + fs[q].base + kk];
+        }
+    };
+    stage(0);
+    for (int x = tid; x < tl.nF * LP; x += 256) {
+        const int q = x / LP, jj = x % LP, lq = tl.la0 + min(jj, tl.nla - 1), lt = lq - fs[q].Nblue;
         const bool a = jj < tl.nla && lt >= 0 && lt < fs[q].Nlam && f.active[(size_t)fs[q].trans * f.Nspect + lq] != 0;
-        sA[x * 3 + 0] = a ? 1.0 : 0.0;
-        sA[x * 3 + 1] = a ? f.alpha[fs[q].wl_off + lt] : 0.0;
+        sA[x] = a ? f.alpha[fs[q].wl_off + lt] : 0.0;
     }
     __syncthreads();
-    if (e >= f.Nspace * f.L) return;
-    const int k = e / f.L, j = e - k * f.L;
-    const size_t o = ((col * f.ntile + t) * f.Nspace) * f.L + e;
-    double chi = f.bgchi_T[o], eta = f.bgeta_T[o];
-    if (j < tl.nla) {
-        const int la = tl.la0 + j;
-        const double E = fast_boltzmann(f, col, la, k), ula = f.u_la[la];
-        for (int q = 0; q < tl.nF; ++q) {
-            const double* A = sA + (size_t)(q * f.L + j) * 3;
-            const double* N = sN + (size_t)(q * KR + (k - k_lo)) * 3;
-            if (A[0] != 0.0) {                                   // fast_value(), same arithmetic
-                const double alf = A[1];
-                const double Vji = (N[2] * E) * alf;
-                const double Uji = ula * Vji;
-                chi += N[0] * alf - N[1] * Vji;
-                eta += N[1] * Uji;
+    const int nLc = tl.nK > 0 ? min(tl.nL, LSX_MAX_TILE_LINES) : 0;
+    const double ula = f.u_la[tl.la0 + min(j, tl.nla - 1)];
+    const size_t plane = (size_t)Ns * f.L;
+    int ks0 = 0;
+    for (int k = kc; k < Ns + kc; k += KR) {                    // (every thread runs every pass; k >= Ns computes nothing)
+        if (k - kc >= ks0 + KS) {                                // next depth segment (deep columns only)
+            ks0 += KS;
+            __syncthreads();
+            stage(ks0);
+            __syncthreads();
+        }
+        double chi = n_chi, eta = n_eta;
+        const double E = n_E;
+        load3(k + KR, n_chi, n_eta, n_E);
+        if (k >= Ns || !lane_on) continue;
+        double EC[LSX_MAX_TILE_LINES] = {0.0, 0.0, 0.0, 0.0}, XCi[LSX_MAX_TILE_LINES] = {0.0, 0.0, 0.0, 0.0},
+               XCj[LSX_MAX_TILE_LINES] = {0.0, 0.0, 0.0, 0.0};
+        for (int q = 0; q < tl.nF; ++q) {                        // rh_method.py:284-286, 453-455, 613-614
+            const double alf = sA[q * LP + j];
+            const double2 n01 = *reinterpret_cast<const double2*>(sN + (size_t)(q * KS + (k - ks0)) * 4);
+            const double nsr = sN[(size_t)(q * KS + (k - ks0)) * 4 + 2];
+            const double Vji = (nsr * E) * alf;
+            const double Uji = ula * Vji;
+            const double chq = n01.x * alf - n01.y * Vji, etq = n01.y * Uji;
+            chi += chq;
+            eta += etq;
+            const unsigned lk = fs[q].lkbits;                    // wave-uniform: which line slots this continuum feeds
+            if (lk) {
+#pragma unroll
+                for (int u = 0; u < LSX_MAX_TILE_LINES; ++u) {
+                    if (lk & (1u << (8 * u))) EC[u] += etq;      // atom.eta, :614
+                    if (lk & (2u << (8 * u))) XCi[u] += chq;     // atom.chi[i_line], :616 (no line touches lj of a linked
+                    if (lk & (4u << (8 * u))) XCj[u] += chq;     // continuum, so only its lower level counts)
+                }
             }
         }
+        const size_t o = tb + (size_t)k * f.L + j;
+        f.bgxchi_T[o] = chi;
+        f.bgxeta_T[o] = eta;
+        if (nLc > 0) {
+            double* cr = f.corr_T + col * f.corr_col_stride + tl.corr_off + (size_t)k * f.L + j;
+#pragma unroll
+            for (int u = 0; u < LSX_MAX_TILE_LINES; ++u)
+                if (u < nLc) {
+                    cr[(size_t)(3 * u + 0) * plane] = EC[u];
+                    cr[(size_t)(3 * u + 1) * plane] = XCi[u];
+                    cr[(size_t)(3 * u + 2) * plane] = XCj[u];
+                }
+        }
     }
-    f.bgxchi_T[o] = chi;
-    f.bgxeta_T[o] = eta;
 }
 
-// Gamma slabs of the fast continua from J and Psibar (both directions summed):
-//   sum_{mu,dir} w (Uji + Vji Ieff - chi_lev_i Psi U_lev_j)  with Ieff = I - Psi eta_atom   (rh_method.py:652, 677-681)
-//   = Uji sW + Vji (sI - eta_atom sPsi) - chi_lev_i U_lev_j sPsi,   sI = 4 pi J, sPsi = sum w Psi*, sW = 4 pi sum_mu w_mu
-//   (w = (w_mu/2) 4 pi per ray and direction, rh_method.py:661-665; all sums over both directions)
-// one block per (depth chunk, fast tile, column); thread = (depth in chunk, wavelength of the tile).
+// Gamma slabs of the fast continua from J, Psibar and PsiPhi (both directions summed).  For continuum c of atom a
+// (rh_method.py:652, 677-681; w = (w_mu/2) 4 pi per ray and direction, :661-665):
+//   sum w (Uji + Vji Ieff - chi_a[i] Psi U_a[j]),  Ieff = I - Psi eta_a
+//   eta_a    = etaC + sum_lines n_j Uc phi            chi_a[i] = XC[i] + sum_lines s(line, i) cB (n_i - g n_j) phi
+//   U_a[j]   = UC[j]   (no line touches a linked continuum's upper level)
+//   chi_a[j] = XC[j]                                  U_a[i]   = UC[i] + sum_lines [j_line == i] Uc phi
+// with etaC, XC, UC the sums over the atom's continua of the tile, s(line, lev) = [i_line == lev] - [j_line == lev], so
+//   = Uji sW + Vji sIe - (XC[i] sPsi + sum_lines s cBn sPP) UC[j],    sIe = sI - etaC sPsi - sum_lines n_j Uc sPP
+// and for the reverse rate  Vij sIe - XC[j] (UC[i] sPsi + sum_lines [j_line == i] Uc sPP);
+//   sI = 4 pi J, sPsi = sum w Psi*, sPP = sum w Psi* phi_line, sW = 4 pi sum_mu w_mu (all over both directions).
+// One block per (depth chunk, fast tile, column); thread = (depth in chunk, wavelength of the tile).
 // Tiles whose fast continua are "simple" (per atom: one common upper level, distinct lower levels, none of them
 // that upper level -- every bound-free set of an ordinary model atom) need three running sums per atom and no
 // level cells; anything else takes the generic path with thread-private LDS cells.  Same arithmetic, same order.
-__global__ void k_fast_gamma(const FastParams f, int KC)
+// One block per (tile, column), NT threads = (depth in chunk, wavelength) with LP = 16 / 32 / 64 lanes per depth row; the block
+// walks the column's depth chunks with the next chunk's loads in flight.
+template <int LP>
+static __device__ __forceinline__ double row_total(double v)     // sum over the LP lanes of a depth row, valid in its last lane
 {
+    v = row_sums(v);
+    if constexpr (LP >= 32) v += dpp_f64<0x142, 0xa>(v);         // row_bcast15: lanes 31 / 63 = two rows
+    if constexpr (LP >= 64) v += dpp_f64<0x143, 0xc>(v);         // row_bcast31: lane 63 = the wave
+    return v;
+}
+template <int LP, int NT>
+__global__ void __launch_bounds__(NT) k_fast_gamma(const FastParams f)
+{
+    constexpr int KR = NT / LP;                              // depths per chunk
     extern __shared__ double sm[];
-    const size_t col = blockIdx.z;
+    const size_t col = blockIdx.y;
     if (f.colmask && !f.colmask[col]) return;
-    const int t = f.fast_tiles[blockIdx.y];
+    const int t = f.fast_tiles[blockIdx.x];
     const DevTile tl = f.tiles[t];
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int kc = tid / f.L, j = tid - kc * f.L;
-    const int k0 = blockIdx.x * KC, k = k0 + kc;
-    const bool on = kc < KC && k < f.Nspace && j < tl.nla;
-    double* red = sm;                                       // red[(q*2 + e) * nt + tid]
+    const int tid = threadIdx.x;
+    const int kc = tid / LP, j = tid % LP;
+    const int Ns = f.Nspace;
     const DevSlot* fs = f.slots + tl.slot0 + tl.nP;
-    const int la = tl.la0 + (j < tl.nla ? j : 0);
-    // operands of the block's (slot, depth) and (slot, wavelength) pairs, staged once:
-    //   sN[(q*KC + kc)*3 + {0,1,2}] = n_i, n_j, nStar_i/nStar_j      sA[(q*L + j)*3 + {0,1,2}] = active, alpha, wlambda
-    double* sN = sm + (size_t)(2 * f.nF_max + (f.generic ? 2 * f.NLtot + f.Natoms : 0)) * nt;
-    double* sA = sN + (size_t)3 * f.nF_max * KC;
-    for (int e = tid; e < tl.nF * KC; e += nt) {
-        const int q = e / KC, kk = min(k0 + e % KC, f.Nspace - 1);
-        sN[e * 3 + 0] = f.n[(col * f.NLtot + fs[q].li) * f.Nspace + kk];
-        sN[e * 3 + 1] = f.n[(col * f.NLtot + fs[q].lj) * f.Nspace + kk];
-        sN[e * 3 + 2] = f.nsr[col * f.Ncont * f.Nspace + fs[q].base + kk];
-    }
-    for (int e = tid; e < tl.nF * f.L; e += nt) {
-        const int q = e / f.L, jj = e % f.L, lq = tl.la0 + min(jj, tl.nla - 1), lt = lq - fs[q].Nblue;
+    const DevSlot* ls = f.slots + tl.slot0;
+    const int nLc = tl.nK > 0 ? min(tl.nL, LSX_MAX_TILE_LINES) : 0;
+    const bool lane_on = j < tl.nla;
+    const int la = tl.la0 + (lane_on ? j : 0);
+    const size_t tb = (col * f.ntile + t) * (size_t)Ns * f.L;
+    const size_t dstride = (size_t)f.ncol * f.ntile * Ns * f.L, pstride = (size_t)f.ncol * f.pp_col_stride, plane = (size_t)Ns * f.L;
+    struct In { double J, P0, P1, E, pp[LSX_MAX_TILE_LINES][2]; };
+    auto load_in = [&](int k, In& x) {
+        const size_t kk = (size_t)((lane_on && k < Ns) ? k : 0) * f.L + (lane_on ? j : 0);
+        x.J = f.J_T[tb + kk];
+        x.P0 = f.Psi2_T[tb + kk];
+        x.P1 = f.Psi2_T[dstride + tb + kk];
+        x.E = f.E_T[tb + kk];
+#pragma unroll
+        for (int u = 0; u < LSX_MAX_TILE_LINES; ++u) {
+            x.pp[u][0] = x.pp[u][1] = 0.0;
+            if (u < nLc) {
+                const double* pp = f.Psi3_T + col * f.pp_col_stride + tl.pp_off + (size_t)u * plane + kk;
+                x.pp[u][0] = pp[0];
+                x.pp[u][1] = pp[pstride];
+            }
+        }
+    };
+    In nxt;
+    load_in(kc, nxt);                                        // first chunk's streams: in flight during the staging
+    // LDS: cells (generic tiles only) | staged once for the whole column: sN[q][k] = {n_i, n_j, nStar_i/nStar_j, -} |
+    // sA[q][j] = {alpha, wlambda} (both 0 where the continuum is inactive: every quantity below is then 0) |
+    // sL[u][k] = {cB (n_i - g n_j), n_j Uc, Uc, -} of line u
+    const int KS = f.seg_depths;                              // depths staged at a time (the whole column where it fits)
+    double* cellbase = sm;
+    double* sN = cellbase + (size_t)(f.generic ? 2 * f.NLtot + f.Natoms : 0) * NT;
+    double* sA = sN + (size_t)4 * f.nF_max * KS;
+    double* sL = sA + (size_t)2 * f.nF_max * LP;
+    auto stage = [&](int ks0) {
+        for (int e = tid; e < tl.nF * KS; e += NT) {
+            const int q = e / KS, kk = min(ks0 + (e - q * KS), Ns - 1);
+            sN[e * 4 + 0] = f.n[(col * f.NLtot + fs[q].li) * Ns + kk];
+            sN[e * 4 + 1] = f.n[(col * f.NLtot + fs[q].lj) * Ns + kk];
+            sN[e * 4 + 2] = f.nsr[col * f.Ncont * Ns + fs[q].base + kk];
+        }
+        for (int e = tid; e < nLc * KS; e += NT) {
+            const int u = e / KS, kk = min(ks0 + (e - u * KS), Ns - 1);
+            const double ni = f.n[(col * f.NLtot + ls[u].li) * Ns + kk], nj = f.n[(col * f.NLtot + ls[u].lj) * Ns + kk];
+            sL[e * 4 + 0] = ls[u].cB * (ni - ls[u].g * nj);      // chi_line = this * phi, rh_method.py:279-280, :613
+            sL[e * 4 + 1] = nj * ls[u].Uc;                       // eta_line = this * phi, :281, :614
+            sL[e * 4 + 2] = ls[u].Uc;                            // Uji_line = this * phi
+        }
+    };
+    stage(0);
+    for (int e = tid; e < tl.nF * LP; e += NT) {
+        const int q = e / LP, jj = e % LP, lq = tl.la0 + min(jj, tl.nla - 1), lt = lq - fs[q].Nblue;
         const bool a = jj < tl.nla && lt >= 0 && lt < fs[q].Nlam && f.active[(size_t)fs[q].trans * f.Nspect + lq] != 0;
-        sA[e * 3 + 0] = a ? 1.0 : 0.0;
-        sA[e * 3 + 1] = a ? f.alpha[fs[q].wl_off + lt] : 0.0;
-        sA[e * 3 + 2] = a ? f.wl[fs[q].wl_off + lt] : 0.0;
+        sA[e * 2 + 0] = a ? f.alpha[fs[q].wl_off + lt] : 0.0;
+        sA[e * 2 + 1] = a ? f.wl[fs[q].wl_off + lt] : 0.0;
     }
     double sW = 0.0;
     for (int m = 0; m < f.Nrays; ++m) sW += 2.0 * f.wmuh[m] * (4.0 * M_PI);   // both directions
-    double sI = 0.0, sPsi = 0.0, E = 0.0;
     const double ula = f.u_la[la];
-    if (on) {
-        const size_t o = ((col * f.ntile + t) * f.Nspace + k) * f.L + j;
-        const size_t dstride = (size_t)f.ncol * f.ntile * f.Nspace * f.L;
-        sI = f.J_T[o] * (4.0 * M_PI);
-        sPsi = f.Psi2_T[o] + f.Psi2_T[dstride + o];
-        E = fast_boltzmann(f, col, la, k);
-    }
     __syncthreads();
-    // fast_value() from the staged operands (same arithmetic)
-    auto value = [&](int q) {
-        FastVal v;
-        const double* A = sA + (size_t)(q * f.L + j) * 3;
-        const double* N = sN + (size_t)(q * KC + (kc < KC ? kc : 0)) * 3;
-        v.a = A[0] != 0.0;
-        v.alf = v.Vji = v.Uji = v.chi = v.eta = 0.0;
-        if (v.a) {
-            v.alf = A[1];
-            v.Vji = (N[2] * E) * v.alf;
-            v.Uji = ula * v.Vji;
-            v.chi = N[0] * v.alf - N[1] * v.Vji;
-            v.eta = N[1] * v.Uji;
+    const bool last_lane = j == LP - 1;
+    int ks0 = 0;
+    for (int k = kc; k < Ns + kc; k += KR) {                 // (every thread runs every pass: the DPP reductions need whole rows)
+        if (k - kc >= ks0 + KS) {                            // next depth segment (deep columns only)
+            ks0 += KS;
+            __syncthreads();
+            stage(ks0);
+            __syncthreads();
         }
-        return v;
-    };
-    if (tl.fast_simple) {
-        for (int q0 = 0; q0 < tl.nF;) {                     // one atom at a time
-            const int atom = fs[q0].atom;
-            int q1 = q0;
-            double chi_j = 0.0, U_j = 0.0, etaA = 0.0;      // atom.chi[j], atom.U[j], atom.eta of rh_method.py:616-627
-            for (; q1 < tl.nF && fs[q1].atom == atom; ++q1) {
-                if (on) {
+        const In x = nxt;
+        load_in(k + KR, nxt);
+        const bool on = lane_on && k < Ns;
+        const int ks = min(k - ks0, KS - 1);                 // staged row of this depth (results dropped if k >= Ns)
+        const double sI = x.J * (4.0 * M_PI), sPsi = x.P0 + x.P1, E = x.E;
+        // the lines' ray sums times their depth coefficients: sum_rays w Psi* {chi, eta, Uji}_line
+        double tchi[LSX_MAX_TILE_LINES], teta[LSX_MAX_TILE_LINES], tU[LSX_MAX_TILE_LINES];
+#pragma unroll
+        for (int u = 0; u < LSX_MAX_TILE_LINES; ++u) {
+            tchi[u] = teta[u] = tU[u] = 0.0;
+            if (u < nLc) {
+                const double* Lq = sL + (size_t)(u * KS + ks) * 4;
+                const double sPP = x.pp[u][0] + x.pp[u][1];
+                tchi[u] = Lq[0] * sPP;
+                teta[u] = Lq[1] * sPP;
+                tU[u] = Lq[2] * sPP;
+            }
+        }
+        // one fast continuum at (lambda, depth) from the staged operands: rh_method.py:284-286, 453-455, 613-614
+        auto value = [&](int q) {
+            FastVal v;
+            const double2 A = *reinterpret_cast<const double2*>(sA + (size_t)(q * LP + j) * 2);
+            const double2 N = *reinterpret_cast<const double2*>(sN + (size_t)(q * KS + ks) * 4);
+            const double nsr = sN[(size_t)(q * KS + ks) * 4 + 2];
+            v.alf = A.x;
+            v.a = A.x != 0.0;
+            v.Vji = (nsr * E) * v.alf;
+            v.Uji = ula * v.Vji;
+            v.chi = N.x * v.alf - N.y * v.Vji;
+            v.eta = N.y * v.Uji;
+            return v;
+        };
+        // the lines' share of (chi_a[lev] Psi) and (U_a[lev] Psi), lev = the lower level of continuum q (its lkbits say which
+        // lines touch it: bit 1 as their lower level, bit 2 as their upper level), and of (eta_a Psi) (bit 0: same atom)
+        auto line_chi = [&](unsigned lk) {
+            double r = 0.0;
+#pragma unroll
+            for (int u = 0; u < LSX_MAX_TILE_LINES; ++u) {
+                if (lk & (2u << (8 * u))) r += tchi[u];
+                if (lk & (4u << (8 * u))) r -= tchi[u];
+            }
+            return r;
+        };
+        auto line_U = [&](unsigned lk) {
+            double r = 0.0;
+#pragma unroll
+            for (int u = 0; u < LSX_MAX_TILE_LINES; ++u)
+                if (lk & (4u << (8 * u))) r += tU[u];
+            return r;
+        };
+        auto line_eta = [&](unsigned lk) {
+            double r = 0.0;
+#pragma unroll
+            for (int u = 0; u < LSX_MAX_TILE_LINES; ++u)
+                if (lk & (1u << (8 * u))) r += teta[u];
+            return r;
+        };
+        // wavelength quadrature of slot q: a DPP reduction over the row (fixed order); its last lane stores the total to
+        // Gpart[slot][e][dir 0][k], direction 1 carries nothing.  (Summing through LDS with two barriers per group of slots was
+        // measured 50 % slower.)
+        auto emit = [&](int q, double g1, double g2) {
+            const double s1 = row_total<LP>(on ? g1 : 0.0), s2 = row_total<LP>(on ? g2 : 0.0);
+            if (last_lane && k < Ns) {
+                double* g = f.Gpart + ((col * f.nslot_total + tl.slot0 + tl.nP + q) * 4) * (size_t)Ns + k;
+                g[0] = s1;
+                g[Ns] = 0.0;
+                g[2 * (size_t)Ns] = s2;
+                g[3 * (size_t)Ns] = 0.0;
+            }
+        };
+        if (tl.fast_simple) {
+            for (int q0 = 0; q0 < tl.nF;) {                 // one atom at a time
+                const int atom = fs[q0].atom;
+                int q1 = q0;
+                double chi_j = 0.0, U_j = 0.0, etaA = 0.0;  // atom.chi[j], atom.U[j], atom.eta of rh_method.py:616-627
+                for (; q1 < tl.nF && fs[q1].atom == atom; ++q1) {
                     const FastVal v = value(q1);
                     chi_j -= v.chi;
                     U_j += v.Uji;
                     etaA += v.eta;
                 }
-            }
-            for (int q = q0; q < q1; ++q) {
-                double g1 = 0.0, g2 = 0.0;
-                if (on) {
+                const double sIe = (sI - etaA * sPsi) - line_eta(fs[q0].lkbits);
+                for (int q = q0; q < q1; ++q) {
                     const FastVal v = value(q);
-                    if (v.a) {
-                        const double chi_i = 0.0 + v.chi, U_i = 0.0;
-                        const double sIe = sI - etaA * sPsi;
-                        const double wla = sA[(size_t)(q * f.L + j) * 3 + 2];
-                        g1 = wla * ((v.Uji * sW + v.Vji * sIe) - (chi_i * U_j) * sPsi);
-                        g2 = wla * ((v.alf * sIe) - (chi_j * U_i) * sPsi);
-                    }
+                    const unsigned lk = fs[q].lkbits;
+                    const double wla = sA[(size_t)(q * LP + j) * 2 + 1];
+                    // (chi_a[i] Psi) U_a[j] with chi_a[i] = this continuum + the lines on its lower level; chi_a[j] (Psi U_a[i])
+                    // with U_a[i] = the lines that end on its lower level (no continuum does in a simple set)
+                    const double cU = (v.chi * U_j) * sPsi + line_chi(lk) * U_j;
+                    const double cU2 = chi_j * line_U(lk);
+                    emit(q, wla * ((v.Uji * sW + v.Vji * sIe) - cU), wla * ((v.alf * sIe) - cU2));
                 }
-                red[(q * 2 + 0) * nt + tid] = g1;
-                red[(q * 2 + 1) * nt + tid] = g2;
+                q0 = q1;
             }
-            q0 = q1;
-        }
-    } else {
-        double* cell = sm + (size_t)2 * f.nF_max * nt + tid;    // thread-private cells: cell[c * nt]
-        const int ncell = 2 * f.NLtot + f.Natoms;
-        for (int c = 0; c < ncell; ++c) cell[c * nt] = 0.0;
-        if (on) {
+        } else {
+            double* cell = cellbase + tid;                   // thread-private cells: cell[c * NT]
+            const int ncell = 2 * f.NLtot + f.Natoms;
+            for (int c = 0; c < ncell; ++c) cell[c * NT] = 0.0;
             for (int q = 0; q < tl.nF; ++q) {
                 const FastVal v = value(q);
-                cell[fs[q].li * nt] += v.chi;
-                cell[fs[q].lj * nt] -= v.chi;
-                cell[(f.NLtot + fs[q].lj) * nt] += v.Uji;
-                cell[(2 * f.NLtot + fs[q].atom) * nt] += v.eta;
+                cell[fs[q].li * NT] += v.chi;
+                cell[fs[q].lj * NT] -= v.chi;
+                cell[(f.NLtot + fs[q].lj) * NT] += v.Uji;
+                cell[(2 * f.NLtot + fs[q].atom) * NT] += v.eta;
             }
-        }
-        for (int q = 0; q < tl.nF; ++q) {
-            double g1 = 0.0, g2 = 0.0;
-            if (on) {
+            for (int q = 0; q < tl.nF; ++q) {
                 const FastVal v = value(q);
-                if (v.a) {
-                    const double etaA = cell[(2 * f.NLtot + fs[q].atom) * nt];
-                    const double chi_i = cell[fs[q].li * nt], chi_j = cell[fs[q].lj * nt];
-                    const double U_i = cell[(f.NLtot + fs[q].li) * nt], U_j = cell[(f.NLtot + fs[q].lj) * nt];
-                    const double sIe = sI - etaA * sPsi;
-                    const double wla = sA[(size_t)(q * f.L + j) * 3 + 2];
-                    g1 = wla * ((v.Uji * sW + v.Vji * sIe) - (chi_i * U_j) * sPsi);
-                    g2 = wla * ((v.alf * sIe) - (chi_j * U_i) * sPsi);
-                }
+                const unsigned lk = fs[q].lkbits;
+                const double etaA = cell[(2 * f.NLtot + fs[q].atom) * NT];
+                const double chi_i = cell[fs[q].li * NT], chi_j = cell[fs[q].lj * NT];
+                const double U_i = cell[(f.NLtot + fs[q].li) * NT], U_j = cell[(f.NLtot + fs[q].lj) * NT];
+                const double sIe = (sI - etaA * sPsi) - line_eta(lk);
+                const double wla = sA[(size_t)(q * LP + j) * 2 + 1];
+                const double cU = (chi_i * U_j) * sPsi + line_chi(lk) * U_j;
+                const double cU2 = (chi_j * U_i) * sPsi + chi_j * line_U(lk);
+                emit(q, wla * ((v.Uji * sW + v.Vji * sIe) - cU), wla * ((v.alf * sIe) - cU2));
             }
-            red[(q * 2 + 0) * nt + tid] = g1;
-            red[(q * 2 + 1) * nt + tid] = g2;
         }
-    }
-    __syncthreads();
-    // wavelength quadrature: fixed-order sum over the tile's wavelengths, one thread per (slot, entry, depth)
-    for (int w = tid; w < tl.nF * 2 * KC; w += nt) {
-        const int kc2 = w % KC, qe = w / KC;
-        const int k2 = blockIdx.x * KC + kc2;
-        if (k2 >= f.Nspace) continue;
-        double acc = 0.0;
-        for (int jj = 0; jj < tl.nla; ++jj) acc += red[(size_t)qe * nt + kc2 * f.L + jj];
-        const int q = qe >> 1, e = qe & 1;
-        double* g = f.Gpart + (((col * f.nslot_total + tl.slot0 + tl.nP + q) * 2 + e) * 2) * f.Nspace + k2;
-        g[0] = acc;               // direction 0 carries the total
-        g[f.Nspace] = 0.0;        // direction 1
     }
 }
 
@@ -875,17 +1001,16 @@ double wlambda(const lsx_ctx* c, const std::vector<double>& wave, const lsx_tran
 
 namespace lsxd {
 
-// what depends on (nStar, temperature) of columns [cc, cc + nb): the continuum g_ij tables (rh_method.py:453-454), one
-// block per (tile, per-ray continuum), and the nStar ratios the fast continua use.  Enqueued on the context's stream.
+// what depends on (nStar, temperature) of columns [cc, cc + nb): the two factors of the continuum g_ij
+// (rh_method.py:453-454) -- the Boltzmann factor per (wavelength, depth) and the nStar ratio per (continuum, depth).
+// Enqueued on the context's stream.
 int rebuild_derived(lsx_ctx* c, size_t cc, size_t nb)
 {
     const int Ns = c->Nspace;
-    for (const DevSlot& sl : c->slots) {
-        if ((sl.flags & (SLOT_LINE | SLOT_FAST)) || sl.len <= 0) continue;
-        dim3 grid((sl.len * Ns + 255) / 256, (unsigned)nb);
-        hipLaunchKernelGGL(k_build_gijc, grid, dim3(256), 0, c->stream, c->d_nStar + cc * c->NLtot * Ns,
-                           c->d_temperature + cc * Ns, c->d_wavelength, c->d_gijc + cc * c->gijc_col + sl.base, sl.li, sl.lj,
-                           sl.first, sl.len, Ns, c->NLtot, c->gijc_col);
+    if (c->d_E) {
+        dim3 grid((unsigned)((c->til_col + 255) / 256), (unsigned)nb);
+        hipLaunchKernelGGL(k_build_E, grid, dim3(256), 0, c->stream, c->d_temperature + cc * Ns, c->d_wavelength,
+                           c->d_E + cc * c->til_col, c->d_tiles, (int)c->tiles.size(), c->L, Ns);
         HIPCHK(hipGetLastError());
     }
     if (c->d_nsr) {
@@ -961,8 +1086,8 @@ void lsx_destroy(lsx_ctx* c)
     void* ptrs[] = {c->d_wavelength, c->d_zmu, c->d_wmuh, c->d_wl, c->d_alpha, c->d_u_la, c->d_active, c->d_trans,
                     c->d_tiles, c->d_slots, c->d_tile_slots, c->d_Nlevel, c->d_lev2_off, c->d_height,
                     c->d_temperature, c->d_nStar, c->d_nTotal, c->d_n, c->d_C, c->d_Gamma, c->d_wphi, c->d_bgchi,
-                    c->d_bgeta, c->d_sca, c->d_phi, c->d_gijc, c->d_J[0], c->d_J[1], c->d_I, c->d_Gpart, c->d_dJpart,
-                    c->d_res, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab, c->d_hck_la, c->d_voigt_w, c->d_muz, c->d_wmu};
+                    c->d_bgeta, c->d_sca, c->d_phi, c->d_E, c->d_corr, c->d_Psi3, c->d_J[0], c->d_J[1], c->d_I, c->d_Gpart, c->d_dJpart,
+                    c->d_res, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab, c->d_voigt_w, c->d_muz, c->d_wmu};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& k : c->classes) {
@@ -1013,6 +1138,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     c->L = LSX_WAVE / d->Nrays;
     c->opt_se_lds = getenv("LSX_SE_LDS") != nullptr;              // diagnostics; the environment is read here only
     c->opt_trace_classes = getenv("LSX_TRACE_CLASSES") != nullptr;
+    c->opt_serial = getenv("LSX_SERIAL") != nullptr;              // every class on the context's stream, one after the other
     const int Ns = c->Nspace, Nspect = c->Nspect;
     for (int a = 0; a < c->Natoms; ++a) {
         if (d->Nlevel[a] < 2) { lsx_destroy(c); return fail(LSX_EINVAL, "lsx_create: Nlevel < 2"); }
@@ -1064,32 +1190,56 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     }
     // ---- tile schedule: L = 64/Nrays consecutive wavelengths per wavefront pair
     const int P_line = c->phi_compact ? 1 : 2 * c->Nrays;
-    size_t phi_run = 0, gij_run = 0;   // running block offsets inside a column's phi_T / gijc_T
+    size_t phi_run = 0, corr_run = 0, pp_run = 0;   // running block offsets inside a column's phi_T / corr_T / Psi3_T
+    // The transitions of the wavelengths [a, b) by role.  Lines are per-ray slots of the sweep.  A continuum is
+    //   fast     its atom has no line in the tile: ray independent, handled by k_fast_prepass / k_fast_gamma;
+    //   linked   its atom has lines in the tile but none of them touches the continuum's UPPER level: its Gamma integrand
+    //            is then affine in I, Psi* and Psi* phi_line with ray-independent coefficients, so it stays out of the
+    //            sweep too -- the sweep stores sum_mu w Psi* phi per line, the pre-pass hands the line three
+    //            ray-independent sums (atom.eta, atom.chi[i], atom.chi[j] of the continua, rh_method.py:616-627);
+    //   per-ray  otherwise (a line ends on the continuum's upper level): goes through the sweep like a line.
+    // If one continuum of an atom has to be per-ray, all continua of that atom in the tile are (their sums couple).
+    struct Roles { std::vector<int> lines, per_ray_conts, fast; int nlinked = 0; };
+    const bool no_linked = getenv("LSX_NO_LINKED") != nullptr;      // diagnostic: the round-1 classification
+    auto roles_of = [&](int a, int b) {
+        Roles r;
+        std::vector<int> conts;
+        unsigned atoms_with_line = 0;
+        for (int t = 0; t < c->Ntrans; ++t) {
+            bool any = false;
+            for (int la = a; la < b && !any; ++la) any = active[(size_t)t * Nspect + la];
+            if (!any) continue;
+            if (c->htrans[t].is_line) { r.lines.push_back(t); atoms_with_line |= 1u << c->htrans[t].atom; }
+            else conts.push_back(t);
+        }
+        unsigned atoms_per_ray = 0;
+        for (int t : conts) {
+            const DevTrans& h = c->htrans[t];
+            if (!((atoms_with_line >> h.atom) & 1u)) continue;
+            bool touches = no_linked;
+            for (int l : r.lines) touches = touches || c->htrans[l].li == h.lj || c->htrans[l].lj == h.lj;
+            if (touches) atoms_per_ray |= 1u << h.atom;
+        }
+        for (int t : conts) {
+            const DevTrans& h = c->htrans[t];
+            if ((atoms_per_ray >> h.atom) & 1u) r.per_ray_conts.push_back(t);
+            else { r.fast.push_back(t); r.nlinked += (atoms_with_line >> h.atom) & 1u; }
+        }
+        return r;
+    };
     // ---- where to cut: a wavefront costs the same for 1 or L wavelengths, and roughly C(nP) per depth
     // step with nP = per-ray slots of the tile (measured shader cycles, profiles/).  Dynamic programme over
     // the cut positions; ties favour fewer tiles.  Any tiling gives the same results.
     std::vector<int> cuts;
     {
-        auto per_ray_slots = [&](int a, int b) {       // wavelengths [a, b)
-            unsigned atoms_with_line = 0;
-            int nlines = 0;
-            std::vector<int> conts;
-            for (int t = 0; t < c->Ntrans; ++t) {
-                bool any = false;
-                for (int la = a; la < b && !any; ++la) any = active[(size_t)t * Nspect + la];
-                if (!any) continue;
-                if (c->htrans[t].is_line) { nlines++; atoms_with_line |= 1u << c->htrans[t].atom; }
-                else conts.push_back(t);
-            }
-            int np = nlines;
-            for (int t : conts) np += (atoms_with_line >> c->htrans[t].atom) & 1u;
-            return np;
-        };
-        auto cost = [](int np) {
+        auto cost = [&](int a, int b) {
             // SIMD time of one wavefront (wave cycles / resident waves per SIMD), PMC-measured on MI355X for the
-            // classes with 0 .. 4 compile-time slots (profiles/); more slots run the generic instance
+            // classes with 0 .. 4 compile-time slots (profiles/); more slots run the generic instance.  Linked continua
+            // cost the sweep three stream loads and one more angle sum per line.
             static const double C[] = {2500.0, 2950.0, 3550.0, 6600.0, 9600.0};
-            return np <= 4 ? C[np] : 14600.0 + 2500.0 * (np - 5);
+            const Roles r = roles_of(a, b);
+            const int np = (int)(r.lines.size() + r.per_ray_conts.size());
+            return (np <= 4 ? C[np] : 14600.0 + 2500.0 * (np - 5)) + (r.nlinked ? 250.0 * r.lines.size() : 0.0);
         };
         const char* env = getenv("LSX_TILER");
         const bool natural = env && std::string(env) == "natural";
@@ -1100,7 +1250,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
             for (int w = 1; w <= c->L && w <= i; ++w) {
                 if (natural && w != c->L && i != Nspect) continue;
                 if (natural && ((i - w) % c->L) != 0) continue;
-                const double v = best[i - w] + cost(per_ray_slots(i - w, i)) + 1.0;
+                const double v = best[i - w] + cost(i - w, i) + 1.0;
                 if (v < best[i]) { best[i] = v; from[i] = i - w; }
             }
         for (int i = Nspect; i > 0; i = from[i]) cuts.push_back(from[i]);
@@ -1117,18 +1267,13 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         tl.la0 = la0;
         tl.nla = cuts[ic + 1] - la0;
         tl.slot0 = (int)c->tile_slots.size();
-        std::vector<int> lines, conts;
+        const Roles roles = roles_of(la0, la0 + tl.nla);
+        const std::vector<int>& lines = roles.lines;
+        // per-ray slots: lines, then the continua that must go through the sweep; fast: the other continua (linked ones flagged)
+        std::vector<int> per_ray = lines, fast = roles.fast;
+        per_ray.insert(per_ray.end(), roles.per_ray_conts.begin(), roles.per_ray_conts.end());
         unsigned atoms_with_line = 0;
-        for (int t = 0; t < c->Ntrans; ++t) {
-            bool any = false;
-            for (int la = la0; la < la0 + tl.nla; ++la) any = any || active[(size_t)t * Nspect + la];
-            if (!any) continue;
-            if (c->htrans[t].is_line) { lines.push_back(t); atoms_with_line |= 1u << c->htrans[t].atom; }
-            else conts.push_back(t);
-        }
-        // per-ray slots: lines, then continua of atoms that have a line in the tile; fast: the other continua
-        std::vector<int> per_ray = lines, fast;
-        for (int t : conts) ((atoms_with_line >> c->htrans[t].atom) & 1u ? per_ray : fast).push_back(t);
+        for (int t : lines) atoms_with_line |= 1u << c->htrans[t].atom;
         if ((int)per_ray.size() > LSX_MAX_PER_RAY || (int)fast.size() > LSX_MAX_FAST) {
             lsx_destroy(c);
             return fail(LSX_EUNSUPPORTED, "lsx_create: more than %d overlapping transitions in wavelengths [%d, %d)",
@@ -1136,6 +1281,15 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         }
         tl.nP = (int)per_ray.size();
         tl.nF = (int)fast.size();
+        tl.nK = roles.nlinked;
+        tl.nL = (int)lines.size();
+        if (tl.nK > 0) {            // the line slots' correction streams and the sweep's sum_mu w Psi* phi streams
+            tl.corr_off = (int)corr_run;
+            corr_run += (size_t)tl.nL * 3 * Ns * c->L;
+            tl.pp_off = (int)pp_run;
+            pp_run += (size_t)tl.nL * Ns * c->L;
+        }
+        c->any_cont = c->any_cont || !fast.empty() || per_ray.size() > lines.size();
         std::vector<int> order = per_ray;
         order.insert(order.end(), fast.begin(), fast.end());
         // tile-local cell ids
@@ -1146,16 +1300,16 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
             v.push_back(x);
             return (int)v.size() - 1;
         };
-        // first-writer bookkeeping follows the execution order of a sweep step: the fast loop, then pass 1
-        std::vector<int> exec = fast;
-        exec.insert(exec.end(), per_ray.begin(), per_ray.end());
+        // level / atom cells of the generic instance: shared among the PER-RAY slots only (fast and linked continua never
+        // enter the sweep's bookkeeping); first-writer flags follow the execution order of pass 1
+        std::vector<int> exec = per_ray;
         std::vector<int> chi_written, u_written, eta_written;
         auto seen = [](std::vector<int>& v, int x) { bool sn = std::find(v.begin(), v.end(), x) != v.end(); if (!sn) v.push_back(x); return sn; };
         std::vector<int> first_flags(c->Ntrans, 0);
         auto share_flags = [&](int t) {
             const DevTrans& h = c->htrans[t];
             int nli = 0, nlj = 0, natom = 0, uiread = 0;
-            for (int v : order) {
+            for (int v : per_ray) {
                 const DevTrans& o = c->htrans[v];
                 if (o.li == h.li || o.lj == h.li) nli++;
                 if (o.li == h.lj || o.lj == h.lj) nlj++;
@@ -1198,12 +1352,20 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
                 phi_run += (size_t)sl.len * P_line * Ns;
                 sl.wphi_off = h.line_idx * Ns;
                 sl.cB = h.cB; sl.g = h.gij; sl.Vc = h.gij * h.cB; sl.Uc = h.AB * (h.gij * h.cB);
-            } else if (std::find(fast.begin(), fast.end(), t) != fast.end()) {
-                sl.flags |= SLOT_FAST;                       // g_ij formed on the fly from the nStar ratio table
-                sl.base = cont_index[t] * Ns;
             } else {
-                sl.base = (int)gij_run;
-                gij_run += (size_t)sl.len * Ns;
+                sl.base = cont_index[t] * Ns;                // row of the nStar-ratio table: g_ij = nsr * E_T
+                if (std::find(fast.begin(), fast.end(), t) != fast.end()) {
+                    sl.flags |= SLOT_FAST;
+                    if ((atoms_with_line >> h.atom) & 1u) {
+                        sl.flags |= SLOT_LINKED;
+                        for (size_t u = 0; u < lines.size() && u < 4; ++u) {
+                            const DevTrans& x = c->htrans[lines[u]];
+                            if (x.atom == h.atom) sl.lkbits |= 1u << (8 * u);
+                            if (x.li == h.li) sl.lkbits |= 2u << (8 * u);
+                            if (x.lj == h.li) sl.lkbits |= 4u << (8 * u);
+                        }
+                    }
+                }
             }
             if (tl.nP >= 2 && tl.nP <= 4 && !(sl.flags & SLOT_FAST)) {
                 int o = 0;
@@ -1247,11 +1409,11 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         const int npt = (tl.nP <= 4 && table_fits) ? tl.nP : -1;
         if (npt >= 0) c->static_max = std::max(c->static_max, npt);
         const int nl = npt >= 0 ? (int)lines.size() : 0;
-        tl.nL = (int)lines.size();
+        const bool lk = tl.nK > 0;
         SweepClass* k = nullptr;
         for (auto& q : c->classes)
-            if (q.npt == npt && q.nl == nl) k = &q;
-        if (!k) { c->classes.push_back(SweepClass()); k = &c->classes.back(); k->npt = npt; k->nl = nl; }
+            if (q.npt == npt && q.nl == nl && q.linked == lk) k = &q;
+        if (!k) { c->classes.push_back(SweepClass()); k = &c->classes.back(); k->npt = npt; k->nl = nl; k->linked = lk; }
         k->tiles.push_back((int)c->tiles.size());
         if (tl.nF > 0) { k->has_fast = true; k->fast_tiles.push_back((int)c->tiles.size()); }
         k->ncell_lev = std::max(k->ncell_lev, (int)lev_ids.size());
@@ -1280,7 +1442,8 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         k.lds_bytes = (size_t)LSX_EXP_TAB * sizeof(double) + (size_t)(2 * (2 * cl + ca + 1) + 2) * LSX_WAVE * sizeof(double) +
                       (size_t)(k.npt >= 0 ? (Ns + 1) * (3 * k.npt + 2) : 0) * sizeof(double) +
                       (size_t)(k.npt > 0 ? 2 * 2 * k.npt * LSX_WAVE : 0) * sizeof(double) +    // parked Gamma totals
-                      (size_t)(k.npt >= 3 ? k.npt * (k.npt - 1) * 5 : 0) * sizeof(double);    // slot-pair factors
+                      (size_t)(k.npt >= 3 ? k.npt * (k.npt - 1) * 5 : 0) * sizeof(double) +   // slot-pair factors
+                      (size_t)(k.linked && k.npt > 0 ? 2 * k.npt * LSX_WAVE : 0) * sizeof(double);   // linked: exchange rows of the Psi* phi sums
         if (k.lds_bytes > 64 * 1024) { lsx_destroy(c); return fail(LSX_EUNSUPPORTED, "lsx_create: a tile needs %zu B of LDS", k.lds_bytes); }
         c->lds_bytes = std::max(c->lds_bytes, k.lds_bytes);
     }
@@ -1302,11 +1465,6 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     TRY(upload(&c->d_wl, wl, c->stream));
     TRY(upload(&c->d_alpha, alpha, c->stream));
     TRY(upload(&c->d_u_la, u_la, c->stream));
-    {
-        std::vector<double> hck(Nspect);
-        for (int la = 0; la < Nspect; ++la) hck[la] = kHC / (kKBoltzmann * kNM_TO_M) / wave[la];
-        TRY(upload(&c->d_hck_la, hck, c->stream));
-    }
     TRY(upload(&c->d_exp2_tab, make_exp2_table(), c->stream));
     TRY(upload(&c->d_active, active, c->stream));
     TRY(upload(&c->d_trans, c->htrans, c->stream));
@@ -1336,10 +1494,11 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     const size_t nc = ncol;
     c->phi_in_col = (size_t)c->SNl * (c->phi_compact ? 1 : 2 * (size_t)c->Nrays) * Ns; // as handed over (rh_method.py:224)
     c->phi_col = phi_run;                                    // as stored: sum of the (tile, line) blocks
-    c->gijc_col = gij_run;
+    c->corr_col = corr_run;
+    c->pp_col = pp_run;
     c->til_col = c->tiles.size() * (size_t)c->L * Ns;        // one tile-major [tile][k][j] array
     c->sca_col = c->sca_per_lambda ? c->til_col : (size_t)Ns;
-    if (c->phi_col > 0x0fffffff || c->gijc_col > 0x0fffffff || c->til_col > 0x0fffffff) { lsx_destroy(c); return fail(LSX_EUNSUPPORTED, "column too large for 32-bit byte offsets"); }
+    if (c->phi_col > 0x0fffffff || c->corr_col > 0x0fffffff || c->til_col > 0x0fffffff) { lsx_destroy(c); return fail(LSX_EUNSUPPORTED, "column too large for 32-bit byte offsets"); }
     TRY(dmalloc(&c->d_height, nc * Ns));
     TRY(dmalloc(&c->d_temperature, nc * Ns));
     TRY(dmalloc(&c->d_nStar, nc * c->NLtot * Ns));
@@ -1352,7 +1511,12 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     TRY(dmalloc(&c->d_bgeta, nc * c->til_col));
     TRY(dmalloc(&c->d_sca, nc * c->sca_col));
     TRY(dmalloc(&c->d_phi, nc * c->phi_col));
-    TRY(dmalloc(&c->d_gijc, nc * c->gijc_col));
+    if (c->any_cont) TRY(dmalloc(&c->d_E, nc * c->til_col));
+    if (c->corr_col) {
+        TRY(dmalloc(&c->d_corr, nc * c->corr_col));
+        TRY(dmalloc(&c->d_Psi3, 2 * nc * c->pp_col));
+        (void)hipMemsetAsync(c->d_Psi3, 0, 2 * nc * c->pp_col * 8, c->stream);
+    }
     TRY(dmalloc(&c->d_J[0], nc * c->til_col));
     TRY(dmalloc(&c->d_J[1], nc * c->til_col));
     TRY(dmalloc(&c->d_I, nc * Nspect * c->Nrays));
@@ -1366,13 +1530,15 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     c->d_singular = reinterpret_cast<unsigned long long*>(c->d_res + 2 * nc);
     c->phi_set.assign(nc, 0);
     TRY(dmalloc(&c->d_debug, 64 * 16));
-    if (!c->fast_tiles.empty()) {
-        TRY(upload(&c->d_fast_tiles, c->fast_tiles, c->stream));
+    if (c->any_cont) {          // the nStar ratio of every continuum (g_ij = ratio x E_T)
         for (int t = 0; t < c->Ntrans; ++t)
             if (!c->htrans[t].is_line) { c->cont_li.push_back(c->htrans[t].li); c->cont_lj.push_back(c->htrans[t].lj); }
         TRY(upload(&c->d_cont_li, c->cont_li, c->stream));
         TRY(upload(&c->d_cont_lj, c->cont_lj, c->stream));
         TRY(dmalloc(&c->d_nsr, nc * c->Ncont * Ns));
+    }
+    if (!c->fast_tiles.empty()) {
+        TRY(upload(&c->d_fast_tiles, c->fast_tiles, c->stream));
         TRY(dmalloc(&c->d_bgxchi, nc * c->til_col));
         TRY(dmalloc(&c->d_bgxeta, nc * c->til_col));
         TRY(dmalloc(&c->d_Psi2, 2 * nc * c->til_col));
@@ -1485,9 +1651,9 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
     p.L = c->L;
     p.wavelength = c->d_wavelength; p.zmu = c->d_zmu; p.wmuh = c->d_wmuh; p.wl = c->d_wl; p.alpha = c->d_alpha;
     p.u_la = c->d_u_la; p.active = c->d_active; p.tiles = c->d_tiles; p.slots = c->d_slots;
-    p.phi_col_stride = (int64_t)c->phi_col; p.gijc_col_stride = (int64_t)c->gijc_col;
+    p.phi_col_stride = (int64_t)c->phi_col; p.corr_col_stride = (int64_t)c->corr_col; p.pp_col_stride = (int64_t)c->pp_col;
     p.height = c->d_height; p.temperature = c->d_temperature; p.n = c->d_n; p.wphi = c->d_wphi;
-    p.bgchi_T = c->d_bgchi; p.bgeta_T = c->d_bgeta; p.bgxchi_T = c->d_bgxchi; p.bgxeta_T = c->d_bgxeta; p.Psi2_T = c->d_Psi2; p.sca = c->d_sca; p.phi_T = c->d_phi; p.gijc_T = c->d_gijc;
+    p.bgchi_T = c->d_bgchi; p.bgeta_T = c->d_bgeta; p.bgxchi_T = c->d_bgxchi; p.bgxeta_T = c->d_bgxeta; p.Psi2_T = c->d_Psi2; p.sca = c->d_sca; p.phi_T = c->d_phi; p.nsr = c->d_nsr; p.Ncont = c->Ncont; p.E_T = c->d_E; p.corr_T = c->d_corr; p.Psi3_T = c->d_Psi3;
     p.Jdag_T = c->d_J[c->jcur]; p.Jnew_T = c->d_J[c->jcur ^ 1];
     p.Iout = c->d_I; p.Gpart = c->d_Gpart; p.dJpart = c->d_dJpart; p.debug = c->d_debug; p.colmask = c->d_colmask; p.exp2_tab = c->d_exp2_tab; p.static_max = c->static_max;
 
@@ -1498,29 +1664,50 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
         ff.L = c->L; ff.NLtot = c->NLtot; ff.Natoms = c->Natoms; ff.nslot_total = (int)c->tile_slots.size();
         ff.n_fast_tiles = (int)c->fast_tiles.size(); ff.tiles = c->d_tiles; ff.slots = c->d_slots; ff.fast_tiles = c->d_fast_tiles;
         ff.active = c->d_active; ff.alpha = c->d_alpha; ff.wl = c->d_wl; ff.u_la = c->d_u_la; ff.wmuh = c->d_wmuh; ff.n = c->d_n;
-        ff.nsr = c->d_nsr; ff.temperature = c->d_temperature; ff.hck_la = c->d_hck_la; ff.Ncont = c->Ncont; ff.nF_max = c->nF_max; ff.generic = c->fast_generic ? 1 : 0;
+        ff.nsr = c->d_nsr; ff.E_T = c->d_E; ff.corr_T = c->d_corr; ff.Psi3_T = c->d_Psi3; ff.corr_col_stride = (int64_t)c->corr_col; ff.pp_col_stride = (int64_t)c->pp_col; ff.Ncont = c->Ncont; ff.nF_max = c->nF_max; ff.generic = c->fast_generic ? 1 : 0;
         ff.bgchi_T = c->d_bgchi; ff.bgeta_T = c->d_bgeta;
         ff.bgxchi_T = c->d_bgxchi; ff.bgxeta_T = c->d_bgxeta; ff.J_T = c->d_J[c->jcur ^ 1]; ff.Psi2_T = c->d_Psi2;
         ff.Gpart = c->d_Gpart; ff.colmask = c->d_colmask;
     }
+    // one block per (tile, column); thread = (depth in chunk, wavelength) with LP = 16 / 32 / 64 lanes per depth row
+    const int LP = c->L <= 16 ? 16 : (c->L <= 32 ? 32 : 64);
+    // depths whose operands are staged in LDS at a time: the whole column if `budget` bytes allow, else a multiple of the
+    // rows per pass
+    auto seg_for = [&](int rows, size_t doubles_per_depth, size_t fixed_doubles, size_t budget) {
+        const size_t room = budget / 8 > fixed_doubles ? budget / 8 - fixed_doubles : 0;
+        long fit = (long)(room / std::max<size_t>(1, doubles_per_depth));
+        if (fit >= c->Nspace) return ((c->Nspace + rows - 1) / rows) * rows;
+        return (int)std::max<long>(rows, fit / rows * rows);
+    };
     auto launch_prepass = [&](hipStream_t st, const int* d_list, size_t n) -> int {
         FastParams fq = ff;
         fq.fast_tiles = d_list; fq.n_fast_tiles = (int)n;
-        dim3 grid((c->Nspace * c->L + 255) / 256, (unsigned)n, (unsigned)c->ncol);
-        const size_t smp = (size_t)3 * c->nF_max * (256 / c->L + 2 + c->L) * sizeof(double);
-        hipLaunchKernelGGL(k_fast_prepass, grid, dim3(256), smp, st, fq);
+        dim3 grid((unsigned)n, (unsigned)c->ncol);
+        fq.seg_depths = seg_for(256 / LP, (size_t)4 * c->nF_max, (size_t)c->nF_max * LP, 24 * 1024);
+        const size_t smp = ((size_t)4 * c->nF_max * fq.seg_depths + (size_t)c->nF_max * LP) * sizeof(double);
+        if (smp > 64 * 1024) return fail(LSX_EUNSUPPORTED, "fast-continuum pre-pass needs %zu B of LDS", smp);
+        if (LP == 16) hipLaunchKernelGGL(k_fast_prepass<16>, grid, dim3(256), smp, st, fq);
+        else if (LP == 32) hipLaunchKernelGGL(k_fast_prepass<32>, grid, dim3(256), smp, st, fq);
+        else hipLaunchKernelGGL(k_fast_prepass<64>, grid, dim3(256), smp, st, fq);
         HIPCHK(hipGetLastError());
         return LSX_OK;
     };
     auto launch_fast_gamma = [&](hipStream_t st, const int* d_list, size_t n) -> int {
         FastParams fq = ff;
         fq.fast_tiles = d_list; fq.n_fast_tiles = (int)n;
-        const int nt = c->L > 64 ? 256 : 128, KC = std::max(1, nt / c->L);
-        const size_t sm = ((size_t)((c->fast_generic ? 2 * c->NLtot + c->Natoms : 0) + 2 * c->nF_max) * nt +
-                           (size_t)3 * c->nF_max * (KC + c->L)) * sizeof(double);
+        int nt = 256;
+        const size_t per_depth = (size_t)4 * (c->nF_max + LSX_MAX_TILE_LINES);
+        auto fixed_for = [&](int ntv) { return (size_t)(c->fast_generic ? 2 * c->NLtot + c->Natoms : 0) * ntv + (size_t)2 * c->nF_max * LP; };
+        while (nt > 64 && fixed_for(nt) * 8 > 24 * 1024) nt >>= 1;
+        fq.seg_depths = seg_for(nt / LP, per_depth, fixed_for(nt), 40 * 1024);
+        const size_t sm = (per_depth * fq.seg_depths + fixed_for(nt)) * sizeof(double);
         if (sm > 64 * 1024) return fail(LSX_EUNSUPPORTED, "fast-continuum epilogue needs %zu B of LDS", sm);
-        dim3 grid((c->Nspace + KC - 1) / KC, (unsigned)n, (unsigned)c->ncol);
-        hipLaunchKernelGGL(k_fast_gamma, grid, dim3(nt), sm, st, fq, KC);
+        dim3 grid((unsigned)n, (unsigned)c->ncol);
+#define LSX_FG(LPV, NTV) if (LP == LPV && nt == NTV) hipLaunchKernelGGL((k_fast_gamma<LPV, NTV>), grid, dim3(NTV), sm, st, fq)
+        LSX_FG(16, 256); LSX_FG(16, 128); LSX_FG(16, 64);
+        LSX_FG(32, 256); LSX_FG(32, 128); LSX_FG(32, 64);
+        LSX_FG(64, 256); LSX_FG(64, 128); LSX_FG(64, 64);
+#undef LSX_FG
         HIPCHK(hipGetLastError());
         return LSX_OK;
     };
@@ -1539,7 +1726,8 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
         const size_t lds = (size_t)LSX_EXP_TAB * sizeof(double) + (size_t)(2 * (2 * p.ncell_lev + p.ncell_atom + 1) + 2) * LSX_WAVE * sizeof(double) +
                            (size_t)(npt_max >= 0 ? (c->Nspace + 1) * (3 * npt_max + 2) : 0) * sizeof(double) +
                            (size_t)(npt_max > 0 ? 2 * 2 * npt_max * LSX_WAVE : 0) * sizeof(double) +
-                           (size_t)(npt_max >= 3 ? npt_max * (npt_max - 1) * 5 : 0) * sizeof(double);
+                           (size_t)(npt_max >= 3 ? npt_max * (npt_max - 1) * 5 : 0) * sizeof(double) +
+                           (size_t)(c->corr_col && npt_max > 0 ? 2 * npt_max * LSX_WAVE : 0) * sizeof(double);
         c->fused_launches++;
         hipError_t e = lsx_launch_sweep(&p, -2, (int)nblocks, lds, c->stream);
         if (e != hipSuccess) return fail(LSX_EDEVICE, "sweep launch (fused): %s", hipGetErrorString(e));
@@ -1548,7 +1736,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
         // The classes of one call run side by side on their own streams, forked from the context's stream and joined
         // back into it.  The fast continua of a class's tiles are handled on the class's own stream, pre-pass before
         // and epilogue after the sweep, so no class waits for another and those two light kernels fill gaps.
-        const bool fork = c->classes.size() > 1;
+        const bool fork = c->classes.size() > 1 && !c->opt_serial;
         if (fork) HIPCHK(hipEventRecord(c->ev_fork, c->stream));
         for (auto& k : c->classes) {
             hipStream_t st = fork ? k.stream : c->stream;
@@ -1560,7 +1748,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
             p.n_class_tiles = (int)k.tiles.size();
             p.ncell_lev = k.npt >= 0 ? 0 : k.ncell_lev; p.ncell_atom = k.npt >= 0 ? 0 : k.ncell_atom; p.nstash = 0;
             k.launches++;
-            hipError_t e = lsx_launch_sweep(&p, k.npt >= 0 ? k.npt * 8 + k.nl : -1, (int)nblocks, k.lds_bytes, st);
+            hipError_t e = lsx_launch_sweep(&p, k.npt >= 0 ? k.npt * 8 + k.nl + (k.linked ? 64 : 0) : (k.linked ? -3 : -1), (int)nblocks, k.lds_bytes, st);
             if (e != hipSuccess) return fail(LSX_EDEVICE, "sweep launch (per-ray slots %d): %s", k.npt, hipGetErrorString(e));
             if (timed) {
                 if (!k.tdone) HIPCHK(hipEventCreate(&k.tdone));
@@ -2009,15 +2197,16 @@ double lsx_hip_info(const lsx_ctx* c, int32_t what)
 }
 
 // HIP-only introspection for the tests: which sweep instantiations a context launches.  Returns the number of tile
-// classes; for 0 <= idx < that number out[0..3] = per-ray slots (compile time, -1 generic), lines among them, tiles per
-// column, launches so far.  idx == -1: out[0] = launches of the fused small-batch kernel.
+// classes; for 0 <= idx < that number out[0..4] = per-ray slots (compile time, -1 generic), lines among them, tiles per
+// column, launches so far, 1 if the class's tiles have linked continua.  idx == -1: out[0] = launches of the fused
+// small-batch kernel.
 int32_t lsx_hip_class_info(const lsx_ctx* c, int32_t idx, int64_t* out)
 {
     if (!c) return 0;
     if (out && idx == -1) out[0] = c->fused_launches;
     if (out && idx >= 0 && idx < (int)c->classes.size()) {
         const SweepClass& k = c->classes[idx];
-        out[0] = k.npt; out[1] = k.nl; out[2] = (int64_t)k.tiles.size(); out[3] = k.launches;
+        out[0] = k.npt; out[1] = k.nl; out[2] = (int64_t)k.tiles.size(); out[3] = k.launches; out[4] = k.linked ? 1 : 0;
     }
     return (int32_t)c->classes.size();
 }

@@ -62,52 +62,6 @@ __device__ __forceinline__ double planck(double temp, double wav)
     return twohnu3_c2 / (exp(hc_Tkla) - 1.0);
 }
 
-#ifdef LSX_REDUCE_SHFL
-__device__ __forceinline__ double wave_sum(double v) // total in every lane
-{
-#pragma unroll
-    for (int m = 1; m < LSX_WAVE; m <<= 1) v += __shfl_xor(v, m, LSX_WAVE);
-    return v;
-}
-__device__ __forceinline__ double reduce_pair(double a, double b)
-{
-    const double sa = wave_sum(a), sb = wave_sum(b);
-    return (threadIdx.x & 63) == 63 ? sb : sa;
-}
-__device__ __forceinline__ double reduce_quad(double a, double b, double c, double d)
-{
-    const double sa = wave_sum(a), sb = wave_sum(b), sc = wave_sum(c), sd = wave_sum(d);
-    const int l = threadIdx.x & 63;
-    return l == 15 ? sa : (l == 31 ? sc : (l == 47 ? sb : sd));
-}
-#else
-// DPP (VALU cross-lane moves, no LDS crossbar traffic).  The total of the 64 lanes ends up in
-// lane 63 (the lane that stores it).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_f64(double v)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    // `old` = the source itself: no zero has to be materialised; lanes a row mask leaves out keep their own
-    // value (their sums are never consumed, see the callers)
-    if constexpr (ROW_MASK == 0xf) {                // every lane is written: no `old` operand to set up
-        lo = __builtin_amdgcn_mov_dpp(lo, CTRL, ROW_MASK, 0xf, true);
-        hi = __builtin_amdgcn_mov_dpp(hi, CTRL, ROW_MASK, 0xf, true);
-    } else {
-        lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
-        hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
-    }
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_sum(double v)
-{
-    v += dpp_f64<0xB1, 0xf>(v);  // quad_perm [1,0,3,2]
-    v += dpp_f64<0x4E, 0xf>(v);  // quad_perm [2,3,0,1]: every lane of a quad holds the quad sum
-    v += dpp_f64<0x141, 0xf>(v); // row_half_mirror: 8-lane sums
-    v += dpp_f64<0x140, 0xf>(v); // row_mirror: 16-lane (row) sums in every lane of the row
-    v += dpp_f64<0x142, 0xa>(v); // row_bcast15 into rows 1 and 3: lane 31 = rows 0+1, lane 63 = rows 2+3
-    v += dpp_f64<0x143, 0xc>(v); // row_bcast31 into rows 2 and 3: lane 63 = all four rows
-    return v;
-}
 // Two values reduced for the price of one: v_permlane32_swap exchanges the upper half of `a` with
 // the lower half of `b`, so ONE add folds both vectors to 32 partial sums each (a's in lanes 0-31,
 // b's in lanes 32-63).  Result: lane 31 = sum(a), lane 63 = sum(b).
@@ -116,14 +70,6 @@ __device__ __forceinline__ double fold32(double a, double b)
     const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
     const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
     return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-}
-__device__ __forceinline__ double row_sums(double v)   // every lane of a 16-lane row gets the row's sum
-{
-    v += dpp_f64<0xB1, 0xf>(v);
-    v += dpp_f64<0x4E, 0xf>(v);
-    v += dpp_f64<0x141, 0xf>(v);
-    v += dpp_f64<0x140, 0xf>(v);
-    return v;
 }
 __device__ __forceinline__ double reduce_pair(double a, double b)   // lane 31: sum(a), lane 63: sum(b)
 {
@@ -141,7 +87,6 @@ __device__ __forceinline__ double reduce_quad(double a, double b, double c, doub
     const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(ab), __double2hiint(cd), false, false);
     return row_sums(__hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]));
 }
-#endif
 
 // element at a 32-bit BYTE offset from a wave-uniform base: one scalar base + one 32-bit vector offset
 // (global_load ... v_off, s[base]) instead of 64-bit vector address arithmetic per access
@@ -202,7 +147,9 @@ __device__ __forceinline__ SlotS load_slot(const __attribute__((address_space(4)
 // it is one scalar per depth.
 // NL: how many of the NPT per-ray slots are lines (they come first, lsx_create) -- the slot kind is then a
 // compile-time property of the unrolled slot index and only one of the two formula sets is emitted.
-template <int NPT, int NL, int NR, bool SCAL>
+// LK: the tile has linked continua (lsx_dev.h, SLOT_LINKED): per line three more streams come in (the continua's share of
+// atom.eta, atom.chi[i], atom.chi[j], written by k_fast_prepass) and one more angle sum goes out (sum_mu w Psi* phi).
+template <int NPT, int NL, int NR, bool SCAL, bool LK>
 __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, const int tile_id)
 {
     extern __shared__ double lds_raw[];
@@ -265,10 +212,16 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     const bool sca_l = SCAL && p.sca_per_lambda;
     const double* __restrict__ sca = sca_l ? p.sca + tbase : p.sca + (size_t)col * Ns;
     const double* __restrict__ phi_col = p.phi_T + (size_t)col * p.phi_col_stride;
-    const double* __restrict__ gijc_col = p.gijc_T + (size_t)col * p.gijc_col_stride;
+    const double* __restrict__ Eb = p.E_T + tbase;                    // Boltzmann factor of the continuum g_ij, [k][j]
+    const auto* nsr_col = LSX_CONST(double, p.nsr + (size_t)col * p.Ncont * Ns);
+    // linked continua: the tile's blocks of the correction streams [line][3][k][j] and of the Psi* phi sums [line][k][j]
+    const int nLt = STATIC ? NL : tilep->nL;
+    const size_t plane = (size_t)Ns * L;
+    const double* __restrict__ corr = LK ? p.corr_T + (size_t)col * p.corr_col_stride + tilep->corr_off : nullptr;
+    double* __restrict__ ppsum = LK ? p.Psi3_T + ((size_t)dir * p.ncol + col) * p.pp_col_stride + tilep->pp_off : nullptr;
     double* __restrict__ gpart = p.Gpart + ((size_t)col * p.nslot_total + slot0) * 4 * Ns;
 
-    //   per slot: lines (cB (n_i - g n_j), n_j, wphi)   continua (n_i, n_j, 1);   then the half length of the
+    //   per slot: lines (cB (n_i - g n_j), n_j, wphi)   continua (n_i, n_j, nStar_i / nStar_j);   then the half length of the
     //   interval ABOVE depth k (0.5 |z[k-1] - z[k]|, formal_solver.py:123/129) and the scattering coefficient
     if constexpr (STATIC) {
         const double* ncolp = p.n + (size_t)col * p.NLtot * Ns;
@@ -281,7 +234,8 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                 const bool line = u < NL;
                 utab[e * TR + 3 * u + 0] = line ? slots[u].cB * (ni - slots[u].g * nj) : ni;   // :279-280, :613
                 utab[e * TR + 3 * u + 1] = nj;
-                utab[e * TR + 3 * u + 2] = line ? p.wphi[(size_t)col * p.Nlines * Ns + slots[u].wphi_off + e] : 1.0;
+                utab[e * TR + 3 * u + 2] = line ? p.wphi[(size_t)col * p.Nlines * Ns + slots[u].wphi_off + e]
+                                                : p.nsr[(size_t)col * p.Ncont * Ns + slots[u].base + e];     // g_ij = this * E, :453
             }
             utab[e * TR + 3 * NPT + 0] = e > 0 ? 0.5 * fabs(zc[e - 1] - zc[e]) : 0.0;
             utab[e * TR + 3 * NPT + 1] = sca_l ? 1.0 : p.sca[(size_t)col * Ns + e];
@@ -290,6 +244,8 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     etab[threadIdx.x] = p.exp2_tab[threadIdx.x];          // 2 x 64 threads, 64 x 2 doubles
     // three- and four-slot tiles: the slot-pair factors of the level bookkeeping, [u][other o][5]
     lds_f64* const ctab = utab + (STATIC ? (p.Nspace + 1) * TR : 0) + (size_t)2 * (2 * NS) * LSX_WAVE;
+    // linked tiles: one more exchange row per line and wave (behind the slot-pair factors)
+    lds_f64* const xrow2 = ctab + (NPT >= 3 ? NPT * (NPT - 1) * 5 : 0) + (size_t)dir * NS * LSX_WAVE;
     if constexpr (NPT >= 3) {
         if (threadIdx.x < NPT * (NPT - 1) * 5) {
             const int u = threadIdx.x / ((NPT - 1) * 5), r = threadIdx.x % ((NPT - 1) * 5);
@@ -333,8 +289,8 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             const int len = slots[u].len;
             const int lb = a ? la - slots[u].first : 0;      // position inside the (tile, transition) block
             (void)Nlam;
-            idx0[u] = slots[u].base + (line ? raysel * len : 0) + lb;
-            kstr[u] = line ? kmul * len : len;
+            idx0[u] = line ? slots[u].base + raysel * len + lb : 0;      // continua read the tile's shared E stream
+            kstr[u] = line ? kmul * len : 0;
             wlv[u] = (a && valid) ? wq_l * p.wl[slots[u].wl_off + l] : 0.0;                // :451/:455, :665
             alv[u] = (a && !line) ? p.alpha[slots[u].wl_off + l] : 0.0;
         }
@@ -354,7 +310,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                 const double pv = a ? phi_col[sl.base + (kk * kmul + raysel) * sl.len + lb] : 0.0;
                 c += (sl.cB * (ni - sl.g * nj)) * pv;
             } else {
-                const double g = a ? gijc_col[sl.base + kk * sl.len + lb] : 0.0;
+                const double g = a ? nsr_col[sl.base + kk] * Eb[kk * L + j] : 0.0;
                 const double alf = a ? p.alpha[sl.wl_off + l] : 0.0;
                 c += ni * alf - nj * (g * alf);
             }
@@ -396,24 +352,31 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     // values) are requested one depth ahead.  Memory returns in order, and the static path issues no
     // other vector load inside a step (slot constants sit in registers; the half-J read comes last),
     // so the requests of step s+1 are in flight during the arithmetic of step s.
-    double n_bc = 0.0, n_be = 0.0, n_jd = 0.0, n_sv[NS];
+    constexpr bool HASC = STATIC && NPT > NL;       // compile-time per-ray continua: they share the tile's E stream
+    constexpr int NLK = (LK && NL > 0) ? NL : 1;
+    // a tile with a single per-ray slot never reads atom.chi[j_line]: it multiplies U[i_line], which only another slot feeds
+    constexpr int NCR = NPT == 1 ? 2 : 3;
+    double n_bc = 0.0, n_be = 0.0, n_jd = 0.0, n_sv[NS], n_E = 0.0, n_cr[NLK][3];
 
-    auto stream_loads = [&](int kk, double& bc, double& be, double& jdv, double (&v)[NS]) {
+    auto stream_loads = [&](int kk, double& bc, double& be, double& jdv, double (&v)[NS], double& Ev, double (&cr)[NLK][3]) {
         const unsigned kko = (unsigned)(kk * L + j) * 8u;
         jdv = at(Jdag, kko);
         bc = at(bgchi, kko);
         be = at(bgeta, kko);
         if constexpr (STATIC) {
 #pragma unroll
-            for (int u = 0; u < NPT; ++u) {
-                const bool a = (pact >> u) & 1u;
-                const double* tab = u < NL ? phi_col : gijc_col;
-                (void)a;    // inactive lanes read the block's first element; the value is dropped where it is consumed
-                v[u] = at(tab, (unsigned)(idx0[u] + kk * kstr[u]) * 8u);
+            for (int u = 0; u < NL; ++u)    // inactive lanes read the block's first element; the value is dropped where it is consumed
+                v[u] = at(phi_col, (unsigned)(idx0[u] + kk * kstr[u]) * 8u);
+            if constexpr (HASC) Ev = at(Eb, kko);
+            if constexpr (LK) {
+#pragma unroll
+                for (int u = 0; u < NL; ++u)
+#pragma unroll
+                    for (int q = 0; q < NCR; ++q) cr[u][q] = at(corr, (unsigned)((3 * u + q) * plane) * 8u + kko);
             }
         }
     };
-    if constexpr (STATIC) stream_loads(kS, n_bc, n_be, n_jd, n_sv);
+    if constexpr (STATIC) stream_loads(kS, n_bc, n_be, n_jd, n_sv, n_E, n_cr);
 
     // Gamma totals wait in LDS, one 64-entry row per (slot, entry) and wave, until 64 depths can leave in one store.
     // The lanes that hold totals after a reduction (31 / 63, or 15 / 47 / 31 / 63) each own one row.
@@ -431,18 +394,26 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         constexpr int PH = decltype(phase_c)::value;
         const int k = kS + dk * s;
         const unsigned kl = (unsigned)(k * L + j) * 8u;     // byte position in the tile-major [k][j] streams
-        double jd, chiTot, be_l;
-        double sv[NS], sni[NS], snj[NS];
+        double jd, chiTot, be_l, Ev = 0.0;
+        double sv[NS], sni[NS], snj[NS], cr[NLK][3];
         const lds_f64* tk = utab + k * TR;
         double jhalf = 0.0;
         if constexpr (PH == 2) {
             if (2 * s == Ns || 2 * s == Ns + 1) __syncthreads();   // the partner wave's first-half stores
         }
         if constexpr (STATIC) {
-            jd = n_jd; chiTot = n_bc; be_l = n_be;
+            jd = n_jd; chiTot = n_bc; be_l = n_be; Ev = n_E;
 #pragma unroll
-            for (int u = 0; u < NPT; ++u) sv[u] = ((pact >> u) & 1u) ? n_sv[u] : 0.0;
-            if (s + 1 < Ns) stream_loads(k + dk, n_bc, n_be, n_jd, n_sv);
+            for (int u = 0; u < NL; ++u) sv[u] = ((pact >> u) & 1u) ? n_sv[u] : 0.0;
+#pragma unroll
+            for (int u = NL; u < NPT; ++u) sv[u] = ((pact >> u) & 1u) ? tk[3 * u + 2] * Ev : 0.0;       // g_ij = (nStar_i / nStar_j) E, :453-454
+            if constexpr (LK) {
+#pragma unroll
+                for (int u = 0; u < NL; ++u)
+#pragma unroll
+                    for (int q = 0; q < NCR; ++q) cr[u][q] = n_cr[u][q];
+            }
+            if (s + 1 < Ns) stream_loads(k + dk, n_bc, n_be, n_jd, n_sv, n_E, n_cr);
             if constexpr (PH == 2) jhalf = at(Jnew, kl);
 #pragma unroll
             for (int u = 0; u < NPT; ++u) {
@@ -450,7 +421,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                 snj[u] = tk[3 * u + 1];
             }
         } else {
-            stream_loads(k, chiTot, be_l, jd, sv);
+            stream_loads(k, chiTot, be_l, jd, sv, Ev, cr);
         }
         double hdzm, scv;
         if constexpr (STATIC) {
@@ -510,7 +481,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                 if (sl.flags & SLOT_LINE) {
                     v = a ? phi_col[sl.base + (k * kmul + raysel) * sl.len + (la - sl.first)] : 0.0;
                 } else {
-                    v = a ? gijc_col[sl.base + k * sl.len + (la - sl.first)] : 0.0;
+                    v = a ? nsr_col[sl.base + k] * at(Eb, kl) : 0.0;
                     alf = a ? p.alpha[sl.wl_off + l] : 0.0;
                 }
                 double pv, chi, Uji, eta;
@@ -556,7 +527,25 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         double Jsum = xrow[j];
 #pragma unroll
         for (int m = 1; m < Nrays; ++m) Jsum += xrow[m * L + j];
-        if (nF > 0) {                                   // Psibar of this direction, for k_fast_gamma
+        if constexpr (LK && STATIC) {                   // Psibar and sum_mu w Psi* phi of every line: one exchange through LDS rows
+            const double wP = wq_l * Psi;
+            __builtin_amdgcn_wave_barrier();
+            xrow[lane] = wP;
+#pragma unroll
+            for (int u = 0; u < NL; ++u) xrow2[u * LSX_WAVE + lane] = wP * spv[u];
+            __builtin_amdgcn_wave_barrier();
+            double sPsi = xrow[j];
+#pragma unroll
+            for (int m = 1; m < Nrays; ++m) sPsi += xrow[m * L + j];
+            at(psibar, kl) = sPsi;
+#pragma unroll
+            for (int u = 0; u < NL; ++u) {
+                double sPP = xrow2[u * LSX_WAVE + j];
+#pragma unroll
+                for (int m = 1; m < Nrays; ++m) sPP += xrow2[u * LSX_WAVE + m * L + j];
+                at(ppsum, (unsigned)(u * plane) * 8u + kl) = sPP;
+            }
+        } else if (nF > 0) {                            // Psibar of this direction, for k_fast_gamma
             __builtin_amdgcn_wave_barrier();
             xrow[lane] = wq_l * Psi;
             __builtin_amdgcn_wave_barrier();
@@ -579,12 +568,12 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             wg2 = wt * g2;
         };
         auto pass2 = [&](const bool line, const SlotS& sl, double pv, double chi, double Uji, double Vij, double eta, double wt,
-                         double& wg1, double& wg2) {
+                         double cEC, double cXi, double cXj, double& wg1, double& wg2) {
             const int fl = NPT == 1 ? 0 : sl.flags;
             const double Vji = line ? sl.Vc * pv : pv;
-            const double etaA = (fl & SLOT_ETA_CELL) ? CETA(sl.ca) : eta;
-            const double chi_i = (fl & SLOT_LI_CELL) ? CCHI(sl.ci) : chi;
-            const double chi_j = (fl & SLOT_LJ_CELL) ? CCHI(sl.cj) : -chi;
+            const double etaA = ((fl & SLOT_ETA_CELL) ? CETA(sl.ca) : eta) + cEC;      // + the linked continua's share
+            const double chi_i = ((fl & SLOT_LI_CELL) ? CCHI(sl.ci) : chi) + cXi;
+            const double chi_j = ((fl & SLOT_LJ_CELL) ? CCHI(sl.cj) : -chi) + cXj;
             const double U_j = (fl & SLOT_LJ_CELL) ? CU(sl.cj) : Uji;
             const double U_i = (fl & SLOT_UI_READ) ? CU(sl.ci) : 0.0;
             const double Ieff = I - Psi * etaA;                            // :652
@@ -602,6 +591,10 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                 const SlotS sl = load_slot(slots + u, Ns);
                 const bool line = u < NL;
                 const double Vij = line ? sl.cB * spv[u] : alv[u];
+                const double wt = line ? wlv[u] * tk[3 * u + 2] : wlv[u];         // :451 (lines: x wphi), :455, :665
+                // linked continua add their ray-independent share to the line's atom.eta, atom.chi[i], atom.chi[j]
+                const double cEC = (LK && line) ? cr[u < NLK ? u : 0][0] : 0.0, cXi = (LK && line) ? cr[u < NLK ? u : 0][1] : 0.0,
+                             cXj = (LK && line && NCR > 2) ? cr[u < NLK ? u : 0][2] : 0.0;
                 if constexpr (NPT >= 3) {
                     // atom.chi / atom.U / atom.eta of this slot's levels, accumulated in transition order; another slot
                     // enters through five factors in {-1, 0, 1} (one fma each), and only if any of them is non-zero
@@ -623,8 +616,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                             }
                         }
                     }
-                    pass2x(line, sl.Vc, spv[u], sUji[u], Vij, wlv[u] * tk[3 * u + 2], etaA, chi_i, chi_j, U_j, U_i,
-                           w1[u], w2v[u]);
+                    pass2x(line, sl.Vc, spv[u], sUji[u], Vij, wt, etaA + cEC, chi_i + cXi, chi_j + cXj, U_j, U_i, w1[u], w2v[u]);
                 } else if constexpr (NPT == 2) {
                     // atom.chi / atom.U / atom.eta of this slot's levels from the two slots' values, in transition
                     // order (a factor 0 drops the other slot, +-1 adds it with one rounding)
@@ -635,10 +627,9 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                     const double chi_j = fma(rel[REL_CJ], schi[v], -schi[u]);
                     const double U_j = fma(rel[REL_UJ], sUji[v], sUji[u]);
                     const double U_i = rel[REL_UI] * sUji[v];
-                    pass2x(line, sl.Vc, spv[u], sUji[u], Vij, wlv[u] * tk[3 * u + 2], etaA, chi_i, chi_j, U_j, U_i,
-                           w1[u], w2v[u]);
+                    pass2x(line, sl.Vc, spv[u], sUji[u], Vij, wt, etaA + cEC, chi_i + cXi, chi_j + cXj, U_j, U_i, w1[u], w2v[u]);
                 } else {
-                    pass2(line, sl, spv[u], schi[u], sUji[u], Vij, seta[u], wlv[u] * tk[3 * u + 2], w1[u], w2v[u]); // :451, :455
+                    pass2(line, sl, spv[u], schi[u], sUji[u], Vij, seta[u], wt, cEC, cXi, cXj, w1[u], w2v[u]);
                 }
             }
             // the totals of step s are parked in entry (s mod 64) of per-(slot, entry) LDS rows and leave as one
@@ -683,12 +674,26 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                     wla *= wphi_col[sl.wphi_off + k];
                 } else {
                     Vij = a ? p.alpha[sl.wl_off + l] : 0.0;
-                    pv = (a ? gijc_col[sl.base + k * sl.len + (la - sl.first)] : 0.0) * Vij;          // Vji
+                    pv = (a ? nsr_col[sl.base + k] * at(Eb, kl) : 0.0) * Vij;                          // Vji
                     Uji = u_la * pv;
                     chi = ni * Vij - nj * pv;
                 }
-                double wg1, wg2;
-                pass2((sl.flags & SLOT_LINE) != 0, sl, pv, chi, Uji, Vij, nj * Uji, (a && valid) ? wq_l * wla : 0.0, wg1, wg2);
+                double wg1, wg2, cEC = 0.0, cXi = 0.0, cXj = 0.0;
+                if constexpr (LK) {
+                    if (u < nLt) {          // line slot of a tile with linked continua: corrections in, sum_mu w Psi* phi out
+                        cEC = at(corr, (unsigned)((3 * u + 0) * plane) * 8u + kl);
+                        cXi = at(corr, (unsigned)((3 * u + 1) * plane) * 8u + kl);
+                        cXj = at(corr, (unsigned)((3 * u + 2) * plane) * 8u + kl);
+                        __builtin_amdgcn_wave_barrier();
+                        xrow[lane] = (wq_l * Psi) * pv;
+                        __builtin_amdgcn_wave_barrier();
+                        double sPP = xrow[j];
+                        for (int m = 1; m < Nrays; ++m) sPP += xrow[m * L + j];
+                        at(ppsum, (unsigned)(u * plane) * 8u + kl) = sPP;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                pass2((sl.flags & SLOT_LINE) != 0, sl, pv, chi, Uji, Vij, nj * Uji, (a && valid) ? wq_l * wla : 0.0, cEC, cXi, cXj, wg1, wg2);
                 const double t = reduce_pair(wg1, wg2);
                 if (lane == 31) *gslot(u, 0) = t;
                 if (lane == 63) *gslot(u, 1) = t;
@@ -759,7 +764,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
 #define LSX_WPE4 (LSX_WAVES_PER_EU - 1)
 #endif
 #define LSX_WPE(NPT) ((NPT) == 0 ? LSX_WPE0 : ((NPT) == 1 ? LSX_WPE1 : ((NPT) == 2 ? LSX_WPE2 : ((NPT) == 3 ? LSX_WPE3 : ((NPT) == 4 ? LSX_WPE4 : LSX_WAVES_PER_EU)))))
-template <int NPT, int NL, int NR, bool SCAL>
+template <int NPT, int NL, int NR, bool SCAL, bool LK>
 __global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(LSX_WPE(NPT))))
 lsx_sweep_kernel(const SweepParams p)
 {
@@ -780,7 +785,7 @@ lsx_sweep_kernel(const SweepParams p)
         for (int e = threadIdx.x; e < p.Nspace * p.L; e += 2 * LSX_WAVE) p.Jnew_T[tb + e] = p.Jdag_T[tb + e];
         return;
     }
-    sweep_tile<NPT, NL, NR, SCAL>(p, vb, tile_id);
+    sweep_tile<NPT, NL, NR, SCAL, LK>(p, vb, tile_id);
 }
 
 // Small batches (a few columns) are latency bound: one launch that dispatches on the tile's class inside
@@ -798,33 +803,37 @@ lsx_sweep_kernel_all(const SweepParams p)
         return;
     }
     const int nP = (LSX_CONST(DevTile, p.tiles) + tile_id)->nP, nL = (LSX_CONST(DevTile, p.tiles) + tile_id)->nL;
-    if (nP > p.static_max) sweep_tile<-1, 0, NR, SCAL>(p, vb, tile_id);
-    else if (nP == 0) sweep_tile<0, 0, NR, SCAL>(p, vb, tile_id);
-    else if (nP == 1) sweep_tile<1, 1, NR, SCAL>(p, vb, tile_id);
-    else if (nP == 2 && nL == 2) sweep_tile<2, 2, NR, SCAL>(p, vb, tile_id);
-    else if (nP == 2 && nL == 1) sweep_tile<2, 1, NR, SCAL>(p, vb, tile_id);
-    else sweep_tile<-1, 0, NR, SCAL>(p, vb, tile_id);     // three-slot tiles take the generic path here (code size)
+    const bool lk = (LSX_CONST(DevTile, p.tiles) + tile_id)->nK > 0;
+    if (nP > p.static_max) { if (lk) sweep_tile<-1, 0, NR, SCAL, true>(p, vb, tile_id); else sweep_tile<-1, 0, NR, SCAL, false>(p, vb, tile_id); }
+    else if (nP == 0) sweep_tile<0, 0, NR, SCAL, false>(p, vb, tile_id);
+    else if (nP == 1 && nL == 1) { if (lk) sweep_tile<1, 1, NR, SCAL, true>(p, vb, tile_id); else sweep_tile<1, 1, NR, SCAL, false>(p, vb, tile_id); }
+    else if (nP == 2 && nL == 2) { if (lk) sweep_tile<2, 2, NR, SCAL, true>(p, vb, tile_id); else sweep_tile<2, 2, NR, SCAL, false>(p, vb, tile_id); }
+    else if (nP == 2 && nL == 1 && !lk) sweep_tile<2, 1, NR, SCAL, false>(p, vb, tile_id);
+    else if (lk) sweep_tile<-1, 0, NR, SCAL, true>(p, vb, tile_id);     // the remaining shapes take the generic path here (code size)
+    else sweep_tile<-1, 0, NR, SCAL, false>(p, vb, tile_id);
 }
 
 template <int NR, bool SCAL>
-static void launch_class(const SweepParams& p, int npt, dim3 g, dim3 b, size_t lds_bytes, hipStream_t st)
+static void launch_class(const SweepParams& p, int code, dim3 g, dim3 b, size_t lds_bytes, hipStream_t st)
 {
-    // npt: -2 fused, -1 generic, else (per-ray slots) * 8 + (lines among them)
-    switch (npt) {
+    // code: -2 fused, -1 generic, -3 generic with linked continua, else (per-ray slots) * 8 + (lines among them) + 64 if the
+    // class's tiles have linked continua (only classes with a line can)
+#define LSX_CASE(NPT, NL) \
+    case NPT * 8 + NL: hipLaunchKernelGGL((lsx_sweep_kernel<NPT, NL, NR, SCAL, false>), g, b, lds_bytes, st, p); break;
+#define LSX_CASE_LK(NPT, NL) \
+    case 64 + NPT * 8 + NL: hipLaunchKernelGGL((lsx_sweep_kernel<NPT, NL, NR, SCAL, true>), g, b, lds_bytes, st, p); break;
+    switch (code) {
     case -2: hipLaunchKernelGGL((lsx_sweep_kernel_all<NR, SCAL>), g, b, lds_bytes, st, p); break;
-    case 0: hipLaunchKernelGGL((lsx_sweep_kernel<0, 0, NR, SCAL>), g, b, lds_bytes, st, p); break;
-    case 8 + 1: hipLaunchKernelGGL((lsx_sweep_kernel<1, 1, NR, SCAL>), g, b, lds_bytes, st, p); break;
-    case 16 + 1: hipLaunchKernelGGL((lsx_sweep_kernel<2, 1, NR, SCAL>), g, b, lds_bytes, st, p); break;
-    case 16 + 2: hipLaunchKernelGGL((lsx_sweep_kernel<2, 2, NR, SCAL>), g, b, lds_bytes, st, p); break;
-    case 24 + 1: hipLaunchKernelGGL((lsx_sweep_kernel<3, 1, NR, SCAL>), g, b, lds_bytes, st, p); break;
-    case 24 + 2: hipLaunchKernelGGL((lsx_sweep_kernel<3, 2, NR, SCAL>), g, b, lds_bytes, st, p); break;
-    case 24 + 3: hipLaunchKernelGGL((lsx_sweep_kernel<3, 3, NR, SCAL>), g, b, lds_bytes, st, p); break;
-    case 32 + 1: hipLaunchKernelGGL((lsx_sweep_kernel<4, 1, NR, SCAL>), g, b, lds_bytes, st, p); break;
-    case 32 + 2: hipLaunchKernelGGL((lsx_sweep_kernel<4, 2, NR, SCAL>), g, b, lds_bytes, st, p); break;
-    case 32 + 3: hipLaunchKernelGGL((lsx_sweep_kernel<4, 3, NR, SCAL>), g, b, lds_bytes, st, p); break;
-    case 32 + 4: hipLaunchKernelGGL((lsx_sweep_kernel<4, 4, NR, SCAL>), g, b, lds_bytes, st, p); break;
-    default: hipLaunchKernelGGL((lsx_sweep_kernel<-1, 0, NR, SCAL>), g, b, lds_bytes, st, p); break;
+    case -3: hipLaunchKernelGGL((lsx_sweep_kernel<-1, 0, NR, SCAL, true>), g, b, lds_bytes, st, p); break;
+    LSX_CASE(0, 0) LSX_CASE(1, 0) LSX_CASE(1, 1)
+    LSX_CASE(2, 0) LSX_CASE(2, 1) LSX_CASE(2, 2)
+    LSX_CASE(3, 1) LSX_CASE(3, 2) LSX_CASE(3, 3)
+    LSX_CASE(4, 1) LSX_CASE(4, 2) LSX_CASE(4, 3) LSX_CASE(4, 4)
+    LSX_CASE_LK(1, 1) LSX_CASE_LK(2, 1) LSX_CASE_LK(2, 2) LSX_CASE_LK(3, 1) LSX_CASE_LK(3, 2) LSX_CASE_LK(3, 3)
+    default: hipLaunchKernelGGL((lsx_sweep_kernel<-1, 0, NR, SCAL, false>), g, b, lds_bytes, st, p); break;
     }
+#undef LSX_CASE
+#undef LSX_CASE_LK
 }
 
 extern "C" hipError_t lsx_launch_sweep(const SweepParams* p, int npt, int nblocks, size_t lds_bytes, hipStream_t st)

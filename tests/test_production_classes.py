@@ -1,7 +1,9 @@
 """GPU parity at the PRODUCTION launch path and workloads (BASELINE configs C3 / C4): >= 32 columns take one kernel
 instantiation per tile class on forked streams (lsx_hip.hip: enqueue_fs), not the fused small-batch kernel the
-single-column tests reach.  C4's tiles with three and four per-ray slots (`lsx_sweep_kernel<3|4, *, 5, false>`) meet
-the oracle here.
+single-column tests reach.  C4 (Ca+H): hydrogen's bound-free continua overlap its lines; they are "linked" continua
+(handled outside the sweep with the line's sum_mu w Psi* phi, lsx_hip.hip: roles_of), so the classes that run are the
+line-only ones with and without linked continua -- all of them meet the oracle here; the classes with three and four
+per-ray slots (round 1's `lsx_sweep_kernel<3|4, ...>`) run with the linking switched off (LSX_NO_LINKED).
 
 Inputs: synth.perturbed_columns(..., device_profiles=True) -- FALC-perturbed columns with a smooth line-of-sight
 velocity (2 km/s), so the line profiles are ray dependent and are built by each library's own lsx_set_line_profiles
@@ -22,17 +24,17 @@ pytestmark = pytest.mark.gpu
 
 
 def class_table(lib, eng):
-    """-> ({(per-ray slots, lines): (tiles, launches)}, fused launches)"""
+    """-> ({(per-ray slots, lines, linked): (tiles, launches)}, fused launches)"""
     f = lib.dll.lsx_hip_class_info
     f.restype = C.c_int32
     f.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
-    out = (C.c_int64 * 4)()
+    out = (C.c_int64 * 5)()
     n = f(eng._h, -1, out)
     fused = int(out[0])
     table = {}
     for i in range(n):
         f(eng._h, i, out)
-        table[(int(out[0]), int(out[1]))] = (int(out[2]), int(out[3]))
+        table[(int(out[0]), int(out[1]), int(out[4]))] = (int(out[2]), int(out[3]))
     return table, fused
 
 
@@ -81,14 +83,25 @@ def _run_pair(hip_lib, oracle_lib, name, ncol, seed, tol, expect_classes):
 
 def test_c3_caii_columns_per_class_path(hip_lib, oracle_lib):
     """C3: CaII, 64 columns, ray-dependent device-built profiles; tile classes 0, 1 (one line), 2 (H & K overlap)"""
-    table = _run_pair(hip_lib, oracle_lib, 'falc_ca.npz', 64, 1234, 1e-12, [(0, 0), (1, 1), (2, 2)])
+    table = _run_pair(hip_lib, oracle_lib, 'falc_ca.npz', 64, 1234, 1e-12, [(0, 0, 0), (1, 1, 0), (2, 2, 0)])
     assert sum(t for t, _ in table.values()) == 25          # DESIGN 4.1: 25 tiles for FALC CaII
 
 
-def test_c4_cah_columns_three_and_four_slot_instances(hip_lib, oracle_lib):
-    """C4: Ca+H, 40 columns: the first time lsx_sweep_kernel<3, {1,2}, 5, false> and <4, {1,2}, 5, false> meet the oracle"""
-    table = _run_pair(hip_lib, oracle_lib, 'falc_cah.npz', 40, 4321, 3e-11, [(1, 1), (2, 1), (2, 2), (3, 1), (3, 2), (4, 1), (4, 2)])
+def test_c4_cah_columns_linked_continua(hip_lib, oracle_lib):
+    """C4: Ca+H, 40 columns.  Every hydrogen line tile carries linked continua: classes (1 line) and (2 lines), each with and
+    without linked continua, plus the continuum-only tiles"""
+    table = _run_pair(hip_lib, oracle_lib, 'falc_cah.npz', 40, 4321, 3e-11, [(0, 0, 0), (1, 1, 0), (1, 1, 1), (2, 2, 0), (2, 2, 1)])
     assert -1 not in [k[0] for k in table]                  # no tile falls back to the generic instance
+    assert max(k[0] for k in table) == 2                    # no continuum goes through the sweep
+
+
+def test_c4_cah_columns_three_and_four_slot_instances(hip_lib, oracle_lib, monkeypatch):
+    """the same columns with the linking switched off: hydrogen's continua become per-ray slots again, and
+    lsx_sweep_kernel<3, {1,2}, 5, false> and <4, {1,2}, 5, false> meet the oracle"""
+    monkeypatch.setenv('LSX_NO_LINKED', '1')
+    table = _run_pair(hip_lib, oracle_lib, 'falc_cah.npz', 40, 4321, 3e-11,
+                      [(1, 1, 0), (2, 1, 0), (2, 2, 0), (3, 1, 0), (3, 2, 0), (4, 1, 0), (4, 2, 0)])
+    assert -1 not in [k[0] for k in table]
 
 
 def test_single_column_reaches_the_fused_kernel(hip_lib):
