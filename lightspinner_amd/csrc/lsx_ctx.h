@@ -27,6 +27,7 @@ struct SweepClass {           // tiles that run the same kernel instantiation, l
     long launches = 0;         // how often this class's kernel has been launched (introspection for the tests)
     int nl = 0;                // lines among them (compile-time too)
     bool linked = false;       // the class's tiles have linked continua (compile-time too)
+    int topo = 0;              // two-line classes: known relation of the two lines (lsx_sweep.hip, TOPO)
     bool has_fast = false;     // some tile of the class has fast continua: the class reads the pre-pass output
     hipEvent_t tdone = nullptr; // timed runs: end of this class's launch
     std::vector<int> fast_tiles; // the class's tiles that have fast continua
@@ -84,7 +85,7 @@ struct lsx_ctx {
     double* d_exp2_tab = nullptr;
     double* d_voigt_w = nullptr;
     double *d_muz = nullptr, *d_wmu = nullptr;
-    int nF_max = 0, Ncont = 0, static_max = -1;
+    int nF_max = 0, Ncont = 0, static_max = -1, nL_linked_max = 0;
     bool fast_generic = false;
     double* d_nsr = nullptr;     // [col][Ncont][k] nStar_i / nStar_j of the continua
     std::vector<int> cont_li, cont_lj;

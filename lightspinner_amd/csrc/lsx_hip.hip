@@ -343,7 +343,7 @@ struct FastVal { double alf, Vji, Uji, chi, eta; bool a; };
 // One block per (tile, column), 256 threads = (depth in chunk, wavelength) with LP = 16 / 32 / 64 lanes per depth row;
 // the block walks the column's depth chunks with the next chunk's loads in flight (the kernel is latency bound otherwise:
 // a staging phase, a barrier and one dependent load per thread for a few dozen instructions of arithmetic).
-template <int LP>
+template <int LP, bool SEG>       // SEG: the column is too deep for its operands to be staged at once
 __global__ void __launch_bounds__(256) k_fast_prepass(const FastParams f)
 {
     constexpr int KR = 256 / LP;                                // depths per chunk
@@ -366,16 +366,18 @@ __global__ void __launch_bounds__(256) k_fast_prepass(const FastParams f)
     double n_chi, n_eta, n_E;
     load3(kc, n_chi, n_eta, n_E);                               // first chunk's streams: in flight during the staging
     // operands of the (slot, depth) and (slot, wavelength) pairs, staged per depth segment of KS depths (the whole column
-    // where it fits): sN[q][k - ks0] = {n_i, n_j, nStar_i/nStar_j, -}, sA[q][j] = alpha where the continuum is active, else 0
-    const int KS = f.seg_depths;
-    double* sN = sm;
-    double* sA = sN + (size_t)4 * f.nF_max * KS;
+    // where it fits): sN[q][k - ks0] = {n_i, n_j}, sR[q][k - ks0] = nStar_i/nStar_j, sA[q][j] = alpha where the continuum is
+    // active, else 0
+    const int KS = SEG ? f.seg_depths : Ns;
+    double* sN = sm;                                            // [q][k]{n_i, n_j}
+    double* sR = sN + (size_t)2 * f.nF_max * KS;                // [q][k] nStar_i / nStar_j
+    double* sA = sR + (size_t)f.nF_max * KS;
     auto stage = [&](int ks0) {
         for (int x = tid; x < tl.nF * KS; x += 256) {
             const int q = x / KS, kk = min(ks0 + (x - q * KS), Ns - 1);
-            sN[x * 4 + 0] = f.n[(col * f.NLtot + fs[q].li) * Ns + kk];
-            sN[x * 4 + 1] = f.n[(col * f.NLtot + fs[q].lj) * Ns + kk];
-            sN[x * 4 + 2] = f.nsr[col * f.Ncont * Ns + fs[q].base + kk];
+            sN[x * 2 + 0] = f.n[(col * f.NLtot + fs[q].li) * Ns + kk];
+            sN[x * 2 + 1] = f.n[(col * f.NLtot + fs[q].lj) * Ns + kk];
+            sR[x] = f.nsr[col * f.Ncont * Ns + fs[q].base + kk];
         }
     };
     stage(0);
@@ -388,14 +390,15 @@ __global__ void __launch_bounds__(256) k_fast_prepass(const FastParams f)
     const int nLc = tl.nK > 0 ? min(tl.nL, LSX_MAX_TILE_LINES) : 0;
     const double ula = f.u_la[tl.la0 + min(j, tl.nla - 1)];
     const size_t plane = (size_t)Ns * f.L;
-    int ks0 = 0;
-    for (int k = kc; k < Ns + kc; k += KR) {                    // (every thread runs every pass; k >= Ns computes nothing)
-        if (k - kc >= ks0 + KS) {                                // next depth segment (deep columns only)
-            ks0 += KS;
-            __syncthreads();
-            stage(ks0);
-            __syncthreads();
-        }
+    const int kpad = Ns + KR - 1 - (Ns + KR - 1) % KR;          // whole passes only
+    for (int ks0 = 0; ks0 < (SEG ? Ns : 1); ks0 += KS) {        // depth segments: one, unless the column is deep
+    if (SEG && ks0 > 0) {
+        __syncthreads();
+        stage(ks0);
+        __syncthreads();
+    }
+    const int kend = SEG ? min(ks0 + KS, kpad) : kpad;
+    for (int k = ks0 + kc; k < kend; k += KR) {                 // (every thread runs every pass; k >= Ns computes nothing)
         double chi = n_chi, eta = n_eta;
         const double E = n_E;
         load3(k + KR, n_chi, n_eta, n_E);
@@ -404,8 +407,8 @@ __global__ void __launch_bounds__(256) k_fast_prepass(const FastParams f)
                XCj[LSX_MAX_TILE_LINES] = {0.0, 0.0, 0.0, 0.0};
         for (int q = 0; q < tl.nF; ++q) {                        // rh_method.py:284-286, 453-455, 613-614
             const double alf = sA[q * LP + j];
-            const double2 n01 = *reinterpret_cast<const double2*>(sN + (size_t)(q * KS + (k - ks0)) * 4);
-            const double nsr = sN[(size_t)(q * KS + (k - ks0)) * 4 + 2];
+            const double2 n01 = *reinterpret_cast<const double2*>(sN + (size_t)(q * KS + (k - ks0)) * 2);
+            const double nsr = sR[q * KS + (k - ks0)];
             const double Vji = (nsr * E) * alf;
             const double Uji = ula * Vji;
             const double chq = n01.x * alf - n01.y * Vji, etq = n01.y * Uji;
@@ -435,6 +438,7 @@ __global__ void __launch_bounds__(256) k_fast_prepass(const FastParams f)
                 }
         }
     }
+    }
 }
 
 // Gamma slabs of the fast continua from J, Psibar and PsiPhi (both directions summed).  For continuum c of atom a
@@ -461,7 +465,7 @@ static __device__ __forceinline__ double row_total(double v)     // sum over the
     if constexpr (LP >= 64) v += dpp_f64<0x143, 0xc>(v);         // row_bcast31: lane 63 = the wave
     return v;
 }
-template <int LP, int NT>
+template <int LP, int NT, bool SEG>
 __global__ void __launch_bounds__(NT) k_fast_gamma(const FastParams f)
 {
     constexpr int KR = NT / LP;                              // depths per chunk
@@ -499,27 +503,26 @@ __global__ void __launch_bounds__(NT) k_fast_gamma(const FastParams f)
     };
     In nxt;
     load_in(kc, nxt);                                        // first chunk's streams: in flight during the staging
-    // LDS: cells (generic tiles only) | staged once for the whole column: sN[q][k] = {n_i, n_j, nStar_i/nStar_j, -} |
-    // sA[q][j] = {alpha, wlambda} (both 0 where the continuum is inactive: every quantity below is then 0) |
-    // sL[u][k] = {cB (n_i - g n_j), n_j Uc, Uc, -} of line u
-    const int KS = f.seg_depths;                              // depths staged at a time (the whole column where it fits)
+    // LDS: cells (generic tiles only) | staged per depth segment (the whole column where it fits): sN, sR, sL | sA[q][j] =
+    // {alpha, wlambda} (both 0 where the continuum is inactive: every quantity below is then 0)
+    const int KS = SEG ? f.seg_depths : Ns;                   // depths staged at a time (the whole column where it fits)
     double* cellbase = sm;
-    double* sN = cellbase + (size_t)(f.generic ? 2 * f.NLtot + f.Natoms : 0) * NT;
-    double* sA = sN + (size_t)4 * f.nF_max * KS;
-    double* sL = sA + (size_t)2 * f.nF_max * LP;
+    double* sN = cellbase + (size_t)(f.generic ? 2 * f.NLtot + f.Natoms : 0) * NT;    // [q][k]{n_i, n_j}
+    double* sR = sN + (size_t)2 * f.nF_max * KS;                                      // [q][k] nStar_i / nStar_j
+    double* sA = sR + (size_t)f.nF_max * KS;                                          // [q][j]{alpha, wlambda}
+    double* sL = sA + (size_t)2 * f.nF_max * LP;                                      // [u][k]{cB (n_i - g n_j), n_j Uc}
     auto stage = [&](int ks0) {
         for (int e = tid; e < tl.nF * KS; e += NT) {
             const int q = e / KS, kk = min(ks0 + (e - q * KS), Ns - 1);
-            sN[e * 4 + 0] = f.n[(col * f.NLtot + fs[q].li) * Ns + kk];
-            sN[e * 4 + 1] = f.n[(col * f.NLtot + fs[q].lj) * Ns + kk];
-            sN[e * 4 + 2] = f.nsr[col * f.Ncont * Ns + fs[q].base + kk];
+            sN[e * 2 + 0] = f.n[(col * f.NLtot + fs[q].li) * Ns + kk];
+            sN[e * 2 + 1] = f.n[(col * f.NLtot + fs[q].lj) * Ns + kk];
+            sR[e] = f.nsr[col * f.Ncont * Ns + fs[q].base + kk];
         }
         for (int e = tid; e < nLc * KS; e += NT) {
             const int u = e / KS, kk = min(ks0 + (e - u * KS), Ns - 1);
             const double ni = f.n[(col * f.NLtot + ls[u].li) * Ns + kk], nj = f.n[(col * f.NLtot + ls[u].lj) * Ns + kk];
-            sL[e * 4 + 0] = ls[u].cB * (ni - ls[u].g * nj);      // chi_line = this * phi, rh_method.py:279-280, :613
-            sL[e * 4 + 1] = nj * ls[u].Uc;                       // eta_line = this * phi, :281, :614
-            sL[e * 4 + 2] = ls[u].Uc;                            // Uji_line = this * phi
+            sL[e * 2 + 0] = ls[u].cB * (ni - ls[u].g * nj);      // chi_line = this * phi, rh_method.py:279-280, :613
+            sL[e * 2 + 1] = nj * ls[u].Uc;                       // eta_line = this * phi, :281, :614 (Uji_line = Uc phi)
         }
     };
     stage(0);
@@ -534,14 +537,15 @@ __global__ void __launch_bounds__(NT) k_fast_gamma(const FastParams f)
     const double ula = f.u_la[la];
     __syncthreads();
     const bool last_lane = j == LP - 1;
-    int ks0 = 0;
-    for (int k = kc; k < Ns + kc; k += KR) {                 // (every thread runs every pass: the DPP reductions need whole rows)
-        if (k - kc >= ks0 + KS) {                            // next depth segment (deep columns only)
-            ks0 += KS;
-            __syncthreads();
-            stage(ks0);
-            __syncthreads();
-        }
+    const int kpad = Ns + KR - 1 - (Ns + KR - 1) % KR;       // whole passes only
+    for (int ks0 = 0; ks0 < (SEG ? Ns : 1); ks0 += KS) {     // depth segments: one, unless the column is deep
+    if (SEG && ks0 > 0) {
+        __syncthreads();
+        stage(ks0);
+        __syncthreads();
+    }
+    const int kend = SEG ? min(ks0 + KS, kpad) : kpad;
+    for (int k = ks0 + kc; k < kend; k += KR) {              // (every thread runs every pass: the DPP reductions need whole rows)
         const In x = nxt;
         load_in(k + KR, nxt);
         const bool on = lane_on && k < Ns;
@@ -553,19 +557,19 @@ __global__ void __launch_bounds__(NT) k_fast_gamma(const FastParams f)
         for (int u = 0; u < LSX_MAX_TILE_LINES; ++u) {
             tchi[u] = teta[u] = tU[u] = 0.0;
             if (u < nLc) {
-                const double* Lq = sL + (size_t)(u * KS + ks) * 4;
+                const double2 Lq = *reinterpret_cast<const double2*>(sL + (size_t)(u * KS + ks) * 2);
                 const double sPP = x.pp[u][0] + x.pp[u][1];
-                tchi[u] = Lq[0] * sPP;
-                teta[u] = Lq[1] * sPP;
-                tU[u] = Lq[2] * sPP;
+                tchi[u] = Lq.x * sPP;
+                teta[u] = Lq.y * sPP;
+                tU[u] = ls[u].Uc * sPP;
             }
         }
         // one fast continuum at (lambda, depth) from the staged operands: rh_method.py:284-286, 453-455, 613-614
         auto value = [&](int q) {
             FastVal v;
             const double2 A = *reinterpret_cast<const double2*>(sA + (size_t)(q * LP + j) * 2);
-            const double2 N = *reinterpret_cast<const double2*>(sN + (size_t)(q * KS + ks) * 4);
-            const double nsr = sN[(size_t)(q * KS + ks) * 4 + 2];
+            const double2 N = *reinterpret_cast<const double2*>(sN + (size_t)(q * KS + ks) * 2);
+            const double nsr = sR[q * KS + ks];
             v.alf = A.x;
             v.a = A.x != 0.0;
             v.Vji = (nsr * E) * v.alf;
@@ -660,6 +664,7 @@ __global__ void __launch_bounds__(NT) k_fast_gamma(const FastParams f)
                 emit(q, wla * ((v.Uji * sW + v.Vji * sIe) - cU), wla * ((v.alf * sIe) - cU2));
             }
         }
+    }
     }
 }
 
@@ -1216,7 +1221,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         for (int t : conts) {
             const DevTrans& h = c->htrans[t];
             if (!((atoms_with_line >> h.atom) & 1u)) continue;
-            bool touches = no_linked;
+            bool touches = no_linked || (int)r.lines.size() > LSX_MAX_TILE_LINES;   // (the fast kernels couple at most that many lines)
             for (int l : r.lines) touches = touches || c->htrans[l].li == h.lj || c->htrans[l].lj == h.lj;
             if (touches) atoms_per_ray |= 1u << h.atom;
         }
@@ -1283,6 +1288,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         tl.nF = (int)fast.size();
         tl.nK = roles.nlinked;
         tl.nL = (int)lines.size();
+        if (tl.nK > 0) c->nL_linked_max = std::max(c->nL_linked_max, tl.nL);
         if (tl.nK > 0) {            // the line slots' correction streams and the sweep's sum_mu w Psi* phi streams
             tl.corr_off = (int)corr_run;
             corr_run += (size_t)tl.nL * 3 * Ns * c->L;
@@ -1410,30 +1416,51 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         if (npt >= 0) c->static_max = std::max(c->static_max, npt);
         const int nl = npt >= 0 ? (int)lines.size() : 0;
         const bool lk = tl.nK > 0;
+        // two lines: is their relation one of the two common cases the sweep has a leaner instance for?
+        int topo = 0;
+        if (npt == 2 && nl == 2 && !getenv("LSX_NO_TOPO")) {
+            const DevTrans &x = c->htrans[per_ray[0]], &y = c->htrans[per_ray[1]];
+            const bool share_any = x.li == y.li || x.li == y.lj || x.lj == y.li || x.lj == y.lj;
+            if (x.atom == y.atom && x.li == y.li && x.lj != y.lj && x.lj != y.li && x.li != y.lj) topo = 1;
+            else if (x.atom != y.atom && !share_any) topo = 2;
+        }
         SweepClass* k = nullptr;
         for (auto& q : c->classes)
-            if (q.npt == npt && q.nl == nl && q.linked == lk) k = &q;
-        if (!k) { c->classes.push_back(SweepClass()); k = &c->classes.back(); k->npt = npt; k->nl = nl; k->linked = lk; }
+            if (q.npt == npt && q.nl == nl && q.linked == lk && q.topo == topo) k = &q;
+        if (!k) { c->classes.push_back(SweepClass()); k = &c->classes.back(); k->npt = npt; k->nl = nl; k->linked = lk; k->topo = topo; }
         k->tiles.push_back((int)c->tiles.size());
         if (tl.nF > 0) { k->has_fast = true; k->fast_tiles.push_back((int)c->tiles.size()); }
         k->ncell_lev = std::max(k->ncell_lev, (int)lev_ids.size());
         k->ncell_atom = std::max(k->ncell_atom, (int)atom_ids.size());
         c->tiles.push_back(tl);
     }
-    // the class whose workgroups run longest goes first and gets the highest stream priority: its tail is the
-    // call's tail, the shorter-lived classes fill in behind it
-    auto wg_cost = [](const SweepClass& k) { return k.npt < 0 ? 100 : k.npt; };
-    // launch order: by workgroup cost; where most tiles carry a pre-pass -> sweep -> epilogue chain (Ca+H: hydrogen
-    // continua nearly everywhere) the chain classes go first, because a serial chain queued behind the other classes'
-    // workgroups would become the call's tail.  Measured both ways on MI355X (C3: cost order, C4: chains first).
-    size_t chain_tiles = 0;
-    for (auto& k : c->classes)
-        if (!k.fast_tiles.empty()) chain_tiles += k.tiles.size();
-    const bool chains_first = 2 * chain_tiles > c->tiles.size();
-    std::stable_sort(c->classes.begin(), c->classes.end(), [&](const SweepClass& a, const SweepClass& b) {
-        if (chains_first && a.fast_tiles.empty() != b.fast_tiles.empty()) return !a.fast_tiles.empty();
-        return wg_cost(a) > wg_cost(b);
-    });
+    // Launch order and stream priority: by the class's estimated share of the call (tiles x measured cost of a tile, a class with a
+    // pre-pass -> sweep -> epilogue chain counting half again), largest first -- the chain of the largest class is the call's
+    // critical path, the small classes fill in behind it.  (LSX_ORDER=cost: round 1's order, by cost of one workgroup.)
+    auto class_work = [](const SweepClass& k) {
+        static const double C[] = {2500.0, 2950.0, 3550.0, 6600.0, 9600.0};
+        const double per_tile = k.npt < 0 ? 14600.0 : C[std::min(k.npt, 4)] * (k.linked ? 1.25 : 1.0);
+        return per_tile * (double)k.tiles.size() * (k.fast_tiles.empty() ? 1.0 : 1.5);
+    };
+    {
+        const char* ord = getenv("LSX_ORDER");
+        if (ord && std::string(ord) == "cost") {
+            auto wg_cost = [](const SweepClass& k) { return k.npt < 0 ? 100 : k.npt; };
+            size_t chain_tiles = 0;
+            for (auto& k : c->classes)
+                if (!k.fast_tiles.empty()) chain_tiles += k.tiles.size();
+            const bool chains_first = 2 * chain_tiles > c->tiles.size();
+            std::stable_sort(c->classes.begin(), c->classes.end(), [&](const SweepClass& a, const SweepClass& b) {
+                if (chains_first && a.fast_tiles.empty() != b.fast_tiles.empty()) return !a.fast_tiles.empty();
+                return wg_cost(a) > wg_cost(b);
+            });
+        } else {
+            std::stable_sort(c->classes.begin(), c->classes.end(),
+                             [&](const SweepClass& a, const SweepClass& b) { return class_work(a) > class_work(b); });
+        }
+    }
+    double work_total = 0.0, work_seen = 0.0;
+    for (auto& k : c->classes) work_total += class_work(k);
     for (auto& k : c->classes) {
         // per wave: level cells, atom cells, angle-sum row; + two cross-wave exchange rows; + the static
         // path's per-depth table of wave-uniform operands, Nspace x (3 npt + 2) doubles
@@ -1481,8 +1508,13 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         // workgroups that need many registers (three or more slots, generic) find room only while the machine is not
         // yet full of small ones: they go first; the light classes fill in behind them
         // ... and so does a class that carries a pre-pass -> sweep -> epilogue chain: a serial chain must not start last
-        const int want = (k.npt < 0 || k.npt >= 3) ? 0 : ((k.npt == 2 || !k.fast_tiles.empty()) ? 1 : 2);
-        const int prio = getenv("LSX_NO_PRIO") ? prio_lo : std::min(prio_lo, prio_hi + want);
+        // the classes that make up the first half of the work (in launch order) get the highest priority, the next third the
+        // middle one
+        const int want = work_seen < 0.5 * work_total ? 0 : (work_seen < 0.85 * work_total ? 1 : 2);
+        work_seen += class_work(k);
+        // (measured on MI355X with the round-2 kernels: equal priorities are as fast or faster on both workloads -- every class
+        // is bound by vector issue, so there is no idle resource for a favoured class to pick up; LSX_PRIO=1 restores the tiers)
+        const int prio = getenv("LSX_PRIO") ? std::min(prio_lo, prio_hi + want) : prio_lo;
         if (c->opt_trace_classes) fprintf(stderr, "class npt=%d nl=%d: stream priority %d (range %d .. %d)\n", k.npt, k.nl, prio, prio_hi, prio_lo);
         if (hipStreamCreateWithPriority(&k.stream, hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&k.done, hipEventDisableTiming) != hipSuccess) { lsx_destroy(c); return fail(LSX_EDEVICE, "class stream"); }
     }
@@ -1676,19 +1708,21 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
     auto seg_for = [&](int rows, size_t doubles_per_depth, size_t fixed_doubles, size_t budget) {
         const size_t room = budget / 8 > fixed_doubles ? budget / 8 - fixed_doubles : 0;
         long fit = (long)(room / std::max<size_t>(1, doubles_per_depth));
-        if (fit >= c->Nspace) return ((c->Nspace + rows - 1) / rows) * rows;
+        if (fit >= c->Nspace) return c->Nspace;
         return (int)std::max<long>(rows, fit / rows * rows);
     };
     auto launch_prepass = [&](hipStream_t st, const int* d_list, size_t n) -> int {
         FastParams fq = ff;
         fq.fast_tiles = d_list; fq.n_fast_tiles = (int)n;
         dim3 grid((unsigned)n, (unsigned)c->ncol);
-        fq.seg_depths = seg_for(256 / LP, (size_t)4 * c->nF_max, (size_t)c->nF_max * LP, 24 * 1024);
-        const size_t smp = ((size_t)4 * c->nF_max * fq.seg_depths + (size_t)c->nF_max * LP) * sizeof(double);
+        fq.seg_depths = seg_for(256 / LP, (size_t)3 * c->nF_max, (size_t)c->nF_max * LP, 24 * 1024);
+        const size_t smp = ((size_t)3 * c->nF_max * fq.seg_depths + (size_t)c->nF_max * LP) * sizeof(double);
         if (smp > 64 * 1024) return fail(LSX_EUNSUPPORTED, "fast-continuum pre-pass needs %zu B of LDS", smp);
-        if (LP == 16) hipLaunchKernelGGL(k_fast_prepass<16>, grid, dim3(256), smp, st, fq);
-        else if (LP == 32) hipLaunchKernelGGL(k_fast_prepass<32>, grid, dim3(256), smp, st, fq);
-        else hipLaunchKernelGGL(k_fast_prepass<64>, grid, dim3(256), smp, st, fq);
+        const bool seg = fq.seg_depths < c->Nspace;
+#define LSX_PP(LPV) if (LP == LPV) { if (seg) hipLaunchKernelGGL((k_fast_prepass<LPV, true>), grid, dim3(256), smp, st, fq); \
+                                     else hipLaunchKernelGGL((k_fast_prepass<LPV, false>), grid, dim3(256), smp, st, fq); }
+        LSX_PP(16) LSX_PP(32) LSX_PP(64)
+#undef LSX_PP
         HIPCHK(hipGetLastError());
         return LSX_OK;
     };
@@ -1696,14 +1730,16 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
         FastParams fq = ff;
         fq.fast_tiles = d_list; fq.n_fast_tiles = (int)n;
         int nt = 256;
-        const size_t per_depth = (size_t)4 * (c->nF_max + LSX_MAX_TILE_LINES);
+        const size_t per_depth = (size_t)3 * c->nF_max + (size_t)2 * std::min(c->nL_linked_max, LSX_MAX_TILE_LINES);
         auto fixed_for = [&](int ntv) { return (size_t)(c->fast_generic ? 2 * c->NLtot + c->Natoms : 0) * ntv + (size_t)2 * c->nF_max * LP; };
         while (nt > 64 && fixed_for(nt) * 8 > 24 * 1024) nt >>= 1;
         fq.seg_depths = seg_for(nt / LP, per_depth, fixed_for(nt), 40 * 1024);
         const size_t sm = (per_depth * fq.seg_depths + fixed_for(nt)) * sizeof(double);
         if (sm > 64 * 1024) return fail(LSX_EUNSUPPORTED, "fast-continuum epilogue needs %zu B of LDS", sm);
         dim3 grid((unsigned)n, (unsigned)c->ncol);
-#define LSX_FG(LPV, NTV) if (LP == LPV && nt == NTV) hipLaunchKernelGGL((k_fast_gamma<LPV, NTV>), grid, dim3(NTV), sm, st, fq)
+        const bool seg = fq.seg_depths < c->Nspace;
+#define LSX_FG(LPV, NTV) if (LP == LPV && nt == NTV) { if (seg) hipLaunchKernelGGL((k_fast_gamma<LPV, NTV, true>), grid, dim3(NTV), sm, st, fq); \
+                                                       else hipLaunchKernelGGL((k_fast_gamma<LPV, NTV, false>), grid, dim3(NTV), sm, st, fq); }
         LSX_FG(16, 256); LSX_FG(16, 128); LSX_FG(16, 64);
         LSX_FG(32, 256); LSX_FG(32, 128); LSX_FG(32, 64);
         LSX_FG(64, 256); LSX_FG(64, 128); LSX_FG(64, 64);
@@ -1748,7 +1784,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
             p.n_class_tiles = (int)k.tiles.size();
             p.ncell_lev = k.npt >= 0 ? 0 : k.ncell_lev; p.ncell_atom = k.npt >= 0 ? 0 : k.ncell_atom; p.nstash = 0;
             k.launches++;
-            hipError_t e = lsx_launch_sweep(&p, k.npt >= 0 ? k.npt * 8 + k.nl + (k.linked ? 64 : 0) : (k.linked ? -3 : -1), (int)nblocks, k.lds_bytes, st);
+            hipError_t e = lsx_launch_sweep(&p, k.npt >= 0 ? k.npt * 8 + k.nl + (k.linked ? 64 : 0) + 128 * k.topo : (k.linked ? -3 : -1), (int)nblocks, k.lds_bytes, st);
             if (e != hipSuccess) return fail(LSX_EDEVICE, "sweep launch (per-ray slots %d): %s", k.npt, hipGetErrorString(e));
             if (timed) {
                 if (!k.tdone) HIPCHK(hipEventCreate(&k.tdone));
@@ -2162,7 +2198,7 @@ int lsx_time_formal_sol(lsx_ctx* c, int32_t warmup, int32_t reps, double* ms_tot
                 if (k.tdone) {
                     float t = 0.f;
                     HIPCHK(hipEventElapsedTime(&t, c->ev0, k.tdone));
-                    if (c->opt_trace_classes && i == reps - 1) fprintf(stderr, "class npt=%d nl=%d fast=%d tiles=%zu: done at %.3f ms\n", k.npt, k.nl, (int)k.has_fast, k.tiles.size(), t);
+                    if (c->opt_trace_classes && i == reps - 1) fprintf(stderr, "class npt=%d nl=%d linked=%d topo=%d fast=%d tiles=%zu (first tile %d): sweep done at %.3f ms\n", k.npt, k.nl, (int)k.linked, k.topo, (int)k.has_fast, k.tiles.size(), k.tiles[0], t);
                     mx = std::max(mx, t);
                 }
             if (mx > 0.f) ms = mx;
@@ -2197,16 +2233,16 @@ double lsx_hip_info(const lsx_ctx* c, int32_t what)
 }
 
 // HIP-only introspection for the tests: which sweep instantiations a context launches.  Returns the number of tile
-// classes; for 0 <= idx < that number out[0..4] = per-ray slots (compile time, -1 generic), lines among them, tiles per
-// column, launches so far, 1 if the class's tiles have linked continua.  idx == -1: out[0] = launches of the fused
-// small-batch kernel.
+// classes; for 0 <= idx < that number out[0..5] = per-ray slots (compile time, -1 generic), lines among them, tiles per
+// column, launches so far, 1 if the class's tiles have linked continua, the two-line relation (TOPO).  idx == -1: out[0] =
+// launches of the fused small-batch kernel.
 int32_t lsx_hip_class_info(const lsx_ctx* c, int32_t idx, int64_t* out)
 {
     if (!c) return 0;
     if (out && idx == -1) out[0] = c->fused_launches;
     if (out && idx >= 0 && idx < (int)c->classes.size()) {
         const SweepClass& k = c->classes[idx];
-        out[0] = k.npt; out[1] = k.nl; out[2] = (int64_t)k.tiles.size(); out[3] = k.launches; out[4] = k.linked ? 1 : 0;
+        out[0] = k.npt; out[1] = k.nl; out[2] = (int64_t)k.tiles.size(); out[3] = k.launches; out[4] = k.linked ? 1 : 0; out[5] = k.topo;
     }
     return (int32_t)c->classes.size();
 }

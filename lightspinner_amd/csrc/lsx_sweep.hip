@@ -149,7 +149,10 @@ __device__ __forceinline__ SlotS load_slot(const __attribute__((address_space(4)
 // compile-time property of the unrolled slot index and only one of the two formula sets is emitted.
 // LK: the tile has linked continua (lsx_dev.h, SLOT_LINKED): per line three more streams come in (the continua's share of
 // atom.eta, atom.chi[i], atom.chi[j], written by k_fast_prepass) and one more angle sum goes out (sum_mu w Psi* phi).
-template <int NPT, int NL, int NR, bool SCAL, bool LK>
+// TOPO (two-slot tiles): how the two transitions are related, when it is one of the two common cases -- 1: same atom, common
+// LOWER level, nothing else shared (Ca II H & K); 2: nothing shared (lines of different atoms); 0: anything else (factors
+// from the slot table).  The known cases drop the terms that vanish (atom.U[i] = 0, atom.chi[j] = -chi, atom.U[j] = Uji).
+template <int NPT, int NL, int NR, bool SCAL, bool LK, int TOPO = 0>
 __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, const int tile_id)
 {
     extern __shared__ double lds_raw[];
@@ -617,6 +620,16 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                         }
                     }
                     pass2x(line, sl.Vc, spv[u], sUji[u], Vij, wt, etaA + cEC, chi_i + cXi, chi_j + cXj, U_j, U_i, w1[u], w2v[u]);
+                } else if constexpr (NPT == 2 && TOPO != 0) {
+                    // rh_method.py:652, 677-681 with atom.U[i] = 0, atom.U[j] = Uji, atom.chi[j] = -chi (TOPO 1 and 2) and
+                    // atom.chi[i] = chi + chi_other, atom.eta = eta + eta_other (TOPO 1: common lower level, same atom)
+                    const int v = 1 - u;
+                    const double etaA = (TOPO == 1 ? seta[u] + seta[v] : seta[u]) + cEC;
+                    const double chi_i = (TOPO == 1 ? schi[u] + schi[v] : schi[u]) + cXi;
+                    const double Vji = line ? sl.Vc * spv[u] : spv[u];
+                    const double Ieff = I - Psi * etaA;
+                    w1[u] = wt * ((sUji[u] + Vji * Ieff) - (chi_i * Psi) * sUji[u]);
+                    w2v[u] = wt * (Vij * Ieff);
                 } else if constexpr (NPT == 2) {
                     // atom.chi / atom.U / atom.eta of this slot's levels from the two slots' values, in transition
                     // order (a factor 0 drops the other slot, +-1 adds it with one rounding)
@@ -764,7 +777,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
 #define LSX_WPE4 (LSX_WAVES_PER_EU - 1)
 #endif
 #define LSX_WPE(NPT) ((NPT) == 0 ? LSX_WPE0 : ((NPT) == 1 ? LSX_WPE1 : ((NPT) == 2 ? LSX_WPE2 : ((NPT) == 3 ? LSX_WPE3 : ((NPT) == 4 ? LSX_WPE4 : LSX_WAVES_PER_EU)))))
-template <int NPT, int NL, int NR, bool SCAL, bool LK>
+template <int NPT, int NL, int NR, bool SCAL, bool LK, int TOPO = 0>
 __global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(LSX_WPE(NPT))))
 lsx_sweep_kernel(const SweepParams p)
 {
@@ -785,7 +798,7 @@ lsx_sweep_kernel(const SweepParams p)
         for (int e = threadIdx.x; e < p.Nspace * p.L; e += 2 * LSX_WAVE) p.Jnew_T[tb + e] = p.Jdag_T[tb + e];
         return;
     }
-    sweep_tile<NPT, NL, NR, SCAL, LK>(p, vb, tile_id);
+    sweep_tile<NPT, NL, NR, SCAL, LK, TOPO>(p, vb, tile_id);
 }
 
 // Small batches (a few columns) are latency bound: one launch that dispatches on the tile's class inside
@@ -817,7 +830,7 @@ template <int NR, bool SCAL>
 static void launch_class(const SweepParams& p, int code, dim3 g, dim3 b, size_t lds_bytes, hipStream_t st)
 {
     // code: -2 fused, -1 generic, -3 generic with linked continua, else (per-ray slots) * 8 + (lines among them) + 64 if the
-    // class's tiles have linked continua (only classes with a line can)
+    // class's tiles have linked continua (only classes with a line can) + 128 * TOPO (two-line classes)
 #define LSX_CASE(NPT, NL) \
     case NPT * 8 + NL: hipLaunchKernelGGL((lsx_sweep_kernel<NPT, NL, NR, SCAL, false>), g, b, lds_bytes, st, p); break;
 #define LSX_CASE_LK(NPT, NL) \
@@ -830,6 +843,11 @@ static void launch_class(const SweepParams& p, int code, dim3 g, dim3 b, size_t 
     LSX_CASE(3, 1) LSX_CASE(3, 2) LSX_CASE(3, 3)
     LSX_CASE(4, 1) LSX_CASE(4, 2) LSX_CASE(4, 3) LSX_CASE(4, 4)
     LSX_CASE_LK(1, 1) LSX_CASE_LK(2, 1) LSX_CASE_LK(2, 2) LSX_CASE_LK(3, 1) LSX_CASE_LK(3, 2) LSX_CASE_LK(3, 3)
+    // two lines with a known relation (TOPO 1 / 2): + 128 / + 256
+    case 128 + 2 * 8 + 2: hipLaunchKernelGGL((lsx_sweep_kernel<2, 2, NR, SCAL, false, 1>), g, b, lds_bytes, st, p); break;
+    case 256 + 2 * 8 + 2: hipLaunchKernelGGL((lsx_sweep_kernel<2, 2, NR, SCAL, false, 2>), g, b, lds_bytes, st, p); break;
+    case 128 + 64 + 2 * 8 + 2: hipLaunchKernelGGL((lsx_sweep_kernel<2, 2, NR, SCAL, true, 1>), g, b, lds_bytes, st, p); break;
+    case 256 + 64 + 2 * 8 + 2: hipLaunchKernelGGL((lsx_sweep_kernel<2, 2, NR, SCAL, true, 2>), g, b, lds_bytes, st, p); break;
     default: hipLaunchKernelGGL((lsx_sweep_kernel<-1, 0, NR, SCAL, false>), g, b, lds_bytes, st, p); break;
     }
 #undef LSX_CASE

@@ -24,17 +24,17 @@ pytestmark = pytest.mark.gpu
 
 
 def class_table(lib, eng):
-    """-> ({(per-ray slots, lines, linked): (tiles, launches)}, fused launches)"""
+    """-> ({(per-ray slots, lines, linked, two-line relation): (tiles, launches)}, fused launches)"""
     f = lib.dll.lsx_hip_class_info
     f.restype = C.c_int32
     f.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
-    out = (C.c_int64 * 5)()
+    out = (C.c_int64 * 6)()
     n = f(eng._h, -1, out)
     fused = int(out[0])
     table = {}
     for i in range(n):
         f(eng._h, i, out)
-        table[(int(out[0]), int(out[1]), int(out[4]))] = (int(out[2]), int(out[3]))
+        table[(int(out[0]), int(out[1]), int(out[4]), int(out[5]))] = (int(out[2]), int(out[3]))
     return table, fused
 
 
@@ -83,14 +83,14 @@ def _run_pair(hip_lib, oracle_lib, name, ncol, seed, tol, expect_classes):
 
 def test_c3_caii_columns_per_class_path(hip_lib, oracle_lib):
     """C3: CaII, 64 columns, ray-dependent device-built profiles; tile classes 0, 1 (one line), 2 (H & K overlap)"""
-    table = _run_pair(hip_lib, oracle_lib, 'falc_ca.npz', 64, 1234, 1e-12, [(0, 0, 0), (1, 1, 0), (2, 2, 0)])
+    table = _run_pair(hip_lib, oracle_lib, 'falc_ca.npz', 64, 1234, 1e-12, [(0, 0, 0, 0), (1, 1, 0, 0), (2, 2, 0, 1)])      # H & K share their lower level: relation 1
     assert sum(t for t, _ in table.values()) == 25          # DESIGN 4.1: 25 tiles for FALC CaII
 
 
 def test_c4_cah_columns_linked_continua(hip_lib, oracle_lib):
     """C4: Ca+H, 40 columns.  Every hydrogen line tile carries linked continua: classes (1 line) and (2 lines), each with and
     without linked continua, plus the continuum-only tiles"""
-    table = _run_pair(hip_lib, oracle_lib, 'falc_cah.npz', 40, 4321, 3e-11, [(0, 0, 0), (1, 1, 0), (1, 1, 1), (2, 2, 0), (2, 2, 1)])
+    table = _run_pair(hip_lib, oracle_lib, 'falc_cah.npz', 40, 4321, 3e-11, [(0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 0), (2, 2, 0, 1), (2, 2, 1, 1)])
     assert -1 not in [k[0] for k in table]                  # no tile falls back to the generic instance
     assert max(k[0] for k in table) == 2                    # no continuum goes through the sweep
 
@@ -100,7 +100,7 @@ def test_c4_cah_columns_three_and_four_slot_instances(hip_lib, oracle_lib, monke
     lsx_sweep_kernel<3, {1,2}, 5, false> and <4, {1,2}, 5, false> meet the oracle"""
     monkeypatch.setenv('LSX_NO_LINKED', '1')
     table = _run_pair(hip_lib, oracle_lib, 'falc_cah.npz', 40, 4321, 3e-11,
-                      [(1, 1, 0), (2, 1, 0), (2, 2, 0), (3, 1, 0), (3, 2, 0), (4, 1, 0), (4, 2, 0)])
+                      [(1, 1, 0, 0), (2, 1, 0, 0), (2, 2, 0, 1), (3, 1, 0, 0), (3, 2, 0, 0), (4, 1, 0, 0), (4, 2, 0, 0)])
     assert -1 not in [k[0] for k in table]
 
 
