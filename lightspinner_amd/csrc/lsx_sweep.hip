@@ -642,7 +642,11 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                     const double U_i = rel[REL_UI] * sUji[v];
                     pass2x(line, sl.Vc, spv[u], sUji[u], Vij, wt, etaA + cEC, chi_i + cXi, chi_j + cXj, U_j, U_i, w1[u], w2v[u]);
                 } else {
-                    pass2(line, sl, spv[u], schi[u], sUji[u], Vij, seta[u], wt, cEC, cXi, cXj, w1[u], w2v[u]);
+                    // a single per-ray slot: atom.U[i] = 0, atom.U[j] = Uji, atom.chi[j] = -chi (its product with U[i] vanishes)
+                    const double Vji = line ? sl.Vc * spv[u] : spv[u];
+                    const double Ieff = I - Psi * (seta[u] + cEC);                                      // :652
+                    w1[u] = wt * ((sUji[u] + Vji * Ieff) - ((schi[u] + cXi) * Psi) * sUji[u]);           // :677
+                    w2v[u] = wt * (Vij * Ieff);                                                          // :680
                 }
             }
             // the totals of step s are parked in entry (s mod 64) of per-(slot, entry) LDS rows and leave as one
