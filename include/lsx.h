@@ -119,7 +119,9 @@ enum {
                           reference does (rh_method.py:691; never zeroed, quirk kept)    */
     LSX_RJI = 9,       /* [Ntrans][Nspace]  t.Rji (rh_method.py:692, uses Vij: quirk kept) */
     LSX_PHI = 10,      /* [SNl][Nrays][2][Nspace] (or [SNl][Nspace] when phi_compact)  t.phi  */
-    LSX_WPHI = 11      /* [Nlines][Nspace]  t.wphi                                     */
+    LSX_WPHI = 11,     /* [Nlines][Nspace]  t.wphi                                     */
+    LSX_VBROAD = 12,   /* [Natoms][Nspace]  atom.vBroad            (after lsx_set_atmosphere)  */
+    LSX_ADAMP = 13     /* [Nlines][Nspace]  line.damping(...)[0]   (after lsx_set_atmosphere)  */
 };
 
 /* Create a context for `ncol` columns on HIP device `device` (ignored by the
@@ -147,6 +149,76 @@ int lsx_set_columns(lsx_ctx* ctx, int32_t col0, int32_t ncol, const lsx_columns*
  * correction, relative error < 1e-13 against scipy.special.wofz for 1e-4 <= aDamp). */
 int lsx_set_line_profiles(lsx_ctx* ctx, int32_t col0, int32_t ncol, const double* aDamp,
                           const double* vBroad, const double* vlos);
+
+/* ---- set-up chain on the device: what Context.__init__ derives from the atmosphere ---------------------
+ * Atomic data as the reference's model classes hold it (atomic_model.py): given once per context, column independent. */
+typedef struct lsx_level {           /* atomic_model.AtomicLevel (:111-137) */
+    double E_SI;                     /* level energy [J] (E_SI, :132-134)             */
+    double g;                        /* statistical weight                            */
+    int32_t stage;                   /* ionisation stage                              */
+    int32_t reserved;
+} lsx_level;
+
+typedef struct lsx_line_model {      /* atomic_model.VoigtLine (:250-502), broadening part */
+    int32_t i, j;                    /* levels; must equal the transition table's line of the same rank */
+    double gRad;                     /* radiative damping [1/s]                       */
+    double stark;                    /* > 0: quadratic Stark coefficient, < 0: -stark * ne, 0: none (:318-345) */
+    int32_t vdw_kind;                /* 0 none, 1 Unsold (:166-198)                   */
+    int32_t reserved;
+    double vdw[2];                   /* VdwUnsold.vals: H and He enhancement factors  */
+} lsx_line_model;
+
+enum { LSX_COLL_OMEGA = 0, LSX_COLL_CI = 1, LSX_COLL_CE = 2 };   /* collisional_rates.py:21-96 */
+typedef struct lsx_collision {
+    int32_t kind;                    /* LSX_COLL_*                                    */
+    int32_t i, j;                    /* levels, i < j                                 */
+    int32_t nT;                      /* points of the temperature grid (2, or >= 4 for the not-a-knot cubic scipy's
+                                        interp1d(kind=3) builds, collisional_rates.py:15-19)             */
+    const double* temperature;       /* [nT] K, ascending                             */
+    const double* rates;             /* [nT]                                          */
+} lsx_collision;
+
+typedef struct lsx_atom_model {
+    double weight;                   /* atomic weight [amu] (atomicTable[name].weight)                */
+    int32_t is_hydrogen;             /* linear Stark broadening applies (atomic_model.py:343-344)     */
+    int32_t Nlevel;
+    const lsx_level* levels;         /* [Nlevel]                                      */
+    int32_t Nline;                   /* lines of this atom in the transition table    */
+    int32_t Ncollision;
+    const lsx_line_model* lines;     /* [Nline], in the table's order                 */
+    const lsx_collision* collisions; /* [Ncollision], in the model's order            */
+} lsx_atom_model;
+
+typedef struct lsx_atomic_data {
+    int32_t Natoms;                  /* = lsx_problem.Natoms, same order              */
+    int32_t reserved;
+    const lsx_atom_model* atoms;
+    double weight_H, weight_He, abundance_He;   /* atomic table entries the Unsold cross-section needs (:183-190) */
+} lsx_atomic_data;
+
+int lsx_set_atomic_data(lsx_ctx* ctx, const lsx_atomic_data* data);
+
+/* Atmosphere of columns [col0, col0 + ncol): every array [ncol][Nspace] unless noted, SI units as after
+ * Atmosphere.nondimensionalise (atmosphere.py:424-436).  From it the library derives, per depth,
+ *   vBroad = sqrt(2 k T / (amu A) + vturb^2)                                  atomic_model.py:66-69
+ *   aDamp  = (gRad + Q_vdW + Q_Stark) lambda0 / (4 pi vBroad)                  :491-502, 166-198, 300-345
+ *   phi, wphi (as lsx_set_line_profiles)                                       rh_method.py:198-243
+ *   nStar  = Saha-Boltzmann with Debye lowering (if lte_pops != 0; n := nStar)  atomic_set.py:105-145
+ *   C      = collisional rates, negatives clamped to 0                          collisional_rates.py:21-96, rh_method.py:474-487
+ * and stores temperature and nTotal.  Needs lsx_set_atomic_data before, and lsx_set_columns for the same columns
+ * (geometry, background, and -- when lte_pops == 0 -- nStar and n). */
+typedef struct lsx_atmosphere {
+    const double* temperature;       /* K                                             */
+    const double* ne;                /* m^-3                                          */
+    const double* vturb;             /* m/s                                           */
+    const double* vlos;              /* m/s, or NULL for 0                            */
+    const double* nHGround;          /* m^-3: eqPops['H'].n[0] (rh_method.py:223)     */
+    const double* nTotal;            /* [ncol][Natoms][Nspace]                        */
+    int32_t lte_pops;
+    int32_t reserved;
+} lsx_atmosphere;
+
+int lsx_set_atmosphere(lsx_ctx* ctx, int32_t col0, int32_t ncol, const lsx_atmosphere* atm);
 
 /* One Context.formal_sol_gamma_matrices() over all columns.  *dJ_max receives the
  * maximum over columns of the reference's return value (rh_method.py:705-708). */

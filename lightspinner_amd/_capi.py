@@ -13,7 +13,8 @@ import numpy as np
 ABI_VERSION = 1
 
 # item selectors (include/lsx.h)
-LSX_I, LSX_J, LSX_N, LSX_GAMMA, LSX_DJ_COL, LSX_DPOPS_COL, LSX_NSTAR, LSX_C, LSX_RIJ, LSX_RJI, LSX_PHI, LSX_WPHI = range(12)
+LSX_I, LSX_J, LSX_N, LSX_GAMMA, LSX_DJ_COL, LSX_DPOPS_COL, LSX_NSTAR, LSX_C, LSX_RIJ, LSX_RJI, LSX_PHI, LSX_WPHI, LSX_VBROAD, LSX_ADAMP = range(14)
+LSX_COLL_OMEGA, LSX_COLL_CI, LSX_COLL_CE = range(3)
 
 ERRORS = {1: 'LSX_EINVAL', 2: 'LSX_EDEVICE', 3: 'LSX_ESINGULAR', 5: 'LSX_EUNSUPPORTED'}
 
@@ -43,13 +44,43 @@ class LsxColumns(C.Structure):
                                    'bg_chi', 'bg_eta', 'bg_sca', 'phi', 'wphi')]
 
 
+class LsxLevel(C.Structure):
+    _fields_ = [('E_SI', C.c_double), ('g', C.c_double), ('stage', C.c_int32), ('reserved', C.c_int32)]
+
+
+class LsxLineModel(C.Structure):
+    _fields_ = [('i', C.c_int32), ('j', C.c_int32), ('gRad', C.c_double), ('stark', C.c_double),
+                ('vdw_kind', C.c_int32), ('reserved', C.c_int32), ('vdw', C.c_double * 2)]
+
+
+class LsxCollision(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('i', C.c_int32), ('j', C.c_int32), ('nT', C.c_int32),
+                ('temperature', _dp), ('rates', _dp)]
+
+
+class LsxAtomModel(C.Structure):
+    _fields_ = [('weight', C.c_double), ('is_hydrogen', C.c_int32), ('Nlevel', C.c_int32),
+                ('levels', C.POINTER(LsxLevel)), ('Nline', C.c_int32), ('Ncollision', C.c_int32),
+                ('lines', C.POINTER(LsxLineModel)), ('collisions', C.POINTER(LsxCollision))]
+
+
+class LsxAtomicData(C.Structure):
+    _fields_ = [('Natoms', C.c_int32), ('reserved', C.c_int32), ('atoms', C.POINTER(LsxAtomModel)),
+                ('weight_H', C.c_double), ('weight_He', C.c_double), ('abundance_He', C.c_double)]
+
+
+class LsxAtmosphere(C.Structure):
+    _fields_ = [(k, _dp) for k in ('temperature', 'ne', 'vturb', 'vlos', 'nHGround', 'nTotal')] + \
+               [('lte_pops', C.c_int32), ('reserved', C.c_int32)]
+
+
 # every symbol include/lsx.h declares
 REQUIRED_SYMBOLS = (
     'lsx_create', 'lsx_destroy', 'lsx_set_columns', 'lsx_formal_sol_gamma', 'lsx_stat_equil',
     'lsx_formal_sol_gamma_async', 'lsx_stat_equil_async', 'lsx_sync', 'lsx_get', 'lsx_set',
     'lsx_piecewise_linear_1d', 'lsx_time_formal_sol', 'lsx_last_error', 'lsx_backend_name',
     'lsx_abi_version', 'lsx_algorithmic_bytes_per_column', 'lsx_set_active_columns', 'lsx_set_line_profiles',
-    'lsx_piecewise_1d_impl', 'lsx_w2', 'lsx_monitors',
+    'lsx_piecewise_1d_impl', 'lsx_w2', 'lsx_monitors', 'lsx_set_atomic_data', 'lsx_set_atmosphere',
 )
 
 
@@ -109,6 +140,8 @@ class LsxLibrary:
                                             _dp, _dp]
         d.lsx_w2.argtypes = [C.c_int32, C.c_int32, _dp, _dp]
         d.lsx_monitors.argtypes = [C.c_void_p, C.c_void_p]
+        d.lsx_set_atomic_data.argtypes = [C.c_void_p, C.POINTER(LsxAtomicData)]
+        d.lsx_set_atmosphere.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(LsxAtmosphere)]
         d.lsx_set_active_columns.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
         d.lsx_set_line_profiles.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp]
         d.lsx_time_formal_sol.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp]

@@ -93,6 +93,12 @@ struct lsx_ctx {
     int jcur = 0; // d_J[jcur] holds the current J (Jdag of the next call)
     size_t phi_col = 0, phi_in_col = 0, corr_col = 0, pp_col = 0, sca_col = 0, til_col = 0;
     bool any_cont = false;      // some tile has a continuum: E_T is kept
+    // set-up chain (lsx_setup.hip): atomic data tables and what lsx_set_atmosphere derives per column
+    char *d_sa_atoms = nullptr, *d_sa_lines = nullptr, *d_sa_colls = nullptr;
+    double *d_sa_spl = nullptr, *d_sa_levE = nullptr, *d_sa_levg = nullptr, *d_sa_levnD = nullptr;
+    int32_t* d_sa_levdZ = nullptr;
+    bool have_atomic_data = false;
+    double *d_vBroad = nullptr, *d_aDamp = nullptr;     // [col][Natoms][k], [col][Nlines][k]
     // staging
     double* d_stage = nullptr;
     size_t stage_doubles = 0;

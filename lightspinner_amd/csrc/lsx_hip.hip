@@ -1092,7 +1092,9 @@ void lsx_destroy(lsx_ctx* c)
                     c->d_tiles, c->d_slots, c->d_tile_slots, c->d_Nlevel, c->d_lev2_off, c->d_height,
                     c->d_temperature, c->d_nStar, c->d_nTotal, c->d_n, c->d_C, c->d_Gamma, c->d_wphi, c->d_bgchi,
                     c->d_bgeta, c->d_sca, c->d_phi, c->d_E, c->d_corr, c->d_Psi3, c->d_J[0], c->d_J[1], c->d_I, c->d_Gpart, c->d_dJpart,
-                    c->d_res, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab, c->d_voigt_w, c->d_muz, c->d_wmu};
+                    c->d_res, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab, c->d_voigt_w, c->d_muz, c->d_wmu,
+                    c->d_sa_atoms, c->d_sa_lines, c->d_sa_colls, c->d_sa_spl, c->d_sa_levE, c->d_sa_levg, c->d_sa_levnD, c->d_sa_levdZ,
+                    c->d_vBroad, c->d_aDamp};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& k : c->classes) {
@@ -1978,6 +1980,12 @@ int lsx_get(lsx_ctx* c, int32_t what, int32_t col0, int32_t ncol, double* dst, s
     case LSX_NSTAR: base = c->d_nStar; per = (size_t)c->NLtot * Ns; break;
     case LSX_C: base = c->d_C; per = (size_t)c->NL2tot * Ns; break;
     case LSX_WPHI: base = c->d_wphi; per = (size_t)c->Nlines * Ns; break;
+    case LSX_VBROAD:
+    case LSX_ADAMP:
+        if (!c->d_vBroad) return fail(LSX_EINVAL, "lsx_get: vBroad / aDamp exist after lsx_set_atmosphere only");
+        base = what == LSX_VBROAD ? c->d_vBroad : c->d_aDamp;
+        per = (size_t)(what == LSX_VBROAD ? c->Natoms : std::max(1, c->Nlines)) * Ns;
+        break;
     case LSX_PHI: per = c->phi_in_col; break;
     case LSX_RIJ:
     case LSX_RJI:

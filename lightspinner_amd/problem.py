@@ -212,6 +212,30 @@ class Engine:
         self.lib.check(self.lib.dll.lsx_set_line_profiles(self._h, int(col0), ncol, _ptr(aDamp), _ptr(vBroad),
                                                           _ptr(vl) if vl is not None else None))
 
+    def set_atomic_data(self, data):
+        """atomdata.AtomicData -> lsx_set_atomic_data (once per engine, before set_atmosphere)"""
+        cd, keep = data.to_c()
+        self.lib.check(self.lib.dll.lsx_set_atomic_data(self._h, C.byref(cd)))
+        del keep
+
+    def set_atmosphere(self, col0, temperature, ne, vturb, nHGround, nTotal, vlos=None, lte_pops=False):
+        """lsx_set_atmosphere for columns [col0, col0 + ncol): the library derives vBroad, aDamp, the line profiles, the
+        collisional rates and (lte_pops) the LTE populations from the atmosphere (rh_method.py:198-243, 474-487;
+        atomic_model.py:66-69, 491-502; atomic_set.py:105-145).  Arrays [ncol][Nspace]; nTotal [ncol][Natoms][Nspace]."""
+        p = self.problem
+        T = f64(temperature)
+        ncol = T.shape[0]
+        T = f64(T, (ncol, p.Nspace))
+        arrs = dict(temperature=T, ne=f64(ne, (ncol, p.Nspace)), vturb=f64(vturb, (ncol, p.Nspace)),
+                    nHGround=f64(nHGround, (ncol, p.Nspace)), nTotal=f64(nTotal, (ncol, p.Natoms, p.Nspace)))
+        if vlos is not None:
+            arrs['vlos'] = f64(vlos, (ncol, p.Nspace))
+        a = _capi.LsxAtmosphere()
+        for k, v in arrs.items():
+            setattr(a, k, _ptr(v))
+        a.lte_pops = 1 if lte_pops else 0
+        self.lib.check(self.lib.dll.lsx_set_atmosphere(self._h, int(col0), ncol, C.byref(a)))
+
     def set(self, what, arr, col0=0):
         arr = f64(arr)
         ncol = arr.shape[0]
@@ -270,7 +294,8 @@ class Engine:
                 _capi.LSX_DJ_COL: (), _capi.LSX_DPOPS_COL: (), _capi.LSX_NSTAR: (p.NLtot, p.Nspace),
                 _capi.LSX_C: (p.NL2tot, p.Nspace), _capi.LSX_RIJ: (p.Ntrans, p.Nspace),
                 _capi.LSX_RJI: (p.Ntrans, p.Nspace), _capi.LSX_PHI: p.phi_shape(),
-                _capi.LSX_WPHI: (p.Nlines, p.Nspace)}[what]
+                _capi.LSX_WPHI: (p.Nlines, p.Nspace), _capi.LSX_VBROAD: (p.Natoms, p.Nspace),
+                _capi.LSX_ADAMP: (max(1, p.Nlines), p.Nspace)}[what]
 
     def get(self, what, col0=0, ncol=None):
         ncol = self.ncol - col0 if ncol is None else ncol

@@ -59,10 +59,17 @@ struct lsx_ctx {
     double *height, *temperature, *nStar, *nTotal, *n, *C, *bg_chi, *bg_eta, *bg_sca, *phi, *wphi;
     double *J, *I, *Gamma, *Rij, *Rji, *dJcol, *dPcol;
     long* sing_col; /* per column: (depth << 8 | atom) of its first singular system in the last stat_equil, or -1 */
+    /* set-up chain: deep copy of the atomic data (lsx_set_atomic_data) and what lsx_set_atmosphere derives */
+    int have_atomic_data;
+    double weight_H, weight_He, abundance_He;
+    lsx_atom_model* am;       /* [Natoms]; levels / lines / collisions (with their tables) owned */
+    double *vBroad, *aDamp;   /* [col][Natoms][k], [col][Nlines][k] */
     int nthreads;
     uint8_t* colmask; /* NULL = all active */
     double last_dJ, last_dP;
 };
+
+static void free_atomic_data(lsx_ctx* c);
 
 static size_t phi_per_col(const lsx_ctx* c)
 {
@@ -144,6 +151,7 @@ void lsx_destroy(lsx_ctx* c)
     free(c->bg_chi); free(c->bg_eta); free(c->bg_sca); free(c->phi); free(c->wphi);
     free(c->colmask);
     free(c->J); free(c->I); free(c->Gamma); free(c->Rij); free(c->Rji); free(c->dJcol); free(c->dPcol); free(c->sing_col);
+    free_atomic_data(c); free(c->vBroad); free(c->aDamp);
     free(c);
 }
 
@@ -254,6 +262,260 @@ int lsx_set_line_profiles(lsx_ctx* c, int32_t col0, int32_t ncol, const double* 
             }
             for (int k = 0; k < Ns; ++k) wphi[k] = 1.0 / wphi[k];
         }
+    }
+    return LSX_OK;
+}
+
+/* ---- set-up chain -------------------------------------------------------------------------------- */
+static const double Amu = 1.6605402E-27, MElectron = 9.1093897E-31, QElectron = 1.60217733E-19, Epsilon0 = 8.854187817E-12,
+                    RBohr = 5.29177349E-11, ERydberg = 2.1798741E-18, ABarH = 7.42E-41, CM_TO_M = 1.0E-02;
+
+static void free_atomic_data(lsx_ctx* c)
+{
+    if (!c->am) return;
+    for (int a = 0; a < c->Natoms; ++a) {
+        for (int q = 0; q < c->am[a].Ncollision; ++q) {
+            free((void*)c->am[a].collisions[q].temperature);
+            free((void*)c->am[a].collisions[q].rates);
+        }
+        free((void*)c->am[a].levels); free((void*)c->am[a].lines); free((void*)c->am[a].collisions);
+    }
+    free(c->am);
+    c->am = NULL;
+    c->have_atomic_data = 0;
+}
+
+static void* dup_bytes(const void* p, size_t n)
+{
+    void* q = malloc(n ? n : 1);
+    if (n) memcpy(q, p, n);
+    return q;
+}
+
+int lsx_set_atomic_data(lsx_ctx* c, const lsx_atomic_data* d)
+{
+    if (!c || !d || !d->atoms) return fail(LSX_EINVAL, "lsx_set_atomic_data: null argument");
+    if (d->Natoms != c->Natoms) return fail(LSX_EINVAL, "lsx_set_atomic_data: number of atoms differs from the context's");
+    for (int a = 0; a < c->Natoms; ++a) {
+        const lsx_atom_model* m = &d->atoms[a];
+        int nl = 0;
+        for (int t = 0; t < c->Ntrans; ++t) nl += c->trans[t].is_line && c->trans[t].atom == a;
+        if (m->Nlevel != c->Nlevel[a] || m->Nline != nl || !(m->weight > 0.0)) return fail(LSX_EINVAL, "lsx_set_atomic_data: atom does not match the context");
+        for (int q = 0; q < m->Ncollision; ++q)
+            if (m->collisions[q].nT < 2 || m->collisions[q].nT == 3 || m->collisions[q].i >= m->collisions[q].j)
+                return fail(LSX_EINVAL, "lsx_set_atomic_data: inconsistent collision");
+    }
+    free_atomic_data(c);
+    c->am = (lsx_atom_model*)calloc((size_t)c->Natoms, sizeof(lsx_atom_model));
+    for (int a = 0; a < c->Natoms; ++a) {
+        const lsx_atom_model* m = &d->atoms[a];
+        c->am[a] = *m;
+        c->am[a].levels = (const lsx_level*)dup_bytes(m->levels, sizeof(lsx_level) * (size_t)m->Nlevel);
+        c->am[a].lines = (const lsx_line_model*)dup_bytes(m->lines, sizeof(lsx_line_model) * (size_t)m->Nline);
+        lsx_collision* K = (lsx_collision*)dup_bytes(m->collisions, sizeof(lsx_collision) * (size_t)m->Ncollision);
+        for (int q = 0; q < m->Ncollision; ++q) {
+            K[q].temperature = (const double*)dup_bytes(m->collisions[q].temperature, 8 * (size_t)K[q].nT);
+            K[q].rates = (const double*)dup_bytes(m->collisions[q].rates, 8 * (size_t)K[q].nT);
+        }
+        c->am[a].collisions = K;
+    }
+    c->weight_H = d->weight_H; c->weight_He = d->weight_He; c->abundance_He = d->abundance_He;
+    c->have_atomic_data = 1;
+    return LSX_OK;
+}
+
+/* VdwUnsold.setup, atomic_model.py:166-194 -> the temperature-independent cross-section */
+static double unsold_cross(const lsx_ctx* c, const lsx_atom_model* m, const lsx_line_model* L)
+{
+    const lsx_level *up = &m->levels[L->j], *lo = &m->levels[L->i];
+    int Z = up->stage + 1, ic = L->j + 1;
+    while (m->levels[ic].stage < Z) ic += 1;
+    const lsx_level* cont = &m->levels[ic];
+    double deltaR = pow(ERydberg / (cont->E_SI - up->E_SI), 2.0) - pow(ERydberg / (cont->E_SI - lo->E_SI), 2.0);
+    double fourPiEps0 = 4.0 * M_PI * Epsilon0;
+    double C625 = pow(2.5 * QElectron * QElectron / fourPiEps0 * ABarH / fourPiEps0 * 2 * M_PI * pow(Z * RBohr, 2.0) / HPlanck * deltaR, 0.4);
+    double vRel35He = pow(8.0 * KBoltzmann / (M_PI * Amu * m->weight) * (1.0 + m->weight / c->weight_He), 0.3);
+    double vRel35H = pow(8.0 * KBoltzmann / (M_PI * Amu * m->weight) * (1.0 + m->weight / c->weight_H), 0.3);
+    return 8.08 * (L->vdw[0] * vRel35H + L->vdw[1] * c->abundance_He * vRel35He) * C625;
+}
+
+/* VoigtLine.stark_broaden, atomic_model.py:318-345, at one depth */
+static double stark_broaden(const lsx_atom_model* m, const lsx_line_model* L, double T, double ne)
+{
+    const lsx_level *up = &m->levels[L->j], *lo = &m->levels[L->i];
+    double stark;
+    if (L->stark > 0.0) {
+        double weight = m->weight;
+        double C = 8.0 * KBoltzmann / (M_PI * Amu * weight);
+        double Cm = pow(1.0 + weight / (MElectron / Amu), 1.0 / 6.0);
+        Cm += pow(1.0 + weight / 28.0, 1.0 / 6.0);
+        int Z = lo->stage + 1, ic = L->i + 1;
+        while (ic < m->Nlevel && m->levels[ic].stage < Z) ic += 1;
+        double E_Ryd = ERydberg / (1.0 + MElectron / (weight * Amu));
+        double neff_l = Z * sqrt(E_Ryd / (m->levels[ic].E_SI - lo->E_SI));
+        double neff_u = Z * sqrt(E_Ryd / (m->levels[ic].E_SI - up->E_SI));
+        double C4 = QElectron * QElectron / (4.0 * M_PI * Epsilon0) * RBohr * (2.0 * M_PI * RBohr * RBohr / HPlanck) / (18.0 * pow((double)Z, 4.0)) *
+                    (pow(neff_u * (5.0 * neff_u * neff_u + 1.0), 2.0) - pow(neff_l * (5.0 * neff_l * neff_l + 1.0), 2.0));
+        double cStark23 = 11.37 * pow(L->stark * C4, 2.0 / 3.0);
+        double vRel = pow(C * T, 1.0 / 6.0) * Cm;
+        stark = cStark23 * vRel * ne;
+    } else if (L->stark < 0.0) {
+        stark = fabs(L->stark) * ne;
+    } else {
+        stark = 0.0;
+    }
+    if (m->is_hydrogen) { /* linear_stark_broaden, :307-316 */
+        int nUpper = (int)lround(sqrt(0.5 * up->g)), nLower = (int)lround(sqrt(0.5 * lo->g));
+        double a1 = (nUpper - nLower == 1) ? 0.642 : 1.0;
+        double Cl = a1 * 0.6 * (nUpper * nUpper - nLower * nLower) * CM_TO_M * CM_TO_M;
+        stark += Cl * pow(ne, 2.0 / 3.0);
+    }
+    return stark;
+}
+
+/* the not-a-knot cubic scipy.interpolate.interp1d(x, y, kind=3) builds (make_interp_spline, k = 3), evaluated through its
+ * second derivatives M; two points: linear.  fill_value = (y[0], y[-1]) outside the grid (collisional_rates.py:15-19) */
+static void spline_moments(int n, const double* x, const double* y, double* M)
+{
+    for (int i = 0; i < n; ++i) M[i] = 0.0;
+    if (n < 4) return;
+    double A[64 * 64], b[64];
+    memset(A, 0, sizeof(double) * (size_t)n * n);
+#define H(i) (x[(i) + 1] - x[(i)])
+    A[0] = H(1); A[1] = -(H(0) + H(1)); A[2] = H(0); b[0] = 0.0;
+    A[(n - 1) * n + n - 3] = H(n - 2); A[(n - 1) * n + n - 2] = -(H(n - 3) + H(n - 2)); A[(n - 1) * n + n - 1] = H(n - 3); b[n - 1] = 0.0;
+    for (int i = 1; i < n - 1; ++i) {
+        A[i * n + i - 1] = H(i - 1); A[i * n + i] = 2.0 * (H(i - 1) + H(i)); A[i * n + i + 1] = H(i);
+        b[i] = 6.0 * ((y[i + 1] - y[i]) / H(i) - (y[i] - y[i - 1]) / H(i - 1));
+    }
+#undef H
+    for (int col = 0; col < n; ++col) {
+        int p = col;
+        for (int r = col + 1; r < n; ++r) if (fabs(A[r * n + col]) > fabs(A[p * n + col])) p = r;
+        if (p != col) { for (int q = 0; q < n; ++q) { double t = A[col * n + q]; A[col * n + q] = A[p * n + q]; A[p * n + q] = t; } double t = b[col]; b[col] = b[p]; b[p] = t; }
+        for (int r = col + 1; r < n; ++r) {
+            double f = A[r * n + col] / A[col * n + col];
+            for (int q = col; q < n; ++q) A[r * n + q] -= f * A[col * n + q];
+            b[r] -= f * b[col];
+        }
+    }
+    for (int r = n - 1; r >= 0; --r) { double sacc = b[r]; for (int q = r + 1; q < n; ++q) sacc -= A[r * n + q] * M[q]; M[r] = sacc / A[r * n + r]; }
+}
+static double spline_eval(int n, const double* x, const double* y, const double* M, double t)
+{
+    if (t < x[0]) return y[0];
+    if (t > x[n - 1]) return y[n - 1];
+    int i = 0;
+    while (i < n - 2 && t > x[i + 1]) ++i;
+    double h = x[i + 1] - x[i], a = x[i + 1] - t, b = t - x[i];
+    return (M[i] * a * a * a + M[i + 1] * b * b * b) / (6.0 * h) + (y[i] / h - M[i] * h / 6.0) * a + (y[i + 1] / h - M[i + 1] * h / 6.0) * b;
+}
+
+int lsx_set_atmosphere(lsx_ctx* c, int32_t col0, int32_t ncol, const lsx_atmosphere* s)
+{
+    if (!c || !s || col0 < 0 || ncol < 1 || col0 + ncol > c->ncol) return fail(LSX_EINVAL, "lsx_set_atmosphere: bad range");
+    if (!c->have_atomic_data) return fail(LSX_EINVAL, "lsx_set_atmosphere: lsx_set_atomic_data has not been called");
+    if (!s->temperature || !s->ne || !s->vturb || !s->nHGround || !s->nTotal) return fail(LSX_EINVAL, "lsx_set_atmosphere: null array pointer");
+    if (c->phi_compact && s->vlos) return fail(LSX_EINVAL, "lsx_set_atmosphere: a phi_compact context takes vlos == NULL");
+    const int Ns = c->Nspace;
+    if (!c->vBroad) {
+        c->vBroad = (double*)calloc((size_t)c->ncol * c->Natoms * Ns, 8);
+        c->aDamp = (double*)calloc((size_t)c->ncol * (c->Nlines ? c->Nlines : 1) * Ns, 8);
+    }
+    for (int cc = 0; cc < ncol; ++cc) {
+        const size_t col = (size_t)col0 + cc;
+        const double *T = s->temperature + (size_t)cc * Ns, *ne = s->ne + (size_t)cc * Ns, *vt = s->vturb + (size_t)cc * Ns,
+                     *nH = s->nHGround + (size_t)cc * Ns;
+        memcpy(c->temperature + col * Ns, T, 8 * (size_t)Ns);
+        memcpy(c->nTotal + col * c->Natoms * Ns, s->nTotal + (size_t)cc * c->Natoms * Ns, 8 * (size_t)c->Natoms * Ns);
+        int line0 = 0;
+        for (int a = 0; a < c->Natoms; ++a) {
+            const lsx_atom_model* m = &c->am[a];
+            double* vB = c->vBroad + (col * c->Natoms + a) * Ns;
+            /* v_broad, atomic_model.py:66-69 */
+            double vTherm = 2.0 * KBoltzmann / (Amu * m->weight);
+            for (int k = 0; k < Ns; ++k) vB[k] = sqrt(vTherm * T[k] + vt[k] * vt[k]);
+            /* damping, :491-502 */
+            for (int q = 0; q < m->Nline; ++q) {
+                const lsx_line_model* L = &m->lines[q];
+                double cross = L->vdw_kind == 1 ? unsold_cross(c, m, L) : 0.0;
+                double cDop = (HC / (m->levels[L->j].E_SI - m->levels[L->i].E_SI)) / (4.0 * M_PI);
+                double* aD = c->aDamp + (col * c->Nlines + line0 + q) * Ns;
+                for (int k = 0; k < Ns; ++k) {
+                    double Qelast = 0.0;
+                    if (L->vdw_kind == 1) Qelast += cross * pow(T[k], 0.3) * nH[k];            /* :197-198 */
+                    Qelast += stark_broaden(m, L, T[k], ne[k]);
+                    aD[k] = (L->gRad + Qelast) * cDop / vB[k];
+                }
+            }
+            line0 += m->Nline;
+            /* lte_pops, atomic_set.py:105-145 */
+            double* nStar = c->nStar + (col * c->NLtot + c->lev_off[a]) * Ns;
+            if (s->lte_pops) {
+                double c1 = (HPlanck / (2.0 * M_PI * MElectron)) * (HPlanck / KBoltzmann);
+                double c2 = sqrt(8.0 * M_PI / KBoltzmann) * pow(QElectron * QElectron / (4.0 * M_PI * Epsilon0), 1.5);
+                double* nn = c->n + (col * c->NLtot + c->lev_off[a]) * Ns;
+                const double* nTot = c->nTotal + (col * c->Natoms + a) * Ns;
+                for (int k = 0; k < Ns; ++k) {
+                    double dEion = c2 * sqrt(ne[k] / T[k]);
+                    double cNe_T = 0.5 * ne[k] * pow(c1 / T[k], 1.5);
+                    double total = 1.0;
+                    for (int i = 1; i < m->Nlevel; ++i) {
+                        double nDebye = 0.0;
+                        int Z = m->levels[i].stage;
+                        for (int mm = 1; mm < m->levels[i].stage - m->levels[0].stage + 1; ++mm) { nDebye += Z; Z += 1; }
+                        double dE = m->levels[i].E_SI - m->levels[0].E_SI;
+                        double gi0 = m->levels[i].g / m->levels[0].g;
+                        int dZ = m->levels[i].stage - m->levels[0].stage;
+                        double dE_kT = (dE - nDebye * dEion) / (KBoltzmann * T[k]);
+                        double nst = gi0 * exp(-dE_kT);
+                        nst /= (dZ == 0 ? 1.0 : dZ == 1 ? cNe_T : dZ == 2 ? cNe_T * cNe_T : pow(cNe_T, (double)dZ));
+                        nStar[(size_t)i * Ns + k] = nst;
+                        total += nst;
+                    }
+                    nStar[k] = nTot[k] / total;
+                    for (int i = 1; i < m->Nlevel; ++i) nStar[(size_t)i * Ns + k] *= nStar[k];
+                    for (int i = 0; i < m->Nlevel; ++i) nn[(size_t)i * Ns + k] = nStar[(size_t)i * Ns + k];
+                }
+            }
+            /* compute_collisions, rh_method.py:474-487 */
+            const int Nl = m->Nlevel;
+            double* Cm = c->C + (col * c->NL2tot + c->lev2_off[a]) * Ns;
+            for (size_t e = 0; e < (size_t)Nl * Nl * Ns; ++e) Cm[e] = 0.0;
+            for (int q = 0; q < m->Ncollision; ++q) {
+                const lsx_collision* K = &m->collisions[q];
+                double M[64];
+                spline_moments(K->nT, K->temperature, K->rates, M);
+                const lsx_level *jL = &m->levels[K->j], *iL = &m->levels[K->i];
+                for (int k = 0; k < Ns; ++k) {
+                    double Cv = spline_eval(K->nT, K->temperature, K->rates, M, T[k]);
+                    double nsi = nStar[(size_t)K->i * Ns + k], nsj = nStar[(size_t)K->j * Ns + k];
+                    double* Cij = &Cm[((size_t)K->i * Nl + K->j) * Ns + k];
+                    double* Cji = &Cm[((size_t)K->j * Nl + K->i) * Ns + k];
+                    if (K->kind == LSX_COLL_OMEGA) {                                       /* collisional_rates.py:38-45 */
+                        double C0 = ERydberg / sqrt(MElectron) * M_PI * RBohr * RBohr * sqrt(8.0 / (M_PI * KBoltzmann));
+                        double Cdown = C0 * ne[k] * Cv / (jL->g * sqrt(T[k]));
+                        *Cij += Cdown;
+                        *Cji += Cdown * nsj / nsi;
+                    } else if (K->kind == LSX_COLL_CI) {                                   /* :62-70 */
+                        double dE = jL->E_SI - iL->E_SI;
+                        double Cup = Cv * ne[k] * exp(-dE / (KBoltzmann * T[k])) * sqrt(T[k]);
+                        *Cji += Cup;
+                        *Cij += Cup * nsi / nsj;
+                    } else {                                                               /* CE, :88-96 */
+                        double gij = iL->g / jL->g;
+                        double Cdown = Cv * ne[k] * gij * sqrt(T[k]);
+                        *Cij += Cdown;
+                        *Cji += Cdown * nsj / nsi;
+                    }
+                }
+            }
+            for (size_t e = 0; e < (size_t)Nl * Nl * Ns; ++e) if (Cm[e] < 0.0) Cm[e] = 0.0;
+        }
+    }
+    if (c->Nlines) {
+        int rc = lsx_set_line_profiles(c, col0, ncol, c->aDamp + (size_t)col0 * c->Nlines * Ns, c->vBroad + (size_t)col0 * c->Natoms * Ns, s->vlos);
+        if (rc) return rc;
     }
     return LSX_OK;
 }
@@ -793,6 +1055,8 @@ static int locate(lsx_ctx* c, int what, double** base, size_t* per)
     case LSX_RJI: *base = c->Rji; *per = (size_t)c->Ntrans * Ns; break;
     case LSX_PHI: *base = c->phi; *per = phi_per_col(c); break;
     case LSX_WPHI: *base = c->wphi; *per = (size_t)c->Nlines * Ns; break;
+    case LSX_VBROAD: *base = c->vBroad; *per = (size_t)c->Natoms * Ns; if (!c->vBroad) return 1; break;
+    case LSX_ADAMP: *base = c->aDamp; *per = (size_t)(c->Nlines ? c->Nlines : 1) * Ns; if (!c->aDamp) return 1; break;
     default: return 1;
     }
     return 0;

@@ -6,9 +6,9 @@
 set -e
 cd "$(dirname "$0")/../lightspinner_amd/csrc"
 NAME=$1; XF=$2; FULL=$3
-[ -f build/lsx_hip.o ] || make -s build/lsx_hip.o
+make -s build/lsx_hip.o build/lsx_setup.o
 ONLY="-DLSX_ONLY_NR5"; [ "$FULL" = full ] && ONLY=""
 mkdir -p ../../ab_so /tmp/lsxvar
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -DLSX_WAVES_PER_EU=4 $ONLY $XF -c lsx_sweep.hip -o /tmp/lsxvar/$NAME.o
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../ab_so/$NAME.so build/lsx_hip.o /tmp/lsxvar/$NAME.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../ab_so/$NAME.so build/lsx_hip.o build/lsx_setup.o /tmp/lsxvar/$NAME.o
 echo "built ab_so/$NAME.so"
