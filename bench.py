@@ -29,41 +29,18 @@ N_SIMD, CLOCK_HZ = 1024, 2.4e9    # 256 CUs x 4 SIMD-32, max clock
 VALU_PEAK = N_SIMD * CLOCK_HZ / 4.0   # wave64 fp64 VALU instructions per second (4 cycles each)
 
 
-def _gen_chunk(args):
-    path, first, n, seed, vlos_sigma, compact, device_profiles = args
+def generate_columns(path, first, ncol, compact, seed=1234):
+    """synthetic ensemble columns [first, first+ncol) -> (ColumnBlock, profile inputs or None); with a line-of-sight velocity
+    (not compact) the profiles are left to the library (lsx_set_line_profiles builds them on the device)"""
     from lightspinner_amd import fixtures, synth
     prob, block, raw = fixtures.load_problem_npz(path, phi_compact=compact)
-    return synth.perturbed_columns(prob, block, raw, ncol=n, seed=seed, first=first, vlos_sigma=vlos_sigma,
-                                   device_profiles=device_profiles)
-
-
-def generate_columns(path, first, ncol, compact, nproc, seed=1234, chunk=25, device_profiles=True):
-    """synthetic ensemble columns [first, first+ncol) (before the GPU is touched: fork is safe).
-    -> (ColumnBlock, profile inputs or None)"""
-    from lightspinner_amd.problem import ColumnBlock
-    jobs = [(path, first + c0, min(chunk, ncol - c0), seed, 0.0 if compact else 2.0e3, compact, device_profiles)
-            for c0 in range(0, ncol, chunk)]
-    if nproc > 1 and len(jobs) > 1 and not device_profiles:
-        import multiprocessing as mp
-        with mp.get_context('fork').Pool(min(nproc, len(jobs))) as pool:
-            blocks = pool.map(_gen_chunk, jobs)
-    else:
-        blocks = [_gen_chunk(j) for j in jobs]
-    if not device_profiles:
-        return ColumnBlock.concatenate(blocks), None
-    prof = [b[1] for b in blocks]
-    vl = None if prof[0][2] is None else np.concatenate([p[2] for p in prof])
-    return ColumnBlock.concatenate([b[0] for b in blocks]), (np.concatenate([p[0] for p in prof]),
-                                                             np.concatenate([p[1] for p in prof]), vl)
+    return synth.perturbed_columns(prob, block, raw, ncol=ncol, seed=seed, first=first, vlos_sigma=0.0 if compact else 2.0e3)
 
 
 def load_columns(eng, batch, prof, c0=0, step=100):
-    """inputs -> engine: arrays by lsx_set_columns, line profiles by lsx_set_line_profiles when they were not built on the host"""
-    for a in range(0, batch.ncol, step):
-        b = min(batch.ncol, a + step)
-        eng.set_columns(c0 + a, batch.slice(a, b))
-    if prof is not None:        # small inputs: all columns in one call keeps the profile kernels wide
-        eng.set_line_profiles(c0, prof[0], prof[1], prof[2])
+    """inputs -> engine: arrays by lsx_set_columns, line profiles by lsx_set_line_profiles where they were not handed over"""
+    from lightspinner_amd import synth
+    synth.load_columns(eng, batch, prof, col0=c0, step=step)
 
 
 def stats_ms(times):
@@ -280,7 +257,7 @@ def measure_share(workload, ncol, local_rank, lib, torch, steps=40, warmup=3, ke
     fixture = os.path.join(ROOT, 'tests', 'golden', 'falc_cah.npz' if workload == 'c4' else 'falc_ca.npz')
     prob, base, raw = fixtures.load_problem_npz(fixture, phi_compact=False)
     t0 = time.time()
-    batch, prof = generate_columns(fixture, 0, ncol, False, 1)
+    batch, prof = generate_columns(fixture, 0, ncol, False)
     t_gen = time.time() - t0
     ts = torch.cuda.Stream()
     eng = Engine(prob, ncol, device=local_rank, stream=ts.cuda_stream, lib=lib)
@@ -306,7 +283,6 @@ def main():
     ap.add_argument('--columns', type=int, default=None, help='columns per GPU (default 1000 / 1 / 1250)')
     ap.add_argument('--compact-phi', action='store_true', help='vlos == 0: ray independent profiles (P = 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--host-profiles', action='store_true', help='build the line profiles on the host (scipy) and upload them')
     ap.add_argument('--kernel-reps', type=int, default=20)
     ap.add_argument('--no-single-column', action='store_true',
                     help='skip the FALC single-column section (used for rocprofv3 runs so that every sweep launch has the workload size)')
@@ -328,9 +304,7 @@ def main():
     from lightspinner_amd.parallel import MaxReducer
     prob, base, raw = fixtures.load_problem_npz(fixture, phi_compact=compact)
     t0 = time.time()
-    nproc = max(1, min(os.cpu_count() or 1, 16 * max(1, world)) // max(1, world))
-    devprof = not args.host_profiles
-    batch, prof = generate_columns(fixture, rank * ncol, ncol, compact, nproc, device_profiles=devprof) if ncol > 1 else (base, None)
+    batch, prof = generate_columns(fixture, rank * ncol, ncol, compact) if ncol > 1 else (base, None)
     t_gen = time.time() - t0
 
     cpu = None
@@ -402,7 +376,7 @@ def main():
                       roofline=roofline, cpu_baseline=cpu, falc_single_column=single,
                       max_dn_over_n_vs_ref=single['max_dn_over_n_vs_ref'] if single else None,
                       setup=dict(generate_s=t_gen, upload_s=t_up, upload_GB=upload_bytes / 1e9,
-                                 line_profiles='built on the device (lsx_set_line_profiles)' if prof is not None else 'built on the host and uploaded',
+                                 line_profiles='built on the device (lsx_set_line_profiles)' if prof is not None else 'ray independent (vlos = 0): the fixture\'s profiles',
                                  note='PCIe-inclusive upload (and the device-side profile build) is outside the timed region (inputs resident in HBM)'))
         if rehearsal:
             result.update(rehearsal)

@@ -277,6 +277,51 @@ int lsx_piecewise_1d_impl(int32_t device, int32_t nray, int32_t Nspace, const do
  * device function the sweep kernel uses.  w0w1: [n][2]. */
 int lsx_w2(int32_t device, int32_t n, const double* dtau, double* w0w1);
 
+/* ---- wavelength grid and active set: RadiativeSet.compute_wavelength_grid (atomic_set.py:377-455) -------------------
+ * Host-side construction of what lsx_problem takes (wavelength, Nblue, Nlambda, active) from the transitions' own grids,
+ * so a caller can hand over an arbitrary set of atoms instead of a pre-built transition table.  All wavelengths in nm. */
+typedef struct lsx_trans_grid {
+    int32_t is_line;
+    int32_t n;                       /* points of the transition's own grid, >= 1                                  */
+    const double* wavelength;        /* [n] ascending: line.wavelength (atomic_model.py:347-380) or cont.wavelength
+                                        (:585-597, 645-660) BEFORE the merge                                       */
+    double lambdaEdge;               /* continua: the edge (atomic_model.py:575-577); lines: ignored               */
+} lsx_trans_grid;
+
+/* grid = unique(sort(extra U {lambdaReference} U line grids U continuum edges U continuum points <= edge));
+ * blueIdx[kr] = searchsorted(grid, wavelength_kr[0]); redIdx[kr] = searchsorted(grid, wavelength_kr[-1]) + 1, walked
+ * down for a continuum while grid[redIdx - 1] > lambdaEdge (atomic_set.py:401-416).  The transition's grid after the
+ * merge is wavelength[blueIdx : redIdx] (Nlambda = redIdx - blueIdx).  extra may be NULL (Nextra = 0).
+ * wavelength: [capacity]; LSX_EINVAL if the merged grid needs more (then *Nspect holds the size needed). */
+int lsx_wavelength_grid(int32_t Ntrans, const lsx_trans_grid* trans, int32_t Nextra, const double* extra,
+                        double lambdaReference, int32_t capacity, double* wavelength, int32_t* Nspect,
+                        int32_t* blueIdx, int32_t* redIdx);
+
+/* active[kr][la] = blueIdx[kr] <= la < redIdx[kr]: the membership table of spect.activeSet (atomic_set.py:418-453) in the
+ * layout of lsx_problem.active */
+int lsx_active_set(int32_t Ntrans, int32_t Nspect, const int32_t* blueIdx, const int32_t* redIdx, uint8_t* active);
+
+/* VoigtLine.setup_wavelength (atomic_model.py:347-380): the line's own grid, 2 (NlambdaGen / 2 rounded as the reference
+ * does) + 1 points, symmetric about lambda0, linear in the core and logarithmic in the wing.  *n receives the count. */
+int lsx_line_wavelength(double lambda0, double qCore, double qWing, int32_t NlambdaGen, int32_t capacity,
+                        double* wavelength, int32_t* n);
+
+/* Continuum cross-section on a new grid: compute_alpha (atomic_model.py:606-612 explicit: not-a-knot cubic through the
+ * tabulated points, zero outside [minLambda, lambdaEdge], linear interpolation instead if the cubic goes negative anywhere;
+ * :662-671 hydrogenic: alpha0 gbf / gbf0 (lambda / lambda0)^3 with Seaton's Gaunt factor, utils.py:24-32). */
+typedef struct lsx_continuum_model {
+    int32_t hydrogenic;
+    int32_t n;                       /* explicit: tabulated points (>= 4 for the cubic)                            */
+    const double* wavelength;        /* explicit: [n] ascending                                                    */
+    const double* alpha;             /* explicit: [n]                                                              */
+    double lambdaEdge, minLambda;
+    double alpha0;                   /* hydrogenic: cross-section at the edge                                      */
+    double E_i, E_j;                 /* hydrogenic: level energies [J]                                             */
+    int32_t stage_j;                 /* hydrogenic: ionisation stage of the upper level (charge Z)                 */
+    int32_t reserved;
+} lsx_continuum_model;
+int lsx_continuum_alpha(const lsx_continuum_model* cont, int32_t n, const double* wavelength, double* alpha);
+
 /* Measurement hooks (bench.py): time `reps` back-to-back FS calls with device events
  * on the context's stream.  ms_total = whole FS call (all kernels), ms_sweep = the
  * dominant sweep kernel(s) alone, both averaged per call. */

@@ -6,11 +6,23 @@
     ctx.I, ctx.J, ctx.activeAtoms[0].n / .Gamma / .C / .nStar / .nTotal / .trans[kr].phi ...
 
 The constructor reads the same (duck-typed) attributes the reference's constructor reads from
-Lightspinner's Atmosphere / SpectrumConfiguration / AtomicStateTable / Background objects and
-calls the same model methods (`v_broad`, `damping`, `compute_rates`) -- the set-up maths of
-ComputationalTransition.compute_phi and ComputationalAtom.compute_collisions is restated in
-lineprofile.py / here.  The two hot calls run on the GPU through the lsx C ABI; there is no
-CPU fallback (the HIP library must be built).
+Lightspinner's Atmosphere / SpectrumConfiguration / AtomicStateTable / Background objects.  Nothing
+numerical happens on the host: everything between the atmosphere and the hot path's inputs is
+evaluated by the library,
+
+  * setup='native' (chosen by 'auto' when the model objects carry their atomic data: levels with
+    E_SI / g / stage, lines with gRad / stark / vdw, collisions that are Omega / CI / CE tables):
+    the data go down once (lsx_set_atomic_data) and lsx_set_atmosphere derives vBroad, aDamp, the
+    line profiles and the collisional rates on the device (rh_method.py:198-243, 474-487;
+    atomic_model.py:66-69, 491-502);
+  * setup='methods' (models that only offer the reference's methods): `atom.v_broad`,
+    `line.damping` and `collision.compute_rates` are CALLED, as the reference calls them, and
+    their results handed over; the profiles are still built on the device
+    (lsx_set_line_profiles).
+
+`t.phi`, `t.wphi`, `t.aDamp`, `atom.vBroad` and `atom.C` are read back from the library.  The two
+hot calls run on the GPU through the lsx C ABI; there is no CPU fallback (the HIP library must be
+built).
 
 Deliberate differences, all outside the numbers the drivers use:
   * `t.Rij` / `t.Rji` are not produced (the reference accumulates them without ever zeroing or
@@ -23,9 +35,11 @@ from typing import List, Optional
 
 import numpy as np
 
-from . import _capi, lineprofile
+from . import _capi, atomdata
 from . import constants as Const
 from .problem import Problem, Transition, ColumnBlock, Engine
+
+_KNOWN_COLLISIONS = ('Omega', 'CI', 'CE')
 
 
 def _same(a, b):
@@ -45,8 +59,30 @@ def _is_line(trans):
     return hasattr(trans, 'Aji') and hasattr(trans, 'lambda0')
 
 
+def models_carry_atomic_data(models, atmos) -> bool:
+    """can lsx_set_atomic_data be filled from these objects (atomdata.from_models)?"""
+    if not all(hasattr(atmos, k) for k in ('ne', 'vturb')):
+        return False
+    for m in models:
+        table = getattr(m, 'atomicTable', None)
+        if table is None:
+            return False
+        try:
+            table[m.name].weight, table['H'].weight, table['He'].abundance
+        except Exception:
+            return False
+        if not all(hasattr(l, 'E_SI') and hasattr(l, 'g') and hasattr(l, 'stage') for l in m.levels):
+            return False
+        if not all(hasattr(l, 'gRad') and hasattr(l, 'stark') for l in m.lines):
+            return False
+        if not all(type(c).__name__ in _KNOWN_COLLISIONS and hasattr(c, 'temperature') and hasattr(c, 'rates')
+                   for c in m.collisions):
+            return False
+    return True
+
+
 class ComputationalTransition:
-    """rh_method.py:25-288 (state only; uv() lives in the sweep kernel)."""
+    """rh_method.py:25-288 (state only; uv() lives in the sweep kernel, compute_phi in the set-up kernels)."""
 
     def __init__(self, trans, compAtom: 'ComputationalAtom', atmos, spect):
         self.transModel = trans
@@ -59,28 +95,50 @@ class ComputationalTransition:
             self.alpha = np.asarray(trans.alpha, dtype=np.float64)
         self.i, self.j = int(trans.i), int(trans.j)
         self.Nblue = int(np.searchsorted(spect.wavelength, self.wavelength[0]))       # :122
-        self.compute_phi(atmos)                                                        # :123
         self.active = np.zeros(spect.wavelength.shape[0], dtype=bool)                  # :124-127
         for la, s in enumerate(spect.activeSet):
             if _contains(s, trans):
                 self.active[la] = True
         self.gij = None
+        self._line_index = None          # position among the lines of the transition table
+        self._phi_offset = None          # first row of this line in LSX_PHI
 
     def lt(self, la: int) -> int:
         return la - self.Nblue
 
     def wlambda(self, la: Optional[int] = None):
-        w = lineprofile.wlambda(self.wavelength, self.lambda0 if self.isLine else None)
+        """rh_method.py:157-196: trapezoid weights of the transition's own grid, in Doppler units for a line"""
+        lam = self.wavelength
+        w = np.empty_like(lam)
+        w[0], w[-1] = 0.5 * (lam[1] - lam[0]), 0.5 * (lam[-1] - lam[-2])
+        w[1:-1] = 0.5 * (lam[2:] - lam[:-2])
+        if self.isLine:
+            w *= Const.CLight / self.lambda0
         return w if la is None else w[la]
 
-    def compute_phi(self, atmos):
-        """rh_method.py:198-243"""
+    # -- read back from the library ------------------------------------------------------
+    def _need_line(self):
         if not self.isLine:
-            return
-        aDamp, _ = self.transModel.damping(atmos, self.atom.vBroad, self.atom.hPops.n[0])
-        self.aDamp = np.asarray(aDamp, dtype=np.float64)
-        self.phi, self.wphi = lineprofile.compute_phi(self.wavelength, self.lambda0, self.aDamp, self.atom.vBroad,
-                                                      atmos.vlos, atmos.muz, atmos.wmu)
+            raise AttributeError('a continuum has no line profile')
+        return self.atom._context
+
+    @property
+    def phi(self):
+        """[Nlambda][Nrays][2][Nspace] (rh_method.py:224)"""
+        ctx = self._need_line()
+        p = ctx.problem
+        phi = ctx._profiles()[0][self._phi_offset:self._phi_offset + self.wavelength.shape[0]]
+        if p.phi_compact:
+            phi = np.broadcast_to(phi[:, None, None, :], (phi.shape[0], p.Nrays, 2, p.Nspace))
+        return phi
+
+    @property
+    def wphi(self):
+        return self._need_line()._profiles()[1][self._line_index]
+
+    @property
+    def aDamp(self):
+        return self._need_line()._damping()[self._line_index]
 
 
 class ComputationalAtom:
@@ -91,7 +149,6 @@ class ComputationalAtom:
         self.atomicTable = getattr(eqPops, 'atomicTable', None)
         self.spect = spect
         self.atmos = atmos
-        self.vBroad = np.asarray(atom.v_broad(atmos), dtype=np.float64)
         self.pops = eqPops[atom.name]
         self.hPops = eqPops['H']
         self.nTotal = self.pops.nTotal
@@ -106,27 +163,30 @@ class ComputationalAtom:
         self.Nlevel = Nlevel
         self.Ntrans = len(self.trans)
         self.Gamma = np.zeros((Nlevel, Nlevel, atmos.Nspace))
-        self.C = np.zeros((Nlevel, Nlevel, atmos.Nspace))
         self.nStar = self.pops.nStar
         if self.pops.pops is not None:                         # warm start, :412-416
             self.n = self.pops.pops
         else:
             self.n = np.copy(self.nStar)
             self.pops.pops = self.n
-        self.compute_collisions()
+        self._context = None
+        self._index = None
 
-    def compute_collisions(self):
-        """rh_method.py:474-487"""
-        self.C = np.zeros_like(self.Gamma)
-        for col in self.atomicModel.collisions:
-            col.compute_rates(self.atmos, self.nStar, self.C)
-        self.C[self.C < 0.0] = 0.0
+    @property
+    def vBroad(self):
+        return self._context._broadening()[self._index]
+
+    @property
+    def C(self):
+        """[Nlevel][Nlevel][Nspace] collisional rates as the library holds them (rh_method.py:474-487)"""
+        ctx = self._context
+        return ctx._engine.gamma_of_atom(ctx._engine.get(_capi.LSX_C), self._index)[0]
 
 
 class Context:
     """rh_method.py:490-745 on the GPU."""
 
-    def __init__(self, atmos, spect, eqPops, background, device: int = 0, stream=None, lib=None):
+    def __init__(self, atmos, spect, eqPops, background, device: int = 0, stream=None, lib=None, setup: str = 'auto'):
         self.atmos = atmos
         self.atmos.nondimensionalise()
         self.spect = spect
@@ -137,14 +197,25 @@ class Context:
         Nspect, Nspace, Nrays = spect.wavelength.shape[0], atmos.Nspace, atmos.Nrays
         self.J = np.zeros((Nspect, Nspace))
         self.I = np.zeros((Nspect, Nrays))
+        models = [a.atomicModel for a in self.activeAtoms]
+        if setup == 'auto':
+            setup = 'native' if models_carry_atomic_data(models, atmos) else 'methods'
+        if setup not in ('native', 'methods'):
+            raise ValueError("setup must be 'auto', 'native' or 'methods'")
+        self.setup = setup
 
         # ---- flatten to the lsx problem description --------------------------------------
         trans, active = [], []
+        nline = off = 0
         for a, atom in enumerate(self.activeAtoms):
+            atom._context, atom._index = self, a
             for t in atom.trans:
                 tr = Transition(atom=a, is_line=t.isLine, i=t.i, j=t.j, Nblue=t.Nblue, Nlambda=t.wavelength.shape[0])
                 if t.isLine:
                     tr.Aji, tr.Bji, tr.Bij, tr.lambda0 = t.Aji, t.Bji, t.Bij, t.lambda0
+                    t._line_index, t._phi_offset = nline, off
+                    nline += 1
+                    off += t.wavelength.shape[0]
                 else:
                     tr.alpha = t.alpha
                 trans.append(tr)
@@ -158,6 +229,10 @@ class Context:
                                sca_per_lambda=sca_per_lambda, phi_compact=phi_compact,
                                atom_names=[a.atomicModel.name for a in self.activeAtoms])
         self._engine = Engine(self.problem, 1, device=device, stream=stream, lib=lib)
+        self._cache = {}
+        if setup == 'native':
+            in_table = lambda m, l: _contains(spect.transitions, l)
+            self._engine.set_atomic_data(atomdata.from_models(models, line_filter=in_table))
         self._upload()
         self._n_synced = self._cat_n()
         self._J_synced = self.J.copy()
@@ -166,33 +241,67 @@ class Context:
     def _cat_n(self):
         return np.concatenate([np.asarray(a.n, dtype=np.float64) for a in self.activeAtoms], axis=0)
 
-    def _block(self) -> ColumnBlock:
-        p, atmos, bg = self.problem, self.atmos, self.background
-        lines = [t for a in self.activeAtoms for t in a.trans if t.isLine]
-        if p.phi_compact:
-            phi = np.concatenate([t.phi[:, 0, 0, :] for t in lines], axis=0) if lines else np.zeros((0, p.Nspace))
-        else:
-            phi = np.concatenate([t.phi for t in lines], axis=0) if lines else np.zeros((0, p.Nrays, 2, p.Nspace))
-        wphi = np.stack([t.wphi for t in lines]) if lines else np.zeros((0, p.Nspace))
-        sca = np.asarray(bg.sca, dtype=np.float64)
-        sca = sca if p.sca_per_lambda else (sca[0] if sca.ndim == 2 else sca)
-        return ColumnBlock(
-            height=np.asarray(atmos.height, dtype=np.float64)[None], temperature=np.asarray(atmos.temperature, dtype=np.float64)[None],
-            nStar=np.concatenate([np.asarray(a.nStar) for a in self.activeAtoms], axis=0)[None],
-            nTotal=np.stack([np.asarray(a.nTotal) for a in self.activeAtoms])[None],
-            n=self._cat_n()[None],
-            C=np.concatenate([a.C.reshape(-1, p.Nspace) for a in self.activeAtoms], axis=0)[None],
-            bg_chi=np.asarray(bg.chi, dtype=np.float64)[None], bg_eta=np.asarray(bg.eta, dtype=np.float64)[None],
-            bg_sca=sca[None], phi=np.ascontiguousarray(phi)[None], wphi=wphi[None])
+    def _row(self, x):
+        return np.asarray(x, dtype=np.float64)[None]
 
     def _upload(self):
-        self._engine.set_columns(0, self._block())
+        """atmosphere, populations, background -> library; then the set-up chain (native) or the models' own numbers
+        (methods) -> vBroad, aDamp, profiles, collisional rates"""
+        p, atmos, bg = self.problem, self.atmos, self.background
+        sca = np.asarray(bg.sca, dtype=np.float64)
+        sca = sca if p.sca_per_lambda else (sca[0] if sca.ndim == 2 else sca)
+        native = self.setup == 'native'
+        if native:
+            C = np.zeros((p.NL2tot, p.Nspace))
+        else:
+            C = np.concatenate([self._model_collisions(a).reshape(-1, p.Nspace) for a in self.activeAtoms], axis=0)
+        nTotal = np.stack([np.asarray(a.nTotal, dtype=np.float64) for a in self.activeAtoms])
+        block = ColumnBlock(
+            height=self._row(atmos.height), temperature=self._row(atmos.temperature),
+            nStar=np.concatenate([np.asarray(a.nStar) for a in self.activeAtoms], axis=0)[None], nTotal=nTotal[None],
+            n=self._cat_n()[None], C=C[None], bg_chi=self._row(bg.chi), bg_eta=self._row(bg.eta), bg_sca=sca[None],
+            phi=None, wphi=None)
+        self._engine.set_columns(0, block)
+        vlos = None if p.phi_compact else self._row(atmos.vlos)
+        self._cache = {}
+        if native:
+            hGround = self.activeAtoms[0].hPops.n[0] if self.activeAtoms else np.zeros(p.Nspace)
+            self._engine.set_atmosphere(0, self._row(atmos.temperature), self._row(atmos.ne), self._row(atmos.vturb),
+                                        self._row(hGround), nTotal[None], vlos=vlos, lte_pops=False)
+        elif p.Nlines:
+            vB = np.stack([np.asarray(a.atomicModel.v_broad(atmos), dtype=np.float64) for a in self.activeAtoms])
+            aD = np.stack([np.asarray(t.transModel.damping(atmos, vB[a], atom.hPops.n[0])[0], dtype=np.float64)
+                           for a, atom in enumerate(self.activeAtoms) for t in atom.trans if t.isLine])
+            self._engine.set_line_profiles(0, aD[None], vB[None], vlos)
+            self._cache.update(vBroad=vB, aDamp=aD)
+
+    def _model_collisions(self, atom):
+        """rh_method.py:474-487 through the models' own compute_rates"""
+        C = np.zeros((atom.Nlevel, atom.Nlevel, self.problem.Nspace))
+        for col in atom.atomicModel.collisions:
+            col.compute_rates(self.atmos, atom.nStar, C)
+        C[C < 0.0] = 0.0
+        return C
+
+    # -- read-back of what the library derived ---------------------------------------------
+    def _profiles(self):
+        if 'phi' not in self._cache:
+            self._cache['phi'] = (self._engine.get(_capi.LSX_PHI)[0], self._engine.get(_capi.LSX_WPHI)[0])
+        return self._cache['phi']
+
+    def _damping(self):
+        if 'aDamp' not in self._cache:
+            self._cache['aDamp'] = self._engine.get(_capi.LSX_ADAMP)[0]
+        return self._cache['aDamp']
+
+    def _broadening(self):
+        if 'vBroad' not in self._cache:
+            self._cache['vBroad'] = self._engine.get(_capi.LSX_VBROAD)[0]
+        return self._cache['vBroad']
 
     def update_collisions(self):
-        """re-evaluate the collisional rates from the atmosphere (the reference does this on every
-        formal solution, rh_method.py:589) and send them to the device"""
-        for a in self.activeAtoms:
-            a.compute_collisions()
+        """re-derive everything that depends on the atmosphere alone (the reference recomputes the collisional rates
+        on every formal solution, rh_method.py:589) and keep J"""
         J = self.J.copy()
         self._upload()
         self._engine.set(_capi.LSX_J, J[None])

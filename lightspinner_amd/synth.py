@@ -5,12 +5,11 @@ Column 0 is the unperturbed base column.  Column c > 0 uses numpy.random.default
 smooth multiplicative log-normal factors (sigma, correlation length in depth points) on the
 background opacity (and emissivity by the same factor), on the populations (nStar, n, nTotal
 jointly), on the collisional rates, and -- when vlos_sigma > 0 -- a smooth line-of-sight velocity
-so that the line profiles become genuinely ray dependent (rebuilt with lineprofile.compute_phi
-from the base column's damping parameters and broadening velocities)."""
+so that the line profiles become genuinely ray dependent (built on the device by lsx_set_line_profiles from the base
+column's damping parameters and broadening velocities)."""
 import numpy as np
 
 from .problem import ColumnBlock, Problem
-from . import lineprofile
 
 
 def _smooth_field(rng, Ns, corr):
@@ -21,18 +20,18 @@ def _smooth_field(rng, Ns, corr):
 
 
 def perturbed_columns(prob: Problem, base: ColumnBlock, raw: dict, ncol: int, seed: int = 1234, sigma: float = 0.05,
-                      corr: int = 8, vlos_sigma: float = 2.0e3, first: int = 0, device_profiles: bool = False):
-    """columns [first, first + ncol) of the synthetic ensemble (deterministic per absolute index).
+                      corr: int = 8, vlos_sigma: float = 2.0e3, first: int = 0):
+    """columns [first, first + ncol) of the synthetic ensemble (deterministic per absolute index)
+    -> (ColumnBlock, profile inputs or None).
 
-    device_profiles=True: the line profiles are not built here; returns (block with phi = wphi = None,
-    (aDamp [ncol][Nlines][Nspace], vBroad [ncol][Natoms][Nspace], vlos [ncol][Nspace] or None)) for
-    Engine.set_line_profiles -- compute_phi then runs on the device (rh_method.py:198-243)."""
+    With a line-of-sight velocity (vlos_sigma > 0 on a context that is not phi_compact) the line profiles are ray
+    dependent and are NOT built here: the block has phi = wphi = None and the second value is (aDamp [ncol][Nlines][Nspace],
+    vBroad [ncol][Natoms][Nspace], vlos [ncol][Nspace]) for Engine.set_line_profiles -- compute_phi then runs on the device
+    (rh_method.py:198-243).  Without one the base column's profiles are copied and the second value is None."""
     Ns = prob.Nspace
     f = lambda a: np.repeat(np.asarray(a), ncol, axis=0).copy()
-    out = {k: f(getattr(base, k)) for k in ('height', 'temperature', 'nStar', 'nTotal', 'n', 'C', 'bg_chi', 'bg_eta',
-                                            'bg_sca', 'wphi')}
+    out = {k: f(getattr(base, k)) for k in ('height', 'temperature', 'nStar', 'nTotal', 'n', 'C', 'bg_chi', 'bg_eta', 'bg_sca')}
     use_vlos = vlos_sigma > 0 and not prob.phi_compact and prob.Nlines > 0
-    phi = None if device_profiles else np.empty((ncol,) + prob.phi_shape())
     vlos = np.zeros((ncol, Ns))
     for q in range(ncol):
         c = first + q
@@ -49,26 +48,20 @@ def perturbed_columns(prob: Problem, base: ColumnBlock, raw: dict, ncol: int, se
         out['C'][q] *= fc
         if use_vlos:
             vlos[q] = vlos_sigma * _smooth_field(rng, Ns, corr)
-    if device_profiles:
+    if use_vlos:
         lines = [kr for kr, t in enumerate(prob.trans) if t.is_line]
         aD = np.repeat(np.stack([raw['t%d_aDamp' % kr] for kr in lines])[None], ncol, axis=0)
         vB = np.repeat(np.stack([raw['a%d_vBroad' % a] for a in range(prob.Natoms)])[None], ncol, axis=0)
-        out['wphi'] = None
-        return ColumnBlock(phi=None, **out).validate(prob), (aD, vB, vlos if use_vlos else None)
-    if use_vlos:
-        o, li = 0, 0
-        for kr, t in enumerate(prob.trans):
-            if not t.is_line:
-                continue
-            ph, wp = lineprofile.compute_phi(raw['t%d_wavelength' % kr], t.lambda0, raw['t%d_aDamp' % kr][None],
-                                             raw['a%d_vBroad' % t.atom][None], vlos, prob.muz, prob.wmu)
-            phi[:, o:o + t.Nlambda] = ph
-            out['wphi'][:, li] = wp
-            o += t.Nlambda
-            li += 1
-        if first == 0:  # column 0 stays bit-identical to the base column
-            phi[0] = base.phi[0]
-            out['wphi'][0] = base.wphi[0]
-    else:
-        phi[:] = base.phi
-    return ColumnBlock(phi=phi, **out).validate(prob)
+        return ColumnBlock(phi=None, wphi=None, **out).validate(prob), (aD, vB, vlos)
+    if base.phi is None:
+        raise ValueError('the base column carries no profiles to copy')
+    return ColumnBlock(phi=f(base.phi), wphi=f(base.wphi), **out).validate(prob), None
+
+
+def load_columns(engine, block: ColumnBlock, prof=None, col0: int = 0, step: int = 100):
+    """block (+ profile inputs) -> engine: lsx_set_columns in chunks, then lsx_set_line_profiles where the profiles were
+    not handed over"""
+    for a in range(0, block.ncol, step):
+        engine.set_columns(col0 + a, block.slice(a, min(block.ncol, a + step)))
+    if prof is not None:
+        engine.set_line_profiles(col0, prof[0], prof[1], prof[2])

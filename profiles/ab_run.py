@@ -16,15 +16,13 @@ wl = sys.argv[2] if len(sys.argv) > 2 else 'c3'
 ncol = int(sys.argv[3]) if len(sys.argv) > 3 else (1000 if wl == 'c3' else 1250)
 fixture = os.path.join(ROOT, 'tests', 'golden', 'falc_cah.npz' if wl == 'c4' else 'falc_ca.npz')
 prob, base, raw = fixtures.load_problem_npz(fixture, phi_compact=False)
-blk, prof = synth.perturbed_columns(prob, base, raw, ncol=ncol, seed=1234, vlos_sigma=2.0e3, device_profiles=True)
+blk, prof = synth.perturbed_columns(prob, base, raw, ncol=ncol, seed=1234, vlos_sigma=2.0e3)
 _capi._share_hip_runtime_with_torch()
 lib = _capi.LsxLibrary(so)
 
 
 def load(eng, b, p, n):
-    for a in range(0, n, 100):
-        eng.set_columns(a, b.slice(a, min(n, a + 100)))
-    eng.set_line_profiles(0, p[0][:n], p[1][:n], p[2][:n])
+    synth.load_columns(eng, b.slice(0, n), tuple(x[:n] for x in p))
 
 
 eng = Engine(prob, ncol, lib=lib)

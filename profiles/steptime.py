@@ -4,10 +4,9 @@ import numpy as np
 from lightspinner_amd import fixtures, synth, Engine
 prob, base, raw = fixtures.load_problem_npz('tests/golden/falc_ca.npz', phi_compact=False)
 ncol = 1000
-blk, prof = synth.perturbed_columns(prob, base, raw, ncol=ncol, device_profiles=True)
+blk, prof = synth.perturbed_columns(prob, base, raw, ncol=ncol)
 eng = Engine(prob, ncol)
-for a in range(0, ncol, 100):
-    eng.set_columns(a, blk.slice(a, a + 100)); eng.set_line_profiles(a, prof[0][a:a+100], prof[1][a:a+100], prof[2][a:a+100])
+synth.load_columns(eng, blk, prof)
 for _ in range(3):
     eng.formal_sol_gamma_async(); eng.stat_equil_async(); eng.sync()
 T = np.zeros(4)

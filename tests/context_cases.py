@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from conftest import golden, relerr, gamma_err
-from helpers import build_fakes
+from helpers import build_fakes, build_data_fakes
 from lightspinner_amd.rh_method import Context
 
 
@@ -66,6 +66,72 @@ def context_two_active_atoms_order_and_shapes(lib):
         off, diag = gamma_err(ctx.activeAtoms[a].Gamma.reshape(-1, 82), d['fs1_Gamma_a%d' % a].reshape(-1, 82),
                               _ONE_ATOM_6)
         assert off < 3e-10 and diag < 3e-11
+
+
+def context_native_setup_chain(lib, name='falc_cah.npz'):
+    """models that carry their atomic data: Context hands them to lsx_set_atomic_data and the library derives vBroad,
+    aDamp, the profiles and the collisional rates from the atmosphere (lsx_set_atmosphere); everything the reference's
+    constructor would have computed is read back and compared with what the reference did compute (1e-13: the device
+    evaluates the same formulas with its own exp / log / sqrt / Faddeeva; phi on a ray-dependent profile 1e-12)"""
+    d = dict(np.load(golden(name)))
+    s = dict(np.load(golden('setup_falc.npz')))
+    atmos, spect, eq, bg = build_data_fakes(d, s)
+    ctx = Context(atmos, spect, eq, bg, lib=lib)
+    assert ctx.setup == 'native'
+    kr = 0
+    for a, atom in enumerate(ctx.activeAtoms):
+        assert relerr(atom.vBroad, d['a%d_vBroad' % a]) < 1e-14
+        C, Cref = atom.C, d['a%d_C' % a]
+        assert C.shape == Cref.shape
+        assert np.max(np.abs(C - Cref)) <= 1e-12 * np.max(np.abs(Cref))
+        for t in atom.trans:
+            if t.isLine:
+                assert relerr(t.aDamp, d['t%d_aDamp' % kr]) < 1e-13
+                assert relerr(t.wphi, d['t%d_wphi' % kr]) < 1e-12
+                if ('t%d_phi' % kr) in d:
+                    ref = d['t%d_phi' % kr]
+                    got = t.phi if ref.ndim == 4 else t.phi[:, 0, 0, :]
+                    assert t.phi.shape == (t.wavelength.shape[0], atmos.Nrays, 2, atmos.Nspace)
+                    assert relerr(got, ref) < 1e-12
+                elif ('t%d_phi_sample' % kr) in d:
+                    assert relerr(t.phi[::7, :, :, ::9], d['t%d_phi_sample' % kr]) < 1e-12
+            kr += 1
+    tol = 1e-10 if name == 'falc_cah.npz' else 1e-11     # set-up differences (1e-13) propagate through Gamma and J
+    for it in range(1, 5):
+        dJ = ctx.formal_sol_gamma_matrices()
+        if 'fs%d_dJ' % it in d:
+            assert dJ == pytest.approx(float(d['fs%d_dJ' % it]), rel=1e-8)
+            assert relerr(ctx.I, d['fs%d_I' % it]) < tol
+            if 'fs%d_J' % it in d:
+                assert relerr(ctx.J, d['fs%d_J' % it]) < tol
+    dP = ctx.stat_equil()
+    if 'se4_dPops' in d:
+        assert dP == pytest.approx(float(d['se4_dPops']), rel=1e-6)
+    J = ctx.J.copy()
+    ctx.update_collisions()                              # re-derivation leaves the state where it was
+    assert np.max(np.abs(ctx.activeAtoms[0].C - d['a0_C'])) <= 1e-12 * np.max(np.abs(d['a0_C']))
+    assert np.array_equal(ctx._engine.get(1)[0], J)   # LSX_J
+    ctx.close()
+
+
+def context_methods_setup_is_still_the_reference_interface(lib):
+    """models that only offer v_broad / damping / compute_rates (the reference's own interface): those are called and the
+    profiles are built by the library from their results"""
+    d = dict(np.load(golden('falc_ca_vlos.npz')))
+    atmos, spect, eq, bg = build_fakes(d)
+    ctx = Context(atmos, spect, eq, bg, lib=lib)
+    assert ctx.setup == 'methods' and not ctx.problem.phi_compact
+    for kr, t in enumerate(ctx.activeAtoms[0].trans):
+        if t.isLine:
+            assert relerr(t.phi[::7, :, :, ::9], d['t%d_phi_sample' % kr]) < 1e-13
+            assert relerr(t.wphi, d['t%d_wphi' % kr]) < 1e-13
+            assert np.array_equal(t.aDamp, d['t%d_aDamp' % kr])
+    assert np.array_equal(ctx.activeAtoms[0].vBroad, d['a0_vBroad'])
+    assert np.array_equal(ctx.activeAtoms[0].C, d['a0_C'])
+    assert ctx.formal_sol_gamma_matrices() == pytest.approx(float(d['fs1_dJ']), rel=1e-9)
+    assert relerr(ctx.I, d['fs1_I']) < 1e-12
+    with pytest.raises(ValueError):
+        Context(*build_fakes(d), lib=lib, setup='other')
 
 
 class _Atmos:

@@ -107,3 +107,90 @@ def build_fakes(d, start_pops=None):
     if 'H' not in eq:
         eq['H'] = FakeState(np.array(d['hGround'])[None], None)
     return atmos, spect, eq, FakeBackground(d)
+
+
+# ---- models that carry their atomic data (what Lightspinner's AtomicModel / VoigtLine / collisional_rates objects hold),
+# rebuilt from tests/golden/setup_falc.npz: Context then takes the library's own set-up chain ------------------------
+class _Level:
+    def __init__(self, E_SI, g, stage):
+        self.E_SI, self.g, self.stage = float(E_SI), float(g), int(stage)
+
+
+class VdwUnsold:
+    def __init__(self, vals):
+        self.vals = [float(v) for v in vals]
+
+
+class VdwNone:
+    vals = []
+
+
+class _TableCollision:
+    def __init__(self, i, j, T, R):
+        self.i, self.j, self.temperature, self.rates = int(i), int(j), np.array(T), np.array(R)
+
+
+class Omega(_TableCollision):
+    pass
+
+
+class CI(_TableCollision):
+    pass
+
+
+class CE(_TableCollision):
+    pass
+
+
+class _Element:
+    def __init__(self, weight, abundance):
+        self.weight, self.abundance = float(weight), float(abundance)
+
+
+class DataLine(FakeLine):
+    """a line that knows gRad / stark / vdw instead of offering damping()"""
+    damping = None
+
+    def __init__(self, d, kr, s, m, q):
+        FakeLine.__init__(self, d, kr)
+        del self._aDamp
+        self.gRad, self.stark = float(s['m%d_line_gRad' % m][q]), float(s['m%d_line_stark' % m][q])
+        self.vdw = VdwUnsold(s['m%d_line_vdw_vals' % m][q]) if s['m%d_line_vdw_unsold' % m][q] else VdwNone()
+
+
+class DataAtom:
+    v_broad = None
+
+    def __init__(self, d, a, s, table):
+        self.name = str(d['atom_names'][a])
+        m = [str(x) for x in s['atom_names']].index(self.name)
+        pre = 'm%d_' % m
+        self.atomicTable = table
+        self.levels = [_Level(E, g, st) for E, g, st in zip(s[pre + 'lev_E_SI'], s[pre + 'lev_g'], s[pre + 'lev_stage'])]
+        self.kr = [kr for kr in range(len(d['t_atom'])) if d['t_atom'][kr] == a]
+        pos = {(int(i), int(j)): q for q, (i, j) in enumerate(zip(s[pre + 'line_i'], s[pre + 'line_j']))}
+        self.lines = [DataLine(d, kr, s, m, pos[(int(d['t_i'][kr]), int(d['t_j'][kr]))]) for kr in self.kr if d['t_isline'][kr]]
+        self.continua = [FakeContinuum(d, kr) for kr in self.kr if not d['t_isline'][kr]]
+        cls = {0: Omega, 1: CI, 2: CE}
+        self.collisions = [cls[int(s[pre + 'col_kind'][q])](s[pre + 'col_i'][q], s[pre + 'col_j'][q],
+                                                            s[pre + 'col_T'][q, :int(s[pre + 'col_nT'][q])],
+                                                            s[pre + 'col_rates'][q, :int(s[pre + 'col_nT'][q])])
+                           for q in range(s[pre + 'col_kind'].shape[0])]
+
+
+def build_data_fakes(d, s, start_pops=None):
+    """like build_fakes, with models that hold atomic data (d: a problem fixture, s: setup_falc.npz)"""
+    names = [str(x) for x in s['atom_names']]
+    table = {n: _Element(s['m%d_weight' % m], s['m%d_abundance' % m]) for m, n in enumerate(names)}
+    table['H'] = _Element(s['weight_H'], 1.0)
+    table['He'] = _Element(s['weight_He'], s['abundance_He'])
+    atmos = FakeAtmos(d)
+    atoms = [DataAtom(d, a, s, table) for a in range(len(d['atom_names']))]
+    spect = FakeSpect(d, atoms)
+    eq = FakePops()
+    for a, atom in enumerate(atoms):
+        eq[atom.name] = FakeState(np.array(d['a%d_nStar' % a]), np.array(d['a%d_nTotal' % a]),
+                                  None if start_pops is None else np.array(start_pops[a]))
+    if 'H' not in eq:
+        eq['H'] = FakeState(np.array(d['hGround'])[None], None)
+    return atmos, spect, eq, FakeBackground(d)

@@ -26,6 +26,15 @@ def test_piecewise_linear_1d_dropin_on_hip(hip_lib):
     context_cases.piecewise_linear_1d_dropin(None)
 
 
+@pytest.mark.parametrize('name', ['falc_cah.npz', 'falc_ca.npz', 'falc_ca_vlos.npz'])
+def test_context_native_setup_chain_on_hip(name):
+    context_cases.context_native_setup_chain(None, name)
+
+
+def test_context_methods_setup_on_hip():
+    context_cases.context_methods_setup_is_still_the_reference_interface(None)
+
+
 def test_golden_w2_and_piecewise_1d_impl_on_hip(hip_lib):
     context_cases.golden_w2_and_piecewise_1d_impl(hip_lib)
 

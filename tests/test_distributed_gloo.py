@@ -31,9 +31,8 @@ def _worker(rank, world, port, ncol_total, out_dir):
     lib = oracle.load()
     prob, base, raw = fixtures.load_problem_npz(golden('falc_ca.npz'), phi_compact=False)
     first, n = shard_columns(ncol_total, rank, world)
-    batch = synth.perturbed_columns(prob, base, raw, ncol=n, seed=99, first=first)
     eng = Engine(prob, n, lib=lib)
-    eng.set_columns(0, batch)
+    synth.load_columns(eng, *synth.perturbed_columns(prob, base, raw, ncol=n, seed=99, first=first))
 
     class A:
         def formal_sol_gamma_matrices(self): return eng.formal_sol_gamma()
@@ -53,9 +52,8 @@ def test_two_rank_sharding_equals_single_process(tmp_path, oracle_lib):
 
     from lightspinner_amd import fixtures, synth, Engine, _capi, drivers
     prob, base, raw = fixtures.load_problem_npz(golden('falc_ca.npz'), phi_compact=False)
-    batch = synth.perturbed_columns(prob, base, raw, ncol=ncol_total, seed=99)
     eng = Engine(prob, ncol_total, lib=oracle_lib)
-    eng.set_columns(0, batch)
+    synth.load_columns(eng, *synth.perturbed_columns(prob, base, raw, ncol=ncol_total, seed=99))
 
     class A:
         def formal_sol_gamma_matrices(self): return eng.formal_sol_gamma()
@@ -89,9 +87,8 @@ def _worker_engine_path(rank, world, port, ncol_total, out_dir):
     lib = oracle.load()
     prob, base, raw = fixtures.load_problem_npz(golden('falc_ca.npz'), phi_compact=False)
     first, n = shard_columns(ncol_total, rank, world)
-    batch = synth.perturbed_columns(prob, base, raw, ncol=n, seed=99, first=first)
     eng = Engine(prob, n, lib=lib)
-    eng.set_columns(0, batch)
+    synth.load_columns(eng, *synth.perturbed_columns(prob, base, raw, ncol=n, seed=99, first=first))
     h = drivers.iterate_mali_engine(eng, reducer=MaxReducer(), max_iter=7)
     np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), first=first, n=eng.get(_capi.LSX_N), J=eng.get(_capi.LSX_J),
              dJ=np.array(h.dJ), dP=np.array(h.dPops))
@@ -107,7 +104,7 @@ def test_four_rank_uneven_shards_engine_monitor_path(tmp_path, oracle_lib):
     from lightspinner_amd import fixtures, synth, Engine, _capi, drivers
     prob, base, raw = fixtures.load_problem_npz(golden('falc_ca.npz'), phi_compact=False)
     eng = Engine(prob, ncol_total, lib=oracle_lib)
-    eng.set_columns(0, synth.perturbed_columns(prob, base, raw, ncol=ncol_total, seed=99))
+    synth.load_columns(eng, *synth.perturbed_columns(prob, base, raw, ncol=ncol_total, seed=99))
     h = drivers.iterate_mali_engine(eng, max_iter=7)
     n, J = eng.get(_capi.LSX_N), eng.get(_capi.LSX_J)
     sizes = []
@@ -194,7 +191,7 @@ def test_max_reducer_over_rccl_single_rank():
         # device buffer on the engine's stream, RCCL reduces it in place, one read-back (MaxReducer.engine)
         from lightspinner_amd import fixtures, synth, Engine, _capi, drivers
         prob, base, raw = fixtures.load_problem_npz(golden('falc_ca.npz'))
-        batch = synth.perturbed_columns(prob, base, raw, ncol=5, seed=3, vlos_sigma=0.0)
+        batch, _ = synth.perturbed_columns(prob, base, raw, ncol=5, seed=3, vlos_sigma=0.0)
         ts = torch.cuda.Stream()
         e1 = Engine(prob, 5, stream=ts.cuda_stream)
         e2 = Engine(prob, 5)

@@ -97,6 +97,7 @@ def test_nonzero_vlos(hip_lib):
     prob, block, d = fixtures.load_problem_npz(golden('falc_ca_vlos.npz'))
     eng = Engine(prob, 1, lib=hip_lib)
     eng.set_columns(0, block)
+    eng.set_line_profiles(0, *fixtures.profile_inputs(prob, d))     # the file holds the profile inputs, not phi itself
     for it in range(1, 5):
         dJ = eng.formal_sol_gamma()
         tag = 'fs%d' % it
@@ -129,7 +130,7 @@ def test_columns_are_independent_and_bitwise_reproducible(hip_lib, oracle_lib):
     alone, whatever its position in the batch (this is what makes multi-GPU sharding exact)."""
     from lightspinner_amd import synth
     prob, block, d = fixtures.load_problem_npz(golden('falc_ca.npz'))
-    batch = synth.perturbed_columns(prob, block, d, ncol=7, seed=1234, vlos_sigma=0.0)
+    batch, _ = synth.perturbed_columns(prob, block, d, ncol=7, seed=1234, vlos_sigma=0.0)
     eng = Engine(prob, 7, lib=hip_lib)
     eng.set_columns(0, batch)
     ora = Engine(prob, 7, lib=oracle_lib)

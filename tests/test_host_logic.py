@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import golden, relerr, gamma_err, ROOT
-from helpers import build_fakes
+from helpers import build_fakes, build_data_fakes
 import context_cases
 from lightspinner_amd import _capi, fixtures, synth, drivers
 from lightspinner_amd.parallel import shard_columns
@@ -64,6 +64,15 @@ def test_context_two_active_atoms_order_and_shapes(oracle_lib):
     context_cases.context_two_active_atoms_order_and_shapes(oracle_lib)
 
 
+@pytest.mark.parametrize('name', ['falc_cah.npz', 'falc_ca.npz', 'falc_ca_vlos.npz'])
+def test_context_native_setup_chain(oracle_lib, name):
+    context_cases.context_native_setup_chain(oracle_lib, name)
+
+
+def test_context_methods_setup(oracle_lib):
+    context_cases.context_methods_setup_is_still_the_reference_interface(oracle_lib)
+
+
 def test_piecewise_linear_1d_dropin(oracle_lib):
     context_cases.piecewise_linear_1d_dropin(oracle_lib)
 
@@ -88,13 +97,16 @@ def test_shard_columns_partitions_exactly():
 
 def test_synthetic_columns_are_deterministic_per_absolute_index():
     prob, block, raw = fixtures.load_problem_npz(golden('falc_ca.npz'), phi_compact=False)
-    whole = synth.perturbed_columns(prob, block, raw, ncol=5, seed=7)
-    part = synth.perturbed_columns(prob, block, raw, ncol=2, seed=7, first=3)
-    for k in ('bg_chi', 'n', 'C', 'phi', 'wphi'):
+    whole, wp = synth.perturbed_columns(prob, block, raw, ncol=5, seed=7)
+    part, pp = synth.perturbed_columns(prob, block, raw, ncol=2, seed=7, first=3)
+    for k in ('bg_chi', 'n', 'C'):
         assert np.array_equal(getattr(whole, k)[3:5], getattr(part, k))
-    assert np.array_equal(whole.phi[0], block.phi[0])               # column 0 is FALC itself
-    assert not np.array_equal(whole.phi[1], whole.phi[2])
-    assert np.any(whole.phi[1][:, 0, 0, :] != whole.phi[1][:, 0, 1, :])   # vlos != 0: direction dependent
+    for w, q in zip(wp, pp):
+        assert np.array_equal(w[3:5], q)
+    assert np.array_equal(whole.bg_chi[0], block.bg_chi[0]) and np.all(wp[2][0] == 0.0)   # column 0 is FALC itself
+    assert not np.array_equal(wp[2][1], wp[2][2])                    # vlos differs from column to column
+    same, none = synth.perturbed_columns(prob, block, raw, ncol=3, seed=7, vlos_sigma=0.0)
+    assert none is None and np.array_equal(same.phi[2], block.phi[0])    # no velocity: the base column's profiles
 
 
 def test_response_function_formula():
@@ -110,11 +122,11 @@ def test_response_function_formula():
 def test_columns_without_profiles_and_device_profile_inputs():
     """ColumnBlock may leave phi / wphi to lsx_set_line_profiles; synth hands over the profile inputs instead"""
     prob, block, raw = fixtures.load_problem_npz(golden('falc_ca.npz'), phi_compact=False)
-    blk, (aD, vB, vlos) = synth.perturbed_columns(prob, block, raw, ncol=4, seed=7, device_profiles=True)
+    blk, (aD, vB, vlos) = synth.perturbed_columns(prob, block, raw, ncol=4, seed=7)
     assert blk.phi is None and blk.wphi is None and blk.ncol == 4
     assert aD.shape == (4, prob.Nlines, prob.Nspace) and vB.shape == (4, prob.Natoms, prob.Nspace) and vlos.shape == (4, prob.Nspace)
     assert np.all(vlos[0] == 0.0) and np.any(vlos[1] != 0.0)            # column 0 is the unperturbed FALC column
-    host = synth.perturbed_columns(prob, block, raw, ncol=4, seed=7)      # same ensemble with host-built profiles
+    host, _ = synth.perturbed_columns(prob, block, raw, ncol=4, seed=7, vlos_sigma=0.0)   # same ensemble, no velocity
     for k in ('bg_chi', 'n', 'C', 'nStar'):
         assert np.array_equal(getattr(blk, k), getattr(host, k))
     part = blk.slice(1, 3)

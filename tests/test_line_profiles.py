@@ -10,18 +10,15 @@ import pytest
 from scipy.special import wofz
 
 from conftest import golden, relerr
-from lightspinner_amd import fixtures, _capi, lineprofile
+import refprofile
+from lightspinner_amd import fixtures, _capi
 from lightspinner_amd.problem import Engine
 
 CASES = [('falc_ca.npz', True), ('falc_ca_vlos.npz', False), ('falc_cah.npz', True), ('falc_ca.npz', False)]
 
 
 def _inputs(prob, raw, compact):
-    lines = [kr for kr, t in enumerate(prob.trans) if t.is_line]
-    aD = np.stack([raw['t%d_aDamp' % kr] for kr in lines])[None]
-    vB = np.stack([raw['a%d_vBroad' % a] for a in range(prob.Natoms)])[None]
-    vlos = None if compact else raw['vlos'][None]
-    return aD, vB, vlos
+    return fixtures.profile_inputs(prob, raw, with_vlos=not compact)
 
 
 def _check(lib, name, compact):
@@ -33,8 +30,15 @@ def _check(lib, name, compact):
     e.set_columns(0, bare)
     e.set_line_profiles(0, aD, vB, vlos)
     phi, wphi = e.get(_capi.LSX_PHI)[0], e.get(_capi.LSX_WPHI)[0]
-    assert relerr(phi, block.phi[0]) < 1e-13
-    assert relerr(wphi, block.wphi[0]) < 1e-13
+    if block.phi is not None:
+        assert relerr(phi, block.phi[0]) < 1e-13
+        assert relerr(wphi, block.wphi[0]) < 1e-13
+    else:                                           # vlos != 0: the file holds a strided sample of the reference's phi
+        o = 0
+        for li, (kr, t) in enumerate([(kr, t) for kr, t in enumerate(prob.trans) if t.is_line]):
+            assert relerr(phi[o:o + t.Nlambda][::7, :, :, ::9], raw['t%d_phi_sample' % kr]) < 1e-13
+            assert relerr(wphi[li], raw['t%d_wphi' % kr]) < 1e-13
+            o += t.Nlambda
     return e, prob, block, raw
 
 
@@ -58,8 +62,8 @@ def test_oracle_profiles_match_the_reference(oracle_lib, name, compact):
     _check(oracle_lib, name, compact)
 
 
-def test_perturbed_columns_match_the_host_setup(oracle_lib):
-    # the package's own host-side compute_phi (scipy wofz, batched) on a column with vlos != 0
+def test_perturbed_profile_inputs_against_scipy(oracle_lib):
+    # tests/refprofile.py (scipy wofz, the routine the reference calls) on a column with vlos != 0 and scaled damping
     prob, block, raw = fixtures.load_problem_npz(golden('falc_ca.npz'), phi_compact=False)
     rng = np.random.default_rng(3)
     Ns = prob.Nspace
@@ -72,7 +76,7 @@ def test_perturbed_columns_match_the_host_setup(oracle_lib):
     phi, wphi = e.get(_capi.LSX_PHI)[0], e.get(_capi.LSX_WPHI)[0]
     o = 0
     for li, (kr, t) in enumerate([(kr, t) for kr, t in enumerate(prob.trans) if t.is_line]):
-        ph, wp = lineprofile.compute_phi(raw['t%d_wavelength' % kr], t.lambda0, aD[0, li], vB[0, t.atom], vlos, prob.muz, prob.wmu)
+        ph, wp = refprofile.profiles(raw['t%d_wavelength' % kr], t.lambda0, aD[0, li], vB[0, t.atom], vlos, prob.muz, prob.wmu)
         assert relerr(phi[o:o + t.Nlambda], ph) < 1e-13
         assert relerr(wphi[li], wp) < 1e-13
         o += t.Nlambda
@@ -85,6 +89,8 @@ def test_hip_profiles_match_the_reference(hip_lib, oracle_lib, name, compact):
     # and the hot path runs on them: one call against the oracle fed with the reference's own profiles
     o = Engine(prob, 1, lib=oracle_lib)
     o.set_columns(0, block)
+    if block.phi is None:
+        o.set_line_profiles(0, *_inputs(prob, raw, compact))
     assert e.formal_sol_gamma() == pytest.approx(o.formal_sol_gamma(), rel=1e-9)
     assert relerr(e.get(_capi.LSX_J), o.get(_capi.LSX_J)) < 1e-11
     assert relerr(e.get(_capi.LSX_I), o.get(_capi.LSX_I)) < 1e-11

@@ -125,19 +125,20 @@ def test_falc_ca_trajectory_and_converged_state(oracle_lib):
 
 
 def test_nonzero_vlos_four_dimensional_profile(oracle_lib):
-    """vlos != 0: phi depends on (mu, direction) (rh_method.py:229-240).  phi is rebuilt by the
-    package's own compute_phi and checked against a strided sample of the reference's."""
+    """vlos != 0: phi depends on (mu, direction) (rh_method.py:229-240).  The fixture holds the profile's inputs and a
+    strided sample of the reference's phi: the profiles are built through lsx_set_line_profiles and checked on it."""
     prob, block, d = fixtures.load_problem_npz(golden('falc_ca_vlos.npz'))
-    assert not prob.phi_compact
+    assert not prob.phi_compact and block.phi is None
+    eng = Engine(prob, 1, lib=oracle_lib)
+    eng.set_columns(0, block)
+    eng.set_line_profiles(0, *fixtures.profile_inputs(prob, d))
+    phi, wphi = eng.get(_capi.LSX_PHI)[0], eng.get(_capi.LSX_WPHI)[0]
     o = 0
     for kr, t in enumerate(prob.trans):
         if t.is_line:
-            ph = block.phi[0, o:o + t.Nlambda]
-            assert relerr(ph[::7, :, :, ::9], d['t%d_phi_sample' % kr]) < 1e-13
-            assert relerr(block.wphi[0, prob.lines.index(t)], d['t%d_wphi' % kr]) < 1e-13
+            assert relerr(phi[o:o + t.Nlambda][::7, :, :, ::9], d['t%d_phi_sample' % kr]) < 1e-13
+            assert relerr(wphi[prob.lines.index(t)], d['t%d_wphi' % kr]) < 1e-13
             o += t.Nlambda
-    eng = Engine(prob, 1, lib=oracle_lib)
-    eng.set_columns(0, block)
     for it in range(1, 6):
         dJ = eng.formal_sol_gamma()
         tag = 'fs%d' % it

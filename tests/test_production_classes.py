@@ -5,7 +5,7 @@ single-column tests reach.  C4 (Ca+H): hydrogen's bound-free continua overlap it
 line-only ones with and without linked continua -- all of them meet the oracle here; the classes with three and four
 per-ray slots (round 1's `lsx_sweep_kernel<3|4, ...>`) run with the linking switched off (LSX_NO_LINKED).
 
-Inputs: synth.perturbed_columns(..., device_profiles=True) -- FALC-perturbed columns with a smooth line-of-sight
+Inputs: synth.perturbed_columns(..., vlos_sigma=2e3) -- FALC-perturbed columns with a smooth line-of-sight
 velocity (2 km/s), so the line profiles are ray dependent and are built by each library's own lsx_set_line_profiles
 (the two Voigt functions agree to 3e-14, tests/test_line_profiles.py).
 
@@ -40,8 +40,7 @@ def class_table(lib, eng):
 
 def _run_pair(hip_lib, oracle_lib, name, ncol, seed, tol, expect_classes):
     prob, base, raw = fixtures.load_problem_npz(golden(name), phi_compact=False)
-    blk, (aD, vB, vlos) = synth.perturbed_columns(prob, base, raw, ncol=ncol, seed=seed, vlos_sigma=2.0e3,
-                                                  device_profiles=True)
+    blk, (aD, vB, vlos) = synth.perturbed_columns(prob, base, raw, ncol=ncol, seed=seed, vlos_sigma=2.0e3)
     assert vlos is not None and np.any(vlos[1] != 0.0)
     engs = []
     for lib in (hip_lib, oracle_lib):
@@ -119,7 +118,7 @@ def test_profiles_must_be_set_before_a_formal_solution(hip_lib):
     """lsx_set_columns with phi == NULL leaves the profiles to lsx_set_line_profiles; a formal solution in between is
     refused instead of reading uninitialised memory"""
     prob, base, raw = fixtures.load_problem_npz(golden('falc_ca.npz'), phi_compact=False)
-    blk, (aD, vB, vlos) = synth.perturbed_columns(prob, base, raw, ncol=2, seed=5, device_profiles=True)
+    blk, (aD, vB, vlos) = synth.perturbed_columns(prob, base, raw, ncol=2, seed=5)
     e = Engine(prob, 2, lib=hip_lib)
     e.set_columns(0, blk)
     with pytest.raises(_capi.LsxError, match='no line profiles'):

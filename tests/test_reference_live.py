@@ -25,10 +25,14 @@ def test_context_against_live_reference(oracle_lib):
     # a second, independent set of reference objects for our Context (Context mutates eqPops in place)
     mine_src = mg.build_ctx(['Ca'])
     mine = Context(mine_src.atmos, mine_src.spect, mine_src.eqPops, mine_src.background, lib=oracle_lib)
+    assert mine.setup == 'native'         # the reference's model objects carry their atomic data: the library's set-up chain
     assert mine.activeAtoms[0].n is mine_src.eqPops['Ca'].n
+    assert relerr(mine.activeAtoms[0].vBroad, ref.activeAtoms[0].vBroad) < 1e-14
     for t_ref, t_mine in zip(ref.activeAtoms[0].trans, mine.activeAtoms[0].trans):
         assert t_ref.Nblue == t_mine.Nblue and np.array_equal(t_ref.active, t_mine.active)
         if t_ref.isLine:
+            aD = t_ref.transModel.damping(ref.atmos, ref.activeAtoms[0].vBroad, ref.activeAtoms[0].hPops.n[0])[0]
+            assert relerr(t_mine.aDamp, aD) < 1e-13 and np.array_equal(t_mine.wlambda(), t_ref.wlambda())
             assert relerr(t_mine.phi, t_ref.phi) < 1e-13 and relerr(t_mine.wphi, t_ref.wphi) < 1e-13
     for it in range(1, 7):
         dJ_ref, dJ = ref.formal_sol_gamma_matrices(), mine.formal_sol_gamma_matrices()
