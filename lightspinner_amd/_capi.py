@@ -74,6 +74,16 @@ class LsxAtmosphere(C.Structure):
                [('lte_pops', C.c_int32), ('reserved', C.c_int32)]
 
 
+class LsxTransGrid(C.Structure):
+    _fields_ = [('is_line', C.c_int32), ('n', C.c_int32), ('wavelength', _dp), ('lambdaEdge', C.c_double)]
+
+
+class LsxContinuumModel(C.Structure):
+    _fields_ = [('hydrogenic', C.c_int32), ('n', C.c_int32), ('wavelength', _dp), ('alpha', _dp), ('lambdaEdge', C.c_double),
+                ('minLambda', C.c_double), ('alpha0', C.c_double), ('E_i', C.c_double), ('E_j', C.c_double),
+                ('stage_j', C.c_int32), ('reserved', C.c_int32)]
+
+
 # every symbol include/lsx.h declares
 REQUIRED_SYMBOLS = (
     'lsx_create', 'lsx_destroy', 'lsx_set_columns', 'lsx_formal_sol_gamma', 'lsx_stat_equil',
@@ -81,6 +91,7 @@ REQUIRED_SYMBOLS = (
     'lsx_piecewise_linear_1d', 'lsx_time_formal_sol', 'lsx_last_error', 'lsx_backend_name',
     'lsx_abi_version', 'lsx_algorithmic_bytes_per_column', 'lsx_set_active_columns', 'lsx_set_line_profiles',
     'lsx_piecewise_1d_impl', 'lsx_w2', 'lsx_monitors', 'lsx_set_atomic_data', 'lsx_set_atmosphere',
+    'lsx_wavelength_grid', 'lsx_active_set', 'lsx_line_wavelength', 'lsx_continuum_alpha',
 )
 
 
@@ -139,6 +150,11 @@ class LsxLibrary:
         d.lsx_piecewise_1d_impl.argtypes = [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.POINTER(C.c_int32), _dp, _dp, _dp,
                                             _dp, _dp]
         d.lsx_w2.argtypes = [C.c_int32, C.c_int32, _dp, _dp]
+        ip = C.POINTER(C.c_int32)
+        d.lsx_wavelength_grid.argtypes = [C.c_int32, C.POINTER(LsxTransGrid), C.c_int32, _dp, C.c_double, C.c_int32, _dp, ip, ip, ip]
+        d.lsx_active_set.argtypes = [C.c_int32, C.c_int32, ip, ip, C.POINTER(C.c_uint8)]
+        d.lsx_line_wavelength.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32, _dp, ip]
+        d.lsx_continuum_alpha.argtypes = [C.POINTER(LsxContinuumModel), C.c_int32, _dp, _dp]
         d.lsx_monitors.argtypes = [C.c_void_p, C.c_void_p]
         d.lsx_set_atomic_data.argtypes = [C.c_void_p, C.POINTER(LsxAtomicData)]
         d.lsx_set_atmosphere.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(LsxAtmosphere)]
@@ -200,6 +216,58 @@ class LsxLibrary:
                                                   to_obs.ctypes.data_as(C.POINTER(C.c_int32)), _ptr(Istart),
                                                   _ptr(chi), _ptr(S), _ptr(I), _ptr(Psi)))
         return I, Psi
+
+    # -- wavelength grid and active set (host side of the library) --------------------------------------------------
+    def wavelength_grid(self, grids, is_line, edges, extra=None, lambda_reference=500.0):
+        """RadiativeSet.compute_wavelength_grid's merge (atomic_set.py:377-416): grids = the transitions' own wavelength
+        arrays -> (wavelength [Nspect], blueIdx [Ntrans], redIdx [Ntrans])"""
+        n = len(grids)
+        keep = [f64(g).reshape(-1) for g in grids]
+        tg = (LsxTransGrid * max(1, n))()
+        for q in range(n):
+            tg[q] = LsxTransGrid(1 if is_line[q] else 0, keep[q].shape[0], _ptr(keep[q]), float(edges[q]) if not is_line[q] else 0.0)
+        ex = f64(extra).reshape(-1) if extra is not None else np.zeros(0)
+        cap = int(sum(k.shape[0] + 1 for k in keep) + ex.shape[0] + 1)
+        wav = np.empty(cap)
+        ns = C.c_int32()
+        blue, red = np.zeros(max(1, n), dtype=np.int32), np.zeros(max(1, n), dtype=np.int32)
+        ip = C.POINTER(C.c_int32)
+        self.check(self.dll.lsx_wavelength_grid(n, tg, ex.shape[0], _ptr(ex), float(lambda_reference), cap, _ptr(wav), C.byref(ns),
+                                                blue.ctypes.data_as(ip), red.ctypes.data_as(ip)))
+        return wav[:ns.value].copy(), blue[:n], red[:n]
+
+    def active_set(self, blue, red, Nspect):
+        """-> bool [Ntrans][Nspect]: lsx_problem.active / the membership of spect.activeSet (atomic_set.py:418-453)"""
+        blue, red = np.ascontiguousarray(blue, dtype=np.int32), np.ascontiguousarray(red, dtype=np.int32)
+        act = np.zeros((blue.shape[0], int(Nspect)), dtype=np.uint8)
+        ip = C.POINTER(C.c_int32)
+        self.check(self.dll.lsx_active_set(blue.shape[0], int(Nspect), blue.ctypes.data_as(ip), red.ctypes.data_as(ip),
+                                           act.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return act.astype(bool)
+
+    def line_wavelength(self, lambda0, qCore, qWing, NlambdaGen):
+        """VoigtLine.setup_wavelength (atomic_model.py:347-380)"""
+        out = np.empty(int(NlambdaGen) + 2)
+        n = C.c_int32()
+        self.check(self.dll.lsx_line_wavelength(float(lambda0), float(qCore), float(qWing), int(NlambdaGen), out.shape[0], _ptr(out),
+                                                C.byref(n)))
+        return out[:n.value].copy()
+
+    def continuum_alpha(self, wavelength, *, edge, min_lambda, table=None, alpha0=0.0, E_i=0.0, E_j=0.0, stage_j=0):
+        """compute_alpha (atomic_model.py:606-612 for table = (wavelength, alpha), :662-671 hydrogenic otherwise)"""
+        w = f64(wavelength).reshape(-1)
+        out = np.empty_like(w)
+        m = LsxContinuumModel()
+        m.lambdaEdge, m.minLambda = float(edge), float(min_lambda)
+        if table is not None:
+            x, y = f64(table[0]).reshape(-1), f64(table[1]).reshape(-1)
+            if x.shape != y.shape:
+                raise ValueError('table: wavelength and alpha differ in length')
+            m.hydrogenic, m.n, m.wavelength, m.alpha = 0, x.shape[0], _ptr(x), _ptr(y)
+        else:
+            m.hydrogenic, m.alpha0, m.E_i, m.E_j, m.stage_j = 1, float(alpha0), float(E_i), float(E_j), int(stage_j)
+        self.check(self.dll.lsx_continuum_alpha(C.byref(m), w.shape[0], _ptr(w), _ptr(out)))
+        return out
 
     def w2(self, dtau, device=0):
         """formal_solver.w2 (formal_solver.py:14-44) on an array -> [n][2] (w0, w1)."""

@@ -520,6 +520,163 @@ int lsx_set_atmosphere(lsx_ctx* c, int32_t col0, int32_t ncol, const lsx_atmosph
     return LSX_OK;
 }
 
+/* ---- wavelength grid, active set, the transitions' own grids ----------------------------------------
+ * atomic_set.py:377-455 step by step: collect, sort, unique; searchsorted for the blue and red ends; trim a continuum at
+ * its edge; membership table.  Checker for lsx_grid.cpp. */
+static int cmp_double(const void* a, const void* b)
+{
+    double x = *(const double*)a, y = *(const double*)b;
+    return (x > y) - (x < y);
+}
+static int32_t searchsorted_left(const double* g, int32_t n, double x)
+{
+    int32_t i = 0;
+    while (i < n && g[i] < x) ++i;
+    return i;
+}
+int lsx_wavelength_grid(int32_t Ntrans, const lsx_trans_grid* trans, int32_t Nextra, const double* extra,
+                        double lambdaReference, int32_t capacity, double* wavelength, int32_t* Nspect,
+                        int32_t* blueIdx, int32_t* redIdx)
+{
+    if (Ntrans < 0 || (Ntrans && !trans) || Nextra < 0 || (Nextra && !extra) || !Nspect || capacity < 0 || (capacity && !wavelength))
+        return fail(LSX_EINVAL, "lsx_wavelength_grid: bad arguments");
+    size_t total = (size_t)Nextra + 1;
+    for (int kr = 0; kr < Ntrans; ++kr) {
+        if (trans[kr].n < 1 || !trans[kr].wavelength) return fail(LSX_EINVAL, "lsx_wavelength_grid: a transition has no grid");
+        for (int q = 1; q < trans[kr].n; ++q)
+            if (trans[kr].wavelength[q] < trans[kr].wavelength[q - 1]) return fail(LSX_EINVAL, "lsx_wavelength_grid: a grid is not ascending");
+        total += (size_t)trans[kr].n + 1;
+    }
+    double* g = (double*)malloc(total * sizeof(double));
+    size_t m = 0;
+    for (int q = 0; q < Nextra; ++q) g[m++] = extra[q];                 /* :381-383 */
+    g[m++] = lambdaReference;
+    for (int kr = 0; kr < Ntrans; ++kr) {                               /* :392-399 */
+        const lsx_trans_grid* t = &trans[kr];
+        if (t->is_line) {
+            for (int q = 0; q < t->n; ++q) g[m++] = t->wavelength[q];
+        } else {
+            g[m++] = t->lambdaEdge;
+            for (int q = 0; q < t->n; ++q) if (t->wavelength[q] <= t->lambdaEdge) g[m++] = t->wavelength[q];
+        }
+    }
+    qsort(g, m, sizeof(double), cmp_double);                            /* :401-403 */
+    size_t u = 0;
+    for (size_t q = 0; q < m; ++q) if (u == 0 || g[q] != g[u - 1]) g[u++] = g[q];
+    *Nspect = (int32_t)u;
+    if ((size_t)capacity < u) { free(g); return fail(LSX_EINVAL, "lsx_wavelength_grid: capacity too small"); }
+    memcpy(wavelength, g, u * sizeof(double));
+    for (int kr = 0; kr < Ntrans; ++kr) {                               /* :407-416 */
+        const lsx_trans_grid* t = &trans[kr];
+        int32_t blue = searchsorted_left(g, (int32_t)u, t->wavelength[0]);
+        int32_t red = searchsorted_left(g, (int32_t)u, t->wavelength[t->n - 1]) + 1;
+        if (!t->is_line) {
+            if (red > (int32_t)u) red = (int32_t)u;
+            while (red > blue && g[red - 1] > t->lambdaEdge) red -= 1;
+        }
+        if (blueIdx) blueIdx[kr] = blue;
+        if (redIdx) redIdx[kr] = red;
+    }
+    free(g);
+    return LSX_OK;
+}
+
+int lsx_active_set(int32_t Ntrans, int32_t Nspect, const int32_t* blueIdx, const int32_t* redIdx, uint8_t* active)
+{
+    if (Ntrans < 0 || Nspect < 0 || (Ntrans && (!blueIdx || !redIdx || !active))) return fail(LSX_EINVAL, "lsx_active_set: bad arguments");
+    for (int kr = 0; kr < Ntrans; ++kr) {
+        if (blueIdx[kr] < 0 || redIdx[kr] > Nspect || blueIdx[kr] > redIdx[kr]) return fail(LSX_EINVAL, "lsx_active_set: range outside the grid");
+        for (int la = 0; la < Nspect; ++la) active[(size_t)kr * Nspect + la] = (blueIdx[kr] <= la && la < redIdx[kr]) ? 1 : 0;   /* :434 */
+    }
+    return LSX_OK;
+}
+
+/* atomic_model.py:347-380 */
+int lsx_line_wavelength(double lambda0, double qCore, double qWing, int32_t NlambdaGen, int32_t capacity,
+                        double* wavelength, int32_t* n)
+{
+    if (!n || NlambdaGen < 3 || !(lambda0 > 0.0) || !(qCore > 0.0) || !(qWing > 0.0)) return fail(LSX_EINVAL, "lsx_line_wavelength: bad arguments");
+    int Nlambda = (NlambdaGen % 2 == 1) ? NlambdaGen / 2 : (NlambdaGen - 1) / 2;
+    Nlambda += 1;
+    int NlambdaFull = 2 * Nlambda - 1;
+    *n = NlambdaFull;
+    if (capacity < NlambdaFull || !wavelength) return fail(LSX_EINVAL, "lsx_line_wavelength: capacity too small");
+    double beta = (qWing <= 2.0 * qCore) ? 1.0 : qWing / (2.0 * qCore);
+    double y = beta + sqrt(beta * beta + (beta - 1.0) * Nlambda + 2.0 - 3.0 * beta);
+    double b = 2.0 * log(y) / (Nlambda - 1);
+    double a = qWing / (Nlambda - 2.0 + y * y);
+    double qToLambda = lambda0 * (3.0e3 / CLight);
+    int Nmid = Nlambda - 1;
+    wavelength[Nmid] = lambda0;
+    for (int nl = 1; nl < Nlambda; ++nl) {
+        double q = a * (nl + (exp(b * nl) - 1.0));
+        wavelength[Nmid - nl] = lambda0 - qToLambda * q;
+        wavelength[Nmid + nl] = lambda0 + qToLambda * q;
+    }
+    return LSX_OK;
+}
+
+/* utils.py:24-32 */
+static double gaunt_bf(double wvl, double nEff, double charge)
+{
+    const double ERyd = 2.1798741E-18;
+    double x = HC / (wvl * NM_TO_M) / (ERyd * charge * charge);
+    double x3 = pow(x, 1.0 / 3.0);
+    double nsqx = 1.0 / (nEff * nEff * x);
+    return 1.0 + 0.1728 * x3 * (1.0 - 2.0 * nsqx) - 0.0496 * x3 * x3 * (1.0 - (1.0 - nsqx) * (2.0 / 3.0) * nsqx);
+}
+
+/* atomic_model.py:606-612 (explicit), :662-671 (hydrogenic) */
+int lsx_continuum_alpha(const lsx_continuum_model* c, int32_t n, const double* wavelength, double* alpha)
+{
+    if (!c || n < 0 || (n && (!wavelength || !alpha))) return fail(LSX_EINVAL, "lsx_continuum_alpha: bad arguments");
+    if (c->hydrogenic) {
+        if (!(c->E_j > c->E_i) || c->stage_j < 1) return fail(LSX_EINVAL, "lsx_continuum_alpha: bad hydrogenic continuum");
+        double Z = c->stage_j;
+        double nEff = Z * sqrt(2.1798741E-18 / (c->E_j - c->E_i));
+        double gbf0 = gaunt_bf(c->lambdaEdge, nEff, Z);
+        for (int q = 0; q < n; ++q) {
+            double gbf = gaunt_bf(wavelength[q], nEff, Z);
+            alpha[q] = c->alpha0 * gbf / gbf0 * pow(wavelength[q] / c->lambdaEdge, 3.0);
+            if (wavelength[q] < c->minLambda) alpha[q] = 0.0;
+            if (wavelength[q] > c->lambdaEdge) alpha[q] = 0.0;
+        }
+        return LSX_OK;
+    }
+    if (c->n < 4 || c->n > 64 || !c->wavelength || !c->alpha) return fail(LSX_EINVAL, "lsx_continuum_alpha: 4 ... 64 tabulated points");
+    const int m = c->n;
+    const double *x = c->wavelength, *y = c->alpha;
+    for (int i = 1; i < m; ++i) if (!(x[i] > x[i - 1])) return fail(LSX_EINVAL, "lsx_continuum_alpha: tabulated wavelengths must ascend strictly");
+    double M[64];
+    spline_moments(m, x, y, M);
+    int anyneg = 0;
+    for (int q = 0; q < n; ++q) {
+        double w = wavelength[q], v = 0.0;
+        if (w >= x[0] && w <= x[m - 1]) {
+            int i = 0;
+            while (i < m - 2 && w >= x[i + 1]) ++i;
+            double h = x[i + 1] - x[i], aa = x[i + 1] - w, bb = w - x[i];
+            v = (M[i] * aa * aa * aa + M[i + 1] * bb * bb * bb) / (6.0 * h) + (y[i] / h - M[i] * h / 6.0) * aa + (y[i + 1] / h - M[i + 1] * h / 6.0) * bb;
+        }
+        if (w < c->minLambda) v = 0.0;
+        if (w > c->lambdaEdge) v = 0.0;
+        alpha[q] = v;
+        if (v < 0.0) anyneg = 1;
+    }
+    if (anyneg)
+        for (int q = 0; q < n; ++q) {                         /* linear interp1d, fill 0, no cuts */
+            double w = wavelength[q];
+            if (w < x[0] || w > x[m - 1]) { alpha[q] = 0.0; continue; }
+            int hi = 0;
+            while (hi < m && x[hi] < w) ++hi;
+            if (hi < 1) hi = 1;
+            if (hi > m - 1) hi = m - 1;
+            double slope = (y[hi] - y[hi - 1]) / (x[hi] - x[hi - 1]);
+            alpha[q] = slope * (w - x[hi - 1]) + y[hi - 1];
+        }
+    return LSX_OK;
+}
+
 /* ---- formal_solver.py:14-44 ------------------------------------------------ */
 static inline void w2(double dtau, double* w)
 {

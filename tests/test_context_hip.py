@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import context_cases
+import grid_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -43,3 +44,14 @@ def test_dead_level_nan_is_dropped_from_dpops_on_hip(hip_lib, oracle_lib):
     a = context_cases.dead_level_nan_is_dropped_from_dpops(hip_lib)
     b = context_cases.dead_level_nan_is_dropped_from_dpops(oracle_lib)
     assert a == pytest.approx(b, rel=1e-6)
+
+
+def test_wavelength_grid_on_the_product_library(hip_lib):
+    """lsx_grid.cpp (host C++ inside liblsx_hip.so): the same bodies as the oracle's CPU run"""
+    grid_cases.reference_grid_bit_exact(hip_lib)
+    grid_cases.line_grids_and_continuum_alpha(hip_lib)
+    grid_cases.random_and_edge_cases(hip_lib)
+
+
+def test_spectrum_configuration_feeds_context_on_hip(hip_lib):
+    grid_cases.spectrum_configuration_feeds_context(None, None)

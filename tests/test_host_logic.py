@@ -10,6 +10,7 @@ import pytest
 from conftest import golden, relerr, gamma_err, ROOT
 from helpers import build_fakes, build_data_fakes
 import context_cases
+import grid_cases
 from lightspinner_amd import _capi, fixtures, synth, drivers
 from lightspinner_amd.parallel import shard_columns
 from lightspinner_amd.rh_method import Context
@@ -83,6 +84,22 @@ def test_golden_w2_and_piecewise_1d_impl_through_the_abi(oracle_lib):
 
 def test_dead_level_nan_is_dropped_from_dpops(oracle_lib):
     context_cases.dead_level_nan_is_dropped_from_dpops(oracle_lib)
+
+
+def test_wavelength_grid_bit_exact_on_the_reference(oracle_lib):
+    grid_cases.reference_grid_bit_exact(oracle_lib)
+
+
+def test_line_grids_and_continuum_alpha(oracle_lib):
+    grid_cases.line_grids_and_continuum_alpha(oracle_lib)
+
+
+def test_wavelength_grid_random_and_edge_cases(oracle_lib):
+    grid_cases.random_and_edge_cases(oracle_lib)
+
+
+def test_spectrum_configuration_feeds_context(oracle_lib):
+    grid_cases.spectrum_configuration_feeds_context(oracle_lib, oracle_lib)
 
 
 def test_shard_columns_partitions_exactly():

@@ -44,3 +44,31 @@ def test_context_against_live_reference(oracle_lib):
             dP_ref, dP = ref.stat_equil(), mine.stat_equil()
             assert dP == pytest.approx(dP_ref, rel=1e-7)
             assert relerr(mine_src.eqPops['Ca'].n, ref.eqPops['Ca'].n) < 1e-7
+
+
+def test_wavelength_grid_against_live_reference(oracle_lib):
+    """the reference's RadiativeSet.compute_wavelength_grid and lightspinner_amd.spectrum.compute_wavelength_grid on two
+    independent sets of the reference's own model objects (CaII + H active): grid, blueIdx and active sets identical,
+    continuum alpha to 1e-14"""
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    argv, sys.argv = sys.argv, ['x']
+    try:
+        import make_golden as mg
+    finally:
+        sys.argv = argv
+    from lightspinner_amd.spectrum import compute_wavelength_grid
+    aSet = mg.RadiativeSet([mg.CaII_atom(), mg.H_6_atom()])
+    aSet.set_active('Ca', 'H')
+    ref = aSet.compute_wavelength_grid()
+    fresh = {m.name: m for m in mg.RadiativeSet([mg.CaII_atom(), mg.H_6_atom()]).atoms}
+    mine = compute_wavelength_grid([fresh[m.name] for m in ref.models], lib=oracle_lib)      # same model order as the reference's set
+    assert np.array_equal(mine.wavelength, ref.wavelength)
+    assert mine.blueIdx == [int(b) for b in ref.blueIdx]
+    assert len(mine.transitions) == len(ref.transitions)
+    for t_ref, t_mine in zip(ref.transitions, mine.transitions):
+        assert (t_ref.i, t_ref.j, t_ref.atom.name) == (t_mine.i, t_mine.j, t_mine.atom.name)
+        assert np.array_equal(t_ref.wavelength, t_mine.wavelength)
+        if not isinstance(t_ref, mg.AtomicLine):
+            assert np.max(np.abs(t_ref.alpha - t_mine.alpha)) <= 1e-14 * np.max(t_ref.alpha)
+    for la in range(ref.wavelength.shape[0]):
+        assert [(t.atom.name, t.i, t.j) for t in ref.activeSet[la]] == [(t.atom.name, t.i, t.j) for t in mine.activeSet[la]]
