@@ -115,9 +115,8 @@ enum {
     LSX_DPOPS_COL = 5, /* [1]  per-column max rel. population change of the last SE   */
     LSX_NSTAR = 6,     /* [NLtot][Nspace]                                             */
     LSX_C = 7,         /* [NL2tot][Nspace]                                            */
-    LSX_RIJ = 8,       /* [Ntrans][Nspace]  t.Rij, accumulated over calls exactly as the
-                          reference does (rh_method.py:691; never zeroed, quirk kept)    */
-    LSX_RJI = 9,       /* [Ntrans][Nspace]  t.Rji (rh_method.py:692, uses Vij: quirk kept) */
+    /* 8, 9: not assigned.  t.Rij / t.Rji (rh_method.py:691-692) are write-only state of the reference -- accumulated
+       over calls without ever being zeroed or read -- and are not part of this interface */
     LSX_PHI = 10,      /* [SNl][Nrays][2][Nspace] (or [SNl][Nspace] when phi_compact)  t.phi  */
     LSX_WPHI = 11,     /* [Nlines][Nspace]  t.wphi                                     */
     LSX_VBROAD = 12,   /* [Natoms][Nspace]  atom.vBroad            (after lsx_set_atmosphere)  */

@@ -13,7 +13,7 @@ import numpy as np
 ABI_VERSION = 1
 
 # item selectors (include/lsx.h)
-LSX_I, LSX_J, LSX_N, LSX_GAMMA, LSX_DJ_COL, LSX_DPOPS_COL, LSX_NSTAR, LSX_C, LSX_RIJ, LSX_RJI, LSX_PHI, LSX_WPHI, LSX_VBROAD, LSX_ADAMP = range(14)
+LSX_I, LSX_J, LSX_N, LSX_GAMMA, LSX_DJ_COL, LSX_DPOPS_COL, LSX_NSTAR, LSX_C, _, _, LSX_PHI, LSX_WPHI, LSX_VBROAD, LSX_ADAMP = range(14)
 LSX_COLL_OMEGA, LSX_COLL_CI, LSX_COLL_CE = range(3)
 
 ERRORS = {1: 'LSX_EINVAL', 2: 'LSX_EDEVICE', 3: 'LSX_ESINGULAR', 5: 'LSX_EUNSUPPORTED'}

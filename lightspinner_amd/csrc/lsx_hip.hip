@@ -1987,10 +1987,6 @@ int lsx_get(lsx_ctx* c, int32_t what, int32_t col0, int32_t ncol, double* dst, s
         per = (size_t)(what == LSX_VBROAD ? c->Natoms : std::max(1, c->Nlines)) * Ns;
         break;
     case LSX_PHI: per = c->phi_in_col; break;
-    case LSX_RIJ:
-    case LSX_RJI:
-        return fail(LSX_EUNSUPPORTED, "lsx_get: radiative rates Rij/Rji are not produced by the HIP backend "
-                                      "(they feed nothing in the reference, rh_method.py:691-692)");
     default: return fail(LSX_EINVAL, "lsx_get: unknown item %d", what);
     }
     if (nbytes != per * ncol * 8) return fail(LSX_EINVAL, "lsx_get: nbytes does not match the item's shape");

@@ -292,8 +292,7 @@ class Engine:
         return {_capi.LSX_I: (p.Nspect, p.Nrays), _capi.LSX_J: (p.Nspect, p.Nspace),
                 _capi.LSX_N: (p.NLtot, p.Nspace), _capi.LSX_GAMMA: (p.NL2tot, p.Nspace),
                 _capi.LSX_DJ_COL: (), _capi.LSX_DPOPS_COL: (), _capi.LSX_NSTAR: (p.NLtot, p.Nspace),
-                _capi.LSX_C: (p.NL2tot, p.Nspace), _capi.LSX_RIJ: (p.Ntrans, p.Nspace),
-                _capi.LSX_RJI: (p.Ntrans, p.Nspace), _capi.LSX_PHI: p.phi_shape(),
+                _capi.LSX_C: (p.NL2tot, p.Nspace), _capi.LSX_PHI: p.phi_shape(),
                 _capi.LSX_WPHI: (p.Nlines, p.Nspace), _capi.LSX_VBROAD: (p.Natoms, p.Nspace),
                 _capi.LSX_ADAMP: (max(1, p.Nlines), p.Nspace)}[what]
 

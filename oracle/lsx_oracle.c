@@ -215,6 +215,17 @@ static double voigt_H(double a, double v)
 
 double lsx_oracle_voigt(double a, double v) { return voigt_H(a, v); }
 
+/* Oracle-only: t.Rij / t.Rji of column `col` (rh_method.py:691-692), [Ntrans][Nspace] each.  Not part of the ABI (the
+ * reference never reads them); the golden files hold them and they pin the oracle's intensity at EVERY depth. */
+int lsx_oracle_rates(lsx_ctx* c, int32_t col, double* Rij, double* Rji)
+{
+    if (!c || col < 0 || col >= c->ncol || !Rij || !Rji) return fail(LSX_EINVAL, "lsx_oracle_rates: bad argument");
+    size_t per = (size_t)c->Ntrans * c->Nspace;
+    memcpy(Rij, c->Rij + per * col, per * 8);
+    memcpy(Rji, c->Rji + per * col, per * 8);
+    return LSX_OK;
+}
+
 /* rh_method.py:198-243 */
 int lsx_set_line_profiles(lsx_ctx* c, int32_t col0, int32_t ncol, const double* aDamp, const double* vBroad,
                           const double* vlos)
@@ -1208,8 +1219,6 @@ static int locate(lsx_ctx* c, int what, double** base, size_t* per)
     case LSX_DPOPS_COL: *base = c->dPcol; *per = 1; break;
     case LSX_NSTAR: *base = c->nStar; *per = (size_t)c->NLtot * Ns; break;
     case LSX_C: *base = c->C; *per = (size_t)c->NL2tot * Ns; break;
-    case LSX_RIJ: *base = c->Rij; *per = (size_t)c->Ntrans * Ns; break;
-    case LSX_RJI: *base = c->Rji; *per = (size_t)c->Ntrans * Ns; break;
     case LSX_PHI: *base = c->phi; *per = phi_per_col(c); break;
     case LSX_WPHI: *base = c->wphi; *per = (size_t)c->Nlines * Ns; break;
     case LSX_VBROAD: *base = c->vBroad; *per = (size_t)c->Natoms * Ns; if (!c->vBroad) return 1; break;

@@ -183,5 +183,5 @@ def test_error_conventions(hip_lib):
     eng.set_columns(0, block)
     with pytest.raises(np.linalg.LinAlgError):   # Gamma all zero -> singular, rh_method.py:739
         eng.stat_equil()
-    with pytest.raises(_capi.LsxError):
-        eng.get(_capi.LSX_RIJ)
+    with pytest.raises(KeyError):
+        eng.get(8)                                # 8, 9 (t.Rij / t.Rji) are not part of the interface
