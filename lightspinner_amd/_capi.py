@@ -281,7 +281,8 @@ _HIP_LIB = None
 
 
 def hip_library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'liblsx_hip.so')
+    """the in-tree product library; LSX_HIP_LIBRARY names another build of it (A/B runs of profiles/ab.sh variants)"""
+    return os.environ.get('LSX_HIP_LIBRARY') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'liblsx_hip.so')
 
 
 def _share_hip_runtime_with_torch():

@@ -32,6 +32,8 @@ struct SweepClass {           // tiles that run the same kernel instantiation, l
     hipEvent_t tdone = nullptr; // timed runs: end of this class's launch
     std::vector<int> fast_tiles; // the class's tiles that have fast continua
     int* d_fast_tiles = nullptr;
+    std::vector<int> fast_cols[4], fast_rest;   // ... split by the kernel that builds their Gamma slabs (k_fast_gamma_cols
+    int *d_fast_cols[4] = {nullptr, nullptr, nullptr, nullptr}, *d_fast_rest = nullptr;   // instance / k_fast_gamma)
     std::vector<int> tiles;
     int* d_tiles = nullptr;
     int ncell_lev = 1, ncell_atom = 1;
@@ -81,6 +83,8 @@ struct lsx_ctx {
     double *d_bgxchi = nullptr, *d_bgxeta = nullptr, *d_Psi2 = nullptr; // fast-continuum side arrays
     std::vector<int> fast_tiles;
     int* d_fast_tiles = nullptr;
+    std::vector<int> fast_cols[4], fast_rest;
+    int *d_fast_cols[4] = {nullptr, nullptr, nullptr, nullptr}, *d_fast_rest = nullptr;
     int *d_cont_li = nullptr, *d_cont_lj = nullptr;
     double* d_exp2_tab = nullptr;
     double* d_voigt_w = nullptr;

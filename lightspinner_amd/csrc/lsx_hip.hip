@@ -337,6 +337,14 @@ struct FastParams {
 // one fast continuum at (lambda, depth): rh_method.py:284-286, 453-455, 613-614, with g_ij = (nStar_i / nStar_j) E
 struct FastVal { double alf, Vji, Uji, chi, eta; bool a; };
 #define LSX_MAX_TILE_LINES 4
+// k_fast_gamma_cols instances by the number of lines the tile's linked continua feed: list v holds the tiles with
+// kLkLines[v - 1] < lines <= kLkLines[v]
+static const int kLkLines[4] = {0, 1, 2, LSX_MAX_TILE_LINES};
+static inline int lkclass(const DevTile& tl)
+{
+    const int n = tl.nK > 0 ? (tl.nL < LSX_MAX_TILE_LINES ? tl.nL : LSX_MAX_TILE_LINES) : 0;
+    return n == 0 ? 0 : (n == 1 ? 1 : (n == 2 ? 2 : 3));
+}
 // effective background of the tiles that have fast continua: bgx = bg + sum over the tile's fast continua; for the
 // lines of a tile with linked continua also the three sums the line's own Gamma integrand needs from them
 // (rh_method.py:616-627: atom.eta, atom.chi[i_line], atom.chi[j_line], continuum part)
@@ -665,6 +673,220 @@ __global__ void __launch_bounds__(NT) k_fast_gamma(const FastParams f)
             }
         }
     }
+    }
+}
+
+// The same Gamma slabs for tiles whose fast continua form "simple" sets of at most LSX_FAST_NQ per atom (every bound-free
+// set of an ordinary model atom), with the work laid out the other way round: TWO lanes per (column, depth), the tile's
+// wavelength pairs dealt alternately to them.  The wavelength quadrature becomes a running sum in registers (one two-lane
+// DPP add at the end instead of a row reduction per wavelength and slot: in k_fast_gamma the reductions cost as much as
+// the arithmetic), the per-depth operands n_i, n_j, nStar_i/nStar_j stay in registers (no staging), every lane works (a
+// row of LP = 16 lanes holds 12 wavelengths at 5 rays) and the slabs leave as coalesced stores.
+// The streams J, Psibar, E, PsiPhi are [depth][wavelength] in memory: read per thread they would be 16-byte pieces at a
+// stride of L doubles (48 cache lines per wave load, measured: the kernel then sits on the vector-memory path at a
+// fifth of its arithmetic rate).  So each wave first copies the contiguous block of its 32 (column, depth) rows into a
+// wave-private LDS area with coalesced 16-byte loads (both directions summed on the way, pad wavelengths zeroed) and the
+// arithmetic reads it from there.  Same terms, same order per wavelength as k_fast_gamma; the sum over the wavelengths
+// runs over the lane's pairs in ascending order, then lane 0 + lane 1.
+#define LSX_FAST_NQ 6
+#define LSX_FGC_ROWS 32       // (column, depth) rows per wave
+template <int NLC>            // NLC: lines of the tile that linked continua feed (0: the tile has no linked continuum)
+__global__ void __launch_bounds__(256) k_fast_gamma_cols(const FastParams f)
+{
+    constexpr bool LINKS = NLC > 0;
+    constexpr int NL1 = NLC > 0 ? NLC : 1, NST = 3 + NLC, R = LSX_FGC_ROWS;
+    extern __shared__ double sm[];
+    const int t = f.fast_tiles[blockIdx.y];
+    const DevTile tl = f.tiles[t];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, Ns = f.Nspace, L = f.L, NP = L / 2;
+    const DevSlot* fs = f.slots + tl.slot0 + tl.nP;
+    const DevSlot* ls = f.slots + tl.slot0;
+    double* sA = sm;                                          // [q][j]{alpha, wlambda}, 0 where the continuum is inactive
+    double* sU = sA + (size_t)2 * f.nF_max * L;               // [j] 2hc/lambda^3
+    double* sS = sU + L + (size_t)wv * NST * R * L;           // this wave's streams: [J | Psibar | E | PsiPhi_u][row][j]
+    for (int e = tid; e < tl.nF * L; e += 256) {
+        const int q = e / L, jj = e - q * L, lq = tl.la0 + min(jj, tl.nla - 1), lt = lq - fs[q].Nblue;
+        const bool a = jj < tl.nla && lt >= 0 && lt < fs[q].Nlam && f.active[(size_t)fs[q].trans * f.Nspect + lq] != 0;
+        sA[e * 2 + 0] = a ? f.alpha[fs[q].wl_off + lt] : 0.0;
+        sA[e * 2 + 1] = a ? f.wl[fs[q].wl_off + lt] : 0.0;
+    }
+    for (int e = tid; e < L; e += 256) sU[e] = f.u_la[tl.la0 + min(e, tl.nla - 1)];
+    __syncthreads();
+    const long nrows = (long)f.ncol * Ns;
+    const long row0 = ((long)blockIdx.x * 4 + wv) * R;        // first (column, depth) row of this wave
+    if (row0 >= nrows) return;
+    const int nLc = LINKS ? min(tl.nL, NLC) : 0;
+    const size_t dstride = (size_t)f.ncol * f.ntile * Ns * L, pstride = (size_t)f.ncol * f.pp_col_stride, plane = (size_t)Ns * L;
+    // ---- the wave's rows, global -> LDS: piece c = 16 bytes = wavelength pair c % NP of row c / NP
+    const double2 zero2 = make_double2(0.0, 0.0);
+    for (int c = lane; c < R * NP; c += 64) {
+        const int r = c / NP, p = c - r * NP;
+        const long g = row0 + r;
+        double2 vJ = zero2, vP = zero2, vE = zero2, vL[NL1];
+#pragma unroll
+        for (int u = 0; u < NL1; ++u) vL[u] = zero2;
+        if (g < nrows) {
+            const int col = (int)(g / Ns), k = (int)(g - (long)col * Ns);
+            if (!f.colmask || f.colmask[col]) {
+                const size_t o = ((size_t)((size_t)col * f.ntile + t) * Ns + k) * L + 2 * p;
+                vJ = *reinterpret_cast<const double2*>(f.J_T + o);
+                const double2 a = *reinterpret_cast<const double2*>(f.Psi2_T + o), b = *reinterpret_cast<const double2*>(f.Psi2_T + dstride + o);
+                vP = make_double2(a.x + b.x, a.y + b.y);
+                vE = *reinterpret_cast<const double2*>(f.E_T + o);
+#pragma unroll
+                for (int u = 0; u < NL1; ++u)
+                    if (LINKS && u < nLc) {
+                        const double* pp = f.Psi3_T + (size_t)col * f.pp_col_stride + tl.pp_off + (size_t)u * plane + (size_t)k * L + 2 * p;
+                        const double2 x = *reinterpret_cast<const double2*>(pp), y = *reinterpret_cast<const double2*>(pp + pstride);
+                        vL[u] = make_double2(x.x + y.x, x.y + y.y);
+                    }
+                if (2 * p + 1 >= tl.nla) {                    // pad wavelengths hold nothing defined: zeros keep them out
+                    vJ.y = vP.y = vE.y = 0.0;
+#pragma unroll
+                    for (int u = 0; u < NL1; ++u) vL[u].y = 0.0;
+                    if (2 * p >= tl.nla) {
+                        vJ.x = vP.x = vE.x = 0.0;
+#pragma unroll
+                        for (int u = 0; u < NL1; ++u) vL[u].x = 0.0;
+                    }
+                }
+            }
+        }
+        *reinterpret_cast<double2*>(sS + (size_t)c * 2) = vJ;
+        *reinterpret_cast<double2*>(sS + (size_t)R * L + (size_t)c * 2) = vP;
+        *reinterpret_cast<double2*>(sS + (size_t)2 * R * L + (size_t)c * 2) = vE;
+#pragma unroll
+        for (int u = 0; u < NL1; ++u)
+            if (LINKS) *reinterpret_cast<double2*>(sS + (size_t)(3 + u) * R * L + (size_t)c * 2) = vL[u];
+    }
+    __builtin_amdgcn_wave_barrier();                          // a wave's LDS operations complete in order
+    // ---- arithmetic: lane = (row, h), h = which of the row's wavelength pairs
+    const int r = lane >> 1, h = lane & 1;
+    const long g = row0 + r;
+    if (g >= nrows) return;
+    const int col = (int)(g / Ns), k = (int)(g - (long)col * Ns);
+    if (f.colmask && !f.colmask[col]) return;
+    double sW = 0.0;
+    for (int m = 0; m < f.Nrays; ++m) sW += 2.0 * f.wmuh[m] * (4.0 * M_PI);   // both directions
+    const double* nc = f.n + (size_t)col * f.NLtot * Ns + k;
+    const double* nsrc = f.nsr + (size_t)col * f.Ncont * Ns + k;
+    // the lines' depth coefficients: chi_line = Lx phi, eta_line = Ly phi (rh_method.py:279-281, 613-614), Uji_line = LU phi
+    double Lx[NL1], Ly[NL1], LU[NL1];
+#pragma unroll
+    for (int u = 0; u < NL1; ++u) {
+        Lx[u] = Ly[u] = LU[u] = 0.0;
+        if (LINKS && u < nLc) {
+            const double ni = nc[(size_t)ls[u].li * Ns], nj = nc[(size_t)ls[u].lj * Ns];
+            Lx[u] = ls[u].cB * (ni - ls[u].g * nj);
+            Ly[u] = nj * ls[u].Uc;
+            LU[u] = ls[u].Uc;
+        }
+    }
+    const double* srow = sS + (size_t)r * L;
+    for (int q0 = 0; q0 < tl.nF;) {                           // one atom at a time
+        const int atom = fs[q0].atom;
+        int q1 = q0;
+        while (q1 < tl.nF && fs[q1].atom == atom) ++q1;
+        const int nq = q1 - q0;                               // <= LSX_FAST_NQ (lsx_create)
+        double ni[LSX_FAST_NQ], nj[LSX_FAST_NQ], nr[LSX_FAST_NQ], a1[LSX_FAST_NQ], a2[LSX_FAST_NQ];
+#pragma unroll
+        for (int q = 0; q < LSX_FAST_NQ; ++q) {
+            ni[q] = nj[q] = nr[q] = a1[q] = a2[q] = 0.0;
+            if (q < nq) {
+                ni[q] = nc[(size_t)fs[q0 + q].li * Ns];
+                nj[q] = nc[(size_t)fs[q0 + q].lj * Ns];
+                nr[q] = nsrc[(size_t)fs[q0 + q].base];
+            }
+        }
+        const unsigned lk0 = fs[q0].lkbits;
+        for (int p = h; p < NP; p += 2) {
+            const double2 J2 = *reinterpret_cast<const double2*>(srow + 2 * p), P2 = *reinterpret_cast<const double2*>(srow + (size_t)R * L + 2 * p),
+                          E2 = *reinterpret_cast<const double2*>(srow + (size_t)2 * R * L + 2 * p), U2 = *reinterpret_cast<const double2*>(sU + 2 * p);
+            double2 L2[NL1];
+#pragma unroll
+            for (int u = 0; u < NL1; ++u) L2[u] = LINKS ? *reinterpret_cast<const double2*>(srow + (size_t)(3 + u) * R * L + 2 * p) : zero2;
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const int jw = 2 * p + w;
+                const double sI = (w ? J2.y : J2.x) * (4.0 * M_PI), sPsi = w ? P2.y : P2.x, E = w ? E2.y : E2.x, ula = w ? U2.y : U2.x;
+                double tchi[NL1], teta[NL1], tU[NL1];
+#pragma unroll
+                for (int u = 0; u < NL1; ++u) {
+                    const double sPP = w ? L2[u].y : L2[u].x;
+                    tchi[u] = Lx[u] * sPP;
+                    teta[u] = Ly[u] * sPP;
+                    tU[u] = LU[u] * sPP;
+                }
+                auto line_chi = [&](unsigned lk) {
+                    double x = 0.0;
+                    if constexpr (LINKS) {
+#pragma unroll
+                        for (int u = 0; u < NL1; ++u) {
+                            if (lk & (2u << (8 * u))) x += tchi[u];
+                            if (lk & (4u << (8 * u))) x -= tchi[u];
+                        }
+                    }
+                    return x;
+                };
+                auto line_U = [&](unsigned lk) {
+                    double x = 0.0;
+                    if constexpr (LINKS) {
+#pragma unroll
+                        for (int u = 0; u < NL1; ++u)
+                            if (lk & (4u << (8 * u))) x += tU[u];
+                    }
+                    return x;
+                };
+                double le = 0.0;
+                if constexpr (LINKS) {
+#pragma unroll
+                    for (int u = 0; u < NL1; ++u)
+                        if (lk0 & (1u << (8 * u))) le += teta[u];
+                }
+                // rh_method.py:284-286, 453-455, 613-614 for the atom's continua; atom.chi[j], atom.U[j], atom.eta of :616-627
+                double Vji[LSX_FAST_NQ], chi[LSX_FAST_NQ], chi_j = 0.0, U_j = 0.0, etaA = 0.0;
+#pragma unroll
+                for (int q = 0; q < LSX_FAST_NQ; ++q) {
+                    Vji[q] = chi[q] = 0.0;
+                    if (q < nq) {
+                        const double alf = sA[(size_t)((q0 + q) * L + jw) * 2];
+                        Vji[q] = (nr[q] * E) * alf;
+                        const double Uji = ula * Vji[q];
+                        chi[q] = ni[q] * alf - nj[q] * Vji[q];
+                        chi_j -= chi[q];
+                        U_j += Uji;
+                        etaA += nj[q] * Uji;
+                    }
+                }
+                const double sIe = (sI - etaA * sPsi) - le;
+#pragma unroll
+                for (int q = 0; q < LSX_FAST_NQ; ++q) {
+                    if (q < nq) {
+                        const unsigned lk = fs[q0 + q].lkbits;
+                        const double2 A = *reinterpret_cast<const double2*>(sA + (size_t)((q0 + q) * L + jw) * 2);
+                        const double Uji = ula * Vji[q];
+                        const double cU = (chi[q] * U_j) * sPsi + line_chi(lk) * U_j;
+                        const double cU2 = chi_j * line_U(lk);
+                        a1[q] += A.y * ((Uji * sW + Vji[q] * sIe) - cU);
+                        a2[q] += A.y * ((A.x * sIe) - cU2);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < LSX_FAST_NQ; ++q) {
+            if (q < nq) {                                     // wave-uniform
+                const double s1 = a1[q] + dpp_f64<0xB1, 0xf>(a1[q]), s2 = a2[q] + dpp_f64<0xB1, 0xf>(a2[q]);   // lane 0 + lane 1 of the row
+                if (h == 0) {
+                    double* gp = f.Gpart + (((size_t)col * f.nslot_total + tl.slot0 + tl.nP + q0 + q) * 4) * (size_t)Ns + k;
+                    gp[0] = s1;
+                    gp[Ns] = 0.0;
+                    gp[2 * (size_t)Ns] = s2;
+                    gp[3 * (size_t)Ns] = 0.0;
+                }
+            }
+        }
+        q0 = q1;
     }
 }
 
@@ -1092,7 +1314,7 @@ void lsx_destroy(lsx_ctx* c)
                     c->d_tiles, c->d_slots, c->d_tile_slots, c->d_Nlevel, c->d_lev2_off, c->d_height,
                     c->d_temperature, c->d_nStar, c->d_nTotal, c->d_n, c->d_C, c->d_Gamma, c->d_wphi, c->d_bgchi,
                     c->d_bgeta, c->d_sca, c->d_phi, c->d_E, c->d_corr, c->d_Psi3, c->d_J[0], c->d_J[1], c->d_I, c->d_Gpart, c->d_dJpart,
-                    c->d_res, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab, c->d_voigt_w, c->d_muz, c->d_wmu,
+                    c->d_res, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_fast_cols[0], c->d_fast_cols[1], c->d_fast_cols[2], c->d_fast_cols[3], c->d_fast_rest, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab, c->d_voigt_w, c->d_muz, c->d_wmu,
                     c->d_sa_atoms, c->d_sa_lines, c->d_sa_colls, c->d_sa_spl, c->d_sa_levE, c->d_sa_levg, c->d_sa_levnD, c->d_sa_levdZ,
                     c->d_vBroad, c->d_aDamp};
     for (void* p : ptrs)
@@ -1102,6 +1324,8 @@ void lsx_destroy(lsx_ctx* c)
         if (k.done) (void)hipEventDestroy(k.done);
         if (k.tdone) (void)hipEventDestroy(k.tdone);
         if (k.d_fast_tiles) (void)hipFree(k.d_fast_tiles);
+        for (int v = 0; v < 4; ++v) if (k.d_fast_cols[v]) (void)hipFree(k.d_fast_cols[v]);
+        if (k.d_fast_rest) (void)hipFree(k.d_fast_rest);
         if (k.stream) { (void)hipStreamSynchronize(k.stream); (void)hipStreamDestroy(k.stream); }
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1408,8 +1632,19 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
                     if (x.atom != y.atom) continue;
                     if (x.lj != y.lj || x.li == y.lj || (a != b && x.li == y.li)) simple = false;
                 }
-            tl.fast_simple = simple ? 1 : 0;
+            // 2: additionally at most LSX_FAST_NQ continua per atom -> k_fast_gamma_cols (LSX_FAST_ROWS: diagnostic, the
+            // row-mapped kernel for every tile)
+            int group = 0, group_max = 0;
+            for (size_t a = 0; a < fast.size(); ++a) {
+                group = (a > 0 && c->htrans[fast[a]].atom == c->htrans[fast[a - 1]].atom) ? group + 1 : 1;
+                group_max = std::max(group_max, group);
+            }
+            const int lkn = tl.nK > 0 ? (int)lines.size() : 0;       // lines the linked continua feed
+            const size_t lds_cols = ((size_t)2 * LSX_MAX_FAST * c->L + c->L + (size_t)4 * (3 + lkn) * LSX_FGC_ROWS * c->L) * sizeof(double);
+            const bool cols = simple && group_max <= LSX_FAST_NQ && c->L % 2 == 0 && lkn <= 2 && lds_cols <= 64 * 1024 && !getenv("LSX_FAST_ROWS");
+            tl.fast_simple = simple ? (cols ? 2 : 1) : 0;
             if (!simple) c->fast_generic = true;
+            (tl.fast_simple == 2 ? c->fast_cols[lkclass(tl)] : c->fast_rest).push_back((int)c->tiles.size());
         }
         // a compile-time slot count needs the per-depth operand table in LDS; very deep columns fall back to the
         // generic instance (runtime slot loops, operands through the scalar cache)
@@ -1431,7 +1666,11 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
             if (q.npt == npt && q.nl == nl && q.linked == lk && q.topo == topo) k = &q;
         if (!k) { c->classes.push_back(SweepClass()); k = &c->classes.back(); k->npt = npt; k->nl = nl; k->linked = lk; k->topo = topo; }
         k->tiles.push_back((int)c->tiles.size());
-        if (tl.nF > 0) { k->has_fast = true; k->fast_tiles.push_back((int)c->tiles.size()); }
+        if (tl.nF > 0) {
+            k->has_fast = true;
+            k->fast_tiles.push_back((int)c->tiles.size());
+            (tl.fast_simple == 2 ? k->fast_cols[lkclass(tl)] : k->fast_rest).push_back((int)c->tiles.size());
+        }
         k->ncell_lev = std::max(k->ncell_lev, (int)lev_ids.size());
         k->ncell_atom = std::max(k->ncell_atom, (int)atom_ids.size());
         c->tiles.push_back(tl);
@@ -1505,6 +1744,8 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     for (auto& k : c->classes) {
         TRY(upload(&k.d_tiles, k.tiles, c->stream));
         if (!k.fast_tiles.empty()) TRY(upload(&k.d_fast_tiles, k.fast_tiles, c->stream));
+        for (int v = 0; v < 4; ++v) if (!k.fast_cols[v].empty()) TRY(upload(&k.d_fast_cols[v], k.fast_cols[v], c->stream));
+        if (!k.fast_rest.empty()) TRY(upload(&k.d_fast_rest, k.fast_rest, c->stream));
         int prio_lo = 0, prio_hi = 0;       // numerically lower = higher priority
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         // workgroups that need many registers (three or more slots, generic) find room only while the machine is not
@@ -1573,6 +1814,8 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     }
     if (!c->fast_tiles.empty()) {
         TRY(upload(&c->d_fast_tiles, c->fast_tiles, c->stream));
+        for (int v = 0; v < 4; ++v) if (!c->fast_cols[v].empty()) TRY(upload(&c->d_fast_cols[v], c->fast_cols[v], c->stream));
+        if (!c->fast_rest.empty()) TRY(upload(&c->d_fast_rest, c->fast_rest, c->stream));
         TRY(dmalloc(&c->d_bgxchi, nc * c->til_col));
         TRY(dmalloc(&c->d_bgxeta, nc * c->til_col));
         TRY(dmalloc(&c->d_Psi2, 2 * nc * c->til_col));
@@ -1728,7 +1971,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
         HIPCHK(hipGetLastError());
         return LSX_OK;
     };
-    auto launch_fast_gamma = [&](hipStream_t st, const int* d_list, size_t n) -> int {
+    auto launch_fast_rows = [&](hipStream_t st, const int* d_list, size_t n) -> int {
         FastParams fq = ff;
         fq.fast_tiles = d_list; fq.n_fast_tiles = (int)n;
         int nt = 256;
@@ -1748,6 +1991,26 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
 #undef LSX_FG
         HIPCHK(hipGetLastError());
         return LSX_OK;
+    };
+    // the column-mapped kernel: one thread per (column, depth), blocks of 256 over the columns' depths x the tiles
+    auto launch_fast_cols = [&](hipStream_t st, const int* d_list, size_t n, int v) -> int {
+        FastParams fq = ff;
+        fq.fast_tiles = d_list; fq.n_fast_tiles = (int)n;
+        const size_t sm = ((size_t)2 * c->nF_max * c->L + c->L + (size_t)4 * (3 + kLkLines[v]) * LSX_FGC_ROWS * c->L) * sizeof(double);
+        if (sm > 64 * 1024) return fail(LSX_EUNSUPPORTED, "fast-continuum epilogue (column mapped) needs %zu B of LDS", sm);
+        dim3 grid((unsigned)(((size_t)c->ncol * c->Nspace + 4 * LSX_FGC_ROWS - 1) / (4 * LSX_FGC_ROWS)), (unsigned)n);
+#define LSX_FC(NLCV) if (kLkLines[v] == NLCV) hipLaunchKernelGGL((k_fast_gamma_cols<NLCV>), grid, dim3(256), sm, st, fq);
+        LSX_FC(0) LSX_FC(1) LSX_FC(2)
+#undef LSX_FC
+        HIPCHK(hipGetLastError());
+        return LSX_OK;
+    };
+    auto launch_fast_gamma = [&](hipStream_t st, const std::vector<int>* cols, int* const* d_cols, const int* d_rest, size_t nrest) -> int {
+        int r = LSX_OK;
+        for (int v = 0; v < 3; ++v)
+            if (!cols[v].empty() && (r = launch_fast_cols(st, d_cols[v], cols[v].size(), v))) return r;
+        if (nrest && (r = launch_fast_rows(st, d_rest, nrest))) return r;
+        return r;
     };
     int rc2 = LSX_OK;
     if (timed) HIPCHK(hipEventRecord(c->ev0, c->stream));
@@ -1769,7 +2032,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
         c->fused_launches++;
         hipError_t e = lsx_launch_sweep(&p, -2, (int)nblocks, lds, c->stream);
         if (e != hipSuccess) return fail(LSX_EDEVICE, "sweep launch (fused): %s", hipGetErrorString(e));
-        if (has_fast && (rc2 = launch_fast_gamma(c->stream, c->d_fast_tiles, c->fast_tiles.size()))) return rc2;
+        if (has_fast && (rc2 = launch_fast_gamma(c->stream, c->fast_cols, c->d_fast_cols, c->d_fast_rest, c->fast_rest.size()))) return rc2;
     } else {
         // The classes of one call run side by side on their own streams, forked from the context's stream and joined
         // back into it.  The fast continua of a class's tiles are handled on the class's own stream, pre-pass before
@@ -1792,7 +2055,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
                 if (!k.tdone) HIPCHK(hipEventCreate(&k.tdone));
                 HIPCHK(hipEventRecord(k.tdone, st));
             }
-            if (!k.fast_tiles.empty() && (rc2 = launch_fast_gamma(st, k.d_fast_tiles, k.fast_tiles.size()))) return rc2;
+            if (!k.fast_tiles.empty() && (rc2 = launch_fast_gamma(st, k.fast_cols, k.d_fast_cols, k.d_fast_rest, k.fast_rest.size()))) return rc2;
             if (fork) {
                 HIPCHK(hipEventRecord(k.done, st));
                 HIPCHK(hipStreamWaitEvent(c->stream, k.done, 0));
