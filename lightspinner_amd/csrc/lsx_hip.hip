@@ -690,6 +690,7 @@ __global__ void __launch_bounds__(NT) k_fast_gamma(const FastParams f)
 // runs over the lane's pairs in ascending order, then lane 0 + lane 1.
 #define LSX_FAST_NQ 6
 #define LSX_FGC_ROWS 32       // (column, depth) rows per wave
+#define LSX_FGC_MAXF 12       // fast continua per tile this kernel takes (sizes its operand table)
 template <int NLC>            // NLC: lines of the tile that linked continua feed (0: the tile has no linked continuum)
 __global__ void __launch_bounds__(256) k_fast_gamma_cols(const FastParams f)
 {
@@ -702,7 +703,7 @@ __global__ void __launch_bounds__(256) k_fast_gamma_cols(const FastParams f)
     const DevSlot* fs = f.slots + tl.slot0 + tl.nP;
     const DevSlot* ls = f.slots + tl.slot0;
     double* sA = sm;                                          // [q][j]{alpha, wlambda}, 0 where the continuum is inactive
-    double* sU = sA + (size_t)2 * f.nF_max * L;               // [j] 2hc/lambda^3
+    double* sU = sA + (size_t)2 * LSX_FGC_MAXF * L;            // [j] 2hc/lambda^3
     double* sS = sU + L + (size_t)wv * NST * R * L;           // this wave's streams: [J | Psibar | E | PsiPhi_u][row][j]
     for (int e = tid; e < tl.nF * L; e += 256) {
         const int q = e / L, jj = e - q * L, lq = tl.la0 + min(jj, tl.nla - 1), lt = lq - fs[q].Nblue;
@@ -1640,8 +1641,8 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
                 group_max = std::max(group_max, group);
             }
             const int lkn = tl.nK > 0 ? (int)lines.size() : 0;       // lines the linked continua feed
-            const size_t lds_cols = ((size_t)2 * LSX_MAX_FAST * c->L + c->L + (size_t)4 * (3 + lkn) * LSX_FGC_ROWS * c->L) * sizeof(double);
-            const bool cols = simple && group_max <= LSX_FAST_NQ && c->L % 2 == 0 && lkn <= 2 && lds_cols <= 64 * 1024 && !getenv("LSX_FAST_ROWS");
+            const size_t lds_cols = ((size_t)2 * LSX_FGC_MAXF * c->L + c->L + (size_t)4 * (3 + lkn) * LSX_FGC_ROWS * c->L) * sizeof(double);
+            const bool cols = simple && group_max <= LSX_FAST_NQ && (int)fast.size() <= LSX_FGC_MAXF && c->L % 2 == 0 && lkn <= 2 && lds_cols <= 64 * 1024 && !getenv("LSX_FAST_ROWS");
             tl.fast_simple = simple ? (cols ? 2 : 1) : 0;
             if (!simple) c->fast_generic = true;
             (tl.fast_simple == 2 ? c->fast_cols[lkclass(tl)] : c->fast_rest).push_back((int)c->tiles.size());
@@ -1996,7 +1997,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
     auto launch_fast_cols = [&](hipStream_t st, const int* d_list, size_t n, int v) -> int {
         FastParams fq = ff;
         fq.fast_tiles = d_list; fq.n_fast_tiles = (int)n;
-        const size_t sm = ((size_t)2 * c->nF_max * c->L + c->L + (size_t)4 * (3 + kLkLines[v]) * LSX_FGC_ROWS * c->L) * sizeof(double);
+        const size_t sm = ((size_t)2 * LSX_FGC_MAXF * c->L + c->L + (size_t)4 * (3 + kLkLines[v]) * LSX_FGC_ROWS * c->L) * sizeof(double);
         if (sm > 64 * 1024) return fail(LSX_EUNSUPPORTED, "fast-continuum epilogue (column mapped) needs %zu B of LDS", sm);
         dim3 grid((unsigned)(((size_t)c->ncol * c->Nspace + 4 * LSX_FGC_ROWS - 1) / (4 * LSX_FGC_ROWS)), (unsigned)n);
 #define LSX_FC(NLCV) if (kLkLines[v] == NLCV) hipLaunchKernelGGL((k_fast_gamma_cols<NLCV>), grid, dim3(256), sm, st, fq);
