@@ -129,3 +129,52 @@ def test_profiles_must_be_set_before_a_formal_solution(hip_lib):
     e.set_line_profiles(1, aD[1:], vB[1:], vlos[1:])
     assert e.formal_sol_gamma() == 1.0
     e.close()
+
+
+@pytest.mark.parametrize('name,ncol,nuniq', [('falc_ca.npz', 1000, 8), ('falc_cah.npz', 1250, 10)])
+def test_full_size_batches_by_size_independent_properties(hip_lib, oracle_lib, name, ncol, nuniq):
+    """BASELINE sizes (C3: 1000 CaII columns, C4: one GPU's 1250 Ca+H columns), where the oracle would take minutes:
+    columns are independent 1-D problems, so a batch built from `nuniq` distinct columns repeated in a scrambled order must
+    give every copy the bits its original gets in a batch of `nuniq` alone -- whatever its position, its neighbours, the
+    launch path (per-class launches here, the fused kernel there) or the size of the grid; the small batch itself is
+    checked against the oracle.  Also: a frozen column keeps its state bit for bit while its neighbours iterate
+    (lsx_set_active_columns), and the device-side monitors equal the maxima of the per-column ones."""
+    prob, base, raw = fixtures.load_problem_npz(golden(name), phi_compact=False)
+    blk, prof = synth.perturbed_columns(prob, base, raw, ncol=nuniq, seed=77, vlos_sigma=2.0e3)
+    rng = np.random.default_rng(5)
+    src = np.concatenate([np.arange(nuniq), rng.integers(0, nuniq, ncol - nuniq)])
+    big_blk = type(blk).concatenate([blk.slice(int(s), int(s) + 1) for s in src])
+    big_prof = tuple(p[src] for p in prof)
+    small, big = Engine(prob, nuniq, lib=hip_lib), Engine(prob, ncol, lib=hip_lib)
+    synth.load_columns(small, blk, prof)
+    synth.load_columns(big, big_blk, big_prof)
+    ora = Engine(prob, nuniq, lib=oracle_lib)
+    synth.load_columns(ora, blk, prof)
+    oracle_lib.dll.lsx_oracle_set_threads(ora._h, 8)
+    for it in range(1, 7):
+        dJs, dJb = small.formal_sol_gamma(), big.formal_sol_gamma()
+        ora.formal_sol_gamma()
+        assert dJs == dJb
+        if it > 3:
+            assert small.stat_equil() == big.stat_equil()
+            ora.stat_equil()
+    for what in (_capi.LSX_J, _capi.LSX_I, _capi.LSX_N, _capi.LSX_GAMMA, _capi.LSX_DJ_COL, _capi.LSX_DPOPS_COL):
+        a, b = small.get(what), big.get(what)
+        assert np.array_equal(b, a[src]), what                     # bit for bit, every copy
+    tol = 1e-8
+    assert relerr(small.get(_capi.LSX_N), ora.get(_capi.LSX_N)) < tol and relerr(small.get(_capi.LSX_I), ora.get(_capi.LSX_I)) < tol
+    table, fused = class_table(hip_lib, big)
+    assert fused == 0 and all(launches == 6 for _, launches in table.values())
+    assert class_table(hip_lib, small)[1] == 6                     # the small batch took the fused kernel
+    # frozen columns: every second column is frozen for two more iterations
+    mask = (np.arange(ncol) % 2 == 0)
+    n0, J0 = big.get(_capi.LSX_N), big.get(_capi.LSX_J)
+    big.set_active_columns(mask)
+    for _ in range(2):
+        big.formal_sol_gamma()
+        big.stat_equil()
+    n1, J1 = big.get(_capi.LSX_N), big.get(_capi.LSX_J)
+    assert np.array_equal(n1[~mask], n0[~mask]) and np.array_equal(J1[~mask], J0[~mask])
+    assert not np.array_equal(n1[mask], n0[mask])
+    big.set_active_columns(None)
+    small.close(); big.close(); ora.close()
