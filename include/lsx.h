@@ -321,6 +321,38 @@ typedef struct lsx_continuum_model {
 } lsx_continuum_model;
 int lsx_continuum_alpha(const lsx_continuum_model* cont, int32_t n, const double* wavelength, double* alpha);
 
+/* ---- higher-order formal solver: monotonic piecewise-parabolic short characteristics ----------------
+ * The extension README.md:19 of the reference names (Auer & Paletou 1994, A&A 285, 675); the reference itself has no such
+ * routine, so there is nothing of the reference to pin this on (parity unpinned: property tests only).  Along a ray, at
+ * point k with upwind neighbour u = k - dk and downwind neighbour d = k + dk, t = optical distance from k towards u:
+ *   dtau_u = (chi_u + chi_k)/2 |z_u - z_k| / mu,   dtau_d likewise,   p = (S_u - S_k)/dtau_u,   q = (S_k - S_d)/dtau_d
+ *   S(t) = S_k + a t + b t^2 on the upwind interval, through (0, S_k) and (dtau_u, S_u) with slope a at k: b = (p - a)/dtau_u
+ *   I_k  = I_u e^{-dtau_u} + w0 S_k + w1 a + w2 b,        w_n = int_0^{dtau_u} t^n e^{-t} dt  (lsx_w3)
+ * The slope is the weighted harmonic mean of the two difference quotients (Fritsch & Butland 1984; Auer 2003),
+ *   a = p q / (alpha q + (1 - alpha) p),  alpha = (1 + dtau_d/(dtau_u + dtau_d))/3   if p q > 0,   a = 0 otherwise,
+ * limited to |a| <= 2 |p|: then S'(t) keeps the sign of p over the whole interval -- the parabola never leaves the range of
+ * the data (monotonic) -- and a depends CONTINUOUSLY on the data.  (A hard switch "parabola through the three points,
+ * linear where it overshoots" was measured first: the accelerated lambda iteration then flips between the two branches from
+ * one iteration to the next and stalls, FALC CaII at dJ = 0.1.)  Third order in the grid spacing where S is monotonic.
+ *   Psi*_k = dI_k/dS_k at fixed I_u, / chi_k = [w0 + (w1 - w2/dtau_u) da/dS_k - w2/dtau_u^2] / chi_k,
+ *   da/dS_k = (beta p^2/dtau_d - alpha q^2/dtau_u)/(alpha q + beta p)^2 (beta = 1 - alpha), -2/dtau_u where the limit is
+ *   active, 0 where a = 0.
+ * Last point of the ray (no downwind neighbour): a = p (the linear rule with its own interval's weights).  First point:
+ * I = Istart, Psi* = 0, as formal_solver.py:116-118.  Arrays as lsx_piecewise_1d_impl. */
+int lsx_piecewise_parabolic_1d_impl(int32_t device, int32_t nray, int32_t Nspace, const double* height,
+                                    const double* mu, const int32_t* to_obs, const double* Istart,
+                                    const double* chi, const double* S, double* I, double* PsiStar);
+/* w0, w1, w2 for n optical-depth steps: below 0.25 the series w_n = sum_m (-1)^m dtau^(m+n+1) / (m! (m+n+1)), m <= 11
+ * (the closed forms cancel there: at the linear rule's switch, 5e-4, w2 would keep 11 digits), (1, 1, 2) above 50, else
+ * w0 = 1 - e, w1 = w0 - dtau e, w2 = 2 w1 - dtau^2 e.  Relative accuracy 1e-13 throughout.  w: [n][3]. */
+int lsx_w3(int32_t device, int32_t n, const double* dtau, double* w);
+
+/* Which rule the context's formal solution uses from the next lsx_formal_sol_gamma on: LSX_SOLVER_LINEAR (default, the
+ * reference's piecewise_linear_1d) or LSX_SOLVER_PARABOLIC (the rule above, boundary conditions of
+ * formal_solver.py:203-209 unchanged). */
+enum { LSX_SOLVER_LINEAR = 0, LSX_SOLVER_PARABOLIC = 1 };
+int lsx_set_formal_solver(lsx_ctx* ctx, int32_t solver);
+
 /* Measurement hooks (bench.py): time `reps` back-to-back FS calls with device events
  * on the context's stream.  ms_total = whole FS call (all kernels), ms_sweep = the
  * dominant sweep kernel(s) alone, both averaged per call. */

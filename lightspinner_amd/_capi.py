@@ -14,6 +14,7 @@ ABI_VERSION = 1
 
 # item selectors (include/lsx.h)
 LSX_I, LSX_J, LSX_N, LSX_GAMMA, LSX_DJ_COL, LSX_DPOPS_COL, LSX_NSTAR, LSX_C, _, _, LSX_PHI, LSX_WPHI, LSX_VBROAD, LSX_ADAMP = range(14)
+LSX_SOLVER_LINEAR, LSX_SOLVER_PARABOLIC = 0, 1
 LSX_COLL_OMEGA, LSX_COLL_CI, LSX_COLL_CE = range(3)
 
 ERRORS = {1: 'LSX_EINVAL', 2: 'LSX_EDEVICE', 3: 'LSX_ESINGULAR', 5: 'LSX_EUNSUPPORTED'}
@@ -92,6 +93,7 @@ REQUIRED_SYMBOLS = (
     'lsx_abi_version', 'lsx_algorithmic_bytes_per_column', 'lsx_set_active_columns', 'lsx_set_line_profiles',
     'lsx_piecewise_1d_impl', 'lsx_w2', 'lsx_monitors', 'lsx_set_atomic_data', 'lsx_set_atmosphere',
     'lsx_wavelength_grid', 'lsx_active_set', 'lsx_line_wavelength', 'lsx_continuum_alpha',
+    'lsx_piecewise_parabolic_1d_impl', 'lsx_w3', 'lsx_set_formal_solver',
 )
 
 
@@ -150,6 +152,10 @@ class LsxLibrary:
         d.lsx_piecewise_1d_impl.argtypes = [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.POINTER(C.c_int32), _dp, _dp, _dp,
                                             _dp, _dp]
         d.lsx_w2.argtypes = [C.c_int32, C.c_int32, _dp, _dp]
+        d.lsx_w3.argtypes = [C.c_int32, C.c_int32, _dp, _dp]
+        d.lsx_piecewise_parabolic_1d_impl.argtypes = [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.POINTER(C.c_int32), _dp, _dp, _dp,
+                                                      _dp, _dp]
+        d.lsx_set_formal_solver.argtypes = [C.c_void_p, C.c_int32]
         ip = C.POINTER(C.c_int32)
         d.lsx_wavelength_grid.argtypes = [C.c_int32, C.POINTER(LsxTransGrid), C.c_int32, _dp, C.c_double, C.c_int32, _dp, ip, ip, ip]
         d.lsx_active_set.argtypes = [C.c_int32, C.c_int32, ip, ip, C.POINTER(C.c_uint8)]
@@ -197,7 +203,11 @@ class LsxLibrary:
         return I, Psi
 
 
-    def piecewise_1d_impl(self, height, mu, to_obs, Istart, chi, S, device=0):
+    def piecewise_parabolic_1d_impl(self, height, mu, to_obs, Istart, chi, S, device=0):
+        """Batched monotonic piecewise-parabolic short characteristics (include/lsx.h, N4); arguments as piecewise_1d_impl."""
+        return self.piecewise_1d_impl(height, mu, to_obs, Istart, chi, S, device=device, _entry='lsx_piecewise_parabolic_1d_impl')
+
+    def piecewise_1d_impl(self, height, mu, to_obs, Istart, chi, S, device=0, _entry='lsx_piecewise_1d_impl'):
         """Batched formal_solver.piecewise_1d_impl (formal_solver.py:46-142): incident intensity handed over."""
         chi = f64(chi)
         S = f64(S, chi.shape)
@@ -212,9 +222,8 @@ class LsxLibrary:
             raise ValueError('to_obs must be [nray]')
         I = np.empty_like(chi)
         Psi = np.empty_like(chi)
-        self.check(self.dll.lsx_piecewise_1d_impl(device, nray, ns, _ptr(height), _ptr(mu),
-                                                  to_obs.ctypes.data_as(C.POINTER(C.c_int32)), _ptr(Istart),
-                                                  _ptr(chi), _ptr(S), _ptr(I), _ptr(Psi)))
+        self.check(getattr(self.dll, _entry)(device, nray, ns, _ptr(height), _ptr(mu), to_obs.ctypes.data_as(C.POINTER(C.c_int32)),
+                                             _ptr(Istart), _ptr(chi), _ptr(S), _ptr(I), _ptr(Psi)))
         return I, Psi
 
     # -- wavelength grid and active set (host side of the library) --------------------------------------------------
@@ -267,6 +276,13 @@ class LsxLibrary:
         else:
             m.hydrogenic, m.alpha0, m.E_i, m.E_j, m.stage_j = 1, float(alpha0), float(E_i), float(E_j), int(stage_j)
         self.check(self.dll.lsx_continuum_alpha(C.byref(m), w.shape[0], _ptr(w), _ptr(out)))
+        return out
+
+    def w3(self, dtau, device=0):
+        """weights of the parabolic rule (include/lsx.h, N4) -> [n][3] (w0, w1, w2)"""
+        dtau = f64(dtau).reshape(-1)
+        out = np.empty((dtau.shape[0], 3))
+        self.check(self.dll.lsx_w3(device, dtau.shape[0], _ptr(dtau), _ptr(out)))
         return out
 
     def w2(self, dtau, device=0):

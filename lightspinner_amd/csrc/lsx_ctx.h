@@ -77,6 +77,7 @@ struct lsx_ctx {
     unsigned long long* d_singular = nullptr;
     std::vector<uint8_t> phi_set;    // per column: line profiles have been handed over or built
     size_t n_phi_set = 0;
+    int solver = 0;               // LSX_SOLVER_* (lsx_set_formal_solver)
     bool opt_se_lds = false, opt_trace_classes = false, opt_serial = false;   // LSX_SE_LDS / LSX_TRACE_CLASSES, read once in lsx_create
     long fused_launches = 0;
     uint8_t* d_colmask = nullptr; // per-column activity, nullptr = all active

@@ -231,6 +231,58 @@ static __device__ __forceinline__ void w2(double dtau, double& w0, double& w1, c
     w1 = small ? t1 : a1;
 }
 
+// Weights of the parabolic rule (include/lsx.h, N4): w_n = int_0^dtau t^n e^-t dt, n = 0, 1, 2; same regimes and the same
+// exponential as w2.
+static __device__ __forceinline__ void w3(double dtau, double& w0, double& w1, double& w2q, const lds_f64* exp2_tab)
+{
+    const bool small = dtau < 0.25;      // series of twelve terms: the closed forms cancel here (oracle/lsx_oracle.c, w3)
+    const bool large = dtau > 50.0;
+    double a0 = 1.0, a1 = 1.0, a2 = 2.0;
+    if (__builtin_amdgcn_ballot_w64(!(small || large)) != 0) {
+        const double dc = fmin(dtau, 700.0);
+        const double e = exp_tab64(-dc, exp2_tab);
+        a0 = 1.0 - e;
+        a1 = a0 - dc * e;
+        a2 = 2.0 * a1 - (dc * dc) * e;
+    }
+    const double x = dtau;
+    const double s0 = x * (1.0 / 1.0 + x * (-1.0 / 2.0 + x * (1.0 / 6.0 + x * (-1.0 / 24.0 + x * (1.0 / 120.0 + x * (-1.0 / 720.0 + x * (1.0 / 5040.0 + x * (-1.0 / 40320.0 + x * (1.0 / 362880.0 + x * (-1.0 / 3628800.0 + x * (1.0 / 39916800.0 + x * (-1.0 / 479001600.0))))))))))));
+    const double s1 = x * x * (1.0 / 2.0 + x * (-1.0 / 3.0 + x * (1.0 / 8.0 + x * (-1.0 / 30.0 + x * (1.0 / 144.0 + x * (-1.0 / 840.0 + x * (1.0 / 5760.0 + x * (-1.0 / 45360.0 + x * (1.0 / 403200.0 + x * (-1.0 / 3991680.0 + x * (1.0 / 43545600.0 + x * (-1.0 / 518918400.0))))))))))));
+    const double s2 = x * x * x * (1.0 / 3.0 + x * (-1.0 / 4.0 + x * (1.0 / 10.0 + x * (-1.0 / 36.0 + x * (1.0 / 168.0 + x * (-1.0 / 960.0 + x * (1.0 / 6480.0 + x * (-1.0 / 50400.0 + x * (1.0 / 443520.0 + x * (-1.0 / 4354560.0 + x * (1.0 / 47174400.0 + x * (-1.0 / 558835200.0))))))))))));
+    w0 = small ? s0 : (large ? 1.0 : a0);
+    w1 = small ? s1 : (large ? 1.0 : a1);
+    w2q = small ? s2 : (large ? 2.0 : a2);
+}
+
+// one point of the monotonic piecewise-parabolic recurrence (include/lsx.h, N4); IEEE divisions: this rule is not the hot one
+struct Para { double I, Lam; };
+static __device__ __forceinline__ Para parabolic_point(double Iu, double S_u, double S_k, double S_d, double dtau_u, double dtau_d, bool has_d,
+                                                       const lds_f64* etab)
+{
+    double w0, w1, w2q;
+    w3(dtau_u, w0, w1, w2q, etab);
+    const double p = (S_u - S_k) / dtau_u;
+    double a = p, dadS = -1.0 / dtau_u;                               // end point: the linear rule
+    if (has_d) {
+        const double q = (S_k - S_d) / dtau_d;
+        if (p * q > 0.0) {
+            const double alpha = (1.0 + dtau_d / (dtau_u + dtau_d)) / 3.0, beta = 1.0 - alpha;
+            const double den = alpha * q + beta * p;
+            a = p * q / den;
+            dadS = (beta * p * p / dtau_d - alpha * q * q / dtau_u) / (den * den);
+            if (fabs(a) > 2.0 * fabs(p)) { a = 2.0 * p; dadS = -2.0 / dtau_u; }
+        } else {
+            a = 0.0;
+            dadS = 0.0;
+        }
+    }
+    const double b = (p - a) / dtau_u;
+    Para r;
+    r.I = Iu * (1.0 - w0) + w0 * S_k + w1 * a + w2q * b;
+    r.Lam = w0 + (w1 - w2q / dtau_u) * dadS - w2q / (dtau_u * dtau_u);
+    return r;
+}
+
 // DPP (VALU cross-lane moves, no LDS crossbar traffic).  The total of the 64 lanes ends up in
 // lane 63 (the lane that stores it).
 template <int CTRL, int ROW_MASK>

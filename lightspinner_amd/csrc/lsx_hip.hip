@@ -1171,6 +1171,51 @@ k_piecewise(int nray, int Ns, const double* __restrict__ z, const double* __rest
     Po[kE] = (w0 - w1 / dtau) / c[kE];
 }
 
+// N4 (include/lsx.h): monotonic piecewise-parabolic short characteristics for independent rays, one ray per thread;
+// one point of the recurrence as a device function the sweep shares
+__global__ void __launch_bounds__(64)
+k_piecewise_parabolic(int nray, int Ns, const double* __restrict__ z, const double* __restrict__ mu, const int* __restrict__ to_obs,
+                      const double* __restrict__ Istart, const double* __restrict__ chi, const double* __restrict__ S,
+                      double* __restrict__ I, double* __restrict__ Psi, const double* __restrict__ exp2_tab)
+{
+    __shared__ double etab_s[LSX_EXP_TAB];
+    for (int e = threadIdx.x; e < LSX_EXP_TAB; e += blockDim.x) etab_s[e] = exp2_tab[e];
+    __syncthreads();
+    const lds_f64* etab = (const lds_f64*)etab_s;
+    const int r0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = r0 < nray ? r0 : nray - 1;                   // every lane walks a ray (w3 is wave-wide); the spare ones store nothing
+    const double* c = chi + (size_t)r * Ns;
+    const double* s = S + (size_t)r * Ns;
+    double* Io = I + (size_t)r * Ns;
+    double* Po = Psi + (size_t)r * Ns;
+    const double zmu = 1.0 / mu[r];
+    const int up = to_obs[r];
+    const int dk = up ? -1 : 1, kS = up ? Ns - 1 : 0, kE = up ? 0 : Ns - 1;
+    double Iu = Istart[r];
+    if (r0 < nray) { Io[kS] = Iu; Po[kS] = 0.0; }
+    for (int k = kS + dk;; k += dk) {
+        const bool has_d = k != kE;
+        const double dtau_u = 0.5 * (c[k - dk] + c[k]) * zmu * fabs(z[k - dk] - z[k]);
+        const double dtau_d = has_d ? 0.5 * (c[k] + c[k + dk]) * zmu * fabs(z[k] - z[k + dk]) : 1.0;
+        const Para p = parabolic_point(Iu, s[k - dk], s[k], has_d ? s[k + dk] : 0.0, dtau_u, dtau_d, has_d, etab);
+        if (r0 < nray) { Io[k] = p.I; Po[k] = p.Lam / c[k]; }
+        Iu = p.I;
+        if (!has_d) break;
+    }
+}
+__global__ void __launch_bounds__(64)
+k_w3(int n, const double* __restrict__ dtau, double* __restrict__ out, const double* __restrict__ exp2_tab)
+{
+    __shared__ double etab_s[LSX_EXP_TAB];
+    for (int e = threadIdx.x; e < LSX_EXP_TAB; e += blockDim.x) etab_s[e] = exp2_tab[e];
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const double x = dtau[i < n ? i : n - 1];
+    double w0, w1, w2q;
+    w3(x, w0, w1, w2q, (const lds_f64*)etab_s);
+    if (i < n) { out[3 * i] = w0; out[3 * i + 1] = w1; out[3 * i + 2] = w2q; }
+}
+
 // formal_solver.py:14-44 on an array: the sweep's w2, one value per lane
 __global__ void __launch_bounds__(64)
 k_w2(int n, const double* __restrict__ dtau, double* __restrict__ out, const double* __restrict__ exp2_tab)
@@ -2015,8 +2060,10 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
     };
     int rc2 = LSX_OK;
     if (timed) HIPCHK(hipEventRecord(c->ev0, c->stream));
-    // small batches: one fused launch (n_class_tiles == ntile, identity tile list is not needed)
-    if (c->ncol < 32) {
+    // small batches: one fused launch (n_class_tiles == ntile, identity tile list is not needed); the parabolic rule (N4) has one
+    // generic instance for every tile and takes the same route at any size
+    const bool parabolic = c->solver == LSX_SOLVER_PARABOLIC;
+    if (c->ncol < 32 || parabolic) {
         if (has_fast && (rc2 = launch_prepass(c->stream, c->d_fast_tiles, c->fast_tiles.size()))) return rc2;
         const long nblocks = (long)c->tiles.size() * c->ncol;
         p.class_tiles = nullptr;
@@ -2030,8 +2077,9 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
                            (size_t)(npt_max > 0 ? 2 * 2 * npt_max * LSX_WAVE : 0) * sizeof(double) +
                            (size_t)(npt_max >= 3 ? npt_max * (npt_max - 1) * 5 : 0) * sizeof(double) +
                            (size_t)(c->corr_col && npt_max > 0 ? 2 * npt_max * LSX_WAVE : 0) * sizeof(double);
+        if (nblocks > 0x7fffffffL) return fail(LSX_EUNSUPPORTED, "grid too large");
         c->fused_launches++;
-        hipError_t e = lsx_launch_sweep(&p, -2, (int)nblocks, lds, c->stream);
+        hipError_t e = lsx_launch_sweep(&p, parabolic ? -4 : -2, (int)nblocks, lds, c->stream);
         if (e != hipSuccess) return fail(LSX_EDEVICE, "sweep launch (fused): %s", hipGetErrorString(e));
         if (has_fast && (rc2 = launch_fast_gamma(c->stream, c->fast_cols, c->d_fast_cols, c->d_fast_rest, c->fast_rest.size()))) return rc2;
     } else {
@@ -2360,7 +2408,7 @@ int pw_scratch(int device, size_t bytes, PwScratch** out)
 
 int run_piecewise(int32_t device, int32_t nray, int32_t Nspace, const double* height, const double* temperature,
                   const double* mu, const int32_t* to_obs, const double* wav, const double* Istart, const double* chi,
-                  const double* S, double* I, double* PsiStar, const char* who)
+                  const double* S, double* I, double* PsiStar, const char* who, bool parabolic = false)
 {
     if (nray < 0 || Nspace < 3) return fail(LSX_EINVAL, "%s: need Nspace >= 3 (formal_solver.py:120-139)", who);
     if (nray == 0) return LSX_OK;
@@ -2394,8 +2442,12 @@ int run_piecewise(int32_t device, int32_t nray, int32_t Nspace, const double* he
     HIPCHK(hipMemcpyAsync(dto, to_obs, nr * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(dchi, chi, nr * Ns * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(dS, S, nr * Ns * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_piecewise, dim3((nray + 63) / 64), dim3(64), 0, st, nray, Nspace, dz, dT, dmu, dto, dwav,
-                       Istart ? dI0 : nullptr, dchi, dS, dI, dP, q->exp_tab);
+    if (parabolic)
+        hipLaunchKernelGGL(k_piecewise_parabolic, dim3((nray + 63) / 64), dim3(64), 0, st, nray, Nspace, dz, dmu, dto, dI0, dchi, dS, dI, dP,
+                           q->exp_tab);
+    else
+        hipLaunchKernelGGL(k_piecewise, dim3((nray + 63) / 64), dim3(64), 0, st, nray, Nspace, dz, dT, dmu, dto, dwav,
+                           Istart ? dI0 : nullptr, dchi, dS, dI, dP, q->exp_tab);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(I, dI, nr * Ns * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(PsiStar, dP, nr * Ns * 8, hipMemcpyDeviceToHost, st));
@@ -2420,6 +2472,40 @@ int lsx_piecewise_1d_impl(int32_t device, int32_t nray, int32_t Nspace, const do
     if (nray > 0 && !Istart) return fail(LSX_EINVAL, "lsx_piecewise_1d_impl: null array pointer");
     return run_piecewise(device, nray, Nspace, height, nullptr, mu, to_obs, nullptr, Istart, chi, S, I, PsiStar,
                          "lsx_piecewise_1d_impl");
+}
+
+int lsx_piecewise_parabolic_1d_impl(int32_t device, int32_t nray, int32_t Nspace, const double* height, const double* mu,
+                                    const int32_t* to_obs, const double* Istart, const double* chi, const double* S, double* I,
+                                    double* PsiStar)
+{
+    if (nray > 0 && !Istart) return fail(LSX_EINVAL, "lsx_piecewise_parabolic_1d_impl: null array pointer");
+    return run_piecewise(device, nray, Nspace, height, nullptr, mu, to_obs, nullptr, Istart, chi, S, I, PsiStar,
+                         "lsx_piecewise_parabolic_1d_impl", true);
+}
+
+int lsx_w3(int32_t device, int32_t n, const double* dtau, double* w)
+{
+    if (n < 0 || (n > 0 && (!dtau || !w))) return fail(LSX_EINVAL, "lsx_w3: bad argument");
+    if (n == 0) return LSX_OK;
+    std::lock_guard<std::mutex> lock(g_pw_mutex);
+    PwScratch* q = nullptr;
+    int rc = pw_scratch(device, (size_t)n * 4 * sizeof(double), &q);
+    if (rc) return rc;
+    double* din = reinterpret_cast<double*>(q->buf);
+    double* dout = din + n;
+    HIPCHK(hipMemcpyAsync(din, dtau, (size_t)n * 8, hipMemcpyHostToDevice, q->stream));
+    hipLaunchKernelGGL(k_w3, dim3((n + 63) / 64), dim3(64), 0, q->stream, n, din, dout, q->exp_tab);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(w, dout, (size_t)n * 24, hipMemcpyDeviceToHost, q->stream));
+    HIPCHK(hipStreamSynchronize(q->stream));
+    return LSX_OK;
+}
+
+int lsx_set_formal_solver(lsx_ctx* c, int32_t solver)
+{
+    if (!c || (solver != LSX_SOLVER_LINEAR && solver != LSX_SOLVER_PARABOLIC)) return fail(LSX_EINVAL, "lsx_set_formal_solver: bad argument");
+    c->solver = solver;
+    return LSX_OK;
 }
 
 int lsx_w2(int32_t device, int32_t n, const double* dtau, double* w0w1)

@@ -762,6 +762,257 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
 #undef CETA
 }
 
+
+// ---- N4: the same tile with the monotonic piecewise-parabolic rule (include/lsx.h) -----------------------------------
+// The parabolic rule at depth k needs chi and S of the DOWNWIND neighbour, so the formal solution (and everything that
+// follows it: angle sums, Gamma integrands, J) of depth m runs one step behind the opacities: step t evaluates chi, S at
+// depth t, then finishes depth t - 1.  One generic instance for every tile (runtime slot loops, lane-private LDS cells for
+// the level bookkeeping, linked continua at run time); the cells of depth m are refilled before its Gamma pass.  Not tuned:
+// this is the "what comes next" row, the linear rule is the product path.
+template <int NR, bool SCAL>
+__device__ __forceinline__ void sweep_tile_parabolic(const SweepParams& p, const int vb, const int tile_id)
+{
+    extern __shared__ double lds_raw[];
+    lds_f64* const etab = (lds_f64*)lds_raw;
+    lds_f64* const lds = etab + LSX_EXP_TAB;
+    const int lane = threadIdx.x & (LSX_WAVE - 1);
+    const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ntile = p.ntile_total;
+    const int col = vb / p.n_class_tiles;
+    const auto* tilep = LSX_CONST(DevTile, p.tiles) + tile_id;
+    const int la0 = tilep->la0, nla = tilep->nla, slot0 = tilep->slot0;
+    const int nP = tilep->nP, nF = tilep->nF;
+    const bool LK = tilep->nK > 0;
+    const int nLt = tilep->nL;
+    const auto* slots = LSX_CONST(DevSlot, p.slots) + slot0;
+    const int Ns = p.Nspace, Nspect = p.Nspect;
+    const int Nrays = NR > 0 ? NR : p.Nrays;
+    constexpr int NRD = NR > 0 ? NR : 1;
+    const int L = NR > 0 ? LSX_WAVE / NRD : p.L;
+    const int mu_raw = lane / L;
+    const int j_raw = lane - mu_raw * L;
+    const bool valid = mu_raw < Nrays && j_raw < nla;
+    const int mu = mu_raw < Nrays ? mu_raw : Nrays - 1;
+    const int j = j_raw < nla ? j_raw : nla - 1;
+    const int la = la0 + j;
+    const bool lead = valid && mu_raw == 0;
+    const int rows = 2 * p.ncell_lev + p.ncell_atom + 1;
+    lds_f64* const wrow = lds + (size_t)dir * rows * LSX_WAVE + lane;
+#define CCHI(c) wrow[(2 * (c)) * LSX_WAVE]
+#define CU(c) wrow[(2 * (c) + 1) * LSX_WAVE]
+#define CETA(a) wrow[(2 * p.ncell_lev + (a)) * LSX_WAVE]
+    lds_f64* const xrow = lds + (size_t)dir * rows * LSX_WAVE + (size_t)(rows - 1) * LSX_WAVE;
+    lds_f64* const xwg = lds + (size_t)2 * rows * LSX_WAVE;
+    const auto* n_col = LSX_CONST(double, p.n + (size_t)col * p.NLtot * Ns);
+    const auto* wphi_col = LSX_CONST(double, p.wphi + (size_t)col * p.Nlines * Ns);
+    const auto* z = LSX_CONST(double, p.height + (size_t)col * Ns);
+    const auto* tcol = LSX_CONST(double, p.temperature + (size_t)col * Ns);
+    const size_t tbase = ((size_t)col * ntile + tile_id) * Ns * L;
+    const double* __restrict__ bgchi = (nF > 0 ? p.bgxchi_T : p.bgchi_T) + tbase;
+    const double* __restrict__ bgeta = (nF > 0 ? p.bgxeta_T : p.bgeta_T) + tbase;
+    double* __restrict__ psibar = p.Psi2_T + ((size_t)dir * p.ncol * ntile) * Ns * L + tbase;
+    const double* __restrict__ Jdag = p.Jdag_T + tbase;
+    double* __restrict__ Jnew = p.Jnew_T + tbase;
+    const bool sca_l = SCAL && p.sca_per_lambda;
+    const double* __restrict__ sca = sca_l ? p.sca + tbase : p.sca + (size_t)col * Ns;
+    const double* __restrict__ phi_col = p.phi_T + (size_t)col * p.phi_col_stride;
+    const double* __restrict__ Eb = p.E_T + tbase;
+    const auto* nsr_col = LSX_CONST(double, p.nsr + (size_t)col * p.Ncont * Ns);
+    const size_t plane = (size_t)Ns * L;
+    const double* __restrict__ corr = LK ? p.corr_T + (size_t)col * p.corr_col_stride + tilep->corr_off : nullptr;
+    double* __restrict__ ppsum = LK ? p.Psi3_T + ((size_t)dir * p.ncol + col) * p.pp_col_stride + tilep->pp_off : nullptr;
+    double* __restrict__ gpart = p.Gpart + ((size_t)col * p.nslot_total + slot0) * 4 * Ns;
+    etab[threadIdx.x] = p.exp2_tab[threadIdx.x];
+    __syncthreads();
+
+    const double wav = p.wavelength[la];
+    const double u_la = p.u_la[la];
+    const double zmu_l = p.zmu[mu];
+    const double wmuh_l = valid ? p.wmuh[mu] : 0.0;
+    const double wq_l = wmuh_l * (4.0 * kPi);
+    const bool compact = p.phi_compact != 0;
+    const int kS = dir ? Ns - 1 : 0;
+    const int dk = dir ? -1 : 1;
+    const int raysel = compact ? 0 : dir * Ns * Nrays + mu;
+    const int kmul = compact ? 1 : Nrays;
+    unsigned pact = 0;
+    for (int u = 0; u < nP; ++u) {
+        const int l = la - slots[u].Nblue;
+        if (l >= 0 && l < slots[u].Nlam && p.active[slots[u].trans * Nspect + la] != 0) pact |= 1u << u;
+    }
+    // one per-ray slot at depth k: rh_method.py:279-286, 453-455
+    struct SlotV { double pv, chi, Uji, Vij, eta, wla; };
+    auto slot_at = [&](int u, const SlotS& sl, int k) {
+        SlotV v;
+        const double ni = n_col[sl.noff_i + k], nj = n_col[sl.noff_j + k];
+        const bool a = (pact >> u) & 1u;
+        const int l = a ? la - sl.Nblue : 0;
+        v.wla = a ? p.wl[sl.wl_off + l] : 0.0;
+        if (sl.flags & SLOT_LINE) {
+            v.pv = a ? phi_col[sl.base + (k * kmul + raysel) * sl.len + (la - sl.first)] : 0.0;
+            v.Vij = sl.cB * v.pv;
+            v.Uji = sl.Uc * v.pv;
+            v.chi = (sl.cB * (ni - sl.g * nj)) * v.pv;
+            v.wla *= wphi_col[sl.wphi_off + k];
+        } else {
+            v.Vij = a ? p.alpha[sl.wl_off + l] : 0.0;
+            v.pv = (a ? nsr_col[sl.base + k] * Eb[k * L + j] : 0.0) * v.Vij;      // Vji
+            v.Uji = u_la * v.pv;
+            v.chi = ni * v.Vij - nj * v.pv;
+        }
+        v.eta = nj * v.Uji;
+        return v;
+    };
+    // opacity and source function at depth k (rh_method.py:601-632); cells: also fill the level / atom cells of that depth
+    auto opac = [&](int k, bool cells, double& chiTot, double& S) {
+        const unsigned kl = (unsigned)(k * L + j) * 8u;
+        chiTot = at(bgchi, kl);
+        const double scv = sca_l ? at(sca, kl) : LSX_CONST(double, sca)[k];
+        double etaTot = at(bgeta, kl) + scv * at(Jdag, kl);
+        for (int u = 0; u < nP; ++u) {
+            const SlotS sl = load_slot(slots + u, Ns);
+            const SlotV v = slot_at(u, sl, k);
+            if (cells) {
+                const int fl = sl.flags;
+                if (fl & SLOT_LI_CELL) cell_acc(&CCHI(sl.ci), v.chi, fl & SLOT_CHI_I_FIRST);
+                if (fl & SLOT_LJ_CELL) {
+                    cell_acc(&CCHI(sl.cj), -v.chi, fl & SLOT_CHI_J_FIRST);
+                    cell_acc(&CU(sl.cj), v.Uji, fl & SLOT_U_J_FIRST);
+                }
+                if (fl & SLOT_ETA_CELL) cell_acc(&CETA(sl.ca), v.eta, fl & SLOT_ETA_FIRST);
+            }
+            chiTot += v.chi;
+            etaTot += v.eta;
+        }
+        S = etaTot / chiTot;
+    };
+    // ---- boundary conditions: formal_solver.py:203-209 (unchanged) ----
+    double Iu = 0.0;
+    double c_u = 1.0, S_u = 0.0, c_k = 1.0, S_k = 0.0, c_d = 1.0, S_d = 0.0;     // upwind / local / downwind of the depth being finished
+    opac(kS, false, c_d, S_d);
+    if (dir) {
+        double c1, S1;
+        opac(kS + dk, false, c1, S1);
+        const double dtau_uw = zmu_l * (c_d + c1) * 0.5 * fabs(z[kS] - z[kS + dk]);
+        const double B0 = planck(tcol[Ns - 2], wav), B1 = planck(tcol[Ns - 1], wav);
+        Iu = B1 - (B0 - B1) / dtau_uw;
+    }
+    double dJ = 0.0;
+    auto gslot = [&](int k, int u, int e) -> double* { return gpart + ((u * 2 + e) * 2 + dir) * Ns + k; };
+
+    // finish depth m (visited by this wave at its step m): formal solution, angle sums, Gamma integrands, J
+    auto finish = [&](const int m, auto phase_c) {
+        constexpr int PH = decltype(phase_c)::value;
+        const int k = kS + dk * m;
+        const unsigned kl = (unsigned)(k * L + j) * 8u;
+        if constexpr (PH == 2) {
+            if (2 * m == Ns || 2 * m == Ns + 1) __syncthreads();
+        }
+        double I, Lam;
+        if (m == 0) {
+            I = Iu;
+            Lam = 0.0;
+        } else {
+            const bool has_d = m < Ns - 1;
+            const double dtau_u = (c_u + c_k) * (0.5 * fabs(z[k - dk] - z[k])) * zmu_l;
+            const double dtau_d = has_d ? (c_k + c_d) * (0.5 * fabs(z[k] - z[k + dk])) * zmu_l : 1.0;
+            const Para r = parabolic_point(Iu, S_u, S_k, has_d ? S_d : 0.0, dtau_u, dtau_d, has_d, etab);
+            I = r.I;
+            Lam = r.Lam;
+        }
+        const double Psi = Lam / c_k;
+        Iu = I;
+        if (m == Ns - 1 && dir == 1 && valid) p.Iout[((size_t)col * Nspect + la) * Nrays + mu] = I;
+        // angle quadrature: J (:640) and Psibar for the fast continua
+        xrow[lane] = wmuh_l * I;
+        __builtin_amdgcn_wave_barrier();
+        double Jsum = xrow[j];
+        for (int q = 1; q < Nrays; ++q) Jsum += xrow[q * L + j];
+        if (nF > 0) {
+            __builtin_amdgcn_wave_barrier();
+            xrow[lane] = wq_l * Psi;
+            __builtin_amdgcn_wave_barrier();
+            double sPsi = xrow[j];
+            for (int q = 1; q < Nrays; ++q) sPsi += xrow[q * L + j];
+            at(psibar, kl) = sPsi;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // Gamma integrands of the per-ray transitions at depth k (rh_method.py:643-681): cells of THIS depth first
+        {
+            double c0, s0;
+            opac(k, true, c0, s0);
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (int u = 0; u < nP; ++u) {
+            const SlotS sl = load_slot(slots + u, Ns);
+            const SlotV v = slot_at(u, sl, k);
+            const bool a = (pact >> u) & 1u;
+            const bool line = (sl.flags & SLOT_LINE) != 0;
+            double cEC = 0.0, cXi = 0.0, cXj = 0.0;
+            if (LK && u < nLt) {          // line slot of a tile with linked continua: corrections in, sum_mu w Psi* phi out
+                cEC = at(corr, (unsigned)((3 * u + 0) * plane) * 8u + kl);
+                cXi = at(corr, (unsigned)((3 * u + 1) * plane) * 8u + kl);
+                cXj = at(corr, (unsigned)((3 * u + 2) * plane) * 8u + kl);
+                __builtin_amdgcn_wave_barrier();
+                xrow[lane] = (wq_l * Psi) * v.pv;
+                __builtin_amdgcn_wave_barrier();
+                double sPP = xrow[j];
+                for (int q = 1; q < Nrays; ++q) sPP += xrow[q * L + j];
+                at(ppsum, (unsigned)(u * plane) * 8u + kl) = sPP;
+                __builtin_amdgcn_wave_barrier();
+            }
+            const int fl = sl.flags;
+            const double Vji = line ? sl.Vc * v.pv : v.pv;
+            const double etaA = ((fl & SLOT_ETA_CELL) ? CETA(sl.ca) : v.eta) + cEC;
+            const double chi_i = ((fl & SLOT_LI_CELL) ? CCHI(sl.ci) : v.chi) + cXi;
+            const double chi_j = ((fl & SLOT_LJ_CELL) ? CCHI(sl.cj) : -v.chi) + cXj;
+            const double U_j = (fl & SLOT_LJ_CELL) ? CU(sl.cj) : v.Uji;
+            const double U_i = (fl & SLOT_UI_READ) ? CU(sl.ci) : 0.0;
+            const double Ieff = I - Psi * etaA;                               // :652
+            const double g1 = (v.Uji + Vji * Ieff) - (chi_i * Psi) * U_j;     // :677
+            const double g2 = (v.Vij * Ieff) - (chi_j * Psi) * U_i;           // :680
+            const double wt = (a && valid) ? wq_l * v.wla : 0.0;
+            const double t = reduce_pair(wt * g1, wt * g2);
+            if (lane == 31) *gslot(k, u, 0) = t;
+            if (lane == 63) *gslot(k, u, 1) = t;
+        }
+        // J: the two directions meet at depth k at different steps
+        const double jd = at(Jdag, kl);
+        if constexpr (PH == 0) {
+            at(Jnew, kl) = Jsum;
+        } else if constexpr (PH == 1) {
+            if (lead) xwg[dir * LSX_WAVE + j] = Jsum;
+            __syncthreads();
+            if (lead && dir == 0) {
+                const double Jv = Jsum + xwg[LSX_WAVE + j];
+                at(Jnew, kl) = Jv;
+                dJ = nanmax(dJ, fabs(1.0 - jd / Jv));
+            }
+        } else {
+            const double Jv = at(Jnew, kl) + Jsum;
+            at(Jnew, kl) = Jv;
+            dJ = nanmax(dJ, fabs(1.0 - jd / Jv));
+        }
+    };
+    // step t: opacities of depth t + 1 (the downwind neighbour), then depth t is finished
+    auto advance = [&](int m) {
+        c_u = c_k; S_u = S_k;
+        c_k = c_d; S_k = S_d;
+        if (m + 1 < Ns) opac(kS + dk * (m + 1), false, c_d, S_d);
+    };
+    {
+        const int nA = Ns / 2;
+        for (int m = 0; m < nA; ++m) { advance(m); finish(m, std::integral_constant<int, 0>{}); }
+        if (Ns & 1) { advance(nA); finish(nA, std::integral_constant<int, 1>{}); }
+        for (int m = nA + (Ns & 1); m < Ns; ++m) { advance(m); finish(m, std::integral_constant<int, 2>{}); }
+    }
+    const double dJw = wave_max_nan(lead ? dJ : 0.0);
+    if (lane == 0) p.dJpart[((size_t)col * ntile + tile_id) * 2 + dir] = dJw;
+#undef CCHI
+#undef CU
+#undef CETA
+}
+
 // One kernel per (NPT, NR, SCAL) class; the host launches the classes of a call on separate streams
 // so they share the machine (a class alone would leave a tail).
 // register budget per class: tiles without per-ray slots fit 5 waves/SIMD, the others 4 (more would spill)
@@ -830,10 +1081,27 @@ lsx_sweep_kernel_all(const SweepParams p)
     else sweep_tile<-1, 0, NR, SCAL, false>(p, vb, tile_id);
 }
 
+
+// N4: every tile of every column through the parabolic instance (one launch, like the fused small-batch kernel)
+template <int NR, bool SCAL>
+__global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(LSX_WAVES_PER_EU)))
+lsx_sweep_kernel_parabolic(const SweepParams p)
+{
+    const int vb = blockIdx.x;
+    const int col = vb / p.ntile_total;
+    const int tile_id = vb - col * p.ntile_total;
+    if (p.colmask && LSX_CONST(uint8_t, p.colmask)[col] == 0) {
+        const size_t tb = (size_t)vb * p.Nspace * p.L;
+        for (int e = threadIdx.x; e < p.Nspace * p.L; e += 2 * LSX_WAVE) p.Jnew_T[tb + e] = p.Jdag_T[tb + e];
+        return;
+    }
+    sweep_tile_parabolic<NR, SCAL>(p, vb, tile_id);
+}
+
 template <int NR, bool SCAL>
 static void launch_class(const SweepParams& p, int code, dim3 g, dim3 b, size_t lds_bytes, hipStream_t st)
 {
-    // code: -2 fused, -1 generic, -3 generic with linked continua, else (per-ray slots) * 8 + (lines among them) + 64 if the
+    // code: -2 fused, -4 every tile with the parabolic rule (N4), -1 generic, -3 generic with linked continua, else (per-ray slots) * 8 + (lines among them) + 64 if the
     // class's tiles have linked continua (only classes with a line can) + 128 * TOPO (two-line classes)
 #define LSX_CASE(NPT, NL) \
     case NPT * 8 + NL: hipLaunchKernelGGL((lsx_sweep_kernel<NPT, NL, NR, SCAL, false>), g, b, lds_bytes, st, p); break;
@@ -841,6 +1109,7 @@ static void launch_class(const SweepParams& p, int code, dim3 g, dim3 b, size_t 
     case 64 + NPT * 8 + NL: hipLaunchKernelGGL((lsx_sweep_kernel<NPT, NL, NR, SCAL, true>), g, b, lds_bytes, st, p); break;
     switch (code) {
     case -2: hipLaunchKernelGGL((lsx_sweep_kernel_all<NR, SCAL>), g, b, lds_bytes, st, p); break;
+    case -4: hipLaunchKernelGGL((lsx_sweep_kernel_parabolic<NR, SCAL>), g, b, lds_bytes, st, p); break;
     case -3: hipLaunchKernelGGL((lsx_sweep_kernel<-1, 0, NR, SCAL, true>), g, b, lds_bytes, st, p); break;
     LSX_CASE(0, 0) LSX_CASE(1, 0) LSX_CASE(1, 1)
     LSX_CASE(2, 0) LSX_CASE(2, 1) LSX_CASE(2, 2)

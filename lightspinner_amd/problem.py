@@ -241,6 +241,11 @@ class Engine:
         ncol = arr.shape[0]
         self.lib.check(self.lib.dll.lsx_set(self._h, what, int(col0), ncol, _ptr(arr), arr.nbytes))
 
+    def set_formal_solver(self, solver):
+        """'linear' (the reference's piecewise_linear_1d, default) or 'parabolic' (monotonic piecewise parabolic, include/lsx.h N4)"""
+        kind = {'linear': _capi.LSX_SOLVER_LINEAR, 'parabolic': _capi.LSX_SOLVER_PARABOLIC}[solver]
+        self.lib.check(self.lib.dll.lsx_set_formal_solver(self._h, kind))
+
     def set_active_columns(self, mask=None):
         """freeze columns whose mask entry is False (None: all active)"""
         if mask is None:

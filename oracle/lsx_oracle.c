@@ -61,6 +61,7 @@ struct lsx_ctx {
     long* sing_col; /* per column: (depth << 8 | atom) of its first singular system in the last stat_equil, or -1 */
     /* set-up chain: deep copy of the atomic data (lsx_set_atomic_data) and what lsx_set_atmosphere derives */
     int have_atomic_data;
+    int solver;                  /* LSX_SOLVER_* (N4) */
     double weight_H, weight_He, abundance_He;
     lsx_atom_model* am;       /* [Natoms]; levels / lines / collisions (with their tables) owned */
     double *vBroad, *aDamp;   /* [col][Natoms][k], [col][Nlines][k] */
@@ -736,6 +737,88 @@ static void piecewise_1d_impl(double muz, int toFrom, double Istart, int Nspace,
     for (int q = 0; q < Nspace; ++q) PsiStar[q] = PsiStar[q] / chi[q];
 }
 
+/* ---- N4: monotonic piecewise-parabolic short characteristics (include/lsx.h; Auer & Paletou 1994).  No counterpart
+ * in the reference: parity unpinned. ---------------------------------------------------------------------------- */
+static inline void w3(double dtau, double* w)
+{
+    if (dtau < 0.25) {
+        /* w_n = sum_m (-1)^m dtau^(m+n+1) / (m! (m+n+1)), m = 0 ... 11: the closed forms below cancel to dtau^(n+1) / (n+1)
+         * here (w2 would lose 5 digits at dtau = 5e-4, the switch of the linear rule's w2; at 0.25 it keeps 13) */
+        double x = dtau;
+        w[0] = x * (1.0 / 1.0 + x * (-1.0 / 2.0 + x * (1.0 / 6.0 + x * (-1.0 / 24.0 + x * (1.0 / 120.0 + x * (-1.0 / 720.0 + x * (1.0 / 5040.0 + x * (-1.0 / 40320.0 + x * (1.0 / 362880.0 + x * (-1.0 / 3628800.0 + x * (1.0 / 39916800.0 + x * (-1.0 / 479001600.0))))))))))));
+        w[1] = x * x * (1.0 / 2.0 + x * (-1.0 / 3.0 + x * (1.0 / 8.0 + x * (-1.0 / 30.0 + x * (1.0 / 144.0 + x * (-1.0 / 840.0 + x * (1.0 / 5760.0 + x * (-1.0 / 45360.0 + x * (1.0 / 403200.0 + x * (-1.0 / 3991680.0 + x * (1.0 / 43545600.0 + x * (-1.0 / 518918400.0))))))))))));
+        w[2] = x * x * x * (1.0 / 3.0 + x * (-1.0 / 4.0 + x * (1.0 / 10.0 + x * (-1.0 / 36.0 + x * (1.0 / 168.0 + x * (-1.0 / 960.0 + x * (1.0 / 6480.0 + x * (-1.0 / 50400.0 + x * (1.0 / 443520.0 + x * (-1.0 / 4354560.0 + x * (1.0 / 47174400.0 + x * (-1.0 / 558835200.0))))))))))));
+    } else if (dtau > 50.0) {
+        w[0] = 1.0;
+        w[1] = 1.0;
+        w[2] = 2.0;
+    } else {
+        double expdt = exp(-dtau);
+        w[0] = 1.0 - expdt;
+        w[1] = w[0] - dtau * expdt;
+        w[2] = 2.0 * w[1] - dtau * dtau * expdt;
+    }
+}
+
+static void piecewise_parabolic_1d_impl(double muz, int toFrom, double Istart, int Nspace, const double* z,
+                                        const double* chi, const double* S, double* I, double* PsiStar)
+{
+    double zmu = 1.0 / muz;
+    int dk, kStart, kEnd;
+    if (toFrom) { dk = -1; kStart = Nspace - 1; kEnd = 0; }
+    else { dk = 1; kStart = 0; kEnd = Nspace - 1; }
+    double Iupw = Istart;
+    I[kStart] = Iupw;
+    PsiStar[kStart] = 0.0;
+    for (int k = kStart + dk;; k += dk) {
+        double w[3];
+        double dtau_uw = 0.5 * (chi[k - dk] + chi[k]) * zmu * fabs(z[k - dk] - z[k]);
+        double p = (S[k - dk] - S[k]) / dtau_uw;
+        w3(dtau_uw, w);
+        double a = p, dadS = -1.0 / dtau_uw;                          /* end point: the linear rule */
+        if (k != kEnd) {
+            double dtau_dw = 0.5 * (chi[k] + chi[k + dk]) * zmu * fabs(z[k] - z[k + dk]);
+            double q = (S[k] - S[k + dk]) / dtau_dw;
+            if (p * q > 0.0) {
+                double alpha = (1.0 + dtau_dw / (dtau_uw + dtau_dw)) / 3.0, beta = 1.0 - alpha;
+                double den = alpha * q + beta * p;
+                a = p * q / den;
+                dadS = (beta * p * p / dtau_dw - alpha * q * q / dtau_uw) / (den * den);
+                if (fabs(a) > 2.0 * fabs(p)) { a = 2.0 * p; dadS = -2.0 / dtau_uw; }
+            } else {
+                a = 0.0;
+                dadS = 0.0;
+            }
+        }
+        double b = (p - a) / dtau_uw;
+        I[k] = Iupw * (1.0 - w[0]) + w[0] * S[k] + w[1] * a + w[2] * b;
+        PsiStar[k] = (w[0] + (w[1] - w[2] / dtau_uw) * dadS - w[2] / (dtau_uw * dtau_uw)) / chi[k];
+        Iupw = I[k];
+        if (k == kEnd) break;
+    }
+}
+
+int lsx_piecewise_parabolic_1d_impl(int32_t device, int32_t nray, int32_t Nspace, const double* height, const double* mu,
+                                    const int32_t* to_obs, const double* Istart, const double* chi, const double* S,
+                                    double* I, double* PsiStar)
+{
+    (void)device;
+    if (nray < 0 || Nspace < 3) return fail(LSX_EINVAL, "lsx_piecewise_parabolic_1d_impl: need Nspace >= 3");
+    if (nray > 0 && (!height || !mu || !to_obs || !Istart || !chi || !S || !I || !PsiStar)) return fail(LSX_EINVAL, "lsx_piecewise_parabolic_1d_impl: null array pointer");
+    for (int r = 0; r < nray; ++r)
+        piecewise_parabolic_1d_impl(mu[r], to_obs[r], Istart[r], Nspace, height, chi + (size_t)r * Nspace, S + (size_t)r * Nspace,
+                                    I + (size_t)r * Nspace, PsiStar + (size_t)r * Nspace);
+    return LSX_OK;
+}
+
+int lsx_w3(int32_t device, int32_t n, const double* dtau, double* w)
+{
+    (void)device;
+    if (n < 0 || (n > 0 && (!dtau || !w))) return fail(LSX_EINVAL, "lsx_w3: bad argument");
+    for (int i = 0; i < n; ++i) w3(dtau[i], w + 3 * (size_t)i);
+    return LSX_OK;
+}
+
 /* ---- utils.py:17-22 -------------------------------------------------------- */
 static inline double planck(double temp, double wav)
 {
@@ -940,6 +1023,15 @@ static void formal_sol_gamma_column(lsx_ctx* c, int col, double* scratch)
                     chiTot[k] += bchi[(size_t)la * Ns + k];
                     S[k] = (etaTot[k] + beta[(size_t)la * Ns + k] + sca[k] * JDag[(size_t)la * Ns + k]) / chiTot[k];
                 }
+                if (c->solver == LSX_SOLVER_PARABOLIC) {   /* N4: same boundary condition (formal_solver.py:203-209), parabolic rule */
+                    double Istart = 0.0;
+                    if (toFrom) {
+                        double dtau_uw = (1.0 / c->muz[mu]) * (chiTot[Ns - 1] + chiTot[Ns - 2]) * 0.5 * fabs(z[Ns - 1] - z[Ns - 2]);
+                        double B0 = planck(T[Ns - 2], wav), B1 = planck(T[Ns - 1], wav);
+                        Istart = B1 - (B0 - B1) / dtau_uw;
+                    }
+                    piecewise_parabolic_1d_impl(c->muz[mu], toFrom, Istart, Ns, z, chiTot, S, I, Psi);
+                } else
                 piecewise_linear_1d(Ns, z, T, c->muz[mu], toFrom, wav, chiTot, S, I, Psi); /* :635 */
                 Iout[(size_t)la * Nrays + mu] = I[0];                                    /* :638 */
                 double hw = 0.5 * c->wmu[mu];
@@ -1170,6 +1262,13 @@ int lsx_stat_equil(lsx_ctx* c, double* dP)
     int rc = lsx_stat_equil_async(c);
     if (rc) return rc;
     if (dP) *dP = c->last_dP;
+    return LSX_OK;
+}
+
+int lsx_set_formal_solver(lsx_ctx* c, int32_t solver)
+{
+    if (!c || (solver != LSX_SOLVER_LINEAR && solver != LSX_SOLVER_PARABOLIC)) return fail(LSX_EINVAL, "lsx_set_formal_solver: bad argument");
+    c->solver = solver;
     return LSX_OK;
 }
 

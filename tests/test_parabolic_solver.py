@@ -1,0 +1,67 @@
+"""the higher-order (monotonic piecewise-parabolic) formal solver.  Parity unpinned -- see
+tests/parabolic_cases.py.  CPU run: the oracle's restatement against the rule's properties; GPU run: the HIP kernels
+against the same properties and against the oracle."""
+import pytest
+
+import parabolic_cases as cases
+
+
+def test_w3_weights_oracle(oracle_lib):
+    cases.weights_are_the_moments(oracle_lib)
+
+
+def test_linear_and_quadratic_sources_oracle(oracle_lib):
+    cases.exact_on_linear_sources_and_close_on_quadratic(oracle_lib)
+
+
+def test_third_order_convergence_oracle(oracle_lib):
+    cases.third_order_convergence(oracle_lib)
+
+
+def test_no_overshoot_and_diagonal_oracle(oracle_lib):
+    cases.no_overshoot_and_diagonal(oracle_lib)
+
+
+def test_context_with_the_parabolic_rule_oracle(oracle_lib):
+    cases.context_with_the_parabolic_rule(oracle_lib)
+
+
+@pytest.mark.gpu
+def test_parabolic_units_on_hip(hip_lib, oracle_lib):
+    cases.weights_are_the_moments(hip_lib)
+    cases.exact_on_linear_sources_and_close_on_quadratic(hip_lib)
+    cases.third_order_convergence(hip_lib)
+    cases.no_overshoot_and_diagonal(hip_lib, finite_diff_lib=oracle_lib)
+
+
+@pytest.mark.gpu
+def test_context_with_the_parabolic_rule_on_hip(hip_lib, oracle_lib):
+    cases.context_with_the_parabolic_rule(hip_lib, ref_lib=oracle_lib)
+
+
+@pytest.mark.gpu
+def test_parabolic_rule_on_production_shapes(hip_lib, oracle_lib):
+    """Ca+H with a line-of-sight velocity, 36 columns (> 32: the size at which the linear rule switches to per-class
+    launches): linked continua, two-line tiles and cells all go through the one parabolic instance"""
+    import numpy as np
+    from conftest import golden, relerr, gamma_err
+    from lightspinner_amd import fixtures, synth, Engine, _capi
+    prob, base, raw = fixtures.load_problem_npz(golden('falc_cah.npz'), phi_compact=False)
+    blk, prof = synth.perturbed_columns(prob, base, raw, ncol=36, seed=4, vlos_sigma=2.0e3)
+    engs = []
+    for lib in (hip_lib, oracle_lib):
+        e = Engine(prob, 36, lib=lib)
+        synth.load_columns(e, blk, prof)
+        e.set_formal_solver('parabolic')
+        engs.append(e)
+    hip, ora = engs
+    oracle_lib.dll.lsx_oracle_set_threads(ora._h, 8)
+    for it in range(1, 6):
+        assert hip.formal_sol_gamma() == pytest.approx(ora.formal_sol_gamma(), rel=1e-7)
+        if it == 1:
+            assert relerr(hip.get(_capi.LSX_J), ora.get(_capi.LSX_J)) < 3e-11 and relerr(hip.get(_capi.LSX_I), ora.get(_capi.LSX_I)) < 3e-11
+            off, diag = gamma_err(hip.get(_capi.LSX_GAMMA), ora.get(_capi.LSX_GAMMA), prob)
+            assert off < 3e-10 and diag < 3e-11, (off, diag)
+        if it > 3:
+            assert hip.stat_equil() == pytest.approx(ora.stat_equil(), rel=1e-6)
+    assert relerr(hip.get(_capi.LSX_N), ora.get(_capi.LSX_N)) < 1e-8
