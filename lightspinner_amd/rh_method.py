@@ -186,7 +186,8 @@ class ComputationalAtom:
 class Context:
     """rh_method.py:490-745 on the GPU."""
 
-    def __init__(self, atmos, spect, eqPops, background, device: int = 0, stream=None, lib=None, setup: str = 'auto'):
+    def __init__(self, atmos, spect, eqPops, background, device: int = 0, stream=None, lib=None, setup: str = 'auto',
+                 formal_solver: str = 'linear'):
         self.atmos = atmos
         self.atmos.nondimensionalise()
         self.spect = spect
@@ -229,6 +230,8 @@ class Context:
                                sca_per_lambda=sca_per_lambda, phi_compact=phi_compact,
                                atom_names=[a.atomicModel.name for a in self.activeAtoms])
         self._engine = Engine(self.problem, 1, device=device, stream=stream, lib=lib)
+        if formal_solver != 'linear':          # 'parabolic': the monotonic piecewise-parabolic rule (include/lsx.h, N4; not in the reference)
+            self._engine.set_formal_solver(formal_solver)
         self._cache = {}
         if setup == 'native':
             in_table = lambda m, l: _contains(spect.transitions, l)
