@@ -21,12 +21,17 @@ CASES = [
     dict(seed=7, Nrays=8, Nspace=21, Nspect=48, ncol=2),              # 8 wavelengths per wavefront, all 64 lanes used
     dict(seed=8, Nrays=3, Nspace=700, Nspect=30, ncol=33),            # deep column: the operand table no longer fits LDS -> generic instance
     dict(seed=9, Nrays=3, Nspace=700, Nspect=30, ncol=2),             # same through the fused small-batch launch
+    # regular bound-free sets on even tile widths: the column-mapped epilogue (k_fast_gamma_cols), with linked continua
+    dict(seed=10, Nrays=4, Nspace=45, Nspect=100, ncol=34, chain=False),
+    dict(seed=11, Nrays=5, Nspace=82, Nspect=140, ncol=3, chain=False),
+    dict(seed=12, Nrays=8, Nspace=31, Nspect=64, ncol=33, chain=False, phi_compact=True),
 ]
 
 
-def _run(lib, prob, block, iters):
+def _run(lib, prob, block, iters, solver='linear'):
     e = Engine(prob, block.ncol, lib=lib)
     e.set_columns(0, block)
+    e.set_formal_solver(solver)
     out = []
     for it in range(iters):
         dJ = e.formal_sol_gamma()
@@ -68,3 +73,18 @@ def test_toy_parity(hip_lib, oracle_lib, kw):
     assert dn.max() < 1e-8
     assert relerr(h[-1]['J'], o[-1]['J']) < 1e-8
     assert abs(h[-1]['dP'] - o[-1]['dP']) <= 1e-6 * max(abs(o[-1]['dP']), 1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kw', [CASES[0], CASES[2], CASES[5], CASES[7], CASES[9]], ids=lambda k: '-'.join('%s%s' % (a[:3], b) for a, b in k.items()))
+def test_toy_parity_parabolic_rule(hip_lib, oracle_lib, kw):
+    """the parabolic rule (N4) on the same topologies: level cells, chained continua, deep columns, per-wavelength
+    scattering -- HIP against the oracle's restatement of the same rule (parity with the reference: unpinned)"""
+    prob, block = toy_problem(**kw)
+    h = _run(hip_lib, prob, block, 6, solver='parabolic')
+    o = _run(oracle_lib, prob, block, 6, solver='parabolic')
+    assert relerr(h[0]['I'], o[0]['I']) < 1e-11 and relerr(h[0]['J'], o[0]['J']) < 1e-11
+    off, diag = gamma_err(h[0]['G'], o[0]['G'], prob)
+    assert off < 1e-10 and diag < 1e-11, (off, diag)
+    dn = np.abs(h[-1]['n'] - o[-1]['n']) / np.abs(o[-1]['n']).max(axis=1, keepdims=True)
+    assert dn.max() < 1e-8 and relerr(h[-1]['J'], o[-1]['J']) < 1e-8
