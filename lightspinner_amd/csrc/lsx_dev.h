@@ -245,10 +245,13 @@ static __device__ __forceinline__ void w3(double dtau, double& w0, double& w1, d
         a1 = a0 - dc * e;
         a2 = 2.0 * a1 - (dc * dc) * e;
     }
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    if (__builtin_amdgcn_ballot_w64(small) != 0) {          // no lane in the series regime (deep layers): skip the 36 fmas
     const double x = dtau;
-    const double s0 = x * (1.0 / 1.0 + x * (-1.0 / 2.0 + x * (1.0 / 6.0 + x * (-1.0 / 24.0 + x * (1.0 / 120.0 + x * (-1.0 / 720.0 + x * (1.0 / 5040.0 + x * (-1.0 / 40320.0 + x * (1.0 / 362880.0 + x * (-1.0 / 3628800.0 + x * (1.0 / 39916800.0 + x * (-1.0 / 479001600.0))))))))))));
-    const double s1 = x * x * (1.0 / 2.0 + x * (-1.0 / 3.0 + x * (1.0 / 8.0 + x * (-1.0 / 30.0 + x * (1.0 / 144.0 + x * (-1.0 / 840.0 + x * (1.0 / 5760.0 + x * (-1.0 / 45360.0 + x * (1.0 / 403200.0 + x * (-1.0 / 3991680.0 + x * (1.0 / 43545600.0 + x * (-1.0 / 518918400.0))))))))))));
-    const double s2 = x * x * x * (1.0 / 3.0 + x * (-1.0 / 4.0 + x * (1.0 / 10.0 + x * (-1.0 / 36.0 + x * (1.0 / 168.0 + x * (-1.0 / 960.0 + x * (1.0 / 6480.0 + x * (-1.0 / 50400.0 + x * (1.0 / 443520.0 + x * (-1.0 / 4354560.0 + x * (1.0 / 47174400.0 + x * (-1.0 / 558835200.0))))))))))));
+    s0 = x * (1.0 / 1.0 + x * (-1.0 / 2.0 + x * (1.0 / 6.0 + x * (-1.0 / 24.0 + x * (1.0 / 120.0 + x * (-1.0 / 720.0 + x * (1.0 / 5040.0 + x * (-1.0 / 40320.0 + x * (1.0 / 362880.0 + x * (-1.0 / 3628800.0 + x * (1.0 / 39916800.0 + x * (-1.0 / 479001600.0))))))))))));
+    s1 = x * x * (1.0 / 2.0 + x * (-1.0 / 3.0 + x * (1.0 / 8.0 + x * (-1.0 / 30.0 + x * (1.0 / 144.0 + x * (-1.0 / 840.0 + x * (1.0 / 5760.0 + x * (-1.0 / 45360.0 + x * (1.0 / 403200.0 + x * (-1.0 / 3991680.0 + x * (1.0 / 43545600.0 + x * (-1.0 / 518918400.0))))))))))));
+    s2 = x * x * x * (1.0 / 3.0 + x * (-1.0 / 4.0 + x * (1.0 / 10.0 + x * (-1.0 / 36.0 + x * (1.0 / 168.0 + x * (-1.0 / 960.0 + x * (1.0 / 6480.0 + x * (-1.0 / 50400.0 + x * (1.0 / 443520.0 + x * (-1.0 / 4354560.0 + x * (1.0 / 47174400.0 + x * (-1.0 / 558835200.0))))))))))));
+    }
     w0 = small ? s0 : (large ? 1.0 : a0);
     w1 = small ? s1 : (large ? 1.0 : a1);
     w2q = small ? s2 : (large ? 2.0 : a2);

@@ -886,6 +886,10 @@ __device__ __forceinline__ void sweep_tile_parabolic(const SweepParams& p, const
         }
         S = etaTot / chiTot;
     };
+    // does any slot of this tile keep level / atom sums in cells (overlapping transitions)?  Only then does the Gamma pass of a
+    // depth need the cells of that depth refilled
+    bool any_cells = false;
+    for (int u = 0; u < nP; ++u) any_cells = any_cells || (slots[u].flags & (SLOT_LI_CELL | SLOT_LJ_CELL | SLOT_ETA_CELL | SLOT_UI_READ)) != 0;
     // ---- boundary conditions: formal_solver.py:203-209 (unchanged) ----
     double Iu = 0.0;
     double c_u = 1.0, S_u = 0.0, c_k = 1.0, S_k = 0.0, c_d = 1.0, S_d = 0.0;     // upwind / local / downwind of the depth being finished
@@ -938,7 +942,7 @@ __device__ __forceinline__ void sweep_tile_parabolic(const SweepParams& p, const
         }
         __builtin_amdgcn_wave_barrier();
         // Gamma integrands of the per-ray transitions at depth k (rh_method.py:643-681): cells of THIS depth first
-        {
+        if (any_cells) {
             double c0, s0;
             opac(k, true, c0, s0);
             __builtin_amdgcn_wave_barrier();
