@@ -348,23 +348,25 @@ static inline int lkclass(const DevTile& tl)
 // effective background of the tiles that have fast continua: bgx = bg + sum over the tile's fast continua; for the
 // lines of a tile with linked continua also the three sums the line's own Gamma integrand needs from them
 // (rh_method.py:616-627: atom.eta, atom.chi[i_line], atom.chi[j_line], continuum part)
-// One block per (tile, column), 256 threads = (depth in chunk, wavelength) with LP = 16 / 32 / 64 lanes per depth row;
+// One block per (tile, column), 256 threads = (depth in chunk, wavelength), rows exactly as wide as the tile;
 // the block walks the column's depth chunks with the next chunk's loads in flight (the kernel is latency bound otherwise:
 // a staging phase, a barrier and one dependent load per thread for a few dozen instructions of arithmetic).
-template <int LP, bool SEG>       // SEG: the column is too deep for its operands to be staged at once
+template <bool SEG>               // SEG: the column is too deep for its operands to be staged at once
 __global__ void __launch_bounds__(256) k_fast_prepass(const FastParams f)
 {
-    constexpr int KR = 256 / LP;                                // depths per chunk
     const size_t col = blockIdx.y;
     if (f.colmask && !f.colmask[col]) return;
     const int t = f.fast_tiles[blockIdx.x];
     const DevTile tl = f.tiles[t];
     extern __shared__ double sm[];
     const int tid = threadIdx.x;
-    const int kc = tid / LP, j = tid % LP;
+    // a (tile, column) plane [depth][wavelength] is one contiguous array: thread t takes element t of a chunk of KR whole rows,
+    // every lane works whatever the tile width (the pre-pass has no row reductions that would want power-of-two rows)
+    const int LP = f.L, KR = 256 / LP;                          // depths per chunk
+    const int kc = tid / LP, j = tid - kc * LP;
     const int Ns = f.Nspace;
     const DevSlot* fs = f.slots + tl.slot0 + tl.nP;
-    const bool lane_on = j < f.L;
+    const bool lane_on = kc < KR;                               // the last 256 - KR L threads of a block idle
     const size_t tb = (col * f.ntile + t) * (size_t)Ns * f.L;
     auto load3 = [&](int k, double& a, double& b, double& c) {
         const bool on = lane_on && k < Ns;
@@ -2006,14 +2008,13 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
         FastParams fq = ff;
         fq.fast_tiles = d_list; fq.n_fast_tiles = (int)n;
         dim3 grid((unsigned)n, (unsigned)c->ncol);
-        fq.seg_depths = seg_for(256 / LP, (size_t)3 * c->nF_max, (size_t)c->nF_max * LP, 24 * 1024);
-        const size_t smp = ((size_t)3 * c->nF_max * fq.seg_depths + (size_t)c->nF_max * LP) * sizeof(double);
+        const int LPp = c->L;                 // the pre-pass rows are exactly as wide as the tile
+        fq.seg_depths = seg_for(256 / LPp, (size_t)3 * c->nF_max, (size_t)c->nF_max * LPp, 24 * 1024);
+        const size_t smp = ((size_t)3 * c->nF_max * fq.seg_depths + (size_t)c->nF_max * LPp) * sizeof(double);
         if (smp > 64 * 1024) return fail(LSX_EUNSUPPORTED, "fast-continuum pre-pass needs %zu B of LDS", smp);
         const bool seg = fq.seg_depths < c->Nspace;
-#define LSX_PP(LPV) if (LP == LPV) { if (seg) hipLaunchKernelGGL((k_fast_prepass<LPV, true>), grid, dim3(256), smp, st, fq); \
-                                     else hipLaunchKernelGGL((k_fast_prepass<LPV, false>), grid, dim3(256), smp, st, fq); }
-        LSX_PP(16) LSX_PP(32) LSX_PP(64)
-#undef LSX_PP
+        if (seg) hipLaunchKernelGGL((k_fast_prepass<true>), grid, dim3(256), smp, st, fq);
+        else hipLaunchKernelGGL((k_fast_prepass<false>), grid, dim3(256), smp, st, fq);
         HIPCHK(hipGetLastError());
         return LSX_OK;
     };
