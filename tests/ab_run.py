@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One variant of the HIP library, timed and checked on one box:
-    python profiles/ab_run.py ab_so/x.so [c3|c4] [ncol]
+    python tests/ab_run.py ab_so/x.so [c3|c4] [ncol]
 prints ONE line: sweep / formal-solution / MALI-step times (HIP events in the library, host clock for the step) and the
 parity of the variant against the oracle on 40 columns of the same ensemble (first call and after 6 iterations).
 Used by profiles/ab.sh to compare prebuilt variants interleaved on the same GPU."""
