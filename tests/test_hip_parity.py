@@ -73,23 +73,25 @@ def test_single_calls_match_reference_and_oracle(hip_lib, oracle_lib, name, comp
         assert dJ == pytest.approx(dJo, rel=1e-9 if tight else 1e-6)
         J, I, G = eng.get(_capi.LSX_J)[0], eng.get(_capi.LSX_I)[0], eng.get(_capi.LSX_GAMMA)[0]
         Jo, Io, Go = ora.get(_capi.LSX_J)[0], ora.get(_capi.LSX_I)[0], ora.get(_capi.LSX_GAMMA)[0]
-        assert relerr(J, Jo) < (tol if tight else 1e-7)
-        assert relerr(I, Io) < (tol if tight else 1e-7)
+        # after the first statistical-equilibrium solve the two sides' populations differ by the LU's rounding times its
+        # conditioning -- measured 1.2e-10 on n, 1.2e-11 on J and I: asserted at ten times that
+        assert relerr(J, Jo) < (tol if tight else 2e-10)
+        assert relerr(I, Io) < (tol if tight else 2e-10)
         off, diag = gamma_err(G, Go, prob)
-        assert off < (10 * tol if tight else 1e-6) and diag < (tol if tight else 1e-7), (it, off, diag)
+        assert off < (10 * tol if tight else 1e-8) and diag < (tol if tight else 1e-9), (it, off, diag)
         tag = 'fs%d' % it
         if tag + '_I' in d:   # golden vectors of the reference itself
-            assert relerr(I, d[tag + '_I']) < (tol if tight else 1e-7)
+            assert relerr(I, d[tag + '_I']) < (tol if tight else 2e-10)
             if tag + '_J' in d:
-                assert relerr(J, d[tag + '_J']) < (tol if tight else 1e-7)
+                assert relerr(J, d[tag + '_J']) < (tol if tight else 2e-10)
             off, diag = gamma_err(G, fixtures.gamma_from_raw(d, tag, prob), prob)
-            assert off < (10 * tol if tight else 1e-6) and diag < (tol if tight else 1e-7)
+            assert off < (10 * tol if tight else 1e-8) and diag < (tol if tight else 1e-9)
         if it > 3:
             dP, dPo = eng.stat_equil(), ora.stat_equil()
             assert dP == pytest.approx(dPo, rel=1e-7)
-            assert relerr(eng.get(_capi.LSX_N)[0], ora.get(_capi.LSX_N)[0]) < 1e-7
+            assert relerr(eng.get(_capi.LSX_N)[0], ora.get(_capi.LSX_N)[0]) < 2e-9
             if 'se%d_dPops' % it in d:
-                assert relerr(eng.get(_capi.LSX_N)[0], fixtures.pops_from_raw(d, 'se%d' % it, prob)) < 1e-7
+                assert relerr(eng.get(_capi.LSX_N)[0], fixtures.pops_from_raw(d, 'se%d' % it, prob)) < 2e-9
     eng.close()
 
 

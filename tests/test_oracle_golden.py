@@ -89,7 +89,7 @@ def test_first_calls_match_reference(oracle_lib, name, compact, tol):
             dP = eng.stat_equil()
             if 'se%d_dPops' % it in d:
                 assert dP == pytest.approx(float(d['se%d_dPops' % it]), rel=1e-7)
-                assert relerr(eng.get(_capi.LSX_N)[0], fixtures.pops_from_raw(d, 'se%d' % it, prob)) < 1e-7
+                assert relerr(eng.get(_capi.LSX_N)[0], fixtures.pops_from_raw(d, 'se%d' % it, prob)) < 2e-9      # measured 1.2e-10
     eng.close()
 
 
