@@ -287,6 +287,9 @@ def main():
     ap.add_argument('--no-single-column', action='store_true',
                     help='skip the FALC single-column section (used for rocprofv3 runs so that every sweep launch has the workload size)')
     ap.add_argument('--no-c4-share', action='store_true', help='skip the C4 per-GPU share measured beside the default workload')
+    ap.add_argument('--physical-columns', action='store_true',
+                    help='columns whose populations, rates and profiles the library derives from each column\'s own perturbed '
+                         'atmosphere (lsx_set_atmosphere, SURVEY 8f N1) instead of input-level perturbations')
     args = ap.parse_args()
 
     rank, local_rank, world = dist_env()
@@ -319,6 +322,19 @@ def main():
     t0 = time.time()
     load_columns(eng, batch, prof)
     t_up = time.time() - t0
+    t_chain = None
+    if args.physical_columns and ncol > 1:
+        # the same ensemble, made physically consistent: broadening, damping, LTE populations, collisional rates and line
+        # profiles from each column's own atmosphere, on the device (outside the timed region, like every set-up step)
+        from lightspinner_amd import atomdata, synth
+        sd = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'setup_falc.npz')))
+        names = [str(x) for x in sd['atom_names']]
+        eng.set_atomic_data(atomdata.from_fixture(sd, atoms=[names.index(n) for n in prob.atom_names]))
+        atm = synth.perturbed_atmospheres(prob, raw, ncol, first=rank * ncol, vlos_sigma=0.0 if compact else 2.0e3)
+        t0 = time.time()
+        eng.set_atmosphere(0, lte_pops=True, **atm)
+        torch.cuda.synchronize()
+        t_chain = time.time() - t0
     upload_bytes = sum(getattr(batch, k).nbytes for k in ('phi', 'bg_chi', 'bg_eta', 'C', 'n', 'nStar') if getattr(batch, k) is not None)
     if prof is not None:
         upload_bytes += sum(p.nbytes for p in prof if p is not None)
@@ -369,13 +385,14 @@ def main():
                                             'c4': 'C4 share: %d FALC-perturbed Ca+H columns per GPU, 82 depth x 777 wavelengths x 5 rays x 2' % ncol}[args.workload],
                                   columns_per_gpu=ncol, columns_total=ncol * world, Nspace=prob.Nspace, Nspect=prob.Nspect,
                                   Nrays=prob.Nrays, profiles='compact (vlos=0)' if compact else 'ray dependent (vlos!=0)',
+                                  columns='populations, rates and profiles derived by the library from each column\'s perturbed atmosphere' if t_chain is not None else 'input-level perturbations (BASELINE C3 / C4)',
                                   parallelism=parallelism_text(world, rehearsal)),
                       step_ms=dict(stats_ms(per_step), note='host clock around each step on rank 0 (a step ends with the read-back of the monitors)'),
                       mali_iters_per_sec=args.steps / dt, column_iters_per_sec=args.steps * ncol * world / dt,
                       last_dJ=dJ, last_dPops=dP,
                       roofline=roofline, cpu_baseline=cpu, falc_single_column=single,
                       max_dn_over_n_vs_ref=single['max_dn_over_n_vs_ref'] if single else None,
-                      setup=dict(generate_s=t_gen, upload_s=t_up, upload_GB=upload_bytes / 1e9,
+                      setup=dict(generate_s=t_gen, upload_s=t_up, upload_GB=upload_bytes / 1e9, device_chain_s=t_chain,
                                  line_profiles='built on the device (lsx_set_line_profiles)' if prof is not None else 'ray independent (vlos = 0): the fixture\'s profiles',
                                  note='PCIe-inclusive upload (and the device-side profile build) is outside the timed region (inputs resident in HBM)'))
         if rehearsal:

@@ -65,3 +65,37 @@ def load_columns(engine, block: ColumnBlock, prof=None, col0: int = 0, step: int
         engine.set_columns(col0 + a, block.slice(a, min(block.ncol, a + step)))
     if prof is not None:
         engine.set_line_profiles(col0, prof[0], prof[1], prof[2])
+
+
+def perturbed_atmospheres(prob: Problem, raw: dict, ncol: int, seed: int = 4321, sigma_T: float = 0.02, sigma_n: float = 0.05,
+                          corr: int = 8, vlos_sigma: float = 2.0e3, first: int = 0):
+    """atmospheres for lsx_set_atmosphere, columns [first, first + ncol) of an ensemble around the fixture's atmosphere
+    (`raw`: a problem file, which holds temperature, ne, vturb, hGround and the atoms' nTotal): smooth log-normal factors on the
+    temperature (sigma_T), jointly on the electron and total densities (sigma_n), on the microturbulence, and a smooth
+    line-of-sight velocity.  With lte_pops the library then derives broadening, damping, LTE populations, collisional rates
+    and line profiles that are consistent with each column's own atmosphere -- unlike perturbed_columns,
+    which perturbs the hot path's inputs directly.  Column 0 is the unperturbed atmosphere.
+    -> dict(temperature, ne, vturb, nHGround [ncol][Nspace], nTotal [ncol][Natoms][Nspace], vlos or None)"""
+    Ns = prob.Nspace
+    rep = lambda a: np.repeat(np.asarray(a, dtype=np.float64)[None], ncol, axis=0).copy()
+    out = dict(temperature=rep(raw['temperature']), ne=rep(raw['ne']), vturb=rep(raw['vturb']), nHGround=rep(raw['hGround']),
+               nTotal=rep(np.stack([raw['a%d_nTotal' % a] for a in range(prob.Natoms)])))
+    use_vlos = vlos_sigma > 0 and not prob.phi_compact
+    vlos = np.zeros((ncol, Ns))
+    for q in range(ncol):
+        c = first + q
+        if c == 0:
+            continue
+        rng = np.random.default_rng(seed + c)
+        fT = np.exp(sigma_T * _smooth_field(rng, Ns, corr))
+        fn = np.exp(sigma_n * _smooth_field(rng, Ns, corr))
+        fv = np.exp(sigma_n * _smooth_field(rng, Ns, corr))
+        out['temperature'][q] *= fT
+        out['ne'][q] *= fn
+        out['nHGround'][q] *= fn
+        out['nTotal'][q] *= fn
+        out['vturb'][q] *= fv
+        if use_vlos:
+            vlos[q] = vlos_sigma * _smooth_field(rng, Ns, corr)
+    out['vlos'] = vlos if use_vlos else None
+    return out

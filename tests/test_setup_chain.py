@@ -83,3 +83,40 @@ def test_hip_setup_chain_matches_the_reference_and_the_oracle(hip_lib, oracle_li
     for what in (_capi.LSX_VBROAD, _capi.LSX_ADAMP, _capi.LSX_NSTAR):
         assert relerr(eh.get(what), eo.get(what)) < 1e-13
     assert relerr(eh.get(_capi.LSX_J), eo.get(_capi.LSX_J)) < 3e-11
+
+
+@pytest.mark.gpu
+def test_setup_chain_at_batch_size_feeds_the_hot_path(hip_lib, oracle_lib):
+    """48 Ca+H columns whose broadening, damping, LTE populations, collisional rates and ray-dependent profiles all come
+    from lsx_set_atmosphere on each column's own (perturbed) atmosphere -- physically consistent columns, SURVEY 8f N1 --
+    then MALI iterations through the per-class launch path: HIP against the oracle"""
+    from lightspinner_amd import synth
+    d = dict(np.load(golden('setup_falc.npz')))
+    prob, base, raw = fixtures.load_problem_npz(golden('falc_cah.npz'), phi_compact=False)
+    ncol = 48
+    blk, _ = synth.perturbed_columns(prob, base, raw, ncol=ncol, seed=11, vlos_sigma=0.0)       # geometry, background, placeholders
+    blk.phi = blk.wphi = None
+    atm = synth.perturbed_atmospheres(prob, raw, ncol, seed=21)
+    assert atm['vlos'] is not None and np.any(atm['temperature'][1] != atm['temperature'][0])
+    engs = []
+    for lib in (hip_lib, oracle_lib):
+        e = Engine(prob, ncol, lib=lib)
+        e.set_columns(0, blk)
+        e.set_atomic_data(atomdata.from_fixture(d))
+        e.set_atmosphere(0, lte_pops=True, **atm)
+        engs.append(e)
+    hip, ora = engs
+    oracle_lib.dll.lsx_oracle_set_threads(ora._h, 8)
+    for what, tol in ((_capi.LSX_VBROAD, 1e-14), (_capi.LSX_ADAMP, 1e-13), (_capi.LSX_NSTAR, 1e-13), (_capi.LSX_WPHI, 1e-13), (_capi.LSX_PHI, 1e-12)):
+        assert relerr(hip.get(what), ora.get(what)) < tol, what
+    Ch, Co = hip.get(_capi.LSX_C), ora.get(_capi.LSX_C)
+    assert np.max(np.abs(Ch - Co) / np.abs(Co).max(axis=1, keepdims=True)) < 1e-13
+    # column 0 is the unperturbed FALC atmosphere: the reference's own numbers
+    assert relerr(hip.get(_capi.LSX_NSTAR, 0, 1)[0], np.concatenate([d['atm0_a%d_nStar' % a] for a in range(2)])) < 1e-13
+    for it in range(1, 7):
+        assert hip.formal_sol_gamma() == pytest.approx(ora.formal_sol_gamma(), rel=1e-7)
+        if it == 1:
+            assert relerr(hip.get(_capi.LSX_J), ora.get(_capi.LSX_J)) < 3e-11 and relerr(hip.get(_capi.LSX_I), ora.get(_capi.LSX_I)) < 3e-11
+        if it > 3:
+            assert hip.stat_equil() == pytest.approx(ora.stat_equil(), rel=1e-6)
+    assert relerr(hip.get(_capi.LSX_N), ora.get(_capi.LSX_N)) < 1e-8
