@@ -68,6 +68,7 @@ struct lsx_ctx {
     uint8_t* d_active = nullptr;
     DevTrans* d_trans = nullptr;
     DevTile* d_tiles = nullptr;
+    std::vector<uint8_t> tile_slot_fast;     // per slot: fast continuum (its slabs use the first direction entry only)
     int *d_tile_slots = nullptr, *d_Nlevel = nullptr, *d_lev2_off = nullptr;
     // device: per column
     double *d_height = nullptr, *d_temperature = nullptr, *d_nStar = nullptr, *d_nTotal = nullptr, *d_n = nullptr,

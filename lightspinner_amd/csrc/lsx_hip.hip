@@ -268,9 +268,13 @@ __global__ void k_gamma_finish(const FinishParams f)
     // slabs in (tile, slot, entry, direction) order = slot-table order; the loads of several slots are in flight at once
 #pragma unroll 4
     for (int u = 0; u < f.nslot_total; ++u) {
-        const DevTrans& tr = f.trans[f.tile_slots[u]];
+        const int ts = f.tile_slots[u];
+        const bool fast = (ts >> 30) & 1;                    // fast continuum: one entry carries both directions
+        const DevTrans& tr = f.trans[ts & 0x3fffffff];
         const double* q = P + (size_t)u * 4 * Ns;
-        const double q0 = q[0], q1 = q[(size_t)Ns], q2 = q[(size_t)2 * Ns], q3 = q[(size_t)3 * Ns];
+        // (unconditional loads, so that the loads of several slots stay in flight together: a fast slot re-reads its first entries)
+        const double q0 = q[0], r1 = q[fast ? 0 : (size_t)Ns], q2 = q[(size_t)2 * Ns], r3 = q[(size_t)(fast ? 2 : 3) * Ns];
+        const double q1 = fast ? 0.0 : r1, q3 = fast ? 0.0 : r3;
         double gij = G[tr.gam_ij * nt], gji = G[tr.gam_ji * nt];
         gij += q0;
         gij += q1;
@@ -621,9 +625,7 @@ __global__ void __launch_bounds__(NT) k_fast_gamma(const FastParams f)
             if (last_lane && k < Ns) {
                 double* g = f.Gpart + ((col * f.nslot_total + tl.slot0 + tl.nP + q) * 4) * (size_t)Ns + k;
                 g[0] = s1;
-                g[Ns] = 0.0;
                 g[2 * (size_t)Ns] = s2;
-                g[3 * (size_t)Ns] = 0.0;
             }
         };
         if (tl.fast_simple) {
@@ -883,9 +885,7 @@ __global__ void __launch_bounds__(256) k_fast_gamma_cols(const FastParams f)
                 if (h == 0) {
                     double* gp = f.Gpart + (((size_t)col * f.nslot_total + tl.slot0 + tl.nP + q0 + q) * 4) * (size_t)Ns + k;
                     gp[0] = s1;
-                    gp[Ns] = 0.0;
                     gp[2 * (size_t)Ns] = s2;
-                    gp[3 * (size_t)Ns] = 0.0;
                 }
             }
         }
@@ -1668,6 +1668,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
             }
             c->slots.push_back(sl);
             c->tile_slots.push_back(t);
+            c->tile_slot_fast.push_back((sl.flags & SLOT_FAST) ? 1 : 0);
         }
         if (tl.nF > 0) {
             c->fast_tiles.push_back((int)c->tiles.size());
@@ -1785,7 +1786,12 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     TRY(upload(&c->d_active, active, c->stream));
     TRY(upload(&c->d_trans, c->htrans, c->stream));
     TRY(upload(&c->d_tiles, c->tiles, c->stream));
-    TRY(upload(&c->d_tile_slots, c->tile_slots, c->stream));
+    {   // the epilogue's copy of the slot table carries "fast continuum" in bit 30: such a slot's slabs hold both directions in
+        // their first entry, the second is neither written nor read
+        std::vector<int> enc(c->tile_slots);
+        for (size_t u = 0; u < enc.size(); ++u) enc[u] |= c->tile_slot_fast[u] ? (1 << 30) : 0;
+        TRY(upload(&c->d_tile_slots, enc, c->stream));
+    }
     TRY(upload(&c->d_slots, c->slots, c->stream));
     TRY(upload(&c->d_Nlevel, c->Nlevel, c->stream));
     TRY(upload(&c->d_lev2_off, c->lev2_off, c->stream));
