@@ -278,7 +278,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     }
 
     // static path: per-slot lane state in registers
-    //   idx0: element index of (depth 0, this ray, this wavelength) in phi_T (line) / gijc_T (continuum)
+    //   idx0: element index of (depth 0, this ray, this wavelength) in phi_T (lines; continua read the tile's shared E stream)
     //   wl: wavelength quadrature weight, al: alpha (continua)
     int idx0[NS], kstr[NS];
     double wlv[NS], alv[NS];    // wlv: (w_mu/2 4pi) x wavelength weight of this ray, 0 where the transition is inactive
