@@ -209,6 +209,15 @@ static __device__ __forceinline__ double exp_tab64(double x, const lds_f64* tab)
     return ldexp(fma(th, m, tl) + th, ki >> 6);
 }
 
+// min of two doubles as ONE instruction: fmin() is preceded by a canonicalising v_max_f64(x, x) (signalling NaNs); the
+// instruction itself already returns the other operand for any NaN, which is all the callers rely on
+static __device__ __forceinline__ double min_noquiet(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // formal_solver.py:14-44.  The three regimes are selected per lane; the exponential is skipped
 // for the whole wavefront when no lane is in the middle regime (top / bottom of the atmosphere).
 static __device__ __forceinline__ void w2(double dtau, double& w0, double& w1, const lds_f64* exp2_tab)
@@ -220,7 +229,7 @@ static __device__ __forceinline__ void w2(double dtau, double& w0, double& w1, c
         // The saturated regime needs no select of its own: for dtau > 50 the middle formulae give exactly (1, 1) --
         // e = exp(-dtau) < 2e-22 is below half an ulp of 1, and so is dtau e (< 1e-17 up to dtau ~ 4e4; beyond that e
         // the product only shrinks).  The argument is clamped so that the table index stays in range for any dtau.
-        const double dc = fmin(dtau, 700.0);
+        const double dc = min_noquiet(dtau, 700.0);
         const double e = exp_tab64(-dc, exp2_tab);
         a0 = 1.0 - e;
         a1 = a0 - dc * e;
@@ -239,7 +248,7 @@ static __device__ __forceinline__ void w3(double dtau, double& w0, double& w1, d
     const bool large = dtau > 50.0;
     double a0 = 1.0, a1 = 1.0, a2 = 2.0;
     if (__builtin_amdgcn_ballot_w64(!(small || large)) != 0) {
-        const double dc = fmin(dtau, 700.0);
+        const double dc = min_noquiet(dtau, 700.0);
         const double e = exp_tab64(-dc, exp2_tab);
         a0 = 1.0 - e;
         a1 = a0 - dc * e;

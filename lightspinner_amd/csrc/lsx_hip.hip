@@ -1822,7 +1822,9 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     // ---- per-column storage
     const size_t nc = ncol;
     c->phi_in_col = (size_t)c->SNl * (c->phi_compact ? 1 : 2 * (size_t)c->Nrays) * Ns; // as handed over (rh_method.py:224)
-    c->phi_col = phi_run;                                    // as stored: sum of the (tile, line) blocks
+    // as stored: the (tile, line) blocks, then two doubles that stay zero -- where the lanes of a tile whose wavelength lies
+    // outside a line's range point their profile loads (no select on the loaded value)
+    c->phi_col = phi_run + (phi_run ? 2 : 0);
     c->corr_col = corr_run;
     c->pp_col = pp_run;
     c->til_col = c->tiles.size() * (size_t)c->L * Ns;        // one tile-major [tile][k][j] array
@@ -1840,6 +1842,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     TRY(dmalloc(&c->d_bgeta, nc * c->til_col));
     TRY(dmalloc(&c->d_sca, nc * c->sca_col));
     TRY(dmalloc(&c->d_phi, nc * c->phi_col));
+    if (c->phi_col) (void)hipMemsetAsync(c->d_phi, 0, nc * c->phi_col * sizeof(double), c->stream);
     if (c->any_cont) TRY(dmalloc(&c->d_E, nc * c->til_col));
     if (c->corr_col) {
         TRY(dmalloc(&c->d_corr, nc * c->corr_col));

@@ -74,7 +74,7 @@ __device__ __forceinline__ double fold32(double a, double b)
 __device__ __forceinline__ double reduce_pair(double a, double b)   // lane 31: sum(a), lane 63: sum(b)
 {
     double t = row_sums(fold32(a, b));
-    t += dpp_f64<0x142, 0xa>(t);
+    t += dpp_f64<0x142, 0xf>(t);      // row_bcast15 into every row (row 0 receives 0): lanes 31 / 63 hold rows 0+1 / 2+3; no `old` copy
     return t;
 }
 // Four values: a second fold with v_permlane16_swap (odd rows of the first operand <-> even rows of
@@ -292,8 +292,9 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             const int len = slots[u].len;
             const int lb = a ? la - slots[u].first : 0;      // position inside the (tile, transition) block
             (void)Nlam;
-            idx0[u] = line ? slots[u].base + raysel * len + lb : 0;      // continua read the tile's shared E stream
-            kstr[u] = line ? kmul * len : 0;
+            // lines: the lane's element of depth 0; a lane outside the line's range reads the column's zero pad at every depth
+            idx0[u] = line ? (a ? slots[u].base + raysel * len + lb : (int)p.phi_col_stride - 1) : 0;      // continua read the tile's shared E stream
+            kstr[u] = (line && a) ? kmul * len : 0;
             wlv[u] = (a && valid) ? wq_l * p.wl[slots[u].wl_off + l] : 0.0;                // :451/:455, :665
             alv[u] = (a && !line) ? p.alpha[slots[u].wl_off + l] : 0.0;
         }
@@ -368,7 +369,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         be = at(bgeta, kko);
         if constexpr (STATIC) {
 #pragma unroll
-            for (int u = 0; u < NL; ++u)    // inactive lanes read the block's first element; the value is dropped where it is consumed
+            for (int u = 0; u < NL; ++u)    // inactive lanes read the column's zero pad
                 v[u] = at(phi_col, (unsigned)(idx0[u] + kk * kstr[u]) * 8u);
             if constexpr (HASC) Ev = at(Eb, kko);
             if constexpr (LK) {
@@ -394,20 +395,21 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     //   phase 1: odd Nspace only, the one depth both waves visit in the same step (exchange through LDS)
     //   phase 2: second visitor (the partner's half is requested at the top of the step, used at its end)
     auto step = [&](const int s, auto phase_c) {
-        constexpr int PH = decltype(phase_c)::value;
+        constexpr int PH = decltype(phase_c)::value;         // 0 first visitor, 1 midpoint, 2 second visitor, 3 its last step (the end point)
+        constexpr bool SECOND = PH >= 2, LAST = PH == 3;
         const int k = kS + dk * s;
         const unsigned kl = (unsigned)(k * L + j) * 8u;     // byte position in the tile-major [k][j] streams
         double jd, chiTot, be_l, Ev = 0.0;
         double sv[NS], sni[NS], snj[NS], cr[NLK][3];
         const lds_f64* tk = utab + k * TR;
         double jhalf = 0.0;
-        if constexpr (PH == 2) {
+        if constexpr (SECOND) {
             if (2 * s == Ns || 2 * s == Ns + 1) __syncthreads();   // the partner wave's first-half stores
         }
         if constexpr (STATIC) {
             jd = n_jd; chiTot = n_bc; be_l = n_be; Ev = n_E;
 #pragma unroll
-            for (int u = 0; u < NL; ++u) sv[u] = ((pact >> u) & 1u) ? n_sv[u] : 0.0;
+            for (int u = 0; u < NL; ++u) sv[u] = n_sv[u];                 // (inactive lanes loaded the zero pad)
 #pragma unroll
             for (int u = NL; u < NPT; ++u) sv[u] = ((pact >> u) & 1u) ? tk[3 * u + 2] * Ev : 0.0;       // g_ij = (nStar_i / nStar_j) E, :453-454
             if constexpr (LK) {
@@ -416,8 +418,8 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
 #pragma unroll
                     for (int q = 0; q < NCR; ++q) cr[u][q] = n_cr[u][q];
             }
-            if (s + 1 < Ns) stream_loads(k + dk, n_bc, n_be, n_jd, n_sv, n_E, n_cr);
-            if constexpr (PH == 2) jhalf = at(Jnew, kl);
+            if constexpr (!LAST) stream_loads(k + dk, n_bc, n_be, n_jd, n_sv, n_E, n_cr);
+            if constexpr (SECOND) jhalf = at(Jnew, kl);
 #pragma unroll
             for (int u = 0; u < NPT; ++u) {
                 sni[u] = tk[3 * u + 0];
@@ -506,7 +508,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             const double dS = (S_prev - S) * rdt;
             // formal_solver.py:138-139: the end point re-uses the PREVIOUS interval's w and
             // S[kEnd - dk] with the fresh dS, dtau (reference behaviour, reproduced deliberately)
-            const bool last = PH == 2 && s == Ns - 1;       // the end point lies in the second-visitor phase (Nspace >= 3)
+            constexpr bool last = LAST;                     // the end point lies in the second-visitor phase (Nspace >= 3): its own instance
             double w0, w1;
             w2(last ? dtau_prev : dtau, w0, w1, etab);
             const double Sx = last ? S_prev : S;
@@ -518,8 +520,8 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         Iu = I;
         chi_prev = chiTot;
         S_prev = S;
-        if constexpr (PH == 2) {
-            if (s == Ns - 1 && dir == 1 && valid)        // emergent intensity, :638
+        if constexpr (LAST) {
+            if (dir == 1 && valid)                       // emergent intensity, :638
                 p.Iout[((size_t)col * Nspect + la) * Nrays + mu] = I;
         }
         STAMP(3);
@@ -596,6 +598,9 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                 const double Vij = line ? sl.cB * spv[u] : alv[u];
                 const double wt = line ? wlv[u] * tk[3 * u + 2] : wlv[u];         // :451 (lines: x wphi), :455, :665
                 // linked continua add their ray-independent share to the line's atom.eta, atom.chi[i], atom.chi[j]
+                // (x + 0.0 is not x to the compiler: the corrections are added only where the instance has them)
+                const bool lkl = LK && line;
+                auto plus = [](double x, double c, bool on) { return on ? x + c : x; };
                 const double cEC = (LK && line) ? cr[u < NLK ? u : 0][0] : 0.0, cXi = (LK && line) ? cr[u < NLK ? u : 0][1] : 0.0,
                              cXj = (LK && line && NCR > 2) ? cr[u < NLK ? u : 0][2] : 0.0;
                 if constexpr (NPT >= 3) {
@@ -619,13 +624,13 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                             }
                         }
                     }
-                    pass2x(line, sl.Vc, spv[u], sUji[u], Vij, wt, etaA + cEC, chi_i + cXi, chi_j + cXj, U_j, U_i, w1[u], w2v[u]);
+                    pass2x(line, sl.Vc, spv[u], sUji[u], Vij, wt, plus(etaA, cEC, lkl), plus(chi_i, cXi, lkl), plus(chi_j, cXj, lkl), U_j, U_i, w1[u], w2v[u]);
                 } else if constexpr (NPT == 2 && TOPO != 0) {
                     // rh_method.py:652, 677-681 with atom.U[i] = 0, atom.U[j] = Uji, atom.chi[j] = -chi (TOPO 1 and 2) and
                     // atom.chi[i] = chi + chi_other, atom.eta = eta + eta_other (TOPO 1: common lower level, same atom)
                     const int v = 1 - u;
-                    const double etaA = (TOPO == 1 ? seta[u] + seta[v] : seta[u]) + cEC;
-                    const double chi_i = (TOPO == 1 ? schi[u] + schi[v] : schi[u]) + cXi;
+                    const double etaA = plus(TOPO == 1 ? seta[u] + seta[v] : seta[u], cEC, lkl);
+                    const double chi_i = plus(TOPO == 1 ? schi[u] + schi[v] : schi[u], cXi, lkl);
                     const double Vji = line ? sl.Vc * spv[u] : spv[u];
                     const double Ieff = I - Psi * etaA;
                     w1[u] = wt * ((sUji[u] + Vji * Ieff) - (chi_i * Psi) * sUji[u]);
@@ -640,12 +645,12 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                     const double chi_j = fma(rel[REL_CJ], schi[v], -schi[u]);
                     const double U_j = fma(rel[REL_UJ], sUji[v], sUji[u]);
                     const double U_i = rel[REL_UI] * sUji[v];
-                    pass2x(line, sl.Vc, spv[u], sUji[u], Vij, wt, etaA + cEC, chi_i + cXi, chi_j + cXj, U_j, U_i, w1[u], w2v[u]);
+                    pass2x(line, sl.Vc, spv[u], sUji[u], Vij, wt, plus(etaA, cEC, lkl), plus(chi_i, cXi, lkl), plus(chi_j, cXj, lkl), U_j, U_i, w1[u], w2v[u]);
                 } else {
                     // a single per-ray slot: atom.U[i] = 0, atom.U[j] = Uji, atom.chi[j] = -chi (its product with U[i] vanishes)
                     const double Vji = line ? sl.Vc * spv[u] : spv[u];
-                    const double Ieff = I - Psi * (seta[u] + cEC);                                      // :652
-                    w1[u] = wt * ((sUji[u] + Vji * Ieff) - ((schi[u] + cXi) * Psi) * sUji[u]);           // :677
+                    const double Ieff = I - Psi * plus(seta[u], cEC, lkl);                              // :652
+                    w1[u] = wt * ((sUji[u] + Vji * Ieff) - (plus(schi[u], cXi, lkl) * Psi) * sUji[u]);   // :677
                     w2v[u] = wt * (Vij * Ieff);                                                          // :680
                 }
             }
@@ -743,7 +748,8 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         const int nA = Ns / 2;                                // depths this wave reaches first: 2 s < Nspace - 1
         for (int s = 0; s < nA; ++s) step(s, std::integral_constant<int, 0>{});
         if (Ns & 1) step(nA, std::integral_constant<int, 1>{});
-        for (int s = nA + (Ns & 1); s < Ns; ++s) step(s, std::integral_constant<int, 2>{});
+        for (int s = nA + (Ns & 1); s < Ns - 1; ++s) step(s, std::integral_constant<int, 2>{});
+        step(Ns - 1, std::integral_constant<int, 3>{});       // the end point (Nspace >= 3: always a second-visitor step)
     }
 
 #ifdef LSX_STAMPS
