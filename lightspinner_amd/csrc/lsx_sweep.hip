@@ -395,7 +395,9 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     //   phase 1: odd Nspace only, the one depth both waves visit in the same step (exchange through LDS)
     //   phase 2: second visitor (the partner's half is requested at the top of the step, used at its end)
     auto step = [&](const int s, auto phase_c) {
-        constexpr int PH = decltype(phase_c)::value;         // 0 first visitor, 1 midpoint, 2 second visitor, 3 its last step (the end point)
+        constexpr int PHX = decltype(phase_c)::value;        // 0 first visitor, 1 midpoint, 2 second visitor, 3 its last step (the end point),
+        constexpr bool FIRST = PHX == 4;                     // 4 the ray's first point (a first-visitor step without a formal solution)
+        constexpr int PH = FIRST ? 0 : PHX;
         constexpr bool SECOND = PH >= 2, LAST = PH == 3;
         const int k = kS + dk * s;
         const unsigned kl = (unsigned)(k * L + j) * 8u;     // byte position in the tile-major [k][j] streams
@@ -499,7 +501,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
 
         // ---- formal solution at this depth (formal_solver.py:107-139) ----
         double I, Lam;
-        if (s == 0) {
+        if constexpr (FIRST) {
             I = Iu;
             Lam = 0.0;
         } else {
@@ -746,7 +748,8 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     };
     {
         const int nA = Ns / 2;                                // depths this wave reaches first: 2 s < Nspace - 1
-        for (int s = 0; s < nA; ++s) step(s, std::integral_constant<int, 0>{});
+        step(0, std::integral_constant<int, 4>{});              // the ray's first point (Nspace >= 3: nA >= 1)
+        for (int s = 1; s < nA; ++s) step(s, std::integral_constant<int, 0>{});
         if (Ns & 1) step(nA, std::integral_constant<int, 1>{});
         for (int s = nA + (Ns & 1); s < Ns - 1; ++s) step(s, std::integral_constant<int, 2>{});
         step(Ns - 1, std::integral_constant<int, 3>{});       // the end point (Nspace >= 3: always a second-visitor step)
