@@ -156,3 +156,17 @@ def test_columns_without_profiles_and_device_profile_inputs():
     bad.wphi = np.zeros((1, prob.Nlines, prob.Nspace))
     with pytest.raises(ValueError):
         bad.validate(prob)
+
+
+def test_header_is_plain_c_and_cxx():
+    """include/lsx.h is the drop-in boundary: it must compile as C99 and as C++11 on its own (no torch, no HIP types)"""
+    import shutil
+    import subprocess
+    hdr = os.path.join(ROOT, 'include', 'lsx.h')
+    for cc, flags in (('gcc', ['-std=c99', '-pedantic', '-x', 'c']), ('g++', ['-std=c++11', '-x', 'c++'])):
+        if shutil.which(cc) is None:
+            pytest.skip(cc + ' not installed')
+        r = subprocess.run([cc, '-Wall', '-Werror', '-fsyntax-only'] + flags + [hdr], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    text = open(hdr).read()
+    assert 'torch' not in text and 'hip/' not in text
