@@ -169,4 +169,4 @@ def test_header_is_plain_c_and_cxx():
         r = subprocess.run([cc, '-Wall', '-Werror', '-fsyntax-only'] + flags + [hdr], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
     text = open(hdr).read()
-    assert 'torch' not in text and 'hip/' not in text
+    assert '#include <torch' not in text and '#include <hip' not in text and 'at::Tensor' not in text      # a stream is passed as void*
