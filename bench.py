@@ -43,6 +43,25 @@ def load_columns(eng, batch, prof, c0=0, step=100):
     synth.load_columns(eng, batch, prof, col0=c0, step=step)
 
 
+_REAL_STDOUT = None
+
+
+def protect_stdout():
+    """stdout carries ONE JSON line: whatever libraries print to file descriptor 1 during the run (gloo's rank chatter in a
+    rehearsal, runtime notices) is sent to stderr instead; emit() writes the line to the real stdout"""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), 'w')
+        os.dup2(2, 1)
+
+
+def emit(result):
+    out = _REAL_STDOUT or sys.stdout
+    out.write(json.dumps(result) + '\n')
+    out.flush()
+
+
 def stats_ms(times):
     t = np.asarray(times) * 1e3
     return dict(min=float(t.min()), median=float(np.median(t)), max=float(t.max()), p10=float(np.percentile(t, 10)),
@@ -143,7 +162,7 @@ def run_c5(args, rank, local_rank, world):
         roofline=None, cpu_baseline=None)
     if rehearsal:
         result.update(rehearsal)
-    print(json.dumps(result))
+    emit(result)
 
 
 def cpu_baseline(prob, batch, prof, seconds_target=12.0):
@@ -292,6 +311,7 @@ def main():
                          'atmosphere (lsx_set_atmosphere, SURVEY 8f N1) instead of input-level perturbations')
     args = ap.parse_args()
 
+    protect_stdout()
     rank, local_rank, world = dist_env()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -405,7 +425,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        emit(result)
 
 
 if __name__ == '__main__':
