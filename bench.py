@@ -293,6 +293,54 @@ def measure_share(workload, ncol, local_rank, lib, torch, steps=40, warmup=3, ke
                 generate_s=t_gen)
 
 
+def dry_run(args, rank, world):
+    """what every rank does around the timed region, without the GPU: rendezvous, one all-reduce(MAX), one line from rank 0"""
+    import torch
+    import torch.distributed as dist
+    top = rank
+    if world > 1:
+        dist.init_process_group('gloo')
+        t = torch.tensor([float(rank)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        top = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        emit(dict(metric='depth_points_x_wavelengths_x_rays_per_sec', value=None, unit='point-updates/s', n_gpus=world,
+                  steps=args.steps, warmup=args.warmup, dry_run=True, max_rank_seen=top,
+                  note='launcher check only (--dry-run): nothing was measured'))
+
+
+def self_launch(ngpus):
+    """`python bench.py --gpus N` without a launcher: this process touches no GPU (no torch, no HIP library) and starts
+    the N ranks as ONE child, `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>`, rendezvous on
+    127.0.0.1 at a free port; rank 0's JSON line is passed through, the exit status is the child's."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ngpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '1')
+    sys.stdout.flush()
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = []
+    for line in proc.stdout:              # the ranks send everything but the result to stderr (protect_stdout)
+        if line.lstrip().startswith('{'):
+            lines.append(line)
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    for line in lines[-1:]:
+        sys.stdout.write(line)
+    sys.stdout.flush()
+    if rc != 0 or not lines:
+        raise SystemExit(rc or 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -309,13 +357,20 @@ def main():
     ap.add_argument('--physical-columns', action='store_true',
                     help='columns whose populations, rates and profiles the library derives from each column\'s own perturbed '
                          'atmosphere (lsx_set_atmosphere, SURVEY 8f N1) instead of input-level perturbations')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='launcher check without a GPU: the ranks rendezvous over gloo, all-reduce(MAX) their rank and rank 0 '
+                         'prints a JSON line with value null')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        return self_launch(args.gpus)
     protect_stdout()
     rank, local_rank, world = dist_env()
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus N` or under torch.distributed.run '
+                         'with --nproc-per-node equal to --gpus' % (args.gpus, world))
     if args.workload == 'c5':
         return run_c5(args, rank, local_rank, world)
     fixture = os.path.join(ROOT, 'tests', 'golden', 'falc_cah.npz' if args.workload == 'c4' else 'falc_ca.npz')

@@ -26,7 +26,7 @@ def iterate_mali(ctx, dJ_tol=2e-3, dPops_tol=1e-3, n_lambda_only=3, max_iter=500
     """`while dJ > 2e-3 or dPops > 1e-3` loop of test.py:20-29 with the reference's
     defaults: the first 3 iterations update J only (`if i > 3`, test.py:27).
 
-    ctx needs formal_sol_gamma_matrices() and stat_equil() (Context, BatchContext or
+    ctx needs formal_sol_gamma_matrices() and stat_equil() (Context or
     an Engine adapter).  reduce_max((dJ, dPops)) -> (dJ, dPops) is the hook where the
     multi-GPU driver takes the max over ranks (parallel.allreduce_max)."""
     h = MaliHistory()

@@ -1,0 +1,60 @@
+"""`python bench.py --gpus N` starts its own ranks (the 1/2/4/8-GPU runs).  CPU checks of the launcher: the
+parent process touches no GPU (it must not, a process that has initialised HIP may not start the ranks), the ranks
+rendezvous over 127.0.0.1 and exactly one JSON line reaches stdout."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def test_self_launch_parent_stays_off_the_gpu():
+    code = r'''
+import json, os, sys
+sys.path.insert(0, %r)
+import bench, subprocess
+seen = {}
+class FakeProc:
+    def __init__(self, cmd, env=None, stdout=None, text=None):
+        seen['cmd'], seen['env'] = cmd, env
+        self.stdout = iter(['rank chatter\n', '{"metric": "m", "n_gpus": 4}\n'])
+    def wait(self): return 0
+subprocess.Popen = FakeProc
+sys.argv = ['bench.py', '--gpus', '4', '--steps', '7', '--warmup', '2']
+os.environ.pop('WORLD_SIZE', None)
+bench.main()
+maps = open('/proc/self/maps').read()
+print(json.dumps(dict(cmd=seen['cmd'], torch='torch' in sys.modules, hip='liblsx_hip' in maps or 'libamdhip64' in maps,
+                      ipc=seen['env'].get('HSA_ENABLE_IPC_MODE_LEGACY'))))
+''' % ROOT
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert json.loads(lines[0]) == {'metric': 'm', 'n_gpus': 4}         # rank 0's line, passed through
+    info = json.loads(lines[1])
+    assert not info['torch'] and not info['hip']                        # the parent never imported torch / loaded HIP
+    assert info['ipc'] == '0'
+    cmd = info['cmd']
+    assert cmd[1:3] == ['-m', 'torch.distributed.run']
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '4' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[-7].endswith('bench.py') and cmd[-6:] == ['--gpus', '4', '--steps', '7', '--warmup', '2']
+
+
+def test_self_launch_two_ranks_dry_run():
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--dry-run'],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 2 and r['steps'] == 3 and r['max_rank_seen'] == 1 and r['dry_run'] is True
+
+
+def test_gpus_must_match_world_size():
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'],
+                         capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert out.returncode != 0 and 'WORLD_SIZE=1' in out.stderr
