@@ -10,6 +10,7 @@
 
 #include "../../include/lsx.h"
 #include "lsx_dev.h"
+#include "lsx_plan.h"
 
 namespace lsxd {
 extern thread_local std::string g_err;
@@ -22,53 +23,32 @@ int fail(int code, const char* fmt, ...);    // records the message lsx_last_err
         if (e_ != hipSuccess) return lsxd::fail(LSX_EDEVICE, "%s: %s", #expr, hipGetErrorString(e_));   \
     } while (0)
 
-struct SweepClass {           // tiles that run the same kernel instantiation, launched on their own stream
-    int npt = -1;              // compile-time per-ray slot count, -1 = generic
+struct SweepClass : lsxd::PlanClass {   // a plan class + what the runtime keeps for it: its own stream, events, device tile lists
     long launches = 0;         // how often this class's kernel has been launched (introspection for the tests)
-    int nl = 0;                // lines among them (compile-time too)
-    bool linked = false;       // the class's tiles have linked continua (compile-time too)
-    int topo = 0;              // two-line classes: known relation of the two lines (lsx_sweep.hip, TOPO)
-    bool has_fast = false;     // some tile of the class has fast continua: the class reads the pre-pass output
     hipEvent_t tdone = nullptr; // timed runs: end of this class's launch
-    std::vector<int> fast_tiles; // the class's tiles that have fast continua
     int* d_fast_tiles = nullptr;
-    std::vector<int> fast_cols[4], fast_rest;   // ... split by the kernel that builds their Gamma slabs (k_fast_gamma_cols
-    int *d_fast_cols[4] = {nullptr, nullptr, nullptr, nullptr}, *d_fast_rest = nullptr;   // instance / k_fast_gamma)
-    std::vector<int> tiles;
+    int *d_fast_cols[4] = {nullptr, nullptr, nullptr, nullptr}, *d_fast_rest = nullptr;
     int* d_tiles = nullptr;
-    int ncell_lev = 1, ncell_atom = 1;
-    size_t lds_bytes = 0;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
 };
 
-struct lsx_ctx {
+struct lsx_ctx : lsxd::LsxPlan {        // the plan (lsx_plan.h: dimensions, tables, tile schedule, strides, launch shapes) + device state
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    int Nspace = 0, Nrays = 0, Nspect = 0, Natoms = 0, Ntrans = 0, ncol = 0;
-    int NLtot = 0, NL2tot = 0, Nlines = 0, SNl = 0, SNc = 0;
-    int sca_per_lambda = 0, phi_compact = 0;
-    std::vector<int> Nlevel, lev_off, lev2_off;
-    std::vector<lsx_transition> trans;
-    std::vector<DevTrans> htrans;
-    std::vector<DevTile> tiles;
-    std::vector<int> tile_slots;
-    std::vector<DevSlot> slots;
+    int ncol = 0;
     DevSlot* d_slots = nullptr;
-    int L = 0;
-    std::vector<SweepClass> classes;
+    std::vector<SweepClass> classes;     // plan_classes, in launch order
     hipEvent_t ev_fork = nullptr;
     double ms_sweep = 0.0, ms_finish = 0.0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
-    size_t lds_bytes = 0;
     // device: column independent
     double *d_wavelength = nullptr, *d_zmu = nullptr, *d_wmuh = nullptr, *d_wl = nullptr, *d_alpha = nullptr,
            *d_u_la = nullptr;
     uint8_t* d_active = nullptr;
     DevTrans* d_trans = nullptr;
     DevTile* d_tiles = nullptr;
-    std::vector<uint8_t> tile_slot_fast;     // per slot: fast continuum (its slabs use the first direction entry only)
     int *d_tile_slots = nullptr, *d_Nlevel = nullptr, *d_lev2_off = nullptr;
     // device: per column
     double *d_height = nullptr, *d_temperature = nullptr, *d_nStar = nullptr, *d_nTotal = nullptr, *d_n = nullptr,
@@ -79,26 +59,19 @@ struct lsx_ctx {
     std::vector<uint8_t> phi_set;    // per column: line profiles have been handed over or built
     size_t n_phi_set = 0;
     int solver = 0;               // LSX_SOLVER_* (lsx_set_formal_solver)
-    bool opt_se_lds = false, opt_trace_classes = false, opt_serial = false;   // LSX_SE_LDS / LSX_TRACE_CLASSES, read once in lsx_create
+    bool opt_se_lds = false, opt_trace_classes = false, opt_serial = false;   // LSX_SE_LDS / LSX_TRACE_CLASSES / LSX_SERIAL, read once in lsx_create
     long fused_launches = 0;
     uint8_t* d_colmask = nullptr; // per-column activity, nullptr = all active
     double *d_bgxchi = nullptr, *d_bgxeta = nullptr, *d_Psi2 = nullptr; // fast-continuum side arrays
-    std::vector<int> fast_tiles;
     int* d_fast_tiles = nullptr;
-    std::vector<int> fast_cols[4], fast_rest;
     int *d_fast_cols[4] = {nullptr, nullptr, nullptr, nullptr}, *d_fast_rest = nullptr;
     int *d_cont_li = nullptr, *d_cont_lj = nullptr;
     double* d_exp2_tab = nullptr;
     double* d_voigt_w = nullptr;
     double *d_muz = nullptr, *d_wmu = nullptr;
-    int nF_max = 0, Ncont = 0, static_max = -1, nL_linked_max = 0;
-    bool fast_generic = false;
     double* d_nsr = nullptr;     // [col][Ncont][k] nStar_i / nStar_j of the continua
-    std::vector<int> cont_li, cont_lj;
     double* d_debug = nullptr;   // 64 x 16 x 8 B, diagnostic builds of the sweep kernel write stamps here
     int jcur = 0; // d_J[jcur] holds the current J (Jdag of the next call)
-    size_t phi_col = 0, phi_in_col = 0, corr_col = 0, pp_col = 0, sca_col = 0, til_col = 0;
-    bool any_cont = false;      // some tile has a continuum: E_T is kept
     // set-up chain (lsx_setup.hip): atomic data tables and what lsx_set_atmosphere derives per column
     char *d_sa_atoms = nullptr, *d_sa_lines = nullptr, *d_sa_colls = nullptr;
     double *d_sa_spl = nullptr, *d_sa_levE = nullptr, *d_sa_levg = nullptr, *d_sa_levnD = nullptr;

@@ -340,15 +340,6 @@ struct FastParams {
 
 // one fast continuum at (lambda, depth): rh_method.py:284-286, 453-455, 613-614, with g_ij = (nStar_i / nStar_j) E
 struct FastVal { double alf, Vji, Uji, chi, eta; bool a; };
-#define LSX_MAX_TILE_LINES 4
-// k_fast_gamma_cols instances by the number of lines the tile's linked continua feed: list v holds the tiles with
-// kLkLines[v - 1] < lines <= kLkLines[v]
-static const int kLkLines[4] = {0, 1, 2, LSX_MAX_TILE_LINES};
-static inline int lkclass(const DevTile& tl)
-{
-    const int n = tl.nK > 0 ? (tl.nL < LSX_MAX_TILE_LINES ? tl.nL : LSX_MAX_TILE_LINES) : 0;
-    return n == 0 ? 0 : (n == 1 ? 1 : (n == 2 ? 2 : 3));
-}
 // effective background of the tiles that have fast continua: bgx = bg + sum over the tile's fast continua; for the
 // lines of a tile with linked continua also the three sums the line's own Gamma integrand needs from them
 // (rh_method.py:616-627: atom.eta, atom.chi[i_line], atom.chi[j_line], continuum part)
@@ -692,9 +683,7 @@ __global__ void __launch_bounds__(NT) k_fast_gamma(const FastParams f)
 // wave-private LDS area with coalesced 16-byte loads (both directions summed on the way, pad wavelengths zeroed) and the
 // arithmetic reads it from there.  Same terms, same order per wavelength as k_fast_gamma; the sum over the wavelengths
 // runs over the lane's pairs in ascending order, then lane 0 + lane 1.
-#define LSX_FAST_NQ 6
-#define LSX_FGC_ROWS 32       // (column, depth) rows per wave
-#define LSX_FGC_MAXF 12       // fast continua per tile this kernel takes (sizes its operand table)
+// (LSX_FAST_NQ, LSX_FGC_ROWS, LSX_FGC_MAXF: lsx_plan.h -- the plan sizes this kernel's LDS and decides which tiles it takes)
 template <int NLC>            // NLC: lines of the tile that linked continua feed (0: the tile has no linked continuum)
 __global__ void __launch_bounds__(256) k_fast_gamma_cols(const FastParams f)
 {
@@ -1259,18 +1248,6 @@ int launch_tiles_pack(lsx_ctx* c, const double* in, double* out, int B, bool unp
     return LSX_OK;
 }
 
-double wlambda(const lsx_ctx* c, const std::vector<double>& wave, const lsx_transition& t, int lt)
-{
-    // rh_method.py:157-196 (single index form)
-    (void)c;
-    const double* wl = wave.data() + t.Nblue;
-    const double dopplerWidth = t.is_line ? kCLight / t.lambda0 : 1.0;
-    const int N = t.Nlambda;
-    if (lt == 0) return 0.5 * (wl[1] - wl[0]) * dopplerWidth;
-    if (lt == N - 1) return 0.5 * (wl[N - 1] - wl[N - 2]) * dopplerWidth;
-    return 0.5 * (wl[lt + 1] - wl[lt - 1]) * dopplerWidth;
-}
-
 
 } // namespace
 
@@ -1390,11 +1367,25 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
 {
     if (!d || !out || ncol < 1) return fail(LSX_EINVAL, "lsx_create: null argument or ncol < 1");
     if (ncol > 65535) return fail(LSX_EUNSUPPORTED, "lsx_create: at most 65535 columns per context (the column is a grid dimension); use several contexts");
-    if (d->abi_version != LSX_ABI_VERSION) return fail(LSX_EINVAL, "lsx_create: ABI version mismatch");
-    if (d->Nspace < 3) return fail(LSX_EINVAL, "lsx_create: Nspace must be >= 3 (formal_solver.py:120-139)");
-    if (d->Nrays < 1 || d->Nspect < 1 || d->Natoms < 1 || d->Ntrans < 0) return fail(LSX_EINVAL, "lsx_create: bad dimensions");
-    if (d->Nrays > LSX_WAVE) return fail(LSX_EUNSUPPORTED, "lsx_create: Nrays > 64 is not supported by this build");
-    if (d->Natoms > LSX_MAX_ATOMS) return fail(LSX_EUNSUPPORTED, "lsx_create: more than %d active atoms", LSX_MAX_ATOMS);
+    // ---- the plan (lsx_plan.cpp, host only): descriptor checks, transition tables, tile schedule, slot table, sweep classes,
+    // strides, LDS sizes and launch shapes.  Nothing below can fail on the problem's shape any more.
+    PlanOptions opt;
+    {   // diagnostic switches; the environment is read here only
+        const char* e;
+        opt.no_linked = getenv("LSX_NO_LINKED") != nullptr;
+        opt.natural_tiles = (e = getenv("LSX_TILER")) && std::string(e) == "natural";
+        opt.no_topo = getenv("LSX_NO_TOPO") != nullptr;
+        opt.fast_rows = getenv("LSX_FAST_ROWS") != nullptr;
+        opt.order_by_cost = (e = getenv("LSX_ORDER")) && std::string(e) == "cost";
+        opt.occ_wg = (e = getenv("LSX_OCC_WG")) ? atoi(e) : 0;
+    }
+    LsxPlan plan;
+    {
+        std::string perr;
+        const int prc = plan_build(d, opt, &plan, &perr);
+        if (prc) return fail(prc, "%s", perr.c_str());
+    }
+    if ((long)plan.tiles.size() * ncol > 0x7fffffffL) return fail(LSX_EUNSUPPORTED, "lsx_create: %zu tiles x %d columns exceed the grid", plan.tiles.size(), ncol);
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(LSX_EDEVICE, "lsx_create: no HIP device visible (this library has no CPU path)");
@@ -1402,7 +1393,13 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     HIPCHK(hipSetDevice(device));
 
     lsx_ctx* c = new lsx_ctx();
+    static_cast<LsxPlan&>(*c) = std::move(plan);
+    for (const PlanClass& pc : c->plan_classes) {
+        c->classes.push_back(SweepClass());
+        static_cast<PlanClass&>(c->classes.back()) = pc;
+    }
     c->device = device;
+    c->ncol = ncol;
     if (stream) {
         c->stream = reinterpret_cast<hipStream_t>(stream);
     } else {
@@ -1410,380 +1407,29 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         if (e != hipSuccess) { delete c; return fail(LSX_EDEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
         c->own_stream = true;
     }
-    c->Nspace = d->Nspace; c->Nrays = d->Nrays; c->Nspect = d->Nspect; c->Natoms = d->Natoms;
-    c->Ntrans = d->Ntrans; c->ncol = ncol;
-    c->sca_per_lambda = d->sca_per_lambda ? 1 : 0;
-    c->phi_compact = d->phi_compact ? 1 : 0;
-    c->L = LSX_WAVE / d->Nrays;
-    c->opt_se_lds = getenv("LSX_SE_LDS") != nullptr;              // diagnostics; the environment is read here only
+    c->opt_se_lds = getenv("LSX_SE_LDS") != nullptr;
     c->opt_trace_classes = getenv("LSX_TRACE_CLASSES") != nullptr;
     c->opt_serial = getenv("LSX_SERIAL") != nullptr;              // every class on the context's stream, one after the other
     const int Ns = c->Nspace, Nspect = c->Nspect;
-    for (int a = 0; a < c->Natoms; ++a) {
-        if (d->Nlevel[a] < 2) { lsx_destroy(c); return fail(LSX_EINVAL, "lsx_create: Nlevel < 2"); }
-        c->Nlevel.push_back(d->Nlevel[a]);
-        c->lev_off.push_back(c->NLtot);
-        c->lev2_off.push_back(c->NL2tot);
-        c->NLtot += d->Nlevel[a];
-        c->NL2tot += d->Nlevel[a] * d->Nlevel[a];
-    }
-
-    std::vector<double> wave(d->wavelength, d->wavelength + Nspect);
-    std::vector<double> wl, alpha;
-    std::vector<uint8_t> active(d->active, d->active + (size_t)c->Ntrans * Nspect);
-    int alpha_in = 0;
-    for (int t = 0; t < c->Ntrans; ++t) {
-        const lsx_transition& tr = d->trans[t];
-        if (tr.atom < 0 || tr.atom >= c->Natoms || tr.i < 0 || tr.j >= c->Nlevel[tr.atom] || tr.i >= tr.j || tr.Nblue < 0 ||
-            tr.Nlambda < 2 || tr.Nblue + tr.Nlambda > Nspect) {
-            lsx_destroy(c);
-            return fail(LSX_EINVAL, "lsx_create: inconsistent transition table entry %d", t);
-        }
-        c->trans.push_back(tr);
-        DevTrans h{};
-        h.atom = tr.atom; h.is_line = tr.is_line ? 1 : 0;
-        h.li = c->lev_off[tr.atom] + tr.i; h.lj = c->lev_off[tr.atom] + tr.j;
-        h.Nblue = tr.Nblue; h.Nlam = tr.Nlambda;
-        h.wl_off = (int)wl.size();
-        const int Nl = c->Nlevel[tr.atom];
-        h.gam_ij = c->lev2_off[tr.atom] + tr.i * Nl + tr.j;
-        h.gam_ji = c->lev2_off[tr.atom] + tr.j * Nl + tr.i;
-        if (tr.is_line) {
-            h.phi_off = c->SNl; h.line_idx = c->Nlines;
-            c->SNl += tr.Nlambda; c->Nlines++;
-            h.cB = (0.25 * kHC / M_PI) * tr.Bij; // rh_method.py:268,279
-            h.gij = tr.Bji / tr.Bij;             // :450
-            h.AB = tr.Aji / tr.Bji;              // :281
-            h.lambda0 = tr.lambda0;
-            for (int lt = 0; lt < tr.Nlambda; ++lt) { wl.push_back(wlambda(c, wave, tr, lt) / kHC); alpha.push_back(0.0); } // :451
-        } else {
-            h.cont_off = c->SNc;
-            c->SNc += tr.Nlambda;
-            for (int lt = 0; lt < tr.Nlambda; ++lt) {
-                wl.push_back(wlambda(c, wave, tr, lt) / wave[tr.Nblue + lt] / kHPlanck); // :455
-                alpha.push_back(d->alpha[alpha_in + lt]);
-            }
-            alpha_in += tr.Nlambda;
-        }
-        c->htrans.push_back(h);
-    }
-    // ---- tile schedule: L = 64/Nrays consecutive wavelengths per wavefront pair
-    const int P_line = c->phi_compact ? 1 : 2 * c->Nrays;
-    size_t phi_run = 0, corr_run = 0, pp_run = 0;   // running block offsets inside a column's phi_T / corr_T / Psi3_T
-    // The transitions of the wavelengths [a, b) by role.  Lines are per-ray slots of the sweep.  A continuum is
-    //   fast     its atom has no line in the tile: ray independent, handled by k_fast_prepass / k_fast_gamma;
-    //   linked   its atom has lines in the tile but none of them touches the continuum's UPPER level: its Gamma integrand
-    //            is then affine in I, Psi* and Psi* phi_line with ray-independent coefficients, so it stays out of the
-    //            sweep too -- the sweep stores sum_mu w Psi* phi per line, the pre-pass hands the line three
-    //            ray-independent sums (atom.eta, atom.chi[i], atom.chi[j] of the continua, rh_method.py:616-627);
-    //   per-ray  otherwise (a line ends on the continuum's upper level): goes through the sweep like a line.
-    // If one continuum of an atom has to be per-ray, all continua of that atom in the tile are (their sums couple).
-    struct Roles { std::vector<int> lines, per_ray_conts, fast; int nlinked = 0; };
-    const bool no_linked = getenv("LSX_NO_LINKED") != nullptr;      // diagnostic: the round-1 classification
-    auto roles_of = [&](int a, int b) {
-        Roles r;
-        std::vector<int> conts;
-        unsigned atoms_with_line = 0;
-        for (int t = 0; t < c->Ntrans; ++t) {
-            bool any = false;
-            for (int la = a; la < b && !any; ++la) any = active[(size_t)t * Nspect + la];
-            if (!any) continue;
-            if (c->htrans[t].is_line) { r.lines.push_back(t); atoms_with_line |= 1u << c->htrans[t].atom; }
-            else conts.push_back(t);
-        }
-        unsigned atoms_per_ray = 0;
-        for (int t : conts) {
-            const DevTrans& h = c->htrans[t];
-            if (!((atoms_with_line >> h.atom) & 1u)) continue;
-            bool touches = no_linked || (int)r.lines.size() > LSX_MAX_TILE_LINES;   // (the fast kernels couple at most that many lines)
-            for (int l : r.lines) touches = touches || c->htrans[l].li == h.lj || c->htrans[l].lj == h.lj;
-            if (touches) atoms_per_ray |= 1u << h.atom;
-        }
-        for (int t : conts) {
-            const DevTrans& h = c->htrans[t];
-            if ((atoms_per_ray >> h.atom) & 1u) r.per_ray_conts.push_back(t);
-            else { r.fast.push_back(t); r.nlinked += (atoms_with_line >> h.atom) & 1u; }
-        }
-        return r;
-    };
-    // ---- where to cut: a wavefront costs the same for 1 or L wavelengths, and roughly C(nP) per depth
-    // step with nP = per-ray slots of the tile (measured shader cycles, profiles/).  Dynamic programme over
-    // the cut positions; ties favour fewer tiles.  Any tiling gives the same results.
-    std::vector<int> cuts;
-    {
-        auto cost = [&](int a, int b) {
-            // SIMD time of one wavefront (wave cycles / resident waves per SIMD), PMC-measured on MI355X for the
-            // classes with 0 .. 4 compile-time slots (profiles/); more slots run the generic instance.  Linked continua
-            // cost the sweep three stream loads and one more angle sum per line.
-            static const double C[] = {2500.0, 2950.0, 3550.0, 6600.0, 9600.0};
-            const Roles r = roles_of(a, b);
-            const int np = (int)(r.lines.size() + r.per_ray_conts.size());
-            return (np <= 4 ? C[np] : 14600.0 + 2500.0 * (np - 5)) + (r.nlinked ? 250.0 * r.lines.size() : 0.0);
-        };
-        const char* env = getenv("LSX_TILER");
-        const bool natural = env && std::string(env) == "natural";
-        std::vector<double> best(Nspect + 1, 1e300);
-        std::vector<int> from(Nspect + 1, 0);
-        best[0] = 0.0;
-        for (int i = 1; i <= Nspect; ++i)
-            for (int w = 1; w <= c->L && w <= i; ++w) {
-                if (natural && w != c->L && i != Nspect) continue;
-                if (natural && ((i - w) % c->L) != 0) continue;
-                const double v = best[i - w] + cost(i - w, i) + 1.0;
-                if (v < best[i]) { best[i] = v; from[i] = i - w; }
-            }
-        for (int i = Nspect; i > 0; i = from[i]) cuts.push_back(from[i]);
-        std::reverse(cuts.begin(), cuts.end());
-        cuts.push_back(Nspect);
-    }
-    std::vector<int> cont_index(c->Ntrans, -1);
-    c->Ncont = 0;
-    for (int t = 0; t < c->Ntrans; ++t)
-        if (!c->htrans[t].is_line) cont_index[t] = c->Ncont++;
-    for (size_t ic = 0; ic + 1 < cuts.size(); ++ic) {
-        const int la0 = cuts[ic];
-        DevTile tl{};
-        tl.la0 = la0;
-        tl.nla = cuts[ic + 1] - la0;
-        tl.slot0 = (int)c->tile_slots.size();
-        const Roles roles = roles_of(la0, la0 + tl.nla);
-        const std::vector<int>& lines = roles.lines;
-        // per-ray slots: lines, then the continua that must go through the sweep; fast: the other continua (linked ones flagged)
-        std::vector<int> per_ray = lines, fast = roles.fast;
-        per_ray.insert(per_ray.end(), roles.per_ray_conts.begin(), roles.per_ray_conts.end());
-        unsigned atoms_with_line = 0;
-        for (int t : lines) atoms_with_line |= 1u << c->htrans[t].atom;
-        if ((int)per_ray.size() > LSX_MAX_PER_RAY || (int)fast.size() > LSX_MAX_FAST) {
-            lsx_destroy(c);
-            return fail(LSX_EUNSUPPORTED, "lsx_create: more than %d overlapping transitions in wavelengths [%d, %d)",
-                        LSX_MAX_PER_RAY, la0, la0 + tl.nla);
-        }
-        tl.nP = (int)per_ray.size();
-        tl.nF = (int)fast.size();
-        tl.nK = roles.nlinked;
-        tl.nL = (int)lines.size();
-        if (tl.nK > 0) c->nL_linked_max = std::max(c->nL_linked_max, tl.nL);
-        if (tl.nK > 0) {            // the line slots' correction streams and the sweep's sum_mu w Psi* phi streams
-            tl.corr_off = (int)corr_run;
-            corr_run += (size_t)tl.nL * 3 * Ns * c->L;
-            tl.pp_off = (int)pp_run;
-            pp_run += (size_t)tl.nL * Ns * c->L;
-        }
-        c->any_cont = c->any_cont || !fast.empty() || per_ray.size() > lines.size();
-        std::vector<int> order = per_ray;
-        order.insert(order.end(), fast.begin(), fast.end());
-        // tile-local cell ids
-        std::vector<int> lev_ids, atom_ids;
-        auto local = [](std::vector<int>& v, int x) {
-            auto it = std::find(v.begin(), v.end(), x);
-            if (it != v.end()) return (int)(it - v.begin());
-            v.push_back(x);
-            return (int)v.size() - 1;
-        };
-        // level / atom cells of the generic instance: shared among the PER-RAY slots only (fast and linked continua never
-        // enter the sweep's bookkeeping); first-writer flags follow the execution order of pass 1
-        std::vector<int> exec = per_ray;
-        std::vector<int> chi_written, u_written, eta_written;
-        auto seen = [](std::vector<int>& v, int x) { bool sn = std::find(v.begin(), v.end(), x) != v.end(); if (!sn) v.push_back(x); return sn; };
-        std::vector<int> first_flags(c->Ntrans, 0);
-        auto share_flags = [&](int t) {
-            const DevTrans& h = c->htrans[t];
-            int nli = 0, nlj = 0, natom = 0, uiread = 0;
-            for (int v : per_ray) {
-                const DevTrans& o = c->htrans[v];
-                if (o.li == h.li || o.lj == h.li) nli++;
-                if (o.li == h.lj || o.lj == h.lj) nlj++;
-                if (o.atom == h.atom) natom++;
-                if (o.lj == h.li) uiread = 1;
-            }
-            int f = h.is_line ? SLOT_LINE : 0;
-            if (nli > 1) f |= SLOT_LI_CELL;
-            if (nlj > 1) f |= SLOT_LJ_CELL;
-            if (uiread) f |= SLOT_UI_READ;
-            if (natom > 1) f |= SLOT_ETA_CELL;
-            return f;
-        };
-        for (int t : exec) {
-            const DevTrans& h = c->htrans[t];
-            int f = share_flags(t);
-            if ((f & SLOT_LI_CELL) && !seen(chi_written, h.li)) f |= SLOT_CHI_I_FIRST;
-            if (f & SLOT_LJ_CELL) {
-                if (!seen(chi_written, h.lj)) f |= SLOT_CHI_J_FIRST;
-                if (!seen(u_written, h.lj)) f |= SLOT_U_J_FIRST;
-            }
-            if ((f & SLOT_ETA_CELL) && !seen(eta_written, h.atom)) f |= SLOT_ETA_FIRST;
-            first_flags[t] = f;
-        }
-        for (int t : order) {
-            const DevTrans& h = c->htrans[t];
-            DevSlot sl{};
-            sl.flags = first_flags[t];
-            sl.li = h.li; sl.lj = h.lj; sl.atom = h.atom;
-            // cells exist only for levels / atoms that two transitions of the tile share
-            sl.ci = (sl.flags & (SLOT_LI_CELL | SLOT_UI_READ)) ? local(lev_ids, h.li) : 0;
-            sl.cj = (sl.flags & SLOT_LJ_CELL) ? local(lev_ids, h.lj) : 0;
-            sl.ca = (sl.flags & SLOT_ETA_CELL) ? local(atom_ids, h.atom) : 0;
-            sl.Nblue = h.Nblue; sl.Nlam = h.Nlam; sl.wl_off = h.wl_off; sl.trans = t;
-            // the block of this (tile, transition): the tile's wavelengths inside the transition's range
-            sl.first = std::max(tl.la0, h.Nblue);
-            sl.len = std::min(tl.la0 + tl.nla, h.Nblue + h.Nlam) - sl.first;
-            if (h.is_line) {
-                sl.base = (int)phi_run;
-                phi_run += (size_t)sl.len * P_line * Ns;
-                sl.wphi_off = h.line_idx * Ns;
-                sl.cB = h.cB; sl.g = h.gij; sl.Vc = h.gij * h.cB; sl.Uc = h.AB * (h.gij * h.cB);
-            } else {
-                sl.base = cont_index[t] * Ns;                // row of the nStar-ratio table: g_ij = nsr * E_T
-                if (std::find(fast.begin(), fast.end(), t) != fast.end()) {
-                    sl.flags |= SLOT_FAST;
-                    if ((atoms_with_line >> h.atom) & 1u) {
-                        sl.flags |= SLOT_LINKED;
-                        for (size_t u = 0; u < lines.size() && u < 4; ++u) {
-                            const DevTrans& x = c->htrans[lines[u]];
-                            if (x.atom == h.atom) sl.lkbits |= 1u << (8 * u);
-                            if (x.li == h.li) sl.lkbits |= 2u << (8 * u);
-                            if (x.lj == h.li) sl.lkbits |= 4u << (8 * u);
-                        }
-                    }
-                }
-            }
-            if (tl.nP >= 2 && tl.nP <= 4 && !(sl.flags & SLOT_FAST)) {
-                int o = 0;
-                for (int tv : per_ray) {
-                    if (tv == t) continue;
-                    const DevTrans& x = c->htrans[tv];
-                    sl.rel[o][REL_CI] = (double)(x.li == h.li) - (double)(x.lj == h.li);
-                    sl.rel[o][REL_CJ] = (double)(x.li == h.lj) - (double)(x.lj == h.lj);
-                    sl.rel[o][REL_UJ] = (double)(x.lj == h.lj);
-                    sl.rel[o][REL_UI] = (double)(x.lj == h.li);
-                    sl.rel[o][REL_EA] = (double)(x.atom == h.atom);
-                    for (int q = 0; q < 5; ++q)
-                        if (sl.rel[o][q] != 0.0) sl.relmask |= 1u << o;
-                    ++o;
-                }
-            }
-            if (tl.nP == 1 && !(sl.flags & SLOT_FAST) && (sl.flags & (SLOT_LI_CELL | SLOT_LJ_CELL | SLOT_UI_READ | SLOT_ETA_CELL))) {
-                lsx_destroy(c);     // the single-slot kernel compiles the cell logic out
-                return fail(LSX_EUNSUPPORTED, "lsx_create: internal: single per-ray slot with shared levels");
-            }
-            c->slots.push_back(sl);
-            c->tile_slots.push_back(t);
-            c->tile_slot_fast.push_back((sl.flags & SLOT_FAST) ? 1 : 0);
-        }
-        if (tl.nF > 0) {
-            c->fast_tiles.push_back((int)c->tiles.size());
-            c->nF_max = std::max(c->nF_max, tl.nF);
-            // simple: per atom one common upper level, distinct lower levels, no lower level equal to that upper level
-            bool simple = true;
-            for (size_t a = 0; a < fast.size() && simple; ++a)
-                for (size_t b = 0; b < fast.size() && simple; ++b) {
-                    const DevTrans &x = c->htrans[fast[a]], &y = c->htrans[fast[b]];
-                    if (x.atom != y.atom) continue;
-                    if (x.lj != y.lj || x.li == y.lj || (a != b && x.li == y.li)) simple = false;
-                }
-            // 2: additionally at most LSX_FAST_NQ continua per atom -> k_fast_gamma_cols (LSX_FAST_ROWS: diagnostic, the
-            // row-mapped kernel for every tile)
-            int group = 0, group_max = 0;
-            for (size_t a = 0; a < fast.size(); ++a) {
-                group = (a > 0 && c->htrans[fast[a]].atom == c->htrans[fast[a - 1]].atom) ? group + 1 : 1;
-                group_max = std::max(group_max, group);
-            }
-            const int lkn = tl.nK > 0 ? (int)lines.size() : 0;       // lines the linked continua feed
-            const size_t lds_cols = ((size_t)2 * LSX_FGC_MAXF * c->L + c->L + (size_t)4 * (3 + lkn) * LSX_FGC_ROWS * c->L) * sizeof(double);
-            const bool cols = simple && group_max <= LSX_FAST_NQ && (int)fast.size() <= LSX_FGC_MAXF && c->L % 2 == 0 && lkn <= 2 && lds_cols <= 64 * 1024 && !getenv("LSX_FAST_ROWS");
-            tl.fast_simple = simple ? (cols ? 2 : 1) : 0;
-            if (!simple) c->fast_generic = true;
-            (tl.fast_simple == 2 ? c->fast_cols[lkclass(tl)] : c->fast_rest).push_back((int)c->tiles.size());
-        }
-        // a compile-time slot count needs the per-depth operand table in LDS; very deep columns fall back to the
-        // generic instance (runtime slot loops, operands through the scalar cache)
-        const bool table_fits = (size_t)(Ns + 1) * (3 * tl.nP + 2) * sizeof(double) <= 32 * 1024;
-        const int npt = (tl.nP <= 4 && table_fits) ? tl.nP : -1;
-        if (npt >= 0) c->static_max = std::max(c->static_max, npt);
-        const int nl = npt >= 0 ? (int)lines.size() : 0;
-        const bool lk = tl.nK > 0;
-        // two lines: is their relation one of the two common cases the sweep has a leaner instance for?
-        int topo = 0;
-        if (npt == 2 && nl == 2 && !getenv("LSX_NO_TOPO")) {
-            const DevTrans &x = c->htrans[per_ray[0]], &y = c->htrans[per_ray[1]];
-            const bool share_any = x.li == y.li || x.li == y.lj || x.lj == y.li || x.lj == y.lj;
-            if (x.atom == y.atom && x.li == y.li && x.lj != y.lj && x.lj != y.li && x.li != y.lj) topo = 1;
-            else if (x.atom != y.atom && !share_any) topo = 2;
-        }
-        SweepClass* k = nullptr;
-        for (auto& q : c->classes)
-            if (q.npt == npt && q.nl == nl && q.linked == lk && q.topo == topo) k = &q;
-        if (!k) { c->classes.push_back(SweepClass()); k = &c->classes.back(); k->npt = npt; k->nl = nl; k->linked = lk; k->topo = topo; }
-        k->tiles.push_back((int)c->tiles.size());
-        if (tl.nF > 0) {
-            k->has_fast = true;
-            k->fast_tiles.push_back((int)c->tiles.size());
-            (tl.fast_simple == 2 ? k->fast_cols[lkclass(tl)] : k->fast_rest).push_back((int)c->tiles.size());
-        }
-        k->ncell_lev = std::max(k->ncell_lev, (int)lev_ids.size());
-        k->ncell_atom = std::max(k->ncell_atom, (int)atom_ids.size());
-        c->tiles.push_back(tl);
-    }
-    // Launch order and stream priority: by the class's estimated share of the call (tiles x measured cost of a tile, a class with a
-    // pre-pass -> sweep -> epilogue chain counting half again), largest first -- the chain of the largest class is the call's
-    // critical path, the small classes fill in behind it.  (LSX_ORDER=cost: round 1's order, by cost of one workgroup.)
-    auto class_work = [](const SweepClass& k) {
-        static const double C[] = {2500.0, 2950.0, 3550.0, 6600.0, 9600.0};
-        const double per_tile = k.npt < 0 ? 14600.0 : C[std::min(k.npt, 4)] * (k.linked ? 1.25 : 1.0);
-        return per_tile * (double)k.tiles.size() * (k.fast_tiles.empty() ? 1.0 : 1.5);
-    };
-    {
-        const char* ord = getenv("LSX_ORDER");
-        if (ord && std::string(ord) == "cost") {
-            auto wg_cost = [](const SweepClass& k) { return k.npt < 0 ? 100 : k.npt; };
-            size_t chain_tiles = 0;
-            for (auto& k : c->classes)
-                if (!k.fast_tiles.empty()) chain_tiles += k.tiles.size();
-            const bool chains_first = 2 * chain_tiles > c->tiles.size();
-            std::stable_sort(c->classes.begin(), c->classes.end(), [&](const SweepClass& a, const SweepClass& b) {
-                if (chains_first && a.fast_tiles.empty() != b.fast_tiles.empty()) return !a.fast_tiles.empty();
-                return wg_cost(a) > wg_cost(b);
-            });
-        } else {
-            std::stable_sort(c->classes.begin(), c->classes.end(),
-                             [&](const SweepClass& a, const SweepClass& b) { return class_work(a) > class_work(b); });
-        }
-    }
     double work_total = 0.0, work_seen = 0.0;
-    for (auto& k : c->classes) work_total += class_work(k);
-    for (auto& k : c->classes) {
-        // per wave: level cells, atom cells, angle-sum row; + two cross-wave exchange rows; + the static
-        // path's per-depth table of wave-uniform operands, Nspace x (3 npt + 2) doubles
-        // (level / atom cells exist only in the generic instance; compile-time classes keep that bookkeeping in registers)
-        const int cl = k.npt >= 0 ? 0 : k.ncell_lev, ca = k.npt >= 0 ? 0 : k.ncell_atom;
-        k.lds_bytes = (size_t)LSX_EXP_TAB * sizeof(double) + (size_t)(2 * (2 * cl + ca + 1) + 2) * LSX_WAVE * sizeof(double) +
-                      (size_t)(k.npt >= 0 ? (Ns + 1) * (3 * k.npt + 2) : 0) * sizeof(double) +
-                      (size_t)(k.npt > 0 ? 2 * 2 * k.npt * LSX_WAVE : 0) * sizeof(double) +    // parked Gamma totals
-                      (size_t)(k.npt >= 3 ? k.npt * (k.npt - 1) * 5 : 0) * sizeof(double) +   // slot-pair factors
-                      (size_t)(k.linked && k.npt > 0 ? 2 * k.npt * LSX_WAVE : 0) * sizeof(double);   // linked: exchange rows of the Psi* phi sums
-        if (k.lds_bytes > 64 * 1024) { lsx_destroy(c); return fail(LSX_EUNSUPPORTED, "lsx_create: a tile needs %zu B of LDS", k.lds_bytes); }
-        c->lds_bytes = std::max(c->lds_bytes, k.lds_bytes);
-    }
+    for (auto& k : c->classes) work_total += k.work;
 
     // ---- uploads of the column independent tables
-    std::vector<double> zmu(c->Nrays, 1.0), wmuh(c->Nrays, 0.0), u_la(Nspect);
-    for (int m = 0; m < c->Nrays; ++m) { zmu[m] = 1.0 / d->muz[m]; wmuh[m] = 0.5 * d->wmu[m]; }
-    for (int la = 0; la < Nspect; ++la) u_la[la] = 2.0 * kHC / std::pow(kNM_TO_M * wave[la], 3.0); // :286
     int rc = LSX_OK;
 #define TRY(x) do { rc = (x); if (rc) { lsx_destroy(c); return rc; } } while (0)
-    TRY(upload(&c->d_wavelength, wave, c->stream));
-    TRY(upload(&c->d_zmu, zmu, c->stream));
+    TRY(upload(&c->d_wavelength, c->wave, c->stream));
+    TRY(upload(&c->d_zmu, c->zmu, c->stream));
     {
         std::vector<double> muzv(d->muz, d->muz + c->Nrays), wmuv(d->wmu, d->wmu + c->Nrays);
         TRY(upload(&c->d_muz, muzv, c->stream));
         TRY(upload(&c->d_wmu, wmuv, c->stream));
     }
-    TRY(upload(&c->d_wmuh, wmuh, c->stream));
-    TRY(upload(&c->d_wl, wl, c->stream));
-    TRY(upload(&c->d_alpha, alpha, c->stream));
-    TRY(upload(&c->d_u_la, u_la, c->stream));
+    TRY(upload(&c->d_wmuh, c->wmuh, c->stream));
+    TRY(upload(&c->d_wl, c->wl, c->stream));
+    TRY(upload(&c->d_alpha, c->alpha, c->stream));
+    TRY(upload(&c->d_u_la, c->u_la, c->stream));
     TRY(upload(&c->d_exp2_tab, make_exp2_table(), c->stream));
-    TRY(upload(&c->d_active, active, c->stream));
+    TRY(upload(&c->d_active, c->active, c->stream));
     TRY(upload(&c->d_trans, c->htrans, c->stream));
     TRY(upload(&c->d_tiles, c->tiles, c->stream));
     {   // the epilogue's copy of the slot table carries "fast continuum" in bit 30: such a slot's slabs hold both directions in
@@ -1808,7 +1454,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         // the classes that make up the first half of the work (in launch order) get the highest priority, the next third the
         // middle one
         const int want = work_seen < 0.5 * work_total ? 0 : (work_seen < 0.85 * work_total ? 1 : 2);
-        work_seen += class_work(k);
+        work_seen += k.work;
         // (measured on MI355X with the round-2 kernels: equal priorities are as fast or faster on both workloads -- every class
         // is bound by vector issue, so there is no idle resource for a favoured class to pick up; LSX_PRIO=1 restores the tiers)
         const int prio = getenv("LSX_PRIO") ? std::min(prio_lo, prio_hi + want) : prio_lo;
@@ -1821,15 +1467,6 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
 
     // ---- per-column storage
     const size_t nc = ncol;
-    c->phi_in_col = (size_t)c->SNl * (c->phi_compact ? 1 : 2 * (size_t)c->Nrays) * Ns; // as handed over (rh_method.py:224)
-    // as stored: the (tile, line) blocks, then two doubles that stay zero -- where the lanes of a tile whose wavelength lies
-    // outside a line's range point their profile loads (no select on the loaded value)
-    c->phi_col = phi_run + (phi_run ? 2 : 0);
-    c->corr_col = corr_run;
-    c->pp_col = pp_run;
-    c->til_col = c->tiles.size() * (size_t)c->L * Ns;        // one tile-major [tile][k][j] array
-    c->sca_col = c->sca_per_lambda ? c->til_col : (size_t)Ns;
-    if (c->phi_col > 0x0fffffff || c->corr_col > 0x0fffffff || c->til_col > 0x0fffffff) { lsx_destroy(c); return fail(LSX_EUNSUPPORTED, "column too large for 32-bit byte offsets"); }
     TRY(dmalloc(&c->d_height, nc * Ns));
     TRY(dmalloc(&c->d_temperature, nc * Ns));
     TRY(dmalloc(&c->d_nStar, nc * c->NLtot * Ns));
@@ -1861,10 +1498,8 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     c->d_dPcol = c->d_res + nc;
     c->d_singular = reinterpret_cast<unsigned long long*>(c->d_res + 2 * nc);
     c->phi_set.assign(nc, 0);
-    TRY(dmalloc(&c->d_debug, 64 * 16));
+    TRY(dmalloc(&c->d_debug, 1024 * 16));
     if (c->any_cont) {          // the nStar ratio of every continuum (g_ij = ratio x E_T)
-        for (int t = 0; t < c->Ntrans; ++t)
-            if (!c->htrans[t].is_line) { c->cont_li.push_back(c->htrans[t].li); c->cont_lj.push_back(c->htrans[t].lj); }
         TRY(upload(&c->d_cont_li, c->cont_li, c->stream));
         TRY(upload(&c->d_cont_lj, c->cont_lj, c->stream));
         TRY(dmalloc(&c->d_nsr, nc * c->Ncont * Ns));
@@ -1878,7 +1513,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         TRY(dmalloc(&c->d_Psi2, 2 * nc * c->til_col));
         (void)hipMemsetAsync(c->d_Psi2, 0, 2 * nc * c->til_col * 8, c->stream);
     }
-    (void)hipMemsetAsync(c->d_debug, 0, 64 * 16 * 8, c->stream);
+    (void)hipMemsetAsync(c->d_debug, 0, 1024 * 16 * 8, c->stream);
 #undef TRY
     if (hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), (2 * nc + 1) * sizeof(double), hipHostMallocDefault) != hipSuccess) {
         lsx_destroy(c);
@@ -2003,40 +1638,23 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
         ff.bgxchi_T = c->d_bgxchi; ff.bgxeta_T = c->d_bgxeta; ff.J_T = c->d_J[c->jcur ^ 1]; ff.Psi2_T = c->d_Psi2;
         ff.Gpart = c->d_Gpart; ff.colmask = c->d_colmask;
     }
-    // one block per (tile, column); thread = (depth in chunk, wavelength) with LP = 16 / 32 / 64 lanes per depth row
-    const int LP = c->L <= 16 ? 16 : (c->L <= 32 ? 32 : 64);
-    // depths whose operands are staged in LDS at a time: the whole column if `budget` bytes allow, else a multiple of the
-    // rows per pass
-    auto seg_for = [&](int rows, size_t doubles_per_depth, size_t fixed_doubles, size_t budget) {
-        const size_t room = budget / 8 > fixed_doubles ? budget / 8 - fixed_doubles : 0;
-        long fit = (long)(room / std::max<size_t>(1, doubles_per_depth));
-        if (fit >= c->Nspace) return c->Nspace;
-        return (int)std::max<long>(rows, fit / rows * rows);
-    };
-    auto launch_prepass = [&](hipStream_t st, const int* d_list, size_t n) -> int {
+    // launch shapes (rows per pass, staged depths, LDS bytes): fixed and checked when the plan was made (lsx_plan.cpp)
+    const LaunchShapes& S = c->shapes;
+    const int LP = S.rows_lp;
+    auto launch_prepass = [&](hipStream_t st, const int* d_list, size_t n) {
         FastParams fq = ff;
         fq.fast_tiles = d_list; fq.n_fast_tiles = (int)n;
+        fq.seg_depths = S.prepass_seg;
         dim3 grid((unsigned)n, (unsigned)c->ncol);
-        const int LPp = c->L;                 // the pre-pass rows are exactly as wide as the tile
-        fq.seg_depths = seg_for(256 / LPp, (size_t)3 * c->nF_max, (size_t)c->nF_max * LPp, 24 * 1024);
-        const size_t smp = ((size_t)3 * c->nF_max * fq.seg_depths + (size_t)c->nF_max * LPp) * sizeof(double);
-        if (smp > 64 * 1024) return fail(LSX_EUNSUPPORTED, "fast-continuum pre-pass needs %zu B of LDS", smp);
-        const bool seg = fq.seg_depths < c->Nspace;
-        if (seg) hipLaunchKernelGGL((k_fast_prepass<true>), grid, dim3(256), smp, st, fq);
-        else hipLaunchKernelGGL((k_fast_prepass<false>), grid, dim3(256), smp, st, fq);
-        HIPCHK(hipGetLastError());
-        return LSX_OK;
+        if (S.prepass_seg < c->Nspace) hipLaunchKernelGGL((k_fast_prepass<true>), grid, dim3(256), S.prepass_lds, st, fq);
+        else hipLaunchKernelGGL((k_fast_prepass<false>), grid, dim3(256), S.prepass_lds, st, fq);
     };
-    auto launch_fast_rows = [&](hipStream_t st, const int* d_list, size_t n) -> int {
+    auto launch_fast_rows = [&](hipStream_t st, const int* d_list, size_t n) {
         FastParams fq = ff;
         fq.fast_tiles = d_list; fq.n_fast_tiles = (int)n;
-        int nt = 256;
-        const size_t per_depth = (size_t)3 * c->nF_max + (size_t)2 * std::min(c->nL_linked_max, LSX_MAX_TILE_LINES);
-        auto fixed_for = [&](int ntv) { return (size_t)(c->fast_generic ? 2 * c->NLtot + c->Natoms : 0) * ntv + (size_t)2 * c->nF_max * LP; };
-        while (nt > 64 && fixed_for(nt) * 8 > 24 * 1024) nt >>= 1;
-        fq.seg_depths = seg_for(nt / LP, per_depth, fixed_for(nt), 40 * 1024);
-        const size_t sm = (per_depth * fq.seg_depths + fixed_for(nt)) * sizeof(double);
-        if (sm > 64 * 1024) return fail(LSX_EUNSUPPORTED, "fast-continuum epilogue needs %zu B of LDS", sm);
+        fq.seg_depths = S.rows_seg;
+        const int nt = S.rows_nt;
+        const size_t sm = S.rows_lds;
         dim3 grid((unsigned)n, (unsigned)c->ncol);
         const bool seg = fq.seg_depths < c->Nspace;
 #define LSX_FG(LPV, NTV) if (LP == LPV && nt == NTV) { if (seg) hipLaunchKernelGGL((k_fast_gamma<LPV, NTV, true>), grid, dim3(NTV), sm, st, fq); \
@@ -2045,83 +1663,67 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
         LSX_FG(32, 256); LSX_FG(32, 128); LSX_FG(32, 64);
         LSX_FG(64, 256); LSX_FG(64, 128); LSX_FG(64, 64);
 #undef LSX_FG
-        HIPCHK(hipGetLastError());
-        return LSX_OK;
     };
-    // the column-mapped kernel: one thread per (column, depth), blocks of 256 over the columns' depths x the tiles
-    auto launch_fast_cols = [&](hipStream_t st, const int* d_list, size_t n, int v) -> int {
+    // the column-mapped kernel: two lanes per (column, depth), blocks of 256 over the columns' depths x the tiles
+    auto launch_fast_cols = [&](hipStream_t st, const int* d_list, size_t n, int v) {
         FastParams fq = ff;
         fq.fast_tiles = d_list; fq.n_fast_tiles = (int)n;
-        const size_t sm = ((size_t)2 * LSX_FGC_MAXF * c->L + c->L + (size_t)4 * (3 + kLkLines[v]) * LSX_FGC_ROWS * c->L) * sizeof(double);
-        if (sm > 64 * 1024) return fail(LSX_EUNSUPPORTED, "fast-continuum epilogue (column mapped) needs %zu B of LDS", sm);
         dim3 grid((unsigned)(((size_t)c->ncol * c->Nspace + 4 * LSX_FGC_ROWS - 1) / (4 * LSX_FGC_ROWS)), (unsigned)n);
-#define LSX_FC(NLCV) if (kLkLines[v] == NLCV) hipLaunchKernelGGL((k_fast_gamma_cols<NLCV>), grid, dim3(256), sm, st, fq);
+#define LSX_FC(NLCV) if (kLkLines[v] == NLCV) hipLaunchKernelGGL((k_fast_gamma_cols<NLCV>), grid, dim3(256), S.cols_lds[v], st, fq);
         LSX_FC(0) LSX_FC(1) LSX_FC(2)
 #undef LSX_FC
-        HIPCHK(hipGetLastError());
-        return LSX_OK;
     };
-    auto launch_fast_gamma = [&](hipStream_t st, const std::vector<int>* cols, int* const* d_cols, const int* d_rest, size_t nrest) -> int {
-        int r = LSX_OK;
+    auto launch_fast_gamma = [&](hipStream_t st, const std::vector<int>* cols, int* const* d_cols, const int* d_rest, size_t nrest) {
         for (int v = 0; v < 3; ++v)
-            if (!cols[v].empty() && (r = launch_fast_cols(st, d_cols[v], cols[v].size(), v))) return r;
-        if (nrest && (r = launch_fast_rows(st, d_rest, nrest))) return r;
-        return r;
+            if (!cols[v].empty()) launch_fast_cols(st, d_cols[v], cols[v].size(), v);
+        if (nrest) launch_fast_rows(st, d_rest, nrest);
     };
-    int rc2 = LSX_OK;
-    if (timed) HIPCHK(hipEventRecord(c->ev0, c->stream));
+    // From here on nothing returns before the class streams have been joined back and jcur / fs_pending advanced: a launch
+    // error is remembered and reported at the end (shapes, LDS sizes and grids were checked when the context was made).
+    hipError_t lerr = hipSuccess;
+    auto note = [&](hipError_t e) { if (e != hipSuccess && lerr == hipSuccess) lerr = e; };
+    if (timed) note(hipEventRecord(c->ev0, c->stream));
     // small batches: one fused launch (n_class_tiles == ntile, identity tile list is not needed); the parabolic rule (N4) has one
     // generic instance for every tile and takes the same route at any size
     const bool parabolic = c->solver == LSX_SOLVER_PARABOLIC;
     if (c->ncol < 32 || parabolic) {
-        if (has_fast && (rc2 = launch_prepass(c->stream, c->d_fast_tiles, c->fast_tiles.size()))) return rc2;
+        if (has_fast) launch_prepass(c->stream, c->d_fast_tiles, c->fast_tiles.size());
         const long nblocks = (long)c->tiles.size() * c->ncol;
         p.class_tiles = nullptr;
         p.n_class_tiles = (int)c->tiles.size();
-        p.ncell_lev = 1; p.ncell_atom = 1;
-        for (auto& k : c->classes) { p.ncell_lev = std::max(p.ncell_lev, k.ncell_lev); p.ncell_atom = std::max(p.ncell_atom, k.ncell_atom); }
-        int npt_max = -1;
-        for (auto& k : c->classes) npt_max = std::max(npt_max, k.npt);
-        const size_t lds = (size_t)LSX_EXP_TAB * sizeof(double) + (size_t)(2 * (2 * p.ncell_lev + p.ncell_atom + 1) + 2) * LSX_WAVE * sizeof(double) +
-                           (size_t)(npt_max >= 0 ? (c->Nspace + 1) * (3 * npt_max + 2) : 0) * sizeof(double) +
-                           (size_t)(npt_max > 0 ? 2 * 2 * npt_max * LSX_WAVE : 0) * sizeof(double) +
-                           (size_t)(npt_max >= 3 ? npt_max * (npt_max - 1) * 5 : 0) * sizeof(double) +
-                           (size_t)(c->corr_col && npt_max > 0 ? 2 * npt_max * LSX_WAVE : 0) * sizeof(double);
-        if (nblocks > 0x7fffffffL) return fail(LSX_EUNSUPPORTED, "grid too large");
+        p.ncell_lev = S.fused_ncell_lev; p.ncell_atom = S.fused_ncell_atom;
         c->fused_launches++;
-        hipError_t e = lsx_launch_sweep(&p, parabolic ? -4 : -2, (int)nblocks, lds, c->stream);
-        if (e != hipSuccess) return fail(LSX_EDEVICE, "sweep launch (fused): %s", hipGetErrorString(e));
-        if (has_fast && (rc2 = launch_fast_gamma(c->stream, c->fast_cols, c->d_fast_cols, c->d_fast_rest, c->fast_rest.size()))) return rc2;
+        note(lsx_launch_sweep(&p, parabolic ? -4 : -2, (int)nblocks, S.fused_lds, c->stream));
+        if (has_fast) launch_fast_gamma(c->stream, c->fast_cols, c->d_fast_cols, c->d_fast_rest, c->fast_rest.size());
     } else {
         // The classes of one call run side by side on their own streams, forked from the context's stream and joined
         // back into it.  The fast continua of a class's tiles are handled on the class's own stream, pre-pass before
         // and epilogue after the sweep, so no class waits for another and those two light kernels fill gaps.
         const bool fork = c->classes.size() > 1 && !c->opt_serial;
-        if (fork) HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+        if (fork) note(hipEventRecord(c->ev_fork, c->stream));
         for (auto& k : c->classes) {
             hipStream_t st = fork ? k.stream : c->stream;
-            if (fork) HIPCHK(hipStreamWaitEvent(st, c->ev_fork, 0));
-            if (!k.fast_tiles.empty() && (rc2 = launch_prepass(st, k.d_fast_tiles, k.fast_tiles.size()))) return rc2;
+            if (fork) note(hipStreamWaitEvent(st, c->ev_fork, 0));
+            if (!k.fast_tiles.empty()) launch_prepass(st, k.d_fast_tiles, k.fast_tiles.size());
             const long nblocks = (long)k.tiles.size() * c->ncol;
-            if (nblocks > 0x7fffffffL) return fail(LSX_EUNSUPPORTED, "grid too large");
             p.class_tiles = k.d_tiles;
             p.n_class_tiles = (int)k.tiles.size();
             p.ncell_lev = k.npt >= 0 ? 0 : k.ncell_lev; p.ncell_atom = k.npt >= 0 ? 0 : k.ncell_atom; p.nstash = 0;
             k.launches++;
-            hipError_t e = lsx_launch_sweep(&p, k.npt >= 0 ? k.npt * 8 + k.nl + (k.linked ? 64 : 0) + 128 * k.topo : (k.linked ? -3 : -1), (int)nblocks, k.lds_bytes, st);
-            if (e != hipSuccess) return fail(LSX_EDEVICE, "sweep launch (per-ray slots %d): %s", k.npt, hipGetErrorString(e));
+            note(lsx_launch_sweep(&p, k.code(), (int)nblocks, k.lds_bytes, st));
             if (timed) {
-                if (!k.tdone) HIPCHK(hipEventCreate(&k.tdone));
-                HIPCHK(hipEventRecord(k.tdone, st));
+                if (!k.tdone) note(hipEventCreate(&k.tdone));
+                if (k.tdone) note(hipEventRecord(k.tdone, st));
             }
-            if (!k.fast_tiles.empty() && (rc2 = launch_fast_gamma(st, k.fast_cols, k.d_fast_cols, k.d_fast_rest, k.fast_rest.size()))) return rc2;
+            if (!k.fast_tiles.empty()) launch_fast_gamma(st, k.fast_cols, k.d_fast_cols, k.d_fast_rest, k.fast_rest.size());
             if (fork) {
-                HIPCHK(hipEventRecord(k.done, st));
-                HIPCHK(hipStreamWaitEvent(c->stream, k.done, 0));
+                note(hipEventRecord(k.done, st));
+                note(hipStreamWaitEvent(c->stream, k.done, 0));
             }
         }
     }
-    if (timed) HIPCHK(hipEventRecord(c->ev1, c->stream));
+    note(hipGetLastError());
+    if (timed) note(hipEventRecord(c->ev1, c->stream));
 
     FinishParams f{};
     f.Nspace = c->Nspace; f.Natoms = c->Natoms; f.NL2tot = c->NL2tot; f.ncol = c->ncol; f.ntile = (int)c->tiles.size();
@@ -2129,17 +1731,12 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
     f.tile_slots = c->d_tile_slots; f.trans = c->d_trans; f.C = c->d_C; f.Gpart = c->d_Gpart; f.dJpart = c->d_dJpart;
     f.Gamma = c->d_Gamma; f.dJcol = c->d_dJcol; f.colmask = c->d_colmask;
     const long nthreads = (long)c->ncol * c->Nspace;
-    {
-        int nt = 128;
-        while (nt > 32 && (size_t)c->NL2tot * nt * sizeof(double) > 48 * 1024) nt >>= 1;
-        const size_t smf = (size_t)c->NL2tot * nt * sizeof(double);
-        if (smf > 64 * 1024) return fail(LSX_EUNSUPPORTED, "gamma epilogue needs %zu B of LDS", smf);
-        hipLaunchKernelGGL(k_gamma_finish, dim3((unsigned)((nthreads + nt - 1) / nt)), dim3(nt), smf, c->stream, f);
-    }
-    HIPCHK(hipGetLastError());
-    if (timed) HIPCHK(hipEventRecord(c->ev2, c->stream));
+    hipLaunchKernelGGL(k_gamma_finish, dim3((unsigned)((nthreads + S.finish_nt - 1) / S.finish_nt)), dim3(S.finish_nt), S.finish_lds, c->stream, f);
+    note(hipGetLastError());
+    if (timed) note(hipEventRecord(c->ev2, c->stream));
     c->jcur ^= 1;
     c->fs_pending = true;
+    if (lerr != hipSuccess) return fail(lerr == hipErrorNotSupported ? LSX_EUNSUPPORTED : LSX_EDEVICE, "formal_sol_gamma: a launch failed: %s", hipGetErrorString(lerr));
     return LSX_OK;
 }
 
@@ -2633,13 +2230,13 @@ double lsx_hip_calibrate_read(int32_t device, double gib, int32_t seg)
     return (double)(waves / 4 * 4) * nwave_rows * per * seg * 8.0;
 }
 
-// diagnostic: copy the sweep kernel's stamp buffer (64 records x 16 x u64) to host
+// diagnostic: copy the sweep kernel's stamp buffer (1024 records x 16 x u64) to host
 int lsx_hip_debug_read(lsx_ctx* c, unsigned long long* out)
 {
     if (!c || !out) return fail(LSX_EINVAL, "null");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(out, c->d_debug, 64 * 16 * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, c->d_debug, 1024 * 16 * 8, hipMemcpyDeviceToHost));
     return LSX_OK;
 }
 

@@ -1,0 +1,119 @@
+// lsx_plan.h -- the host-side PLAN of a context: everything lsx_create derives from the problem descriptor before it
+// touches the device -- transition tables, the tile schedule (where the wavelength axis is cut, which transition of a
+// tile is a per-ray slot / fast / linked continuum), the slot table, the sweep classes, HBM strides and 32-bit offset
+// checks, LDS sizes and launch shapes of every kernel of a formal-solution call.  Plain C++ (no HIP types): the same
+// translation unit (lsx_plan.cpp) is built into the product library and, with -fsanitize=address,undefined, into a
+// CPU test library (tests/test_plan_sanitized.py).
+//
+// The device-side half of SURVEY 8f N3 ("lambda-signature grouping as a device-side schedule") is this plan:
+// atomic_set.py:377-455 gives every transition its [Nblue, Nblue + Nlambda) range and the `active` table; the plan groups
+// the wavelengths by the set of transitions active on them.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/lsx.h"
+#include "lsx_dev.h"
+
+#define LSX_MAX_TILE_LINES 4  // lines of one tile that linked continua may couple to (k_fast_prepass / k_fast_gamma)
+#define LSX_FAST_NQ 6         // k_fast_gamma_cols: fast continua per atom
+#define LSX_FGC_ROWS 32       // k_fast_gamma_cols: (column, depth) rows per wave
+#define LSX_FGC_MAXF 12       // k_fast_gamma_cols: fast continua per tile (sizes its operand table)
+
+// ---- the compiled instances of lsx_sweep_kernel<NPT, NL, NR, SCAL, LK, TOPO> (per-ray slots, lines among them, linked
+// continua, two-line relation): ONE list.  lsx_sweep.hip expands it into the launch switch, the plan asks it before it
+// files a tile under a class; a tile whose shape has no instance runs the generic one (runtime slot loops).
+#define LSX_SWEEP_INSTANCES(X)                                                                                   \
+    X(0, 0, false, 0) X(1, 0, false, 0) X(1, 1, false, 0) X(2, 0, false, 0) X(2, 1, false, 0) X(2, 2, false, 0)  \
+    X(3, 1, false, 0) X(3, 2, false, 0) X(3, 3, false, 0)                                                        \
+    X(4, 1, false, 0) X(4, 2, false, 0) X(4, 3, false, 0) X(4, 4, false, 0)                                      \
+    X(1, 1, true, 0) X(2, 1, true, 0) X(2, 2, true, 0) X(3, 1, true, 0) X(3, 2, true, 0) X(3, 3, true, 0)        \
+    X(2, 2, false, 1) X(2, 2, false, 2) X(2, 2, true, 1) X(2, 2, true, 2)
+// launch code of a class: >= 0 a compiled instance; -1 generic, -3 generic with linked continua, -2 fused small-batch
+// kernel, -4 parabolic rule (N4)
+constexpr int lsx_class_code(int npt, int nl, bool lk, int topo) { return npt * 8 + nl + (lk ? 64 : 0) + 128 * topo; }
+inline bool lsx_sweep_instance_exists(int npt, int nl, bool lk, int topo)
+{
+    switch (lsx_class_code(npt, nl, lk, topo)) {
+#define LSX_X(NPT, NL, LK, TOPO) case lsx_class_code(NPT, NL, LK, TOPO):
+        LSX_SWEEP_INSTANCES(LSX_X)
+#undef LSX_X
+        return npt >= 0;
+    default: return false;
+    }
+}
+
+namespace lsxd {
+
+struct PlanClass {             // tiles that run the same kernel instantiation
+    int npt = -1;              // compile-time per-ray slot count, -1 = generic
+    int nl = 0;                // lines among them (compile-time too)
+    bool linked = false;       // the class's tiles have linked continua (compile-time too)
+    int topo = 0;              // two-line classes: known relation of the two lines (lsx_sweep.hip, TOPO)
+    bool has_fast = false;     // some tile of the class has fast continua: the class reads the pre-pass output
+    std::vector<int> tiles;
+    std::vector<int> fast_tiles;                  // the class's tiles that have fast continua ...
+    std::vector<int> fast_cols[4], fast_rest;     // ... split by the kernel that builds their Gamma slabs
+    int ncell_lev = 1, ncell_atom = 1;
+    size_t lds_bytes = 0;
+    double work = 0.0;         // estimated share of the call (launch order; stream priority tiers under LSX_PRIO)
+    int code() const { return npt >= 0 ? lsx_class_code(npt, nl, linked, topo) : (linked ? -3 : -1); }
+};
+
+struct PlanOptions {           // diagnostic switches (lsx_create reads them from the environment, once)
+    bool no_linked = false;    // LSX_NO_LINKED: round-1 classification (continua of an atom with a line go through the sweep)
+    bool natural_tiles = false; // LSX_TILER=natural: cut every L wavelengths
+    bool no_topo = false;      // LSX_NO_TOPO
+    bool fast_rows = false;    // LSX_FAST_ROWS: the row-mapped epilogue for every tile
+    bool order_by_cost = false; // LSX_ORDER=cost
+    int occ_wg = 0;            // LSX_OCC_WG: at most this many workgroups per CU (through the LDS request)
+};
+
+// launch shapes of the kernels around the sweep, fixed when the plan is made so that no enqueue path can fail on them
+struct LaunchShapes {
+    int prepass_seg = 0; size_t prepass_lds = 0;                  // k_fast_prepass: depths staged at a time, LDS bytes
+    int rows_lp = 16, rows_nt = 256, rows_seg = 0; size_t rows_lds = 0;   // k_fast_gamma
+    size_t cols_lds[3] = {0, 0, 0};                              // k_fast_gamma_cols<0, 1, 2>
+    int finish_nt = 128; size_t finish_lds = 0;                   // k_gamma_finish
+    size_t fused_lds = 0; int fused_ncell_lev = 1, fused_ncell_atom = 1;   // fused small-batch / parabolic launch
+};
+
+struct LsxPlan {
+    int Nspace = 0, Nrays = 0, Nspect = 0, Natoms = 0, Ntrans = 0;
+    int NLtot = 0, NL2tot = 0, Nlines = 0, SNl = 0, SNc = 0;
+    int sca_per_lambda = 0, phi_compact = 0;
+    int L = 0;                                   // wavelengths per tile = 64 / Nrays
+    std::vector<int> Nlevel, lev_off, lev2_off;
+    std::vector<lsx_transition> trans;
+    std::vector<DevTrans> htrans;
+    std::vector<double> wave, wl, alpha, zmu, wmuh, u_la;   // column-independent tables as uploaded
+    std::vector<uint8_t> active;
+    std::vector<DevTile> tiles;
+    std::vector<int> tile_slots;
+    std::vector<uint8_t> tile_slot_fast;         // per slot: fast continuum (its slabs use the first direction entry only)
+    std::vector<DevSlot> slots;
+    std::vector<PlanClass> plan_classes;         // in launch order
+    std::vector<int> fast_tiles, fast_cols[4], fast_rest;
+    std::vector<int> cont_li, cont_lj;
+    int nF_max = 0, Ncont = 0, static_max = -1, nL_linked_max = 0;
+    bool fast_generic = false, any_cont = false;
+    size_t lds_bytes = 0;                        // largest sweep class
+    // per-column strides in doubles
+    size_t phi_col = 0, phi_in_col = 0, corr_col = 0, pp_col = 0, sca_col = 0, til_col = 0;
+    LaunchShapes shapes;
+};
+
+// -> LSX_OK or an error code with the message in *err.  Checks the descriptor like lsx_create did.
+int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::string* err);
+
+// k_fast_gamma_cols instance list a tile belongs to: kLkLines[v - 1] < lines fed by linked continua <= kLkLines[v]
+static const int kLkLines[4] = {0, 1, 2, LSX_MAX_TILE_LINES};
+inline int lkclass(const DevTile& tl)
+{
+    const int n = tl.nK > 0 ? (tl.nL < LSX_MAX_TILE_LINES ? tl.nL : LSX_MAX_TILE_LINES) : 0;
+    return n == 0 ? 0 : (n == 1 ? 1 : (n == 2 ? 2 : 3));
+}
+
+} // namespace lsxd

@@ -36,6 +36,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "lsx_dev.h"
+#include "lsx_plan.h"
 
 namespace {
 
@@ -156,6 +157,10 @@ template <int NPT, int NL, int NR, bool SCAL, bool LK, int TOPO = 0>
 __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, const int tile_id)
 {
     extern __shared__ double lds_raw[];
+#if defined(LSX_STAMPS) || defined(LSX_CLOCK)
+    unsigned long long tk_entry;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk_entry)::"memory");
+#endif
     lds_f64* const etab = (lds_f64*)lds_raw;            // [64][2] exp table (16-byte aligned pairs)
     lds_f64* const lds = etab + LSX_EXP_TAB;
     constexpr bool STATIC = NPT >= 0;
@@ -337,13 +342,19 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     double zprev = z[kS];
     // diagnostic build only (-DLSX_STAMPS): per-segment shader-clock totals of a few sample waves go
     // to p.debug, a buffer nothing else reads (cdna_hip_programming.md, In-kernel stamps)
+    // -DLSX_CLOCK: only the two clock reads around the loop (the production instruction stream between them): the clock the
+    // chip holds under this load = shader ticks / 100 MHz ticks
+#if defined(LSX_STAMPS) || defined(LSX_CLOCK)
+    unsigned long long T[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0, t1, tk0, tr0, tk1, tr1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk0), "=s"(tr0)::"memory");   // shader clock / 100 MHz clock
+    t0 = tk0;
+    (void)t0; (void)t1;
+#endif
 #ifdef LSX_STAMPS
-    unsigned long long T[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0, t1;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
 #define STAMP(i)                                                                                          \
     do {                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory"); \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory"); \
         __builtin_amdgcn_sched_barrier(0);                                                                \
         T[i] += t1 - t0;                                                                                  \
         t0 = t1;                                                                                          \
@@ -364,6 +375,24 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
 
     auto stream_loads = [&](int kk, double& bc, double& be, double& jdv, double (&v)[NS], double& Ev, double (&cr)[NLK][3]) {
         const unsigned kko = (unsigned)(kk * L + j) * 8u;
+#ifdef LSX_ABL_NOLOAD     // diagnostic build (profiles/ablate.sh): what the step costs without its HBM streams; results are meaningless
+        {
+            const double f = 1.0 + 1e-3 * (double)(kko & 1023u);
+            jdv = 1e-9 * f; bc = 1e-6 * f; be = 1e-15 * f;
+            if constexpr (STATIC) {
+#pragma unroll
+                for (int u = 0; u < NL; ++u) v[u] = 1e-12 * f;
+                if constexpr (HASC) Ev = 0.5 * f;
+                if constexpr (LK) {
+#pragma unroll
+                    for (int u = 0; u < NL; ++u)
+#pragma unroll
+                        for (int q = 0; q < NCR; ++q) cr[u][q] = 1e-20 * f;
+                }
+            }
+            return;
+        }
+#endif
         jdv = at(Jdag, kko);
         bc = at(bgchi, kko);
         be = at(bgeta, kko);
@@ -725,8 +754,6 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         }
         STAMP(5);
 
-        STAMP(6);
-
         // ---- J: the two directions meet at depth k at different steps ----
         // (the Nrays lanes of a wavelength hold the same Jsum and write the same word: stores need no branch)
         if constexpr (PH == 0) {
@@ -745,6 +772,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             at(Jnew, kl) = Jv;
             dJ = nanmax(dJ, fabs(1.0 - jd * rcp(Jv)));         // :705
         }
+        STAMP(6);
     };
     {
         const int nA = Ns / 2;                                // depths this wave reaches first: 2 s < Nspace - 1
@@ -755,12 +783,19 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
         step(Ns - 1, std::integral_constant<int, 3>{});       // the end point (Nspace >= 3: always a second-visitor step)
     }
 
-#ifdef LSX_STAMPS
+#if defined(LSX_STAMPS) || defined(LSX_CLOCK)
     STAMP(7);
-    if (lane == 0 && dir == 0 && p.debug && (vb % 997) == 5 && vb / 997 < 64) {
-        unsigned long long* D = (unsigned long long*)p.debug + (size_t)(vb / 997) * 16;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk1), "=s"(tr1)::"memory");
+    T[7] = tk1 - tk0;                  // the loop in shader-clock ticks ...
+#ifdef LSX_CLOCK
+    T[0] = tk0 - tk_entry;             // ... and the wave's prologue (operand table, boundary condition, first loads)
+    T[1] = tr0;                        // when the loop started (100 MHz ticks, absolute): the order the grid's waves ran in
+#endif
+    if (lane == 0 && dir == 0 && p.debug && col % 100 == 5) {    // every tile of columns 5, 105, ... (1024 records), down-going wave
+        unsigned long long* D = (unsigned long long*)p.debug + (size_t)(((col / 100) * ntile + tile_id) & 1023) * 16;
         for (int i = 0; i < 8; ++i) D[i] = T[i];
-        D[8] = tile_id; D[9] = nP; D[10] = nF; D[11] = col;
+        D[8] = tile_id; D[9] = nP; D[10] = nF; D[11] = col; D[12] = STATIC ? NL : nLt; D[13] = LK; D[14] = TOPO;
+        D[15] = tr1 - tr0;             // ... and in 100 MHz ticks: clock = D[7] / D[15] x 100 MHz (MI355X_MICROARCH.md, DVFS give-back 6)
     }
 #endif
 #undef STAMP
@@ -1112,43 +1147,33 @@ lsx_sweep_kernel_parabolic(const SweepParams p)
 }
 
 template <int NR, bool SCAL>
-static void launch_class(const SweepParams& p, int code, dim3 g, dim3 b, size_t lds_bytes, hipStream_t st)
+static hipError_t launch_class(const SweepParams& p, int code, dim3 g, dim3 b, size_t lds_bytes, hipStream_t st)
 {
-    // code: -2 fused, -4 every tile with the parabolic rule (N4), -1 generic, -3 generic with linked continua, else (per-ray slots) * 8 + (lines among them) + 64 if the
-    // class's tiles have linked continua (only classes with a line can) + 128 * TOPO (two-line classes)
-#define LSX_CASE(NPT, NL) \
-    case NPT * 8 + NL: hipLaunchKernelGGL((lsx_sweep_kernel<NPT, NL, NR, SCAL, false>), g, b, lds_bytes, st, p); break;
-#define LSX_CASE_LK(NPT, NL) \
-    case 64 + NPT * 8 + NL: hipLaunchKernelGGL((lsx_sweep_kernel<NPT, NL, NR, SCAL, true>), g, b, lds_bytes, st, p); break;
+    // code: -2 fused, -4 every tile with the parabolic rule (N4), -1 generic, -3 generic with linked continua, else
+    // lsx_class_code(per-ray slots, lines among them, linked continua, TOPO) of a compiled instance (lsx_plan.h: the list the
+    // plan consults before it files a tile under a class).  Anything else is refused, never mapped to another instance.
     switch (code) {
     case -2: hipLaunchKernelGGL((lsx_sweep_kernel_all<NR, SCAL>), g, b, lds_bytes, st, p); break;
     case -4: hipLaunchKernelGGL((lsx_sweep_kernel_parabolic<NR, SCAL>), g, b, lds_bytes, st, p); break;
     case -3: hipLaunchKernelGGL((lsx_sweep_kernel<-1, 0, NR, SCAL, true>), g, b, lds_bytes, st, p); break;
-    LSX_CASE(0, 0) LSX_CASE(1, 0) LSX_CASE(1, 1)
-    LSX_CASE(2, 0) LSX_CASE(2, 1) LSX_CASE(2, 2)
-    LSX_CASE(3, 1) LSX_CASE(3, 2) LSX_CASE(3, 3)
-    LSX_CASE(4, 1) LSX_CASE(4, 2) LSX_CASE(4, 3) LSX_CASE(4, 4)
-    LSX_CASE_LK(1, 1) LSX_CASE_LK(2, 1) LSX_CASE_LK(2, 2) LSX_CASE_LK(3, 1) LSX_CASE_LK(3, 2) LSX_CASE_LK(3, 3)
-    // two lines with a known relation (TOPO 1 / 2): + 128 / + 256
-    case 128 + 2 * 8 + 2: hipLaunchKernelGGL((lsx_sweep_kernel<2, 2, NR, SCAL, false, 1>), g, b, lds_bytes, st, p); break;
-    case 256 + 2 * 8 + 2: hipLaunchKernelGGL((lsx_sweep_kernel<2, 2, NR, SCAL, false, 2>), g, b, lds_bytes, st, p); break;
-    case 128 + 64 + 2 * 8 + 2: hipLaunchKernelGGL((lsx_sweep_kernel<2, 2, NR, SCAL, true, 1>), g, b, lds_bytes, st, p); break;
-    case 256 + 64 + 2 * 8 + 2: hipLaunchKernelGGL((lsx_sweep_kernel<2, 2, NR, SCAL, true, 2>), g, b, lds_bytes, st, p); break;
-    default: hipLaunchKernelGGL((lsx_sweep_kernel<-1, 0, NR, SCAL, false>), g, b, lds_bytes, st, p); break;
+    case -1: hipLaunchKernelGGL((lsx_sweep_kernel<-1, 0, NR, SCAL, false>), g, b, lds_bytes, st, p); break;
+#define LSX_X(NPT, NL, LK, TOPO) \
+    case lsx_class_code(NPT, NL, LK, TOPO): hipLaunchKernelGGL((lsx_sweep_kernel<NPT, NL, NR, SCAL, LK, TOPO>), g, b, lds_bytes, st, p); break;
+    LSX_SWEEP_INSTANCES(LSX_X)
+#undef LSX_X
+    default: return hipErrorNotSupported;
     }
-#undef LSX_CASE
-#undef LSX_CASE_LK
+    return hipGetLastError();
 }
 
 extern "C" hipError_t lsx_launch_sweep(const SweepParams* p, int npt, int nblocks, size_t lds_bytes, hipStream_t st)
 {
     const dim3 g(nblocks), b(2 * LSX_WAVE);
-    if (!p->sca_per_lambda && p->Nrays == 5) launch_class<5, false>(*p, npt, g, b, lds_bytes, st);
+    if (!p->sca_per_lambda && p->Nrays == 5) return launch_class<5, false>(*p, npt, g, b, lds_bytes, st);
 #ifndef LSX_ONLY_NR5    // diagnostic builds (profiles/ab.sh variants) compile the 5-ray instances only
-    else if (!p->sca_per_lambda && p->Nrays == 3) launch_class<3, false>(*p, npt, g, b, lds_bytes, st);
-    else launch_class<0, true>(*p, npt, g, b, lds_bytes, st);
+    if (!p->sca_per_lambda && p->Nrays == 3) return launch_class<3, false>(*p, npt, g, b, lds_bytes, st);
+    return launch_class<0, true>(*p, npt, g, b, lds_bytes, st);
 #else
-    else return hipErrorNotSupported;
+    return hipErrorNotSupported;
 #endif
-    return hipGetLastError();
 }

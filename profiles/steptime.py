@@ -14,12 +14,14 @@ prob, base, raw = fixtures.load_problem_npz('tests/golden/falc_cah.npz' if wl ==
 blk, prof = synth.perturbed_columns(prob, base, raw, ncol=ncol)
 eng = Engine(prob, ncol)
 synth.load_columns(eng, blk, prof)
+fs_only = os.environ.get('LSX_FS_ONLY') == '1'      # ablation variants (meaningless results): formal solutions only
+se = (lambda: None) if fs_only else eng.stat_equil_async
 for _ in range(3):
-    eng.formal_sol_gamma_async(); eng.stat_equil_async(); eng.sync()
+    eng.formal_sol_gamma_async(); se(); eng.sync()
 T = np.zeros(4)
 for _ in range(N):
     t0 = time.perf_counter(); eng.formal_sol_gamma_async()
-    t1 = time.perf_counter(); eng.stat_equil_async()
+    t1 = time.perf_counter(); se()
     t2 = time.perf_counter(); eng.sync()
     t3 = time.perf_counter()
     T += [t1 - t0, t2 - t1, t3 - t2, t3 - t0]

@@ -25,6 +25,13 @@ CASES = [
     dict(seed=10, Nrays=4, Nspace=45, Nspect=100, ncol=34, chain=False),
     dict(seed=11, Nrays=5, Nspace=82, Nspect=140, ncol=3, chain=False),
     dict(seed=12, Nrays=8, Nspace=31, Nspect=64, ncol=33, chain=False, phi_compact=True),
+    # multiplets under linked continua: three per-ray slots (the <3, 3, linked> instance) and four (no such instance: the plan
+    # files the tile under the generic linked kernel), through the per-class launches (>= 32 columns) and the fused launch
+    dict(seed=13, Nrays=5, Nspace=41, Nspect=120, ncol=34, multiplet=3),
+    dict(seed=14, Nrays=5, Nspace=41, Nspect=120, ncol=3, multiplet=3),
+    dict(seed=15, Nrays=5, Nspace=41, Nspect=120, ncol=34, multiplet=4),
+    dict(seed=16, Nrays=5, Nspace=41, Nspect=120, ncol=3, multiplet=4),
+    dict(seed=17, Nrays=3, Nspace=30, Nspect=150, ncol=33, multiplet=4, phi_compact=True),
 ]
 
 
@@ -58,9 +65,12 @@ def test_toy_parity(hip_lib, oracle_lib, kw):
     prob, block = toy_problem(**kw)
     h = _run(hip_lib, prob, block, 8)
     o = _run(oracle_lib, prob, block, 8)
-    # single call (identical inputs on both sides)
-    assert relerr(h[0]['I'], o[0]['I']) < 1e-11
-    assert relerr(h[0]['J'], o[0]['J']) < 1e-11
+    # single call (identical inputs on both sides).  The multiplet cases have an interval whose optical depth lies just above
+    # the 5e-4 switch of w2, where w1 = (1 - e) - dtau e cancels to dtau^2 / 2 and a 1-ulp difference between the two exp()
+    # implementations is an error of up to 1e-9 of that ray's contribution (tolerances): measured 7e-11
+    tol = 2e-10 if kw.get('multiplet') else 1e-11
+    assert relerr(h[0]['I'], o[0]['I']) < tol
+    assert relerr(h[0]['J'], o[0]['J']) < tol
     off, diag = gamma_err(h[0]['G'], o[0]['G'], prob)
     assert off < 1e-10 and diag < 1e-11, (off, diag)
     assert abs(h[0]['dJ'] - o[0]['dJ']) <= 1e-11 * abs(o[0]['dJ'])

@@ -23,7 +23,7 @@ def _gl(n):
 
 
 def toy_problem(seed=0, Nspace=37, Nrays=3, Nspect=90, ncol=3, sca_per_lambda=False, phi_compact=False, chain=True,
-                dead_level=False):
+                dead_level=False, multiplet=0):
     """dead_level: atom 1 gets a fourth level that no radiative transition touches and no collision populates
     (only collisions out of it): statistical equilibrium drives it to exactly 0, so the next stat_equil sees
     0/0 = NaN in its relative change (the case rh_method.py:741's builtin max drops)."""
@@ -44,9 +44,16 @@ def toy_problem(seed=0, Nspace=37, Nrays=3, Nspect=90, ncol=3, sca_per_lambda=Fa
               ('c', 1, 4, 0.00, 0.40), ('c', 2, 4, 0.05, 0.62), ('c', 3, 4, 0.20, 0.99)]
     if chain:
         specs0.append(('c', 0, 1, 0.00, 0.28))
+    if multiplet:
+        # a multiplet: `multiplet` lines from the ground level to distinct upper levels, all overlapping in wavelength, under
+        # two bound-free continua of the same atom whose upper level (5) no line touches -- three / four per-ray slots in one
+        # tile WITH linked continua (one of them starting on a line's upper level)
+        assert 2 <= multiplet <= 4
+        specs0 = [('l', 0, u, 0.30 + 0.02 * u, 0.60 + 0.03 * u) for u in range(1, multiplet + 1)]
+        specs0 += [('c', 0, 5, 0.00, 0.95), ('c', 1, 5, 0.00, 0.55)]
     # atom 1: continua only, 3 levels
     specs1 = [('c', 0, 2, 0.00, 0.35), ('c', 1, 2, 0.10, 0.75)]
-    Nlevel = [5, 4 if dead_level else 3]
+    Nlevel = [6 if multiplet else 5, 4 if dead_level else 3]
     for atom, specs in enumerate((specs0, specs1)):
         for kind, i, j, lo, hi in specs:
             Nblue, Nlam = rng_range(lo, hi)
