@@ -178,12 +178,23 @@ static __device__ __forceinline__ double rcp(double x)
 // v_mov_b64 whenever c must survive (polynomial coefficients, running sums that are read again).
 static __device__ __forceinline__ double fma3(double a, double b, double c)
 {
-#ifdef LSX_FMA3
+#ifndef LSX_NO_FMA3
     double d;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 #else
     return fma(a, b, c);
+#endif
+}
+// the same with a wave-uniform second factor (a literal constant: one scalar register pair, no vector registers)
+static __device__ __forceinline__ double fma3s(double a, double b_uniform, double c)
+{
+#ifndef LSX_NO_FMA3
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_uniform), "v"(c));
+    return d;
+#else
+    return fma(a, b_uniform, c);
 #endif
 }
 
@@ -201,7 +212,7 @@ static __device__ __forceinline__ double exp_tab64(double x, const lds_f64* tab)
     const int ki = (int)kf;
     const lds_f64* e = tab + 2 * (ki & 63);
     const double th = e[0], tl = e[1];
-    double t = fma3(r, 1.0 / 720.0, 1.0 / 120.0);
+    double t = fma3s(r, 1.0 / 720.0, 1.0 / 120.0);
     t = fma3(r, t, 1.0 / 24.0);
     t = fma3(r, t, 1.0 / 6.0);
     t = fma(r, t, 0.5);
@@ -222,9 +233,25 @@ static __device__ __forceinline__ double min_noquiet(double a, double b)
 // for the whole wavefront when no lane is in the middle regime (top / bottom of the atmosphere).
 static __device__ __forceinline__ void w2(double dtau, double& w0, double& w1, const lds_f64* exp2_tab)
 {
+#ifdef LSX_W2_SELECT    // diagnostic variant: round 2's form (the series always, two selects)
     const bool small = dtau < 5e-4;
     const bool large = dtau > 50.0;
     double a0 = 1.0, a1 = 1.0;
+    if (__builtin_amdgcn_ballot_w64(!(small || large)) != 0) {
+        const double dc = min_noquiet(dtau, 700.0);
+        const double e = exp_tab64(-dc, exp2_tab);
+        a0 = 1.0 - e;
+        a1 = a0 - dc * e;
+    }
+    const double t0 = dtau * (1.0 - 0.5 * dtau);
+    const double t1 = (dtau * dtau) * (0.5 - dtau * (1.0 / 3.0));
+    w0 = small ? t0 : a0;
+    w1 = small ? t1 : a1;
+}
+#else
+    const bool small = dtau < 5e-4;
+    const bool large = dtau > 50.0;
+    double a0, a1;
     if (__builtin_amdgcn_ballot_w64(!(small || large)) != 0) {
         // The saturated regime needs no select of its own: for dtau > 50 the middle formulae give exactly (1, 1) --
         // e = exp(-dtau) < 2e-22 is below half an ulp of 1, and so is dtau e (< 1e-17 up to dtau ~ 4e4; beyond that e
@@ -233,12 +260,22 @@ static __device__ __forceinline__ void w2(double dtau, double& w0, double& w1, c
         const double e = exp_tab64(-dc, exp2_tab);
         a0 = 1.0 - e;
         a1 = a0 - dc * e;
+    } else {
+        a0 = 1.0;             // every lane small or saturated
+        a1 = 1.0;
     }
-    const double t0 = dtau * (1.0 - 0.5 * dtau);
-    const double t1 = (dtau * dtau) * (0.5 - dtau * (1.0 / 3.0));
-    w0 = small ? t0 : a0;     // lanes of a wave that skipped the exponential are all small or saturated: a0 = a1 = 1
-    w1 = small ? t1 : a1;
+    // the series and its selects only where some lane of the wavefront needs them (below the top of the atmosphere none does)
+    if (__builtin_amdgcn_fcmp(dtau, 5e-4, 4 /* ordered < */) != 0) {       // the lane mask of `small`, as the compare writes it
+        const double t0 = dtau * (1.0 - 0.5 * dtau);
+        const double t1 = (dtau * dtau) * (0.5 - dtau * (1.0 / 3.0));
+        a0 = small ? t0 : a0;
+        a1 = small ? t1 : a1;
+        asm volatile("" : "+v"(a0), "+v"(a1));      // keeps this a branch (the compiler would speculate the block and select twice)
+    }
+    w0 = a0;
+    w1 = a1;
 }
+#endif
 
 // Weights of the parabolic rule (include/lsx.h, N4): w_n = int_0^dtau t^n e^-t dt, n = 0, 1, 2; same regimes and the same
 // exponential as w2.

@@ -398,15 +398,9 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
     }
     for (auto& k : P.plan_classes) {
         k.work = class_work(k);
-        // per wave: level cells, atom cells, angle-sum row; + two cross-wave exchange rows; + the static
-        // path's per-depth table of wave-uniform operands, Nspace x (3 npt + 2) doubles
-        // (level / atom cells exist only in the generic instance; compile-time classes keep that bookkeeping in registers)
+        // level / atom cells exist only in the generic instance; compile-time classes keep that bookkeeping in registers
         const int cl = k.npt >= 0 ? 0 : k.ncell_lev, ca = k.npt >= 0 ? 0 : k.ncell_atom;
-        k.lds_bytes = (size_t)LSX_EXP_TAB * sizeof(double) + (size_t)(2 * (2 * cl + ca + 1) + 2) * LSX_WAVE * sizeof(double) +
-                      (size_t)(k.npt >= 0 ? (Ns + 1) * (3 * k.npt + 2) : 0) * sizeof(double) +
-                      (size_t)(k.npt > 0 ? 2 * 2 * k.npt * LSX_WAVE : 0) * sizeof(double) +    // parked Gamma totals
-                      (size_t)(k.npt >= 3 ? k.npt * (k.npt - 1) * 5 : 0) * sizeof(double) +   // slot-pair factors
-                      (size_t)(k.linked && k.npt > 0 ? 2 * k.npt * LSX_WAVE : 0) * sizeof(double);   // linked: exchange rows of the Psi* phi sums
+        k.lds_bytes = (size_t)lsx_sweep_lds(k.npt, k.linked, Ns, cl, ca).total * sizeof(double);
         if (k.lds_bytes > 64 * 1024) { return perr(err, LSX_EUNSUPPORTED, "lsx_create: a tile needs %zu B of LDS", k.lds_bytes); }
         // diagnostic (profiles/occupancy.sh): at most LSX_OCC_WG workgroups per CU, enforced through the LDS request -- how a
         // class's time depends on the waves resident per SIMD (workgroups / 2)
@@ -474,11 +468,10 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
     {
         int npt_max = -1;
         for (auto& k : P.plan_classes) npt_max = std::max(npt_max, k.npt);
-        S.fused_lds = (size_t)LSX_EXP_TAB * sizeof(double) + (size_t)(2 * (2 * S.fused_ncell_lev + S.fused_ncell_atom + 1) + 2) * LSX_WAVE * sizeof(double) +
-                      (size_t)(npt_max >= 0 ? (Ns + 1) * (3 * npt_max + 2) : 0) * sizeof(double) +
-                      (size_t)(npt_max > 0 ? 2 * 2 * npt_max * LSX_WAVE : 0) * sizeof(double) +
-                      (size_t)(npt_max >= 3 ? npt_max * (npt_max - 1) * 5 : 0) * sizeof(double) +
-                      (size_t)(P.corr_col && npt_max > 0 ? 2 * npt_max * LSX_WAVE : 0) * sizeof(double);
+        // every instance the fused kernel may dispatch to lays its own LDS out from its own slot count, with the cell rows of
+        // the largest generic tile in front
+        for (int q = -1; q <= npt_max; ++q)
+            S.fused_lds = std::max(S.fused_lds, (size_t)lsx_sweep_lds(q, P.corr_col > 0, Ns, S.fused_ncell_lev, S.fused_ncell_atom).total * sizeof(double));
         if (S.fused_lds > 64 * 1024) return perr(err, LSX_EUNSUPPORTED, "lsx_create: the fused sweep launch needs %zu B of LDS", S.fused_lds);
     }
     return LSX_OK;

@@ -45,6 +45,56 @@ inline bool lsx_sweep_instance_exists(int npt, int nl, bool lk, int topo)
     }
 }
 
+// ---- LDS layout of one sweep workgroup (doubles from the start of dynamic LDS), shared by the kernel (offsets) and the plan
+// (bytes to request).  Lane sums of the Gamma integrands go through a transposition buffer: the lanes park their values for
+// LSX_RED_T(npt) depth steps ([step][value][lane], rows padded to 66 doubles: conflict-free 16-byte reads), then every lane
+// adds up one chunk of one row and a short DPP tail finishes -- 4 to 8 vector instructions per step instead of 18 to 42.
+#ifndef LSX_RED_T1
+#define LSX_RED_T1 4
+#endif
+#ifndef LSX_RED_T2
+#define LSX_RED_T2 2
+#endif
+constexpr int lsx_red_steps(int npt) { return npt == 1 ? LSX_RED_T1 : (npt == 2 ? LSX_RED_T2 : 1); }   // depth steps per batch
+constexpr int lsx_red_vectors(int npt) { return npt > 0 ? 2 * npt * lsx_red_steps(npt) : 0; }        // rows per batch: 8, 8, 6, 8
+#ifdef LSX_RED_DPP      // diagnostic variant (round 2's reduction): [2 waves][2 npt] parked rows of 64 totals instead
+#define LSX_RED_ROW 64
+#undef LSX_RED_T1
+#undef LSX_RED_T2
+#define LSX_RED_T1 1
+#define LSX_RED_T2 1
+#else
+#define LSX_RED_ROW 66
+#endif
+struct SweepLds {
+    int rows;        // 64-double rows per wave: level cells, atom cells, one angle-sum row
+    int xwg;         // [2][64] cross-wave exchange
+    int utab;        // [(Ns + 1)][3 npt + 2] per-depth wave-uniform operands (compile-time slot counts only)
+    int tb;          // [2 waves][vectors][LSX_RED_ROW] transposition buffer
+    int gpk;         // -DLSX_RED_PARK: [2 waves][2 npt][64] totals parked until 64 depths can leave in one store
+    int ctab;        // [npt][npt - 1][5] slot-pair factors (three and four slots)
+    int xrow2;       // [2 waves][npt][64] linked tiles: exchange rows of the Psi* phi sums
+    int total;
+};
+constexpr SweepLds lsx_sweep_lds(int npt, bool linked, int Ns, int ncell_lev, int ncell_atom)
+{
+    SweepLds l{};
+    l.rows = 2 * ncell_lev + ncell_atom + 1;
+    l.xwg = LSX_EXP_TAB + 2 * l.rows * LSX_WAVE;
+    l.utab = l.xwg + 2 * LSX_WAVE;
+    l.tb = l.utab + (npt >= 0 ? (Ns + 1) * (3 * npt + 2) : 0);
+    l.tb += l.tb & 1;                                           // 16-byte aligned rows
+    l.gpk = l.tb + 2 * lsx_red_vectors(npt) * LSX_RED_ROW;
+#if defined(LSX_RED_PARK) && !defined(LSX_RED_DPP)
+    l.ctab = l.gpk + (npt > 0 ? 2 * 2 * npt * LSX_WAVE : 0);
+#else
+    l.ctab = l.gpk;
+#endif
+    l.xrow2 = l.ctab + (npt >= 3 ? npt * (npt - 1) * 5 : 0);
+    l.total = l.xrow2 + (linked && npt > 0 ? 2 * npt * LSX_WAVE : 0);
+    return l;
+}
+
 namespace lsxd {
 
 struct PlanClass {             // tiles that run the same kernel instantiation

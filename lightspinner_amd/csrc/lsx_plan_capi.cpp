@@ -128,9 +128,7 @@ void verify(const LsxPlan& P, Checker& ck)
     if (P.phi_col * 8 > 0x7fffffffu || P.corr_col * 8 > 0x7fffffffu || P.til_col * 8 > 0x7fffffffu) ck.fail("a column block exceeds 32-bit byte offsets");
     for (auto& k : P.plan_classes) {
         const int cl = k.npt >= 0 ? 0 : k.ncell_lev, ca = k.npt >= 0 ? 0 : k.ncell_atom;
-        const size_t need = (size_t)LSX_EXP_TAB * 8 + (size_t)(2 * (2 * cl + ca + 1) + 2) * LSX_WAVE * 8 + (size_t)(k.npt >= 0 ? (Ns + 1) * (3 * k.npt + 2) : 0) * 8 +
-                            (size_t)(k.npt > 0 ? 2 * 2 * k.npt * LSX_WAVE : 0) * 8 + (size_t)(k.npt >= 3 ? k.npt * (k.npt - 1) * 5 : 0) * 8 +
-                            (size_t)(k.linked && k.npt > 0 ? 2 * k.npt * LSX_WAVE : 0) * 8;
+        const size_t need = (size_t)lsx_sweep_lds(k.npt, k.linked, Ns, cl, ca).total * 8;
         if (k.lds_bytes < need || k.lds_bytes > 64 * 1024) ck.fail("class code %ld: LDS %ld B, needs %ld", k.code(), (long)k.lds_bytes, (long)need);
         if (k.tiles.empty()) ck.fail("empty class");
     }

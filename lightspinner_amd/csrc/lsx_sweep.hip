@@ -156,7 +156,7 @@ __device__ __forceinline__ SlotS load_slot(const __attribute__((address_space(4)
 template <int NPT, int NL, int NR, bool SCAL, bool LK, int TOPO = 0>
 __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, const int tile_id)
 {
-    extern __shared__ double lds_raw[];
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
 #if defined(LSX_STAMPS) || defined(LSX_CLOCK)
     unsigned long long tk_entry;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk_entry)::"memory");
@@ -190,19 +190,20 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     const int la = la0 + j;
     const bool lead = valid && mu_raw == 0; // one lane per wavelength: owns J[la, k]
 
-    // LDS rows (64 doubles each), private to this wave except the two exchange rows at the end
-    const int rows = 2 * p.ncell_lev + p.ncell_atom + 1;
+    // LDS layout (lsx_plan.h, lsx_sweep_lds): rows of 64 doubles private to this wave, then the two cross-wave exchange rows
+    constexpr int TR = STATIC ? 3 * NPT + 2 : 1;
+    const SweepLds lay = lsx_sweep_lds(STATIC ? NPT : -1, LK, p.Nspace, p.ncell_lev, p.ncell_atom);
+    const int rows = lay.rows;
     lds_f64* const wrow = lds + (size_t)dir * rows * LSX_WAVE + lane;
 #define CCHI(c) wrow[(2 * (c)) * LSX_WAVE]
 #define CU(c) wrow[(2 * (c) + 1) * LSX_WAVE]
 #define CETA(a) wrow[(2 * p.ncell_lev + (a)) * LSX_WAVE]
     lds_f64* const xrow = lds + (size_t)dir * rows * LSX_WAVE + (size_t)(rows - 1) * LSX_WAVE; // angle sums
-    lds_f64* const xwg = lds + (size_t)2 * rows * LSX_WAVE;                                    // [2][64] cross-wave
+    lds_f64* const xwg = etab + lay.xwg;                                                       // [2][64] cross-wave
     // static path: per-depth wave-uniform operands of the tile (n_i, n_j, wphi per slot, z, sigma) are
     // staged once per workgroup as a depth-major table utab[k][TR] -> one address register, immediate
     // offsets, counted LDS waits (scalar-cache loads return out of order and serialise on lgkmcnt(0))
-    constexpr int TR = STATIC ? 3 * NPT + 2 : 1;
-    lds_f64* const utab = xwg + 2 * LSX_WAVE;
+    lds_f64* const utab = etab + lay.utab;
 
     // column bases; wave-uniform reads go through the scalar cache
     const auto* n_col = LSX_CONST(double, p.n + (size_t)col * p.NLtot * Ns);
@@ -251,9 +252,9 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     }
     etab[threadIdx.x] = p.exp2_tab[threadIdx.x];          // 2 x 64 threads, 64 x 2 doubles
     // three- and four-slot tiles: the slot-pair factors of the level bookkeeping, [u][other o][5]
-    lds_f64* const ctab = utab + (STATIC ? (p.Nspace + 1) * TR : 0) + (size_t)2 * (2 * NS) * LSX_WAVE;
+    lds_f64* const ctab = etab + lay.ctab;
     // linked tiles: one more exchange row per line and wave (behind the slot-pair factors)
-    lds_f64* const xrow2 = ctab + (NPT >= 3 ? NPT * (NPT - 1) * 5 : 0) + (size_t)dir * NS * LSX_WAVE;
+    lds_f64* const xrow2 = etab + lay.xrow2 + (size_t)dir * NS * LSX_WAVE;
     if constexpr (NPT >= 3) {
         if (threadIdx.x < NPT * (NPT - 1) * 5) {
             const int u = threadIdx.x / ((NPT - 1) * 5), r = threadIdx.x % ((NPT - 1) * 5);
@@ -411,13 +412,31 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     };
     if constexpr (STATIC) stream_loads(kS, n_bc, n_be, n_jd, n_sv, n_E, n_cr);
 
+#ifdef LSX_RED_DPP     // diagnostic variant: round 2's lane reduction (DPP / permlane trees, totals parked in 64-entry LDS rows)
     // Gamma totals wait in LDS, one 64-entry row per (slot, entry) and wave, until 64 depths can leave in one store.
     // The lanes that hold totals after a reduction (31 / 63, or 15 / 47 / 31 / 63) each own one row.
-    lds_f64* const gpk = utab + (STATIC ? (p.Nspace + 1) * TR : 0) + (size_t)dir * (2 * NS) * LSX_WAVE;
+    lds_f64* const gpk = etab + lay.tb + (size_t)dir * (2 * NS) * LSX_WAVE;
     const bool own_pair = lane == 31 || lane == 63, own_quad = (lane & 15) == 15;
     const int row_pair = (lane >> 5) * LSX_WAVE;                                   // 31 -> row 0, 63 -> row 1
     const int row_quad = ((((lane >> 4) & 1) << 1) | (lane >> 5)) * LSX_WAVE;      // 15 -> 0, 47 -> 1, 31 -> 2, 63 -> 3
 
+#else
+    // Lane sums of the Gamma integrands: the lanes park their 2 NPT values of RT consecutive depth steps in this wave's
+    // transposition buffer tb[step in batch][value][lane] (rows of LSX_RED_ROW doubles); at the end of a batch every lane adds
+    // up one chunk of one row and a DPP tail over the chunk's lanes finishes (lsx_plan.h).  The first lane of a row's group
+    // stores the total: each batch leaves as ONE store instruction with one lane per (depth, value).
+    constexpr int RT = lsx_red_steps(NPT > 0 ? NPT : 1), NV = 2 * NS, RV = NV * RT;     // RV rows per batch (<= 8)
+    constexpr int RVP = RV <= 4 ? 4 : 8, LPV = LSX_WAVE / RVP;                           // lanes per row; doubles per lane = RVP
+    lds_f64* const tb = etab + lay.tb + (size_t)dir * RV * LSX_RED_ROW;
+#ifdef LSX_RED_PARK
+    lds_f64* const gpk = etab + lay.gpk + (size_t)dir * (2 * NS) * LSX_WAVE;
+#endif
+    const int rv_raw = lane / LPV, rc = lane - rv_raw * LPV;
+    const int rv = rv_raw < RV ? rv_raw : RV - 1;                                         // (RV = 6: the last two groups idle)
+    const int rt = rv / NV, rq = rv - rt * NV;                                            // step in batch, value index (2 slot + entry)
+    const bool r_own = rc == 0 && rv_raw < RV;
+
+#endif
     // A sweep runs in three phases with a fixed set of memory operations each, so the compiler's wait counts are
     // exact and neither a store acknowledgement nor the half-J read-back is waited for inside a step:
     //   phase 0: this wave is the first visitor of its depths (stores its half of J)
@@ -525,17 +544,25 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             }
         }
         STAMP(2);
-        const double rchi = rcp(chiTot);
-        const double S = etaTot * rchi;                 // :632
-
         // ---- formal solution at this depth (formal_solver.py:107-139) ----
-        double I, Lam;
+        // the two divisions of a step (by chi, :632, and by dtau, :113/:121) share ONE reciprocal, 1 / (chi dtau)
+        double I, Lam, rchi, S;
         if constexpr (FIRST) {
+            rchi = rcp(chiTot);
+            S = etaTot * rchi;                          // :632
             I = Iu;
             Lam = 0.0;
         } else {
             const double dtau = (chi_prev + chiTot) * hdzm;
+#ifdef LSX_RCP2        // diagnostic variant: one reciprocal per division
+            rchi = rcp(chiTot);
             const double rdt = rcp(dtau);
+#else
+            const double rcd = rcp(chiTot * dtau);
+            rchi = rcd * dtau;
+            const double rdt = rcd * chiTot;
+#endif
+            S = etaTot * rchi;                          // :632
             const double dS = (S_prev - S) * rdt;
             // formal_solver.py:138-139: the end point re-uses the PREVIOUS interval's w and
             // S[kEnd - dk] with the fresh dS, dtau (reference behaviour, reproduced deliberately)
@@ -627,7 +654,11 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                 const SlotS sl = load_slot(slots + u, Ns);
                 const bool line = u < NL;
                 const double Vij = line ? sl.cB * spv[u] : alv[u];
+#ifdef LSX_RED_DPP
                 const double wt = line ? wlv[u] * tk[3 * u + 2] : wlv[u];         // :451 (lines: x wphi), :455, :665
+#else
+                const double wt = wlv[u];         // :455, :665; the lines' wphi (:451) is wave-uniform: applied to the lane sum
+#endif
                 // linked continua add their ray-independent share to the line's atom.eta, atom.chi[i], atom.chi[j]
                 // (x + 0.0 is not x to the compiler: the corrections are added only where the instance has them)
                 const bool lkl = LK && line;
@@ -685,6 +716,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                     w2v[u] = wt * (Vij * Ieff);                                                          // :680
                 }
             }
+#ifdef LSX_RED_DPP
             // the totals of step s are parked in entry (s mod 64) of per-(slot, entry) LDS rows and leave as one
             // 64-wide store every 64 steps: no store (and no store acknowledgement to wait for) inside a step
             const int sl64 = s & 63;
@@ -710,6 +742,53 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                     for (int q = 0; q < 2 * NPT; ++q) gpart[(q * 2 + dir) * Ns + ks] = gpk[q * LSX_WAVE + lane];
                 }
             }
+#else
+            if constexpr (NPT >= 1) {
+                const int pos = s & (RT - 1);
+                lds_f64* const tbw = tb + pos * NV * LSX_RED_ROW + lane;
+#pragma unroll
+                for (int u = 0; u < NPT; ++u) {
+                    tbw[(2 * u) * LSX_RED_ROW] = w1[u];
+                    tbw[(2 * u + 1) * LSX_RED_ROW] = w2v[u];
+                }
+                if (pos == RT - 1 || s == Ns - 1) {
+                    __builtin_amdgcn_wave_barrier();
+                    // 16-byte reads (ds_read_b128: 64 banks, conflict free on rows of LSX_RED_ROW doubles; the 8-byte forms
+                    // would put a 16-lane group on two banks)
+                    typedef double lds_pair __attribute__((ext_vector_type(2)));
+                    const auto* src = (const __attribute__((address_space(3))) lds_pair*)(tb + rv * LSX_RED_ROW + rc * RVP);   // 16-byte aligned (lsx_sweep_lds)
+                    lds_pair v2 = src[0];
+                    double acc = v2.x + v2.y;
+#pragma unroll
+                    for (int e = 1; e < RVP / 2; ++e) { v2 = src[e]; acc += v2.x + v2.y; }
+                    acc += dpp_f64<0xB1, 0xf>(acc);                          // quad_perm [1,0,3,2]
+                    acc += dpp_f64<0x4E, 0xf>(acc);                          // quad_perm [2,3,0,1]
+                    acc += dpp_f64<0x141, 0xf>(acc);                         // row_half_mirror: 8-lane sums
+                    if constexpr (LPV == 16) acc += dpp_f64<0x140, 0xf>(acc); // row_mirror: 16-lane sums
+                    const int kt = kS + dk * (s - pos + rt);                 // the depth this lane's row belongs to
+                    if (r_own && rt <= pos) {
+                        // lines: x wphi of that depth (rh_method.py:451); continua (:455) carry their whole weight in wlv
+                        const double wn = (rq >> 1) < NL ? utab[kt * TR + 3 * (rq >> 1) + 2] : 1.0;
+#ifdef LSX_RED_PARK
+                        gpk[rq * LSX_WAVE + ((s - pos + rt) & 63)] = acc * wn;
+#else
+                        gpart[(rq * 2 + dir) * Ns + kt] = acc * wn;
+#endif
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#ifdef LSX_RED_PARK
+                    const int sl64 = s & 63;
+                    if (sl64 == 63 || s == Ns - 1) {
+                        const int ks = kS + dk * (s - sl64 + lane);         // the depth parked in entry `lane` of every row
+                        if (lane <= sl64) {
+#pragma unroll
+                            for (int q = 0; q < 2 * NPT; ++q) gpart[(q * 2 + dir) * Ns + ks] = gpk[q * LSX_WAVE + lane];
+                        }
+                    }
+#endif
+                }
+            }
+#endif
         } else {
             for (int u = 0; u < nP; ++u) {
                 const SlotS sl = load_slot(slots + u, Ns);
@@ -816,7 +895,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
 template <int NR, bool SCAL>
 __device__ __forceinline__ void sweep_tile_parabolic(const SweepParams& p, const int vb, const int tile_id)
 {
-    extern __shared__ double lds_raw[];
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     lds_f64* const etab = (lds_f64*)lds_raw;
     lds_f64* const lds = etab + LSX_EXP_TAB;
     const int lane = threadIdx.x & (LSX_WAVE - 1);

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Build one variant of the HIP library for profiles/ab.sh without touching the in-tree build:
 #   bash profiles/mkvariant.sh NAME "-DLSX_SOMETHING ..." [sweep|full|host]
-# sweep (default): compiles lsx_sweep.hip with the extra flags (5-ray instances only), `full`: all its instances, `host`:
-# compiles lsx_hip.hip (runtime + fast-continuum kernels) with the flags instead; links with the other in-tree objects
-# into ab_so/NAME.so.
+# sweep (default): compiles lsx_sweep.hip (5-ray instances only) and the host-side plan lsx_plan.cpp (they share the LDS
+# layout of lsx_plan.h) with the extra flags, `full`: all instances, `host`: compiles lsx_hip.hip (runtime +
+# fast-continuum kernels) with the flags instead; links with the other in-tree objects into ab_so/NAME.so.
 set -e
 cd "$(dirname "$0")/../lightspinner_amd/csrc"
 NAME=$1; XF=$2; MODE=${3:-sweep}
@@ -16,6 +16,7 @@ if [ "$MODE" = host ]; then
 else
   ONLY="-DLSX_ONLY_NR5"; [ "$MODE" = full ] && ONLY=""
   /opt/rocm/bin/hipcc $CF $ONLY $XF -c lsx_sweep.hip -o /tmp/lsxvar/$NAME.o
-  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../ab_so/$NAME.so build/lsx_hip.o build/lsx_setup.o build/lsx_grid.o build/lsx_plan.o /tmp/lsxvar/$NAME.o
+  g++ -O2 -std=c++17 -fPIC $XF -c lsx_plan.cpp -o /tmp/lsxvar/${NAME}_plan.o
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../ab_so/$NAME.so build/lsx_hip.o build/lsx_setup.o build/lsx_grid.o /tmp/lsxvar/${NAME}_plan.o /tmp/lsxvar/$NAME.o
 fi
 echo "built ab_so/$NAME.so"
