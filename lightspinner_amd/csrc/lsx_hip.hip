@@ -48,6 +48,8 @@ using namespace lsxd;
 
 // launcher defined in lsx_sweep.hip
 extern "C" hipError_t lsx_launch_sweep(const SweepParams*, int, int, size_t, hipStream_t);
+// launcher defined in lsx_sweep_rs.hip (ray-serial instances)
+extern "C" hipError_t lsx_launch_sweep_rs(const SweepParams*, int, hipStream_t);
 
 namespace {
 
@@ -1378,6 +1380,8 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         opt.fast_rows = getenv("LSX_FAST_ROWS") != nullptr;
         opt.order_by_cost = (e = getenv("LSX_ORDER")) && std::string(e) == "cost";
         opt.occ_wg = (e = getenv("LSX_OCC_WG")) ? atoi(e) : 0;
+        opt.no_rs = getenv("LSX_NO_RS") != nullptr;
+        if ((e = getenv("LSX_RS_MIN_COLUMNS"))) opt.rs_min_columns = atoi(e);
     }
     LsxPlan plan;
     {
@@ -1710,7 +1714,8 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
             p.n_class_tiles = (int)k.tiles.size();
             p.ncell_lev = k.npt >= 0 ? 0 : k.ncell_lev; p.ncell_atom = k.npt >= 0 ? 0 : k.ncell_atom; p.nstash = 0;
             k.launches++;
-            note(lsx_launch_sweep(&p, k.code(), (int)nblocks, k.lds_bytes, st));
+            if (k.rs && c->ncol >= c->rs_min_columns) note(lsx_launch_sweep_rs(&p, k.code(), st));       // five columns per wavefront
+            else note(lsx_launch_sweep(&p, k.code(), (int)nblocks, k.lds_bytes, st));
             if (timed) {
                 if (!k.tdone) note(hipEventCreate(&k.tdone));
                 if (k.tdone) note(hipEventRecord(k.tdone, st));
@@ -2194,8 +2199,9 @@ double lsx_hip_info(const lsx_ctx* c, int32_t what)
 }
 
 // HIP-only introspection for the tests: which sweep instantiations a context launches.  Returns the number of tile
-// classes; for 0 <= idx < that number out[0..5] = per-ray slots (compile time, -1 generic), lines among them, tiles per
-// column, launches so far, 1 if the class's tiles have linked continua, the two-line relation (TOPO).  idx == -1: out[0] =
+// classes; for 0 <= idx < that number out[0..6] = per-ray slots (compile time, -1 generic), lines among them, tiles per
+// column, launches so far, 1 if the class's tiles have linked continua, the two-line relation (TOPO), 1 if the class runs the
+// ray-serial kernel (lsx_sweep_rs.hip) in this context.  idx == -1: out[0] =
 // launches of the fused small-batch kernel.
 int32_t lsx_hip_class_info(const lsx_ctx* c, int32_t idx, int64_t* out)
 {
@@ -2204,6 +2210,7 @@ int32_t lsx_hip_class_info(const lsx_ctx* c, int32_t idx, int64_t* out)
     if (out && idx >= 0 && idx < (int)c->classes.size()) {
         const SweepClass& k = c->classes[idx];
         out[0] = k.npt; out[1] = k.nl; out[2] = (int64_t)k.tiles.size(); out[3] = k.launches; out[4] = k.linked ? 1 : 0; out[5] = k.topo;
+        out[6] = (k.rs && c->ncol >= c->rs_min_columns) ? 1 : 0;
     }
     return (int32_t)c->classes.size();
 }

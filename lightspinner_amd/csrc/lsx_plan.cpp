@@ -426,6 +426,14 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
     P.sca_col = P.sca_per_lambda ? P.til_col : (size_t)Ns;
     if (P.phi_col > 0x0fffffff || P.corr_col > 0x0fffffff || P.til_col > 0x0fffffff) return perr(err, LSX_EUNSUPPORTED, "column too large for 32-bit byte offsets");
 
+    // ---- ray-serial sweep: five columns per wavefront, addressed as one base + 32-bit byte offsets
+    {
+        const size_t big = std::max(std::max(P.til_col, P.phi_col), std::max(std::max(P.corr_col, P.pp_col), (size_t)std::max(P.NLtot, std::max(P.Nlines, P.Ncont)) * Ns));
+        P.rs_ok = !opt.no_rs && P.Nrays == LSX_RS_RAYS && !P.sca_per_lambda && (LSX_RS_COLS + 1) * big * 8 < 0xffffffffull;
+        P.rs_min_columns = opt.rs_min_columns;
+        for (auto& k : P.plan_classes) k.rs = P.rs_ok && k.npt >= 0 && lsx_rs_instance_exists(k.npt, k.nl, k.linked, k.topo);
+    }
+
     // ---- launch shapes of the kernels around the sweep: decided (and refused) here, not inside a half-enqueued call
     LaunchShapes& S = P.shapes;
     // depths whose operands are staged in LDS at a time: the whole column if `budget` bytes allow, else a multiple of `rows`

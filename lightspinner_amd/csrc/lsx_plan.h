@@ -46,9 +46,11 @@ inline bool lsx_sweep_instance_exists(int npt, int nl, bool lk, int topo)
 }
 
 // ---- LDS layout of one sweep workgroup (doubles from the start of dynamic LDS), shared by the kernel (offsets) and the plan
-// (bytes to request).  Lane sums of the Gamma integrands go through a transposition buffer: the lanes park their values for
-// LSX_RED_T(npt) depth steps ([step][value][lane], rows padded to 66 doubles: conflict-free 16-byte reads), then every lane
-// adds up one chunk of one row and a short DPP tail finishes -- 4 to 8 vector instructions per step instead of 18 to 42.
+// (bytes to request).  -DLSX_RED_LDS (measured variant, not the product): lane sums of the Gamma integrands through a
+// transposition buffer -- the lanes park their values for lsx_red_steps(npt) depth steps ([step][value][lane], rows padded to
+// 66 doubles: conflict-free 16-byte reads), then every lane adds up one chunk of one row and a short DPP tail finishes: 12 %
+// fewer vector instructions per step, 3-5 % MORE time on C3 (the added LDS round trip lengthens each wave's serial chain;
+// profiles/r03_bound_evidence.md).
 #ifndef LSX_RED_T1
 #define LSX_RED_T1 4
 #endif
@@ -57,7 +59,7 @@ inline bool lsx_sweep_instance_exists(int npt, int nl, bool lk, int topo)
 #endif
 constexpr int lsx_red_steps(int npt) { return npt == 1 ? LSX_RED_T1 : (npt == 2 ? LSX_RED_T2 : 1); }   // depth steps per batch
 constexpr int lsx_red_vectors(int npt) { return npt > 0 ? 2 * npt * lsx_red_steps(npt) : 0; }        // rows per batch: 8, 8, 6, 8
-#ifdef LSX_RED_DPP      // diagnostic variant (round 2's reduction): [2 waves][2 npt] parked rows of 64 totals instead
+#ifndef LSX_RED_LDS      // the product's reduction (DPP / permlane trees): [2 waves][2 npt] parked rows of 64 totals instead
 #define LSX_RED_ROW 64
 #undef LSX_RED_T1
 #undef LSX_RED_T2
@@ -85,7 +87,7 @@ constexpr SweepLds lsx_sweep_lds(int npt, bool linked, int Ns, int ncell_lev, in
     l.tb = l.utab + (npt >= 0 ? (Ns + 1) * (3 * npt + 2) : 0);
     l.tb += l.tb & 1;                                           // 16-byte aligned rows
     l.gpk = l.tb + 2 * lsx_red_vectors(npt) * LSX_RED_ROW;
-#if defined(LSX_RED_PARK) && !defined(LSX_RED_DPP)
+#if defined(LSX_RED_PARK) && defined(LSX_RED_LDS)
     l.ctab = l.gpk + (npt > 0 ? 2 * 2 * npt * LSX_WAVE : 0);
 #else
     l.ctab = l.gpk;
@@ -94,6 +96,37 @@ constexpr SweepLds lsx_sweep_lds(int npt, bool linked, int Ns, int ncell_lev, in
     l.total = l.xrow2 + (linked && npt > 0 ? 2 * npt * LSX_WAVE : 0);
     return l;
 }
+
+// ---- the ray-serial sweep (lsx_sweep_rs.hip): lane = one wavelength of one column, the lane's LSX_RS_RAYS rays one after the
+// other in registers, LSX_RS_COLS columns per wavefront.  Instances exist for the classes below (at most two per-ray slots);
+// a context uses them when it has LSX_RS_RAYS rays, a wavelength-independent scattering coefficient, enough columns to fill
+// the machine with five-column wavefronts, and column blocks small enough for 32-bit offsets across a column group.
+#define LSX_RS_RAYS 5
+#define LSX_RS_COLS 5
+#define LSX_RS_MIN_COLUMNS 160         // default of PlanOptions::rs_min_columns
+#define LSX_RS_INSTANCES(X)                                                                                      \
+    X(0, 0, false, 0) X(1, 0, false, 0) X(1, 1, false, 0) X(2, 0, false, 0) X(2, 1, false, 0) X(2, 2, false, 0)  \
+    X(1, 1, true, 0) X(2, 1, true, 0) X(2, 2, true, 0)                                                           \
+    X(2, 2, false, 1) X(2, 2, false, 2) X(2, 2, true, 1) X(2, 2, true, 2)
+#ifndef LSX_RS_WPE1
+#define LSX_RS_WPE1 2
+#endif
+#ifndef LSX_RS_WPE2
+#define LSX_RS_WPE2 2
+#endif
+#define LSX_RS_WPE(NPT, LK) ((NPT) <= 1 ? LSX_RS_WPE1 : LSX_RS_WPE2)       // register budget: waves per SIMD the compiler aims for
+inline bool lsx_rs_instance_exists(int npt, int nl, bool lk, int topo)
+{
+    switch (lsx_class_code(npt, nl, lk, topo)) {
+#define LSX_X(NPT, NL, LK, TOPO) case lsx_class_code(NPT, NL, LK, TOPO):
+        LSX_RS_INSTANCES(LSX_X)
+#undef LSX_X
+        return npt >= 0;
+    default: return false;
+    }
+}
+// LDS doubles of a ray-serial workgroup: exp table, [2 waves][2 npt + 1] rows of 64 (parked Gamma integrands, dJ), [2][64] J exchange
+constexpr int lsx_rs_lds_doubles(int npt) { return LSX_EXP_TAB + 2 * (2 * (npt > 0 ? npt : 1) + 1) * 64 + 2 * LSX_WAVE; }
 
 namespace lsxd {
 
@@ -109,6 +142,7 @@ struct PlanClass {             // tiles that run the same kernel instantiation
     int ncell_lev = 1, ncell_atom = 1;
     size_t lds_bytes = 0;
     double work = 0.0;         // estimated share of the call (launch order; stream priority tiers under LSX_PRIO)
+    bool rs = false;           // the class has a ray-serial instance (lsx_sweep_rs.hip); lsx_create decides by the column count
     int code() const { return npt >= 0 ? lsx_class_code(npt, nl, linked, topo) : (linked ? -3 : -1); }
 };
 
@@ -119,6 +153,8 @@ struct PlanOptions {           // diagnostic switches (lsx_create reads them fro
     bool fast_rows = false;    // LSX_FAST_ROWS: the row-mapped epilogue for every tile
     bool order_by_cost = false; // LSX_ORDER=cost
     int occ_wg = 0;            // LSX_OCC_WG: at most this many workgroups per CU (through the LDS request)
+    bool no_rs = false;        // LSX_NO_RS: every class through lsx_sweep.hip (one ray per lane)
+    int rs_min_columns = LSX_RS_MIN_COLUMNS;   // LSX_RS_MIN_COLUMNS: contexts with fewer columns keep one ray per lane (too few wavefronts otherwise)
 };
 
 // launch shapes of the kernels around the sweep, fixed when the plan is made so that no enqueue path can fail on them
@@ -153,6 +189,8 @@ struct LsxPlan {
     // per-column strides in doubles
     size_t phi_col = 0, phi_in_col = 0, corr_col = 0, pp_col = 0, sca_col = 0, til_col = 0;
     LaunchShapes shapes;
+    bool rs_ok = false;        // the context's shape admits the ray-serial sweep (rays, scattering, 32-bit offsets over a column group)
+    int rs_min_columns = LSX_RS_MIN_COLUMNS;
 };
 
 // -> LSX_OK or an error code with the message in *err.  Checks the descriptor like lsx_create did.

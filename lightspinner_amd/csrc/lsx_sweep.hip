@@ -412,7 +412,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     };
     if constexpr (STATIC) stream_loads(kS, n_bc, n_be, n_jd, n_sv, n_E, n_cr);
 
-#ifdef LSX_RED_DPP     // diagnostic variant: round 2's lane reduction (DPP / permlane trees, totals parked in 64-entry LDS rows)
+#ifndef LSX_RED_LDS     // lane reduction by DPP / permlane trees, totals parked in 64-entry LDS rows (-DLSX_RED_LDS: the measured alternative)
     // Gamma totals wait in LDS, one 64-entry row per (slot, entry) and wave, until 64 depths can leave in one store.
     // The lanes that hold totals after a reduction (31 / 63, or 15 / 47 / 31 / 63) each own one row.
     lds_f64* const gpk = etab + lay.tb + (size_t)dir * (2 * NS) * LSX_WAVE;
@@ -654,7 +654,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                 const SlotS sl = load_slot(slots + u, Ns);
                 const bool line = u < NL;
                 const double Vij = line ? sl.cB * spv[u] : alv[u];
-#ifdef LSX_RED_DPP
+#ifndef LSX_RED_LDS
                 const double wt = line ? wlv[u] * tk[3 * u + 2] : wlv[u];         // :451 (lines: x wphi), :455, :665
 #else
                 const double wt = wlv[u];         // :455, :665; the lines' wphi (:451) is wave-uniform: applied to the lane sum
@@ -716,7 +716,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                     w2v[u] = wt * (Vij * Ieff);                                                          // :680
                 }
             }
-#ifdef LSX_RED_DPP
+#ifndef LSX_RED_LDS
             // the totals of step s are parked in entry (s mod 64) of per-(slot, entry) LDS rows and leave as one
             // 64-wide store every 64 steps: no store (and no store acknowledgement to wait for) inside a step
             const int sl64 = s & 63;

@@ -1,0 +1,561 @@
+// lsx_sweep_rs.hip -- the "ray-serial" sweep: the same fused eta/chi/U-V build + piecewise-linear short-characteristics
+// sweep + Psi*/Gamma/J accumulation as lsx_sweep.hip (rh_method.py:595-692, formal_solver.py:14-212), for the tile classes
+// with at most two per-ray slots and five rays, mapped onto the wavefront the other way round:
+//
+//   lsx_sweep.hip     lane = one RAY (wavelength, mu);       wavefront = one direction of (tile, column)
+//   this file         lane = one WAVELENGTH of one column;   wavefront = one direction of (tile, FIVE columns);
+//                     the lane walks its five rays one after the other inside every depth step (registers).
+//
+// Why (measured, profiles/r03_bound_evidence.md): with one ray per lane the sweep runs at the vector-issue rate of the clock
+// the chip holds under it AND on its own serial chain -- removing vector instructions did not make it faster while each
+// wave still had one dependency chain and three LDS round trips per depth step.  Here
+//   * everything that does not depend on the angle -- background, sigma J-dagger, the per-depth level populations, stream
+//     addressing, the J / Psi-bar / Psi* phi sums, the J store and dJ -- is done once per wavelength instead of once per ray;
+//   * the angle quadrature is a sum in registers: the LDS exchanges of a depth step are gone, and so is the operand table
+//     (per-depth operands of the lane's own column arrive as ordinary, 12-lane-uniform loads one depth ahead);
+//   * the wavelength quadrature of Gamma is reduced across lanes once per five rays;
+//   * a lane carries five independent recurrences: the latency of one ray's reciprocal / exponential / fma chain is filled
+//     by the other four.
+// Results: the same terms as lsx_sweep.hip; the sums over mu and over wavelength are associated differently (last-bit
+// differences, inside the stated tolerances; a column's result still does not depend on its position in the batch: the
+// five columns of a wavefront share nothing but the instruction stream).
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "lsx_dev.h"
+#include "lsx_plan.h"
+
+namespace {
+
+constexpr double kCLight = 2.99792458E+08;
+constexpr double kHPlanck = 6.6260755E-34;
+constexpr double kKBoltzmann = 1.380658E-23;
+constexpr double kNM_TO_M = 1.0E-09;
+constexpr double kHC = kHPlanck * kCLight;
+constexpr double kPi = 3.14159265358979323846;
+
+#define LSX_CONST(T, ptr) ((const __attribute__((address_space(4))) T*)(ptr))
+
+__device__ __forceinline__ double planck(double temp, double wav)     // utils.py:17-22
+{
+    const double hc_Tkla = kHC / (kKBoltzmann * kNM_TO_M * wav) / temp;
+    const double x = kNM_TO_M * wav;
+    const double twohnu3_c2 = (2.0 * kHC) / (x * x * x);
+    return twohnu3_c2 / (exp(hc_Tkla) - 1.0);
+}
+__device__ __forceinline__ const double& at(const double* base, unsigned byte_off)
+{
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ double& at(double* base, unsigned byte_off)
+{
+    return *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + byte_off);
+}
+__device__ __forceinline__ double nanmax(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : fmax(a, b); }
+
+constexpr int NR = LSX_RS_RAYS;        // rays per wavelength (compile time: the ray loop is unrolled)
+constexpr int NC = LSX_RS_COLS;        // columns per wavefront
+constexpr int LW = LSX_WAVE / NR;      // wavelengths per tile (the context's tile width for NR rays)
+constexpr int RROW = 64;               // doubles per row of the reduction buffer
+
+} // namespace
+
+// NPT per-ray slots (0 .. 2), NL of them lines (they come first), LK: the tile has linked continua, TOPO: relation of the two
+// slots of a two-line tile (lsx_sweep.hip).
+template <int NPT, int NL, bool LK, int TOPO>
+__global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(LSX_RS_WPE(NPT, LK))))
+lsx_sweep_rs_kernel(const SweepParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    lds_f64* const etab = (lds_f64*)lds_raw;                         // [64][2] exp table
+    constexpr int NS = NPT > 0 ? NPT : 1;
+    constexpr int NV = 2 * NS;                                       // Gamma integrands per lane and depth
+    constexpr bool HASC = NPT > NL;                                  // per-ray continua: they share the tile's E stream
+    constexpr int NLK = (LK && NL > 0) ? NL : 1;
+    constexpr int NCR = NPT == 1 ? 2 : 3;                            // a single slot never reads atom.chi[j_line]
+    const int lane = threadIdx.x & (LSX_WAVE - 1);
+    const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0: down (toFrom False), 1: up (True)
+    lds_f64* const red = etab + LSX_EXP_TAB + (size_t)dir * (NV + 1) * RROW;   // this wave's reduction rows (+ one for dJ)
+
+    // XCD-aware block -> (column group, tile): every XCD gets a contiguous range (speed only)
+    int vb;
+    {
+        const int nb = gridDim.x, x = blockIdx.x & 7, q = blockIdx.x >> 3;
+        const int nb8 = nb >> 3, rem = nb & 7;
+        vb = x * nb8 + (x < rem ? x : rem) + q;
+    }
+    const int grp = vb / p.n_class_tiles;
+    const int tile_id = LSX_CONST(int32_t, p.class_tiles)[vb - grp * p.n_class_tiles];
+    const int col0 = grp * NC;
+    const int ncg = min(NC, p.ncol - col0);                          // columns of this group
+    const auto* tilep = LSX_CONST(DevTile, p.tiles) + tile_id;
+    const int la0 = tilep->la0, nla = tilep->nla, slot0 = tilep->slot0, nF = tilep->nF;
+    const auto* slots = LSX_CONST(DevSlot, p.slots) + slot0;
+    const int Ns = p.Nspace, Nspect = p.Nspect, ntile = p.ntile_total;
+
+    // lane -> (column of the group, wavelength of the tile); lanes without one shadow a real one and store nothing
+    const int c_raw = lane / LW, j_raw = lane - c_raw * LW;
+    const int cc = c_raw < ncg ? c_raw : ncg - 1;
+    const int j = j_raw < nla ? j_raw : nla - 1;
+    const int col = col0 + cc;
+    const int la = la0 + j;
+    const bool live_col = p.colmask ? p.colmask[col] != 0 : true;    // a frozen column keeps everything; J only changes buffers
+    const bool valid = c_raw < ncg && j_raw < nla;
+    const bool act = valid && live_col;
+
+    etab[threadIdx.x] = p.exp2_tab[threadIdx.x];
+    __syncthreads();
+
+    // ---- per-lane bases: every stream of a column is addressed as (wave-uniform base of column col0) + 32-bit byte offset
+    const size_t til_col = (size_t)ntile * Ns * LW;
+    const size_t tb0 = ((size_t)col0 * ntile + tile_id) * Ns * LW;
+    const unsigned o_til = (unsigned)((size_t)cc * til_col * 8u) + (unsigned)j * 8u;           // + k * LW * 8
+    const double* __restrict__ bgchi = (nF > 0 ? p.bgxchi_T : p.bgchi_T) + tb0;
+    const double* __restrict__ bgeta = (nF > 0 ? p.bgxeta_T : p.bgeta_T) + tb0;
+    const double* __restrict__ Jdag = p.Jdag_T + tb0;
+    double* __restrict__ Jnew = p.Jnew_T + tb0;
+    double* __restrict__ psibar = p.Psi2_T + ((size_t)dir * p.ncol * ntile) * Ns * LW + tb0;
+    const double* __restrict__ Eb = p.E_T + tb0;
+    const double* __restrict__ phi0 = p.phi_T + (size_t)col0 * p.phi_col_stride;
+    const unsigned o_phi = (unsigned)((size_t)cc * p.phi_col_stride * 8u);
+    const double* __restrict__ corr = LK ? p.corr_T + (size_t)col0 * p.corr_col_stride + tilep->corr_off : nullptr;
+    const unsigned o_corr = LK ? (unsigned)((size_t)cc * p.corr_col_stride * 8u) + (unsigned)j * 8u : 0u;
+    double* __restrict__ ppsum = LK ? p.Psi3_T + ((size_t)dir * p.ncol + col0) * p.pp_col_stride + tilep->pp_off : nullptr;
+    const unsigned o_pp = LK ? (unsigned)((size_t)cc * p.pp_col_stride * 8u) + (unsigned)j * 8u : 0u;
+    const size_t plane = (size_t)Ns * LW;
+    // per-depth operands of the lane's column (12 lanes share an address): populations, line normalisation / nStar ratio,
+    // height, scattering coefficient
+    const double* __restrict__ ncolb = p.n + (size_t)col0 * p.NLtot * Ns;
+    const unsigned o_n = (unsigned)((size_t)cc * p.NLtot * Ns * 8u);
+    const double* __restrict__ wphib = p.wphi + (size_t)col0 * p.Nlines * Ns;
+    const unsigned o_wphi = (unsigned)((size_t)cc * p.Nlines * Ns * 8u);
+    const double* __restrict__ nsrb = p.nsr + (size_t)col0 * p.Ncont * Ns;
+    const unsigned o_nsr = (unsigned)((size_t)cc * p.Ncont * Ns * 8u);
+    const double* __restrict__ zb = p.height + (size_t)col0 * Ns;
+    const double* __restrict__ scab = p.sca + (size_t)col0 * Ns;
+    const unsigned o_col = (unsigned)((size_t)cc * Ns * 8u);
+
+    const int kS = dir ? Ns - 1 : 0;
+    const int dk = dir ? -1 : 1;
+    const bool compact = p.phi_compact != 0;
+    const double wav = p.wavelength[la];
+    const double u_la = p.u_la[la];
+    // angle quadrature: wave-uniform
+    double zmu[NR], wmuh[NR];
+#pragma unroll
+    for (int m = 0; m < NR; ++m) {
+        zmu[m] = LSX_CONST(double, p.zmu)[m];
+        wmuh[m] = LSX_CONST(double, p.wmuh)[m];                       // w_mu / 2; the 4 pi of rh_method.py:661-665 goes into wlam
+        // kept in vector registers (the kernel has them to spare at two waves per SIMD; its scalar registers are what runs out)
+        asm volatile("" : "+v"(zmu[m]), "+v"(wmuh[m]));
+    }
+
+    // ---- per-slot lane constants
+    unsigned pact = 0;
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) {
+        const int l = la - slots[u].Nblue;
+        if (l >= 0 && l < slots[u].Nlam && p.active[slots[u].trans * Nspect + la] != 0) pact |= 1u << u;
+    }
+    unsigned phi_o[NS], phi_k[NS], phi_m[NS];       // lines: byte offset of (depth 0, ray 0), per depth, per ray
+    unsigned nio[NS], njo[NS], wo[NS];              // byte offsets of n_i, n_j and wphi / nStar ratio at depth 0
+    double wlam[NS], alv[NS], cB[NS], gq[NS], Vc[NS], Uc[NS];
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) {
+        const bool a = (pact >> u) & 1u;
+        const bool line = u < NL;
+        const int l = a ? la - slots[u].Nblue : 0;
+        const int len = slots[u].len;
+        const int lb = a ? la - slots[u].first : 0;
+        // element ((dir Ns + k) Nrays + mu) len + lb of the (tile, line) block (compact: k len + lb); a lane outside the line's
+        // range reads the column's zero pad at every depth and ray
+        const long e0 = line ? (a ? (long)slots[u].base + (compact ? 0L : (long)dir * Ns * NR * len) + lb : (long)p.phi_col_stride - 1) : 0L;
+        phi_o[u] = o_phi + (unsigned)(e0 * 8);
+        phi_k[u] = (line && a) ? (unsigned)((compact ? 1 : NR) * len * 8) : 0u;
+        phi_m[u] = (line && a && !compact) ? (unsigned)(len * 8) : 0u;
+        nio[u] = o_n + (unsigned)(slots[u].li * Ns * 8);
+        njo[u] = o_n + (unsigned)(slots[u].lj * Ns * 8);
+        wo[u] = line ? o_wphi + (unsigned)(slots[u].wphi_off * 8) : o_nsr + (unsigned)(slots[u].base * 8);
+        wlam[u] = (a && act) ? (4.0 * kPi) * p.wl[slots[u].wl_off + l] : 0.0;   // :451/:455, :665 without the angle weight
+        alv[u] = (a && !line) ? p.alpha[slots[u].wl_off + l] : 0.0;
+        cB[u] = slots[u].cB; gq[u] = slots[u].g; Vc[u] = slots[u].Vc; Uc[u] = slots[u].Uc;
+        if constexpr (NPT == 1) asm volatile("" : "+v"(cB[u]), "+v"(gq[u]), "+v"(Vc[u]), "+v"(Uc[u]));
+    }
+
+    // ---- one depth's operands ------------------------------------------------------------------------------------------
+    struct Ops {
+        double bc, be, jd, E, zk, sc;
+        double ni[NS], nj[NS], w3[NS];       // populations; wphi (lines) | nStar_i / nStar_j (continua)
+        double ph[NS][NR];                   // line profile per ray
+        double cr[NLK][3];                   // linked tiles: the continua's share of atom.eta, atom.chi[i], atom.chi[j]
+    };
+    auto load_ops = [&](int kk, Ops& o) {
+        const unsigned kt = o_til + (unsigned)(kk * LW) * 8u;
+        const unsigned kc = (unsigned)kk * 8u;
+        o.jd = at(Jdag, kt);
+        o.bc = at(bgchi, kt);
+        o.be = at(bgeta, kt);
+        o.zk = at(zb, o_col + kc);
+        o.sc = at(scab, o_col + kc);
+        o.E = 0.0;
+        if constexpr (HASC) o.E = at(Eb, kt);
+#pragma unroll
+        for (int u = 0; u < NPT; ++u) {
+            o.ni[u] = at(ncolb, nio[u] + kc);
+            o.nj[u] = at(ncolb, njo[u] + kc);
+            o.w3[u] = u < NL ? at(wphib, wo[u] + kc) : at(nsrb, wo[u] + kc);
+        }
+#pragma unroll
+        for (int u = 0; u < NL; ++u)
+#pragma unroll
+            for (int m = 0; m < NR; ++m) o.ph[u][m] = at(phi0, phi_o[u] + (unsigned)kk * phi_k[u] + (unsigned)m * phi_m[u]);
+        if constexpr (LK) {
+            const unsigned kq = o_corr + (unsigned)(kk * LW) * 8u;
+#pragma unroll
+            for (int u = 0; u < NL; ++u)
+#pragma unroll
+                for (int q = 0; q < NCR; ++q) o.cr[u][q] = at(corr, (unsigned)((3 * u + q) * plane) * 8u + kq);
+        }
+    };
+    // total opacity of ray m from one depth's operands (rh_method.py:613, 279-285)
+    auto chi_of = [&](const Ops& o, int m) {
+        double c = o.bc;
+#pragma unroll
+        for (int u = 0; u < NPT; ++u) {
+            if (u < NL) c = fma(cB[u] * (o.ni[u] - gq[u] * o.nj[u]), o.ph[u][m], c);
+            else {
+                const bool a = (pact >> u) & 1u;
+                const double Vji = a ? (o.w3[u] * o.E) * alv[u] : 0.0;
+                c += o.ni[u] * alv[u] - o.nj[u] * Vji;
+            }
+        }
+        return c;
+    };
+
+    // ---- boundary conditions: formal_solver.py:203-209 ------------------------------------------------------------------
+    double Iu[NR], chi_prev[NR], S_prev[NR], dtau_prev[NR];
+#pragma unroll
+    for (int m = 0; m < NR; ++m) { Iu[m] = 0.0; chi_prev[m] = 1.0; S_prev[m] = 0.0; dtau_prev[m] = 1.0; }
+    Ops cur, nxt;
+    load_ops(kS, cur);
+    load_ops(kS + dk, nxt);
+    if (dir) {
+        const auto* tcol = p.temperature + (size_t)col * Ns;
+        const double B0 = planck(tcol[Ns - 2], wav), B1 = planck(tcol[Ns - 1], wav);
+        const double hz = 0.5 * fabs(cur.zk - nxt.zk);
+#pragma unroll
+        for (int m = 0; m < NR; ++m) {
+            const double dtau_uw = zmu[m] * (chi_of(cur, m) + chi_of(nxt, m)) * hz;
+            Iu[m] = B1 - (B0 - B1) / dtau_uw;
+        }
+    }
+    double zprev = cur.zk;
+    double dJ = 0.0;
+
+    // Gamma integrands of the previous depth wait in this wave's reduction rows [value][lane]; lane (c, q) of the first
+    // NC x NV lanes adds up the 12 wavelengths of column c for value q and stores the total: one store per depth.
+    const int o_c = lane / NV, o_q = lane - o_c * NV;
+    const bool own = lane < NC * NV && o_c < ncg && (p.colmask ? p.colmask[col0 + o_c] != 0 : true);
+    double* __restrict__ gown = p.Gpart + (((size_t)(col0 + (o_c < ncg ? o_c : 0)) * p.nslot_total + slot0) * 4 + (size_t)(o_q * 2 + dir)) * Ns;
+    auto flush = [&](int kprev) {
+        if constexpr (NPT >= 1) {
+            typedef double lds_pair __attribute__((ext_vector_type(2)));
+            const auto* src = (const __attribute__((address_space(3))) lds_pair*)(red + o_q * RROW + (o_c < NC ? o_c : 0) * LW);
+            lds_pair v2 = src[0];
+            double acc = v2.x + v2.y;
+#pragma unroll
+            for (int e = 1; e < LW / 2; ++e) { v2 = src[e]; acc += v2.x + v2.y; }
+            if (own) gown[kprev] = acc;
+        }
+    };
+
+    auto step = [&](const int s, auto phase_c) {
+        constexpr int PHX = decltype(phase_c)::value;        // 0 first visitor, 1 midpoint, 2 second visitor, 3 the end point, 4 the first point
+        constexpr bool FIRST = PHX == 4;
+        constexpr int PH = FIRST ? 0 : PHX;
+        constexpr bool SECOND = PH >= 2, LAST = PH == 3;
+        const int k = kS + dk * s;
+        const unsigned kt = o_til + (unsigned)(k * LW) * 8u;
+        if constexpr (SECOND) {
+            if (2 * s == Ns || 2 * s == Ns + 1) __syncthreads();   // the partner wave's first-half stores
+        }
+        // this depth's operands were requested one step ago; request the next depth's
+        if constexpr (!FIRST) cur = nxt;
+        if constexpr (!LAST && !FIRST) load_ops(k + dk, nxt);
+        double jhalf = 0.0;
+        if constexpr (SECOND) jhalf = at(Jnew, kt);
+        // the Gamma totals of the previous depth (their values were parked at the end of the previous step)
+        if constexpr (!FIRST && NPT >= 1) {
+            __builtin_amdgcn_wave_barrier();
+            flush(k - dk);
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // ---- ray-independent part (rh_method.py:601-632): continuum slots, emissivity without the lines
+        const double hdz = 0.5 * fabs(zprev - cur.zk);
+        zprev = cur.zk;
+        double etaB = cur.be + cur.sc * cur.jd;
+        double chiB = cur.bc;
+        double X[NS], Vjc[NS], Ujc[NS], chic[NS];            // lines: X = cB (n_i - g n_j); continua: Vji, Uji, chi
+#pragma unroll
+        for (int u = 0; u < NPT; ++u) {
+            if (u < NL) {
+                X[u] = cB[u] * (cur.ni[u] - gq[u] * cur.nj[u]);           // :279-280, :613
+                Vjc[u] = Ujc[u] = chic[u] = 0.0;
+            } else {
+                const bool a = (pact >> u) & 1u;
+                X[u] = 0.0;
+                Vjc[u] = a ? (cur.w3[u] * cur.E) * alv[u] : 0.0;          // g_ij alpha, :284-285, :453
+                Ujc[u] = u_la * Vjc[u];                                   // :286
+                chic[u] = cur.ni[u] * alv[u] - cur.nj[u] * Vjc[u];
+                chiB += chic[u];
+                etaB = fma(cur.nj[u], Ujc[u], etaB);
+            }
+        }
+
+        // ---- the five rays of this wavelength, in three straight-line passes so that the five independent chains interleave
+        // (a branch per ray -- the skipped exponential, the skipped series of w2 -- would cut the instruction stream into
+        // blocks the scheduler cannot mix; the regime tests of w2 are taken for the five rays together instead)
+        // pass A: opacity, source function, optical depth of the interval behind each ray (formal_solver.py:107-129)
+        double rchi[NR], Sv[NR], dS[NR], rdt[NR], dt[NR], w0[NR], w1[NR];
+#pragma unroll
+        for (int m = 0; m < NR; ++m) {
+            double chiTot = chiB, etaTot = etaB;
+#pragma unroll
+            for (int u = 0; u < NL; ++u) {
+                chiTot = fma(X[u], cur.ph[u][m], chiTot);                  // n_i Vij - n_j Vji, :613
+                etaTot = fma(cur.nj[u] * Uc[u], cur.ph[u][m], etaTot);     // n_j Uji, :281, :614
+            }
+            if constexpr (FIRST) {
+                rchi[m] = rcp(chiTot);
+                Sv[m] = etaTot * rchi[m];                                  // :632
+                dS[m] = rdt[m] = 0.0;
+                dt[m] = 1.0;
+            } else {
+                // the two divisions of a step (by chi, :632, and by dtau, :113/:121) share one reciprocal, 1 / (chi dtau)
+                const double dtau = (chi_prev[m] + chiTot) * (hdz * zmu[m]);
+                const double rcd = rcp(chiTot * dtau);
+                rchi[m] = rcd * dtau;
+                rdt[m] = rcd * chiTot;
+                Sv[m] = etaTot * rchi[m];
+                dS[m] = (S_prev[m] - Sv[m]) * rdt[m];
+                // formal_solver.py:138-139: the end point re-uses the PREVIOUS interval's w (and S[kEnd - dk]) with the fresh dS, dtau
+                dt[m] = LAST ? dtau_prev[m] : dtau;
+                dtau_prev[m] = dtau;
+            }
+            chi_prev[m] = chiTot;
+        }
+        // pass B: w2 (formal_solver.py:14-44) of the five rays; the exponential and the series each behind ONE wave-uniform test
+        if constexpr (!FIRST) {
+            unsigned long long m_mid = 0, m_small = 0;
+#pragma unroll
+            for (int m = 0; m < NR; ++m) {
+                m_small |= __builtin_amdgcn_fcmp(dt[m], 5e-4, 4 /* ordered < */);
+                m_mid |= __builtin_amdgcn_ballot_w64(!(dt[m] < 5e-4 || dt[m] > 50.0));
+            }
+            if (m_mid != 0) {
+                // (saturated lanes need no select: for dtau > 50 the formulae give exactly (1, 1); lsx_dev.h, w2)
+                // exp(-dtau) of the five rays, staged by hand (lsx_dev.h, exp_tab64): all five table reads are in flight
+                // before the first polynomial starts
+                double dc[NR], r[NR], th[NR], tl[NR];
+                int ki[NR];
+#pragma unroll
+                for (int m = 0; m < NR; ++m) {
+                    dc[m] = min_noquiet(dt[m], 700.0);
+                    const double kf = __builtin_rint(-dc[m] * 0x1.71547652b82fep+6);       // 64 / ln2
+                    r[m] = fma(kf, -0x1.62e42fef80000p-7, -dc[m]);
+                    r[m] = fma(kf, -0x1.1cf79abc9e3b4p-42, r[m]);
+                    ki[m] = (int)kf;
+                }
+#pragma unroll
+                for (int m = 0; m < NR; ++m) {
+                    const lds_f64* e = etab + 2 * (ki[m] & 63);
+                    th[m] = e[0];
+                    tl[m] = e[1];
+                }
+#pragma unroll
+                for (int m = 0; m < NR; ++m) {
+                    double t = fma3s(r[m], 1.0 / 720.0, 1.0 / 120.0);
+                    t = fma3(r[m], t, 1.0 / 24.0);
+                    t = fma3(r[m], t, 1.0 / 6.0);
+                    t = fma(r[m], t, 0.5);
+                    r[m] = fma(r[m] * r[m], t, r[m]);                                       // exp(r) - 1
+                }
+#pragma unroll
+                for (int m = 0; m < NR; ++m) {
+                    const double e = ldexp(fma(th[m], r[m], tl[m]) + th[m], ki[m] >> 6);
+                    w0[m] = 1.0 - e;
+                    w1[m] = w0[m] - dc[m] * e;
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < NR; ++m) w0[m] = w1[m] = 1.0;
+            }
+            if (m_small != 0) {
+#pragma unroll
+                for (int m = 0; m < NR; ++m) {
+                    const bool small = dt[m] < 5e-4;
+                    const double t0 = dt[m] * (1.0 - 0.5 * dt[m]);
+                    const double t1 = (dt[m] * dt[m]) * (0.5 - dt[m] * (1.0 / 3.0));
+                    w0[m] = small ? t0 : w0[m];
+                    w1[m] = small ? t1 : w1[m];
+                    asm volatile("" : "+v"(w0[m]), "+v"(w1[m]));          // keeps the block a branch
+                }
+            }
+        }
+        // pass C: intensity, Psi*, the angle sums and the Gamma integrands (rh_method.py:638-681)
+        double Jacc = 0.0, Pacc = 0.0, PP[NLK], G1[NS], G2[NS];
+#pragma unroll
+        for (int u = 0; u < NLK; ++u) PP[u] = 0.0;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) G1[u] = G2[u] = 0.0;
+#pragma unroll
+        for (int m = 0; m < NR; ++m) {
+            double I, Lam;
+            if constexpr (FIRST) {
+                I = Iu[m];
+                Lam = 0.0;
+            } else {
+                const double Sx = LAST ? S_prev[m] : Sv[m];
+                I = Iu[m] * (1.0 - w0[m]) + w0[m] * Sx + w1[m] * dS[m];
+                Lam = w0[m] - w1[m] * rdt[m];
+            }
+            const double Psi = Lam * rchi[m];
+            Iu[m] = I;
+            S_prev[m] = Sv[m];
+            if constexpr (LAST) {
+                if (dir == 1 && act) p.Iout[((size_t)col * Nspect + la) * NR + m] = I;      // emergent intensity, :638
+            }
+            Jacc = fma(wmuh[m], I, Jacc);                                  // :640
+            const double wP = wmuh[m] * Psi;                               // (x 4 pi where the sums leave)
+            Pacc += wP;
+            if constexpr (LK) {
+#pragma unroll
+                for (int u = 0; u < NL; ++u) PP[u] = fma(wP, cur.ph[u][m], PP[u]);
+            }
+            // the level bookkeeping of :616-627 from the tile's (at most two) slots
+            double chi[NS], Uji[NS], eta[NS];
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                if (u < NL) {
+                    chi[u] = X[u] * cur.ph[u][m];
+                    Uji[u] = Uc[u] * cur.ph[u][m];                         // :281
+                    eta[u] = cur.nj[u] * Uji[u];                           // :614
+                } else { chi[u] = chic[u]; Uji[u] = Ujc[u]; eta[u] = cur.nj[u] * Ujc[u]; }
+            }
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                const bool line = u < NL;
+                const double pv = line ? cur.ph[u][m] : 0.0;
+                const double Vij = line ? cB[u] * pv : alv[u];
+                const double Vji = line ? Vc[u] * pv : Vjc[u];
+                double etaA = eta[u], chi_i = chi[u], chi_j = -chi[u], U_j = Uji[u], U_i = 0.0;
+                if constexpr (NPT == 2) {
+                    const int v = 1 - u;
+                    if constexpr (TOPO == 1) { etaA += eta[v]; chi_i += chi[v]; }       // same atom, common lower level
+                    else if constexpr (TOPO == 0) {
+                        const auto* rel = slots[u].rel[0];
+                        etaA = fma(rel[REL_EA], eta[v], etaA);
+                        chi_i = fma(rel[REL_CI], chi[v], chi_i);
+                        chi_j = fma(rel[REL_CJ], chi[v], chi_j);
+                        U_j = fma(rel[REL_UJ], Uji[v], U_j);
+                        U_i = rel[REL_UI] * Uji[v];
+                    }
+                }
+                if constexpr (LK) {
+                    if (line) {
+                        etaA += cur.cr[u < NLK ? u : 0][0];
+                        chi_i += cur.cr[u < NLK ? u : 0][1];
+                        if constexpr (NCR > 2) chi_j += cur.cr[u < NLK ? u : 0][2];
+                    }
+                }
+                const double Ieff = I - Psi * etaA;                            // :652
+                double g1 = (Uji[u] + Vji * Ieff) - (chi_i * Psi) * U_j;        // :677
+                double g2 = Vij * Ieff;                                        // :680
+                if constexpr (NPT == 2 && TOPO == 0) g2 -= (chi_j * Psi) * U_i;
+                G1[u] = fma(wmuh[m], g1, G1[u]);                               // w_mu / 2 (:661); 4 pi and the wavelength weight below
+                G2[u] = fma(wmuh[m], g2, G2[u]);
+            }
+        }
+        Pacc *= 4.0 * kPi;
+        if constexpr (LK) {
+#pragma unroll
+            for (int u = 0; u < NL; ++u) PP[u] *= 4.0 * kPi;
+        }
+
+        // ---- the wavelength's sums leave: Psibar, Psi* phi, the Gamma integrands (parked for the lane reduction), J
+        if (nF > 0 && act) at(psibar, kt) = Pacc;
+        if constexpr (LK) {
+            if (act) {
+#pragma unroll
+                for (int u = 0; u < NL; ++u) at(ppsum, (unsigned)(u * plane) * 8u + o_pp + (unsigned)(k * LW) * 8u) = PP[u];
+            }
+        }
+        if constexpr (NPT >= 1) {
+            // lanes (c, j) -> element c * 12 + j of the value's row (= the lane number); idle lanes park zeros
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                const double wt = u < NL ? wlam[u] * cur.w3[u] : wlam[u];      // lines: x wphi (rh_method.py:451); continua :455
+                red[(2 * u) * RROW + lane] = wt * G1[u];
+                red[(2 * u + 1) * RROW + lane] = wt * G2[u];
+            }
+        }
+        if constexpr (PH == 0) {
+            if (valid) at(Jnew, kt) = live_col ? Jacc : cur.jd;           // first visitor stores its half (frozen: J moves over)
+        } else if constexpr (PH == 1) {                                   // odd Nspace: both waves are at the same depth
+            lds_f64* const xwg = etab + LSX_EXP_TAB + 2 * (NV + 1) * RROW;
+            xwg[dir * LSX_WAVE + lane] = Jacc;
+            __syncthreads();
+            if (dir == 0 && valid) {
+                const double Jv = Jacc + xwg[LSX_WAVE + lane];
+                at(Jnew, kt) = live_col ? Jv : cur.jd;
+                if (live_col) dJ = nanmax(dJ, fabs(1.0 - cur.jd * rcp(Jv)));    // :705
+            }
+        } else {
+            const double Jv = jhalf + Jacc;
+            if (valid) at(Jnew, kt) = live_col ? Jv : cur.jd;
+            if (act) dJ = nanmax(dJ, fabs(1.0 - cur.jd * rcp(Jv)));             // :705
+        }
+    };
+    {
+        const int nA = Ns / 2;
+        step(0, std::integral_constant<int, 4>{});
+        for (int s = 1; s < nA; ++s) step(s, std::integral_constant<int, 0>{});
+        if (Ns & 1) step(nA, std::integral_constant<int, 1>{});
+        for (int s = nA + (Ns & 1); s < Ns - 1; ++s) step(s, std::integral_constant<int, 2>{});
+        step(Ns - 1, std::integral_constant<int, 3>{});
+        if constexpr (NPT >= 1) {
+            __builtin_amdgcn_wave_barrier();
+            flush(kS + dk * (Ns - 1));
+        }
+    }
+    // dJ of every (column, tile, direction): the maximum over the column's wavelengths (NaN propagates, rh_method.py:706)
+    __builtin_amdgcn_wave_barrier();
+    red[NV * RROW + lane] = act ? dJ : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < ncg && (p.colmask ? p.colmask[col0 + lane] != 0 : true)) {
+        double m = 0.0;
+        for (int e = 0; e < nla; ++e) m = nanmax(m, red[NV * RROW + lane * LW + e]);
+        p.dJpart[((size_t)(col0 + lane) * ntile + tile_id) * 2 + dir] = m;
+    }
+}
+
+template <int NPT, int NL, bool LK, int TOPO>
+static hipError_t launch_rs(const SweepParams& p, int ngroups, hipStream_t st)
+{
+    const dim3 g((unsigned)(ngroups * p.n_class_tiles)), b(2 * LSX_WAVE);
+    hipLaunchKernelGGL((lsx_sweep_rs_kernel<NPT, NL, LK, TOPO>), g, b, lsx_rs_lds_doubles(NPT) * sizeof(double), st, p);
+    return hipGetLastError();
+}
+
+// the ray-serial instance of a class (code = lsx_class_code of the class), NC columns per wavefront
+extern "C" hipError_t lsx_launch_sweep_rs(const SweepParams* p, int code, hipStream_t st)
+{
+    if (p->Nrays != LSX_RS_RAYS || p->sca_per_lambda || p->L != LW) return hipErrorNotSupported;
+    const int ngroups = (p->ncol + NC - 1) / NC;
+    switch (code) {
+#define LSX_X(NPT, NL, LK, TOPO) case lsx_class_code(NPT, NL, LK, TOPO): return launch_rs<NPT, NL, LK, TOPO>(*p, ngroups, st);
+        LSX_RS_INSTANCES(LSX_X)
+#undef LSX_X
+    default: return hipErrorNotSupported;
+    }
+}

@@ -3,7 +3,7 @@
 summed over dispatches and divided by the number of dispatches"""
 import csv, collections, glob, os, re, sys
 def short(n):
-    m = re.search(r'(lsx_sweep_kernel(?:_all)?<[^>]*>)', n)
+    m = re.search(r'(lsx_sweep_(?:rs_)?kernel(?:_all)?<[^>]*>)', n)
     if m: return m.group(1).replace(' ', '')
     m = re.search(r'(k_\w+(<[^>]*>)?)', n); return m.group(1) if m else n[:30]
 for d in sys.argv[1:]:

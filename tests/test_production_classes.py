@@ -28,13 +28,15 @@ def class_table(lib, eng):
     f = lib.dll.lsx_hip_class_info
     f.restype = C.c_int32
     f.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
-    out = (C.c_int64 * 6)()
+    out = (C.c_int64 * 8)()
     n = f(eng._h, -1, out)
     fused = int(out[0])
     table = {}
+    class_table.ray_serial = {}
     for i in range(n):
         f(eng._h, i, out)
         table[(int(out[0]), int(out[1]), int(out[4]), int(out[5]))] = (int(out[2]), int(out[3]))
+        class_table.ray_serial[(int(out[0]), int(out[1]), int(out[4]), int(out[5]))] = bool(out[6])
     return table, fused
 
 
@@ -80,18 +82,28 @@ def _run_pair(hip_lib, oracle_lib, name, ncol, seed, tol, expect_classes):
     return table
 
 
-def test_c3_caii_columns_per_class_path(hip_lib, oracle_lib):
-    """C3: CaII, 64 columns, ray-dependent device-built profiles; tile classes 0, 1 (one line), 2 (H & K overlap)"""
+# Both sweep kernels are production paths: one ray per lane (lsx_sweep.hip; what contexts with few columns run) and the
+# ray-serial kernel (lsx_sweep_rs.hip: five columns per wavefront; contexts with LSX_RS_MIN_COLUMNS = 160 columns or more).
+# The threshold is lowered / raised through the environment so that both meet the oracle on the same columns.
+@pytest.mark.parametrize('ray_serial', [False, True], ids=['ray-per-lane', 'ray-serial'])
+def test_c3_caii_columns_per_class_path(hip_lib, oracle_lib, monkeypatch, ray_serial):
+    """C3: CaII, 64 columns (12 full column groups + one of 4), ray-dependent device-built profiles; tile classes 0, 1 (one
+    line), 2 (H & K overlap)"""
+    monkeypatch.setenv('LSX_RS_MIN_COLUMNS', '1' if ray_serial else '1000000')
     table = _run_pair(hip_lib, oracle_lib, 'falc_ca.npz', 64, 1234, 1e-12, [(0, 0, 0, 0), (1, 1, 0, 0), (2, 2, 0, 1)])      # H & K share their lower level: relation 1
     assert sum(t for t, _ in table.values()) == 25          # DESIGN 4.1: 25 tiles for FALC CaII
+    assert all(v == ray_serial for v in class_table.ray_serial.values()), class_table.ray_serial
 
 
-def test_c4_cah_columns_linked_continua(hip_lib, oracle_lib):
-    """C4: Ca+H, 40 columns.  Every hydrogen line tile carries linked continua: classes (1 line) and (2 lines), each with and
+@pytest.mark.parametrize('ray_serial', [False, True], ids=['ray-per-lane', 'ray-serial'])
+def test_c4_cah_columns_linked_continua(hip_lib, oracle_lib, monkeypatch, ray_serial):
+    """C4: Ca+H, 41 columns.  Every hydrogen line tile carries linked continua: classes (1 line) and (2 lines), each with and
     without linked continua, plus the continuum-only tiles"""
-    table = _run_pair(hip_lib, oracle_lib, 'falc_cah.npz', 40, 4321, 3e-11, [(0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 0), (2, 2, 0, 1), (2, 2, 1, 1)])
+    monkeypatch.setenv('LSX_RS_MIN_COLUMNS', '1' if ray_serial else '1000000')
+    table = _run_pair(hip_lib, oracle_lib, 'falc_cah.npz', 41, 4321, 3e-11, [(0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 0), (2, 2, 0, 1), (2, 2, 1, 1)])
     assert -1 not in [k[0] for k in table]                  # no tile falls back to the generic instance
     assert max(k[0] for k in table) == 2                    # no continuum goes through the sweep
+    assert all(v == ray_serial for v in class_table.ray_serial.values()), class_table.ray_serial
 
 
 def test_c4_cah_columns_three_and_four_slot_instances(hip_lib, oracle_lib, monkeypatch):
@@ -131,23 +143,32 @@ def test_profiles_must_be_set_before_a_formal_solution(hip_lib):
     e.close()
 
 
+@pytest.mark.parametrize('ray_serial', [True, False], ids=['ray-serial', 'ray-per-lane'])
 @pytest.mark.parametrize('name,ncol,nuniq', [('falc_ca.npz', 1000, 8), ('falc_cah.npz', 1250, 10)])
-def test_full_size_batches_by_size_independent_properties(hip_lib, oracle_lib, name, ncol, nuniq):
+def test_full_size_batches_by_size_independent_properties(hip_lib, oracle_lib, monkeypatch, name, ncol, nuniq, ray_serial):
     """BASELINE sizes (C3: 1000 CaII columns, C4: one GPU's 1250 Ca+H columns), where the oracle would take minutes:
     columns are independent 1-D problems, so a batch built from `nuniq` distinct columns repeated in a scrambled order must
-    give every copy the bits its original gets in a batch of `nuniq` alone -- whatever its position, its neighbours, the
-    launch path (per-class launches here, the fused kernel there) or the size of the grid; the small batch itself is
-    checked against the oracle.  Also: a frozen column keeps its state bit for bit while its neighbours iterate
-    (lsx_set_active_columns), and the device-side monitors equal the maxima of the per-column ones."""
+    give every copy the bits its original gets in a small batch -- whatever its position, its neighbours, its place inside
+    a five-column wavefront or the size of the grid; the small batch itself is checked against the oracle.
+    ray-serial (the default at these sizes): the small batch is 37 columns (seven column groups and one of two) forced
+    onto the same kernel; ray-per-lane (LSX_NO_RS): the small batch takes the fused launch, the big one the per-class
+    launches.  Also: a frozen column keeps its state bit for bit while its neighbours iterate (lsx_set_active_columns)."""
     prob, base, raw = fixtures.load_problem_npz(golden(name), phi_compact=False)
     blk, prof = synth.perturbed_columns(prob, base, raw, ncol=nuniq, seed=77, vlos_sigma=2.0e3)
     rng = np.random.default_rng(5)
     src = np.concatenate([np.arange(nuniq), rng.integers(0, nuniq, ncol - nuniq)])
-    big_blk = type(blk).concatenate([blk.slice(int(s), int(s) + 1) for s in src])
-    big_prof = tuple(p[src] for p in prof)
-    small, big = Engine(prob, nuniq, lib=hip_lib), Engine(prob, ncol, lib=hip_lib)
-    synth.load_columns(small, blk, prof)
-    synth.load_columns(big, big_blk, big_prof)
+    nsmall = 37 if ray_serial else nuniq
+    ssrc = src[:nsmall]
+    pick = lambda idx: (type(blk).concatenate([blk.slice(int(q), int(q) + 1) for q in idx]), tuple(p[idx] for p in prof))
+    if ray_serial:
+        monkeypatch.setenv('LSX_RS_MIN_COLUMNS', '1')
+    else:
+        monkeypatch.setenv('LSX_NO_RS', '1')
+    small = Engine(prob, nsmall, lib=hip_lib)
+    monkeypatch.delenv('LSX_RS_MIN_COLUMNS', raising=False)
+    big = Engine(prob, ncol, lib=hip_lib)
+    synth.load_columns(small, *pick(ssrc))
+    synth.load_columns(big, *pick(src))
     ora = Engine(prob, nuniq, lib=oracle_lib)
     synth.load_columns(ora, blk, prof)
     oracle_lib.dll.lsx_oracle_set_threads(ora._h, 8)
@@ -158,14 +179,21 @@ def test_full_size_batches_by_size_independent_properties(hip_lib, oracle_lib, n
         if it > 3:
             assert small.stat_equil() == big.stat_equil()
             ora.stat_equil()
+    first = np.array([int(np.nonzero(ssrc == q)[0][0]) for q in range(nuniq)])      # where each original sits in the small batch
     for what in (_capi.LSX_J, _capi.LSX_I, _capi.LSX_N, _capi.LSX_GAMMA, _capi.LSX_DJ_COL, _capi.LSX_DPOPS_COL):
         a, b = small.get(what), big.get(what)
-        assert np.array_equal(b, a[src]), what                     # bit for bit, every copy
+        assert np.array_equal(a, a[first][ssrc]), what             # every copy inside the small batch
+        assert np.array_equal(b, a[first][src]), what              # bit for bit, every copy of the big one
     tol = 1e-8
-    assert relerr(small.get(_capi.LSX_N), ora.get(_capi.LSX_N)) < tol and relerr(small.get(_capi.LSX_I), ora.get(_capi.LSX_I)) < tol
+    assert relerr(small.get(_capi.LSX_N)[first], ora.get(_capi.LSX_N)) < tol and relerr(small.get(_capi.LSX_I)[first], ora.get(_capi.LSX_I)) < tol
     table, fused = class_table(hip_lib, big)
     assert fused == 0 and all(launches == 6 for _, launches in table.values())
-    assert class_table(hip_lib, small)[1] == 6                     # the small batch took the fused kernel
+    assert all(v == ray_serial for v in class_table.ray_serial.values())
+    if ray_serial:
+        table, fused = class_table(hip_lib, small)
+        assert fused == 0 and all(class_table.ray_serial.values())  # the small batch ran the same kernels
+    else:
+        assert class_table(hip_lib, small)[1] == 6                 # the small batch took the fused kernel
     # frozen columns: every second column is frozen for two more iterations
     mask = (np.arange(ncol) % 2 == 0)
     n0, J0 = big.get(_capi.LSX_N), big.get(_capi.LSX_J)
