@@ -1382,6 +1382,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         opt.occ_wg = (e = getenv("LSX_OCC_WG")) ? atoi(e) : 0;
         opt.no_rs = getenv("LSX_NO_RS") != nullptr;
         if ((e = getenv("LSX_RS_MIN_COLUMNS"))) opt.rs_min_columns = atoi(e);
+        if ((e = getenv("LSX_RS_MAX_NPT"))) opt.rs_max_npt = atoi(e);
     }
     LsxPlan plan;
     {

@@ -155,6 +155,7 @@ struct PlanOptions {           // diagnostic switches (lsx_create reads them fro
     int occ_wg = 0;            // LSX_OCC_WG: at most this many workgroups per CU (through the LDS request)
     bool no_rs = false;        // LSX_NO_RS: every class through lsx_sweep.hip (one ray per lane)
     int rs_min_columns = LSX_RS_MIN_COLUMNS;   // LSX_RS_MIN_COLUMNS: contexts with fewer columns keep one ray per lane (too few wavefronts otherwise)
+    int rs_max_npt = 1;        // LSX_RS_MAX_NPT: classes with more per-ray slots keep one ray per lane (measured: the two-slot ray-serial instances need 240+ registers and lose to lsx_sweep.hip at C3 sizes)
 };
 
 // launch shapes of the kernels around the sweep, fixed when the plan is made so that no enqueue path can fail on them

@@ -72,6 +72,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
     constexpr bool HASC = NPT > NL;                                  // per-ray continua: they share the tile's E stream
     constexpr int NLK = (LK && NL > 0) ? NL : 1;
     constexpr int NCR = NPT == 1 ? 2 : 3;                            // a single slot never reads atom.chi[j_line]
+    constexpr bool FACT = NPT >= 1 && NL == NPT && (NPT == 1 || TOPO != 0);    // factored Gamma integrands (step, pass C)
     const int lane = threadIdx.x & (LSX_WAVE - 1);
     const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0: down (toFrom False), 1: up (True)
     lds_f64* const red = etab + LSX_EXP_TAB + (size_t)dir * (NV + 1) * RROW;   // this wave's reduction rows (+ one for dJ)
@@ -188,7 +189,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
         double ph[NS][NR];                   // line profile per ray
         double cr[NLK][3];                   // linked tiles: the continua's share of atom.eta, atom.chi[i], atom.chi[j]
     };
-    auto load_ops = [&](int kk, Ops& o) {
+    auto load_ops = [&](int kk, Ops& o) __attribute__((always_inline)) {
         const unsigned kt = o_til + (unsigned)(kk * LW) * 8u;
         const unsigned kc = (unsigned)kk * 8u;
         o.jd = at(Jdag, kt);
@@ -217,7 +218,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
         }
     };
     // total opacity of ray m from one depth's operands (rh_method.py:613, 279-285)
-    auto chi_of = [&](const Ops& o, int m) {
+    auto chi_of = [&](const Ops& o, int m) __attribute__((always_inline)) {
         double c = o.bc;
 #pragma unroll
         for (int u = 0; u < NPT; ++u) {
@@ -235,10 +236,11 @@ lsx_sweep_rs_kernel(const SweepParams p)
     double Iu[NR], chi_prev[NR], S_prev[NR], dtau_prev[NR];
 #pragma unroll
     for (int m = 0; m < NR; ++m) { Iu[m] = 0.0; chi_prev[m] = 1.0; S_prev[m] = 0.0; dtau_prev[m] = 1.0; }
-    Ops cur, nxt;
-    load_ops(kS, cur);
-    load_ops(kS + dk, nxt);
+    Ops opA, opB;
+    load_ops(kS, opA);
+    load_ops(kS + dk, opB);
     if (dir) {
+        const Ops &cur = opA, &nxt = opB;
         const auto* tcol = p.temperature + (size_t)col * Ns;
         const double B0 = planck(tcol[Ns - 2], wav), B1 = planck(tcol[Ns - 1], wav);
         const double hz = 0.5 * fabs(cur.zk - nxt.zk);
@@ -248,7 +250,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
             Iu[m] = B1 - (B0 - B1) / dtau_uw;
         }
     }
-    double zprev = cur.zk;
+    double zprev = opA.zk;
     double dJ = 0.0;
 
     // Gamma integrands of the previous depth wait in this wave's reduction rows [value][lane]; lane (c, q) of the first
@@ -256,7 +258,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
     const int o_c = lane / NV, o_q = lane - o_c * NV;
     const bool own = lane < NC * NV && o_c < ncg && (p.colmask ? p.colmask[col0 + o_c] != 0 : true);
     double* __restrict__ gown = p.Gpart + (((size_t)(col0 + (o_c < ncg ? o_c : 0)) * p.nslot_total + slot0) * 4 + (size_t)(o_q * 2 + dir)) * Ns;
-    auto flush = [&](int kprev) {
+    auto flush = [&](int kprev) __attribute__((always_inline)) {
         if constexpr (NPT >= 1) {
             typedef double lds_pair __attribute__((ext_vector_type(2)));
             const auto* src = (const __attribute__((address_space(3))) lds_pair*)(red + o_q * RROW + (o_c < NC ? o_c : 0) * LW);
@@ -268,7 +270,9 @@ lsx_sweep_rs_kernel(const SweepParams p)
         }
     };
 
-    auto step = [&](const int s, auto phase_c) {
+    // `cur` holds the operands of this step's depth (requested one step ago), the next depth's are requested into `nxt`: the
+    // two buffers swap roles from step to step (even steps: cur = opA), so nothing is copied
+    auto step = [&](const int s, auto phase_c, Ops& cur, Ops& nxt) __attribute__((always_inline)) {
         constexpr int PHX = decltype(phase_c)::value;        // 0 first visitor, 1 midpoint, 2 second visitor, 3 the end point, 4 the first point
         constexpr bool FIRST = PHX == 4;
         constexpr int PH = FIRST ? 0 : PHX;
@@ -278,9 +282,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
         if constexpr (SECOND) {
             if (2 * s == Ns || 2 * s == Ns + 1) __syncthreads();   // the partner wave's first-half stores
         }
-        // this depth's operands were requested one step ago; request the next depth's
-        if constexpr (!FIRST) cur = nxt;
-        if constexpr (!LAST && !FIRST) load_ops(k + dk, nxt);
+        if constexpr (!LAST && !FIRST) load_ops(k + dk, nxt);          // (the first point's neighbour was loaded for the boundary condition)
         double jhalf = 0.0;
         if constexpr (SECOND) jhalf = at(Jnew, kt);
         // the Gamma totals of the previous depth (their values were parked at the end of the previous step)
@@ -295,15 +297,16 @@ lsx_sweep_rs_kernel(const SweepParams p)
         zprev = cur.zk;
         double etaB = cur.be + cur.sc * cur.jd;
         double chiB = cur.bc;
-        double X[NS], Vjc[NS], Ujc[NS], chic[NS];            // lines: X = cB (n_i - g n_j); continua: Vji, Uji, chi
+        double X[NS], Vjc[NS], Ujc[NS], chic[NS], njUc[NS];  // lines: X = cB (n_i - g n_j), n_j Uc; continua: Vji, Uji, chi
 #pragma unroll
         for (int u = 0; u < NPT; ++u) {
             if (u < NL) {
                 X[u] = cB[u] * (cur.ni[u] - gq[u] * cur.nj[u]);           // :279-280, :613
+                njUc[u] = cur.nj[u] * Uc[u];                              // eta = n_j Uji = (n_j Uc) phi, :281, :614
                 Vjc[u] = Ujc[u] = chic[u] = 0.0;
             } else {
                 const bool a = (pact >> u) & 1u;
-                X[u] = 0.0;
+                X[u] = njUc[u] = 0.0;
                 Vjc[u] = a ? (cur.w3[u] * cur.E) * alv[u] : 0.0;          // g_ij alpha, :284-285, :453
                 Ujc[u] = u_la * Vjc[u];                                   // :286
                 chic[u] = cur.ni[u] * alv[u] - cur.nj[u] * Vjc[u];
@@ -323,7 +326,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
 #pragma unroll
             for (int u = 0; u < NL; ++u) {
                 chiTot = fma(X[u], cur.ph[u][m], chiTot);                  // n_i Vij - n_j Vji, :613
-                etaTot = fma(cur.nj[u] * Uc[u], cur.ph[u][m], etaTot);     // n_j Uji, :281, :614
+                etaTot = fma(njUc[u], cur.ph[u][m], etaTot);               // n_j Uji, :281, :614
             }
             if constexpr (FIRST) {
                 rchi[m] = rcp(chiTot);
@@ -432,6 +435,38 @@ lsx_sweep_rs_kernel(const SweepParams p)
 #pragma unroll
                 for (int u = 0; u < NL; ++u) PP[u] = fma(wP, cur.ph[u][m], PP[u]);
             }
+            if constexpr (FACT) {
+                // Line-only tiles whose lines share at most their lower level (one line; two lines with TOPO 1 / 2): every term
+                // of rh_method.py:652, 677-681 carries the line's profile, atom.U[i] = 0 and atom.U[j] = Uji, so
+                //   Gamma_ij integrand = phi [Uc (1 - Psi* chi_i) + Vc Ieff],   Gamma_ji integrand = cB phi Ieff
+                // and only a = phi Ieff, b = phi (1 - Psi* chi_i) are summed over the rays (Uc, Vc, cB applied to the sums)
+                double qv[NS];
+#pragma unroll
+                for (int u = 0; u < NPT; ++u) qv[u] = Psi * cur.ph[u][m];
+                double Ie[NS], tv[NS];
+                if constexpr (NPT == 2 && TOPO == 1) {              // same atom, common lower level: atom.eta, atom.chi[i] are the sums
+                    const double Ic = fma(-njUc[1], qv[1], fma(-njUc[0], qv[0], I));
+                    const double tc = fma(-X[1], qv[1], fma(-X[0], qv[0], 1.0));
+                    Ie[0] = Ie[1] = Ic;
+                    tv[0] = tv[1] = tc;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < NPT; ++u) {
+                        Ie[u] = fma(-njUc[u], qv[u], I);            // Ieff = I - Psi* eta, :652
+                        tv[u] = fma(-X[u], qv[u], 1.0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NPT; ++u) {
+                    if constexpr (LK) {                             // + the linked continua's share of atom.eta, atom.chi[i]
+                        Ie[u] = fma(-cur.cr[u < NLK ? u : 0][0], Psi, Ie[u]);
+                        tv[u] = fma(-cur.cr[u < NLK ? u : 0][1], Psi, tv[u]);
+                    }
+                    const double wph = wmuh[m] * cur.ph[u][m];
+                    G2[u] = fma(wph, Ie[u], G2[u]);                 // sum w phi Ieff
+                    G1[u] = fma(wph, tv[u], G1[u]);                 // sum w phi (1 - Psi* chi_i)
+                }
+            } else {
             // the level bookkeeping of :616-627 from the tile's (at most two) slots
             double chi[NS], Uji[NS], eta[NS];
 #pragma unroll
@@ -475,6 +510,15 @@ lsx_sweep_rs_kernel(const SweepParams p)
                 G1[u] = fma(wmuh[m], g1, G1[u]);                               // w_mu / 2 (:661); 4 pi and the wavelength weight below
                 G2[u] = fma(wmuh[m], g2, G2[u]);
             }
+            }
+        }
+        if constexpr (FACT) {
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                const double A = G2[u], B = G1[u];
+                G1[u] = fma(Uc[u], B, Vc[u] * A);                   // :677
+                G2[u] = cB[u] * A;                                  // :680
+            }
         }
         Pacc *= 4.0 * kPi;
         if constexpr (LK) {
@@ -517,12 +561,30 @@ lsx_sweep_rs_kernel(const SweepParams p)
         }
     };
     {
+        // tiles with at most one per-ray slot: the operand buffers swap roles, two steps per loop trip; two slots: one step per trip
+        // and one copy of the operands per step (the two-step body of a two-slot tile needs more registers than there are)
+        constexpr bool SWAP = NPT <= 1;
+        auto one = [&](int s, auto ph) __attribute__((always_inline)) {
+            if constexpr (SWAP) { if (s & 1) step(s, ph, opB, opA); else step(s, ph, opA, opB); }
+            else { step(s, ph, opA, opB); opA = opB; }
+        };
+        auto run = [&](int s0, int s1, auto ph) __attribute__((always_inline)) {           // steps [s0, s1) of one phase
+            int s = s0;
+            if constexpr (SWAP) {
+                if (s < s1 && (s & 1)) { step(s, ph, opB, opA); ++s; }
+                for (; s + 1 < s1; s += 2) { step(s, ph, opA, opB); step(s + 1, ph, opB, opA); }
+                if (s < s1) step(s, ph, opA, opB);
+            } else {
+                for (; s < s1; ++s) { step(s, ph, opA, opB); opA = opB; }
+            }
+        };
         const int nA = Ns / 2;
-        step(0, std::integral_constant<int, 4>{});
-        for (int s = 1; s < nA; ++s) step(s, std::integral_constant<int, 0>{});
-        if (Ns & 1) step(nA, std::integral_constant<int, 1>{});
-        for (int s = nA + (Ns & 1); s < Ns - 1; ++s) step(s, std::integral_constant<int, 2>{});
-        step(Ns - 1, std::integral_constant<int, 3>{});
+        step(0, std::integral_constant<int, 4>{}, opA, opB);          // the ray's first point (depth 1 is already requested: its load is skipped there)
+        if constexpr (!SWAP) opA = opB;
+        run(1, nA, std::integral_constant<int, 0>{});
+        if (Ns & 1) one(nA, std::integral_constant<int, 1>{});
+        run(nA + (Ns & 1), Ns - 1, std::integral_constant<int, 2>{});
+        one(Ns - 1, std::integral_constant<int, 3>{});
         if constexpr (NPT >= 1) {
             __builtin_amdgcn_wave_barrier();
             flush(kS + dk * (Ns - 1));

@@ -90,6 +90,7 @@ def test_c3_caii_columns_per_class_path(hip_lib, oracle_lib, monkeypatch, ray_se
     """C3: CaII, 64 columns (12 full column groups + one of 4), ray-dependent device-built profiles; tile classes 0, 1 (one
     line), 2 (H & K overlap)"""
     monkeypatch.setenv('LSX_RS_MIN_COLUMNS', '1' if ray_serial else '1000000')
+    monkeypatch.setenv('LSX_RS_MAX_NPT', '2')          # every ray-serial instance, also the two-slot ones the default leaves to lsx_sweep.hip
     table = _run_pair(hip_lib, oracle_lib, 'falc_ca.npz', 64, 1234, 1e-12, [(0, 0, 0, 0), (1, 1, 0, 0), (2, 2, 0, 1)])      # H & K share their lower level: relation 1
     assert sum(t for t, _ in table.values()) == 25          # DESIGN 4.1: 25 tiles for FALC CaII
     assert all(v == ray_serial for v in class_table.ray_serial.values()), class_table.ray_serial
@@ -100,6 +101,7 @@ def test_c4_cah_columns_linked_continua(hip_lib, oracle_lib, monkeypatch, ray_se
     """C4: Ca+H, 41 columns.  Every hydrogen line tile carries linked continua: classes (1 line) and (2 lines), each with and
     without linked continua, plus the continuum-only tiles"""
     monkeypatch.setenv('LSX_RS_MIN_COLUMNS', '1' if ray_serial else '1000000')
+    monkeypatch.setenv('LSX_RS_MAX_NPT', '2')
     table = _run_pair(hip_lib, oracle_lib, 'falc_cah.npz', 41, 4321, 3e-11, [(0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 0), (2, 2, 0, 1), (2, 2, 1, 1)])
     assert -1 not in [k[0] for k in table]                  # no tile falls back to the generic instance
     assert max(k[0] for k in table) == 2                    # no continuum goes through the sweep
@@ -143,16 +145,19 @@ def test_profiles_must_be_set_before_a_formal_solution(hip_lib):
     e.close()
 
 
-@pytest.mark.parametrize('ray_serial', [True, False], ids=['ray-serial', 'ray-per-lane'])
+@pytest.mark.parametrize('mode', ['default', 'ray-serial', 'ray-per-lane'])
 @pytest.mark.parametrize('name,ncol,nuniq', [('falc_ca.npz', 1000, 8), ('falc_cah.npz', 1250, 10)])
-def test_full_size_batches_by_size_independent_properties(hip_lib, oracle_lib, monkeypatch, name, ncol, nuniq, ray_serial):
+def test_full_size_batches_by_size_independent_properties(hip_lib, oracle_lib, monkeypatch, name, ncol, nuniq, mode):
     """BASELINE sizes (C3: 1000 CaII columns, C4: one GPU's 1250 Ca+H columns), where the oracle would take minutes:
     columns are independent 1-D problems, so a batch built from `nuniq` distinct columns repeated in a scrambled order must
     give every copy the bits its original gets in a small batch -- whatever its position, its neighbours, its place inside
     a five-column wavefront or the size of the grid; the small batch itself is checked against the oracle.
-    ray-serial (the default at these sizes): the small batch is 37 columns (seven column groups and one of two) forced
-    onto the same kernel; ray-per-lane (LSX_NO_RS): the small batch takes the fused launch, the big one the per-class
-    launches.  Also: a frozen column keeps its state bit for bit while its neighbours iterate (lsx_set_active_columns)."""
+    default (what a context of this size runs: the ray-serial kernel for tiles with at most one per-ray slot, one ray per
+    lane for the others) and ray-serial (every class that has a ray-serial instance): the small batch is 37 columns (seven
+    column groups and one of two) forced onto the same kernels; ray-per-lane (LSX_NO_RS): the small batch takes the fused
+    launch, the big one the per-class launches.  Also: a frozen column keeps its state bit for bit while its neighbours
+    iterate (lsx_set_active_columns)."""
+    ray_serial = mode != 'ray-per-lane'
     prob, base, raw = fixtures.load_problem_npz(golden(name), phi_compact=False)
     blk, prof = synth.perturbed_columns(prob, base, raw, ncol=nuniq, seed=77, vlos_sigma=2.0e3)
     rng = np.random.default_rng(5)
@@ -162,6 +167,8 @@ def test_full_size_batches_by_size_independent_properties(hip_lib, oracle_lib, m
     pick = lambda idx: (type(blk).concatenate([blk.slice(int(q), int(q) + 1) for q in idx]), tuple(p[idx] for p in prof))
     if ray_serial:
         monkeypatch.setenv('LSX_RS_MIN_COLUMNS', '1')
+        if mode == 'ray-serial':
+            monkeypatch.setenv('LSX_RS_MAX_NPT', '2')
     else:
         monkeypatch.setenv('LSX_NO_RS', '1')
     small = Engine(prob, nsmall, lib=hip_lib)
@@ -188,10 +195,11 @@ def test_full_size_batches_by_size_independent_properties(hip_lib, oracle_lib, m
     assert relerr(small.get(_capi.LSX_N)[first], ora.get(_capi.LSX_N)) < tol and relerr(small.get(_capi.LSX_I)[first], ora.get(_capi.LSX_I)) < tol
     table, fused = class_table(hip_lib, big)
     assert fused == 0 and all(launches == 6 for _, launches in table.values())
-    assert all(v == ray_serial for v in class_table.ray_serial.values())
+    expect = {key: (ray_serial and (mode == 'ray-serial' or key[0] <= 1)) for key in table}
+    assert class_table.ray_serial == expect, class_table.ray_serial
     if ray_serial:
         table, fused = class_table(hip_lib, small)
-        assert fused == 0 and all(class_table.ray_serial.values())  # the small batch ran the same kernels
+        assert fused == 0 and class_table.ray_serial == expect      # the small batch ran the same kernels
     else:
         assert class_table(hip_lib, small)[1] == 6                 # the small batch took the fused kernel
     # frozen columns: every second column is frozen for two more iterations
