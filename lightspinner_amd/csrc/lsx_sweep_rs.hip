@@ -282,7 +282,6 @@ lsx_sweep_rs_kernel(const SweepParams p)
         if constexpr (SECOND) {
             if (2 * s == Ns || 2 * s == Ns + 1) __syncthreads();   // the partner wave's first-half stores
         }
-        if constexpr (!LAST && !FIRST) load_ops(k + dk, nxt);          // (the first point's neighbour was loaded for the boundary condition)
         double jhalf = 0.0;
         if constexpr (SECOND) jhalf = at(Jnew, kt);
         // the Gamma totals of the previous depth (their values were parked at the end of the previous step)
@@ -315,32 +314,26 @@ lsx_sweep_rs_kernel(const SweepParams p)
             }
         }
 
+        // the next depth's operands are requested HERE, after the ray-independent part has consumed this depth's background,
+        // populations and geometry: their registers are free again, so the two operand sets overlap only in the profiles
+        // (the first point's neighbour was loaded for the boundary condition)
+        if constexpr (!LAST && !FIRST) load_ops(k + dk, nxt);
+
         // ---- the five rays of this wavelength, in three straight-line passes so that the five independent chains interleave
         // (a branch per ray -- the skipped exponential, the skipped series of w2 -- would cut the instruction stream into
         // blocks the scheduler cannot mix; the regime tests of w2 are taken for the five rays together instead)
-        // pass A: opacity, source function, optical depth of the interval behind each ray (formal_solver.py:107-129)
-        double rchi[NR], Sv[NR], dS[NR], rdt[NR], dt[NR], w0[NR], w1[NR];
+        // pass A: opacity and the optical depth of the interval behind each ray (formal_solver.py:107-129).  What the later
+        // passes need of it IS the recurrence's state (chi_prev, dtau_prev now hold this depth's values): nothing else is kept
+        double dt[NR], w0[NR], w1[NR];
 #pragma unroll
         for (int m = 0; m < NR; ++m) {
-            double chiTot = chiB, etaTot = etaB;
+            double chiTot = chiB;
 #pragma unroll
-            for (int u = 0; u < NL; ++u) {
-                chiTot = fma(X[u], cur.ph[u][m], chiTot);                  // n_i Vij - n_j Vji, :613
-                etaTot = fma(njUc[u], cur.ph[u][m], etaTot);               // n_j Uji, :281, :614
-            }
+            for (int u = 0; u < NL; ++u) chiTot = fma(X[u], cur.ph[u][m], chiTot);       // n_i Vij - n_j Vji, :613
             if constexpr (FIRST) {
-                rchi[m] = rcp(chiTot);
-                Sv[m] = etaTot * rchi[m];                                  // :632
-                dS[m] = rdt[m] = 0.0;
                 dt[m] = 1.0;
             } else {
-                // the two divisions of a step (by chi, :632, and by dtau, :113/:121) share one reciprocal, 1 / (chi dtau)
                 const double dtau = (chi_prev[m] + chiTot) * (hdz * zmu[m]);
-                const double rcd = rcp(chiTot * dtau);
-                rchi[m] = rcd * dtau;
-                rdt[m] = rcd * chiTot;
-                Sv[m] = etaTot * rchi[m];
-                dS[m] = (S_prev[m] - Sv[m]) * rdt[m];
                 // formal_solver.py:138-139: the end point re-uses the PREVIOUS interval's w (and S[kEnd - dk]) with the fresh dS, dtau
                 dt[m] = LAST ? dtau_prev[m] : dtau;
                 dtau_prev[m] = dtau;
@@ -413,18 +406,31 @@ lsx_sweep_rs_kernel(const SweepParams p)
         for (int u = 0; u < NS; ++u) G1[u] = G2[u] = 0.0;
 #pragma unroll
         for (int m = 0; m < NR; ++m) {
-            double I, Lam;
+            const double chiTot = chi_prev[m];                              // (this depth's, pass A)
+            double etaTot = etaB;
+#pragma unroll
+            for (int u = 0; u < NL; ++u) etaTot = fma(njUc[u], cur.ph[u][m], etaTot);     // n_j Uji, :281, :614
+            double I, Lam, rchi, Sv;
             if constexpr (FIRST) {
+                rchi = rcp(chiTot);
+                Sv = etaTot * rchi;                                        // :632
                 I = Iu[m];
                 Lam = 0.0;
             } else {
-                const double Sx = LAST ? S_prev[m] : Sv[m];
-                I = Iu[m] * (1.0 - w0[m]) + w0[m] * Sx + w1[m] * dS[m];
-                Lam = w0[m] - w1[m] * rdt[m];
+                // the two divisions of a step (by chi, :632, and by dtau, :113/:121) share one reciprocal, 1 / (chi dtau)
+                const double dtau = dtau_prev[m];
+                const double rcd = rcp(chiTot * dtau);
+                rchi = rcd * dtau;
+                const double rdt = rcd * chiTot;
+                Sv = etaTot * rchi;
+                const double dS = (S_prev[m] - Sv) * rdt;
+                const double Sx = LAST ? S_prev[m] : Sv;
+                I = Iu[m] * (1.0 - w0[m]) + w0[m] * Sx + w1[m] * dS;
+                Lam = w0[m] - w1[m] * rdt;
             }
-            const double Psi = Lam * rchi[m];
+            const double Psi = Lam * rchi;
             Iu[m] = I;
-            S_prev[m] = Sv[m];
+            S_prev[m] = Sv;
             if constexpr (LAST) {
                 if (dir == 1 && act) p.Iout[((size_t)col * Nspect + la) * NR + m] = I;      // emergent intensity, :638
             }
