@@ -26,6 +26,19 @@ def test_context_with_the_parabolic_rule_oracle(oracle_lib):
     cases.context_with_the_parabolic_rule(oracle_lib)
 
 
+def test_parabolic_rule_is_closer_to_the_refined_linear_solution_oracle(oracle_lib):
+    cases.closer_to_the_refined_linear_solution_than_the_linear_rule(oracle_lib)
+
+
+@pytest.mark.gpu
+def test_parabolic_rule_is_closer_to_the_refined_linear_solution_on_hip(hip_lib):
+    """the end-to-end pin of N4 that does not come from the builder's restatement: FALC CaII, the reference's linear rule on
+    a 4x (and 8x) refined depth grid as the yardstick, the parabolic rule on 82 points closer to it than the linear rule on
+    82 points at the five anchor wavelengths of SURVEY 8c -- all four solutions by the HIP kernels"""
+    r = cases.closer_to_the_refined_linear_solution_than_the_linear_rule(hip_lib)
+    assert r['median_err_parabolic'] < 0.6 * r['median_err_linear']
+
+
 @pytest.mark.gpu
 def test_parabolic_units_on_hip(hip_lib, oracle_lib):
     cases.weights_are_the_moments(hip_lib)
