@@ -200,12 +200,18 @@ def cpu_baseline(prob, batch, prof, seconds_target=12.0):
 
 def profile_figures(workload):
     """counter-derived figures of an EARLIER, builder-run rocprofv3 collection (profiles/pmc_figures.json, written by
-    profiles/summarize.py): HBM bytes and VALU work per column per formal-solution call.  Static: labelled as such."""
+    profiles/summarize.py): HBM bytes and VALU instructions per column per formal-solution call, with the hash of the kernel
+    sources they were collected from.  -> (figures or None, file name, stale: the sources beside this library differ)"""
     path = os.path.join(ROOT, 'profiles', 'pmc_figures.json')
     try:
-        return json.load(open(path)).get(workload), 'profiles/pmc_figures.json'
+        fig = json.load(open(path)).get(workload)
     except Exception:
-        return None, None
+        return None, None, None
+    if not fig:
+        return None, None, None
+    sys.path.insert(0, os.path.join(ROOT, 'profiles'))
+    import srchash
+    return fig, 'profiles/pmc_figures.json', fig.get('csrc_hash') != srchash.csrc_hash()
 
 
 def roofline_block(eng, lib, prob, ncol, workload, kernel_reps):
@@ -218,40 +224,43 @@ def roofline_block(eng, lib, prob, ncol, workload, kernel_reps):
     balg = eng.algorithmic_bytes_per_column()      # SURVEY 8d formula, whole FS call
     bsweep = info(0)                               # the part of it the sweep kernel itself moves
     ach = bsweep * ncol / (ms_sweep * 1e-3) / 1e9
-    fig, src = profile_figures(workload)
+    fig, src, stale = profile_figures(workload)
     traffic = valu = None
-    bound = 'hbm'
-    if fig:
+    if fig and not stale:
         if fig.get('hbm_bytes_per_call_per_column') is not None:
             traffic = fig['hbm_bytes_per_call_per_column'] * ncol
         if fig.get('valu_insts_per_call_per_column') is not None:
             rate = fig['valu_insts_per_call_per_column'] * ncol / (ms_sweep * 1e-3)
             valu = dict(achieved=rate, peak=VALU_PEAK, unit='wave64 VALU instructions/s', frac=rate / VALU_PEAK,
-                        peak_definition='1024 SIMDs x 2.4 GHz / 4 cycles: the issue rate of fp64 VALU instructions (wave64 on a '
-                                        'SIMD-32 at half rate); 32-bit VALU instructions take 2 cycles, so frac slightly '
-                                        'overstates the pipe share of a mixed stream -- pmc_busy_frac is the counter ratio',
-                        pmc_busy_frac=fig.get('valu_busy_frac'), f64_share_of_valu_insts=fig.get('f64_share_of_valu_insts'),
+                        peak_definition='1024 SIMDs x 2.4 GHz / 4 cycles: the issue rate of fp64 VALU instructions at the MAXIMUM clock. '
+                                        'The chip holds 1.6 - 1.8 GHz under this kernel (in-kernel s_memtime / s_memrealtime, '
+                                        'profiles/r03_bound_evidence.md), so the share of the issue rate actually available is frac x 2.4 / clock',
+                        f64_share_of_valu_insts=fig.get('f64_share_of_valu_insts'),
                         insts_per_launch=fig['valu_insts_per_call_per_column'] * ncol,
-                        source='%s (instruction counts from a builder-run rocprofv3 --pmc pass of this command, per column; '
-                               'divided by the LIVE duration)' % src)
-            if valu['frac'] > ach / HBM_PEAK_GBPS:
-                bound = 'valu'
-    return dict(bound=bound, kernel='lsx_sweep_kernel<slots,lines,rays,sca> (one instance per tile class, launched side by side; '
-                                    'duration = span)',
+                        source='%s (instruction counts from a builder-run rocprofv3 --pmc pass of this command at source hash %s, per '
+                               'column; divided by the LIVE duration)' % (src, fig.get('csrc_hash')))
+    return dict(bound='hbm', kernel='the sweep of one formal solution: lsx_sweep_rs_kernel<slots,lines,linked,topo> (five columns per wavefront, '
+                                    'tiles with at most one per-ray slot) and lsx_sweep_kernel<slots,lines,rays,sca,linked,topo> (the others), one '
+                                    'instance per tile class, launched side by side; duration = span',
                 achieved=ach, peak=HBM_PEAK_GBPS, unit='GB/s', frac=ach / HBM_PEAK_GBPS, traffic=traffic,
-                traffic_source=('%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a builder run, (2*FETCH_SIZE + WRITE_SIZE)'
-                                '*1024 per call per column x columns; not measured in this run' % src) if traffic is not None else None,
+                traffic_stale=bool(stale) if fig else None,
+                traffic_source=('%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a builder run at source hash %s, (2*FETCH_SIZE + '
+                                'WRITE_SIZE)*1024 per call per column x columns; not measured in this run%s'
+                                % (src, fig.get('csrc_hash'), '; STALE: the kernel sources have changed since, so the figure is withheld' if stale else ''))
+                if fig else None,
                 valu=valu, alg_bytes_per_launch=bsweep * ncol, avg_launch_ms=ms_sweep,
+                limited_by='not HBM: with its loads removed the sweep is 13-25 % faster, with 2 -> 5 waves per SIMD 1.4x; it runs on vector '
+                           'issue at the clock the chip holds under fp64 load (1.6 - 1.8 GHz) and on each wave\'s serial chain '
+                           '(profiles/r03_bound_evidence.md: in-kernel clock, per-segment stamps, occupancy sweep, no-load ablation)',
                 fs_call=dict(ms=ms_total, ms_sweep_kernel=ms_sweep, ms_epilogue_kernels=info(4), alg_bytes=balg * ncol,
                              achieved_GBps=balg * ncol / (ms_total * 1e-3) / 1e9,
                              frac=balg * ncol / (ms_total * 1e-3) / 1e9 / HBM_PEAK_GBPS),
                 point_updates_per_sec_kernel=prob.work_units_per_column() * ncol / (ms_sweep * 1e-3),
                 tiles_per_column=info(1), wavelengths_per_tile=info(3), lds_bytes_per_workgroup=info(2),
                 slab_bytes_per_column=info(5),
-                note='achieved/peak/frac = algorithmic bytes against the HBM peak (HIP-event duration on the launch streams, from '
-                     'before the first class launch to after the last class joined back; profiles/README.md). `bound` names the '
-                     'resource with the larger fraction: the sweep issues ~150 fp64-rate VALU instructions per 13 algorithmic '
-                     'bytes, so vector issue, not HBM, is what it runs against (valu.frac, valu.pmc_busy_frac)')
+                note='achieved / peak / frac = ALGORITHMIC bytes (SURVEY 8d) over the HIP-event duration of the sweep (events on the launch '
+                     'streams: before the first class launch -> after the last class joined back; profiles/README.md), against the HBM peak '
+                     'the metric is defined on.  `limited_by` says what the kernel actually runs against.')
 
 
 def timed_steps(eng, reducer, nsteps, warmup, barrier):
@@ -449,7 +458,10 @@ def main():
                           point_updates_per_sec=p1.work_units_per_column() * h.n_iter / t_c2,
                           max_dn_over_n_vs_ref=float(np.max(np.abs(n1 - nref) / np.abs(nref))),
                           max_dI_over_I_vs_ref=float(np.max(np.abs(e1.get(_capi.LSX_I)[0] - r1['conv_I']) / np.abs(r1['conv_I']))),
-                          reference_python_iters_per_sec=0.9)
+                          reference_python_iters_per_sec=0.9,
+                          reference_python_note='0.9 it/s is NOT measured in this run: the reference\'s own Python on one core of the survey '
+                                                'container, numba absent (SURVEY.md 6); the reference cannot travel to the GPU box',
+                          us_per_mali_iteration=t_c2 / max(h.n_iter, 1) * 1e6)
             e1.close()
 
         result = dict(metric='depth_points_x_wavelengths_x_rays_per_sec', value=units / dt, unit='point-updates/s',

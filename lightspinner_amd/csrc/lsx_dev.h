@@ -332,6 +332,37 @@ static __device__ __forceinline__ Para parabolic_point(double Iu, double S_u, do
     return r;
 }
 
+// the same point with the divisions as v_rcp_f64 + one Newton step (four reciprocals instead of nine divisions): the
+// compile-time tile classes of the parabolic rule (lsx_sweep.hip, sweep_tile_par); relative differences of a few 1e-15
+static __device__ __forceinline__ Para parabolic_point_fast(double Iu, double S_u, double S_k, double S_d, double dtau_u, double dtau_d, bool has_d,
+                                                            const lds_f64* etab)
+{
+    double w0, w1, w2q;
+    w3(dtau_u, w0, w1, w2q, etab);
+    const double ru = rcp(dtau_u);
+    const double p = (S_u - S_k) * ru;
+    double a = p, dadS = -ru;                                        // end point: the linear rule
+    if (has_d) {
+        const double rd = rcp(dtau_d);
+        const double q = (S_k - S_d) * rd;
+        if (p * q > 0.0) {
+            const double alpha = (1.0 + dtau_d * rcp(dtau_u + dtau_d)) * (1.0 / 3.0), beta = 1.0 - alpha;
+            const double rden = rcp(alpha * q + beta * p);
+            a = (p * q) * rden;
+            dadS = ((beta * p) * p * rd - (alpha * q) * q * ru) * (rden * rden);
+            if (fabs(a) > 2.0 * fabs(p)) { a = 2.0 * p; dadS = -2.0 * ru; }
+        } else {
+            a = 0.0;
+            dadS = 0.0;
+        }
+    }
+    const double b = (p - a) * ru;
+    Para r;
+    r.I = Iu * (1.0 - w0) + w0 * S_k + w1 * a + w2q * b;
+    r.Lam = w0 + (w1 - w2q * ru) * dadS - (w2q * ru) * ru;
+    return r;
+}
+
 // DPP (VALU cross-lane moves, no LDS crossbar traffic).  The total of the 64 lanes ends up in
 // lane 63 (the lane that stores it).
 template <int CTRL, int ROW_MASK>

@@ -50,6 +50,8 @@ using namespace lsxd;
 extern "C" hipError_t lsx_launch_sweep(const SweepParams*, int, int, size_t, hipStream_t);
 // launcher defined in lsx_sweep_rs.hip (ray-serial instances)
 extern "C" hipError_t lsx_launch_sweep_rs(const SweepParams*, int, hipStream_t);
+// the parabolic rule (N4) for one class: compile-time instance or the generic one on the class's tile list (lsx_sweep.hip)
+extern "C" hipError_t lsx_launch_sweep_par(const SweepParams*, int, int, size_t, hipStream_t);
 
 namespace {
 
@@ -1691,7 +1693,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
     // small batches: one fused launch (n_class_tiles == ntile, identity tile list is not needed); the parabolic rule (N4) has one
     // generic instance for every tile and takes the same route at any size
     const bool parabolic = c->solver == LSX_SOLVER_PARABOLIC;
-    if (c->ncol < 32 || parabolic) {
+    if (c->ncol < 32) {
         if (has_fast) launch_prepass(c->stream, c->d_fast_tiles, c->fast_tiles.size());
         const long nblocks = (long)c->tiles.size() * c->ncol;
         p.class_tiles = nullptr;
@@ -1715,7 +1717,13 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
             p.n_class_tiles = (int)k.tiles.size();
             p.ncell_lev = k.npt >= 0 ? 0 : k.ncell_lev; p.ncell_atom = k.npt >= 0 ? 0 : k.ncell_atom; p.nstash = 0;
             k.launches++;
-            if (k.rs && c->ncol >= c->rs_min_columns) note(lsx_launch_sweep_rs(&p, k.code(), st));       // five columns per wavefront
+            if (parabolic) {
+                // a class with a compile-time instance of the rule runs it on its own LDS layout; every other class runs the
+                // generic instance (level / atom cells, the fused launch's layout) on the class's tile list
+                const bool inst = c->Nrays == LSX_RS_RAYS && !c->sca_per_lambda && k.npt >= 0 && lsx_rs_instance_exists(k.npt, k.nl, k.linked, k.topo);
+                if (!inst) { p.ncell_lev = S.fused_ncell_lev; p.ncell_atom = S.fused_ncell_atom; }
+                note(lsx_launch_sweep_par(&p, inst ? k.code() : -1, (int)nblocks, inst ? k.lds_bytes : S.fused_lds, st));
+            } else if (k.rs && c->ncol >= c->rs_min_columns) note(lsx_launch_sweep_rs(&p, k.code(), st));       // five columns per wavefront
             else note(lsx_launch_sweep(&p, k.code(), (int)nblocks, k.lds_bytes, st));
             if (timed) {
                 if (!k.tdone) note(hipEventCreate(&k.tdone));

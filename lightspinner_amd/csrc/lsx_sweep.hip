@@ -1140,6 +1140,323 @@ __device__ __forceinline__ void sweep_tile_parabolic(const SweepParams& p, const
 #undef CETA
 }
 
+// ---- N4 with compile-time tile classes: the monotonic piecewise-parabolic rule (include/lsx.h) for tiles with at most two
+// per-ray slots, on the one-ray-per-lane mapping of sweep_tile's static path (slot state in registers, per-depth operands in
+// the LDS table, streams requested one depth ahead, DPP / permlane lane sums).  The rule at depth m needs the source function
+// and the opacity of the DOWNWIND neighbour, so step s evaluates opacity and source function at depth s and then FINISHES depth
+// s - 1 (formal solution, angle sums, Gamma integrands, J) from the values step s - 1 left behind; the last depth is finished
+// after the loop with the linear end rule.  Same terms as sweep_tile_parabolic (the generic instance, which stays for the
+// other tile shapes and small batches); the reciprocals are v_rcp_f64 + one Newton step there IEEE divisions.
+template <int NPT, int NL, int NR, bool LK, int TOPO>
+__device__ __forceinline__ void sweep_tile_par(const SweepParams& p, const int vb, const int tile_id)
+{
+    static_assert(NPT >= 0 && NPT <= 2 && NR > 0, "compile-time classes with at most two per-ray slots");
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    lds_f64* const etab = (lds_f64*)lds_raw;
+    lds_f64* const lds = etab + LSX_EXP_TAB;
+    constexpr int NS = NPT > 0 ? NPT : 1;
+    constexpr int TR = 3 * NPT + 2;
+    constexpr bool HASC = NPT > NL;
+    constexpr int NLK = (LK && NL > 0) ? NL : 1;
+    constexpr int NCR = NPT == 1 ? 2 : 3;
+    constexpr int L = LSX_WAVE / NR;
+    const int lane = threadIdx.x & (LSX_WAVE - 1);
+    const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ntile = p.ntile_total;
+    const int col = vb / p.n_class_tiles;
+    const auto* tilep = LSX_CONST(DevTile, p.tiles) + tile_id;
+    const int la0 = tilep->la0, nla = tilep->nla, slot0 = tilep->slot0, nF = tilep->nF;
+    const auto* slots = LSX_CONST(DevSlot, p.slots) + slot0;
+    const int Ns = p.Nspace, Nspect = p.Nspect;
+    const int mu_raw = lane / L, j_raw = lane - mu_raw * L;
+    const bool valid = mu_raw < NR && j_raw < nla;
+    const int mu = mu_raw < NR ? mu_raw : NR - 1;
+    const int j = j_raw < nla ? j_raw : nla - 1;
+    const int la = la0 + j;
+    const bool lead = valid && mu_raw == 0;
+    const SweepLds lay = lsx_sweep_lds(NPT, LK, p.Nspace, p.ncell_lev, p.ncell_atom);
+    const int rows = lay.rows;
+    lds_f64* const xrow = lds + (size_t)dir * rows * LSX_WAVE + (size_t)(rows - 1) * LSX_WAVE;
+    lds_f64* const xwg = etab + lay.xwg;
+    lds_f64* const utab = etab + lay.utab;
+    lds_f64* const xrow2 = etab + lay.xrow2 + (size_t)dir * NS * LSX_WAVE;
+    const auto* z = LSX_CONST(double, p.height + (size_t)col * Ns);
+    const auto* tcol = LSX_CONST(double, p.temperature + (size_t)col * Ns);
+    const size_t tbase = ((size_t)col * ntile + tile_id) * Ns * L;
+    const double* __restrict__ bgchi = (nF > 0 ? p.bgxchi_T : p.bgchi_T) + tbase;
+    const double* __restrict__ bgeta = (nF > 0 ? p.bgxeta_T : p.bgeta_T) + tbase;
+    double* __restrict__ psibar = p.Psi2_T + ((size_t)dir * p.ncol * ntile) * Ns * L + tbase;
+    const double* __restrict__ Jdag = p.Jdag_T + tbase;
+    double* __restrict__ Jnew = p.Jnew_T + tbase;
+    const double* __restrict__ phi_col = p.phi_T + (size_t)col * p.phi_col_stride;
+    const double* __restrict__ Eb = p.E_T + tbase;
+    const size_t plane = (size_t)Ns * L;
+    const double* __restrict__ corr = LK ? p.corr_T + (size_t)col * p.corr_col_stride + tilep->corr_off : nullptr;
+    double* __restrict__ ppsum = LK ? p.Psi3_T + ((size_t)dir * p.ncol + col) * p.pp_col_stride + tilep->pp_off : nullptr;
+    double* __restrict__ gpart = p.Gpart + ((size_t)col * p.nslot_total + slot0) * 4 * Ns;
+    // the per-depth operand table (as sweep_tile): per slot lines (cB (n_i - g n_j), n_j, wphi) / continua (n_i, n_j, nStar ratio),
+    // then the half length of the interval above depth k and the scattering coefficient
+    {
+        const double* ncolp = p.n + (size_t)col * p.NLtot * Ns;
+        const double* zc = p.height + (size_t)col * Ns;
+        if (threadIdx.x < TR) utab[Ns * TR + threadIdx.x] = 0.0;
+        for (int e = threadIdx.x; e < Ns; e += 2 * LSX_WAVE) {
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                const double ni = ncolp[(size_t)slots[u].li * Ns + e], nj = ncolp[(size_t)slots[u].lj * Ns + e];
+                const bool line = u < NL;
+                utab[e * TR + 3 * u + 0] = line ? slots[u].cB * (ni - slots[u].g * nj) : ni;
+                utab[e * TR + 3 * u + 1] = nj;
+                utab[e * TR + 3 * u + 2] = line ? p.wphi[(size_t)col * p.Nlines * Ns + slots[u].wphi_off + e]
+                                                : p.nsr[(size_t)col * p.Ncont * Ns + slots[u].base + e];
+            }
+            utab[e * TR + 3 * NPT + 0] = e > 0 ? 0.5 * fabs(zc[e - 1] - zc[e]) : 0.0;
+            utab[e * TR + 3 * NPT + 1] = p.sca[(size_t)col * Ns + e];
+        }
+    }
+    etab[threadIdx.x] = p.exp2_tab[threadIdx.x];
+    __syncthreads();
+
+    const double wav = p.wavelength[la];
+    const double u_la = p.u_la[la];
+    const double zmu_l = p.zmu[mu];
+    const double wmuh_l = valid ? p.wmuh[mu] : 0.0;
+    const double wq_l = wmuh_l * (4.0 * kPi);
+    const bool compact = p.phi_compact != 0;
+    const int kS = dir ? Ns - 1 : 0;
+    const int dk = dir ? -1 : 1;
+    const int raysel = compact ? 0 : dir * Ns * NR + mu;
+    const int kmul = compact ? 1 : NR;
+    unsigned pact = 0;
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) {
+        const int l = la - slots[u].Nblue;
+        if (l >= 0 && l < slots[u].Nlam && p.active[slots[u].trans * Nspect + la] != 0) pact |= 1u << u;
+    }
+    int idx0[NS], kstr[NS];
+    double wlv[NS], alv[NS];
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) {
+        const bool a = (pact >> u) & 1u;
+        const int l = a ? la - slots[u].Nblue : 0;
+        const bool line = u < NL;
+        const int len = slots[u].len;
+        const int lb = a ? la - slots[u].first : 0;
+        idx0[u] = line ? (a ? slots[u].base + raysel * len + lb : (int)p.phi_col_stride - 1) : 0;
+        kstr[u] = (line && a) ? kmul * len : 0;
+        wlv[u] = (a && valid) ? wq_l * p.wl[slots[u].wl_off + l] : 0.0;
+        alv[u] = (a && !line) ? p.alpha[slots[u].wl_off + l] : 0.0;
+    }
+
+    // ---- one depth: the streams (requested one depth ahead) and what the front half of a step makes of them
+    struct Str { double bc, be, jd, E, sv[NS], cr[NLK][3]; };
+    auto stream_loads = [&](int kk, Str& o) __attribute__((always_inline)) {
+        const unsigned kko = (unsigned)(kk * L + j) * 8u;
+        o.jd = at(Jdag, kko);
+        o.bc = at(bgchi, kko);
+        o.be = at(bgeta, kko);
+        o.E = 0.0;
+#pragma unroll
+        for (int u = 0; u < NL; ++u) o.sv[u] = at(phi_col, (unsigned)(idx0[u] + kk * kstr[u]) * 8u);
+        if constexpr (HASC) o.E = at(Eb, kko);
+        if constexpr (LK) {
+#pragma unroll
+            for (int u = 0; u < NL; ++u)
+#pragma unroll
+                for (int q = 0; q < NCR; ++q) o.cr[u][q] = at(corr, (unsigned)((3 * u + q) * plane) * 8u + kko);
+        }
+    };
+    struct Dep { double chi, rchi, S, jd, pv[NS], ch[NS], Uji[NS], eta[NS], cr[NLK][3]; };
+    // opacity, emissivity, source function of depth k from its streams (rh_method.py:601-632)
+    auto front = [&](int k, const Str& o, Dep& d) __attribute__((always_inline)) {
+        const lds_f64* tk = utab + k * TR;
+        double chiTot = o.bc, etaTot = o.be + tk[3 * NPT + 1] * o.jd;
+#pragma unroll
+        for (int u = 0; u < NPT; ++u) {
+            const double ni = tk[3 * u + 0], nj = tk[3 * u + 1];
+            if (u < NL) {
+                d.pv[u] = o.sv[u];
+                d.ch[u] = ni * d.pv[u];                                    // (the table holds cB (n_i - g n_j))
+                d.Uji[u] = slots[u].Uc * d.pv[u];
+            } else {
+                const double g = ((pact >> u) & 1u) ? tk[3 * u + 2] * o.E : 0.0;
+                d.pv[u] = g * alv[u];                                      // Vji
+                d.ch[u] = ni * alv[u] - nj * d.pv[u];
+                d.Uji[u] = u_la * d.pv[u];
+            }
+            d.eta[u] = nj * d.Uji[u];
+            chiTot += d.ch[u];
+            etaTot += d.eta[u];
+        }
+        d.chi = chiTot;
+        d.rchi = rcp(chiTot);
+        d.S = etaTot * d.rchi;
+        d.jd = o.jd;
+        if constexpr (LK) {
+#pragma unroll
+            for (int u = 0; u < NL; ++u)
+#pragma unroll
+                for (int q = 0; q < NCR; ++q) d.cr[u][q] = o.cr[u][q];
+        }
+    };
+
+    // ---- boundary conditions: formal_solver.py:203-209 (unchanged by the rule)
+    Str sA, sB;
+    Dep dprev, dcur;
+    stream_loads(kS, sA);
+    stream_loads(kS + dk, sB);
+    front(kS, sA, dprev);
+    double Iu = 0.0;
+    if (dir) {
+        Dep d1;
+        front(kS + dk, sB, d1);
+        const double dtau_uw = zmu_l * (dprev.chi + d1.chi) * 0.5 * fabs(z[kS] - z[kS + dk]);
+        const double B0 = planck(tcol[Ns - 2], wav), B1 = planck(tcol[Ns - 1], wav);
+        Iu = B1 - (B0 - B1) / dtau_uw;
+    }
+    double S_u = 0.0, dtau_u = 1.0;          // source function of the upwind depth, optical depth of the interval behind the local one
+    double dJ = 0.0;
+
+    // finish depth m (this wave's m-th): formal solution, angle sums, Gamma integrands, J.  `d`: the depth's own values,
+    // (Sd, dtau_d, has_d): its downwind neighbour
+    auto finish = [&](const int m, auto phase_c, const Dep& d, double Sd, double dtau_d, bool has_d) __attribute__((always_inline)) {
+        constexpr int PH = decltype(phase_c)::value;      // 0 first visitor, 1 midpoint, 2 second visitor
+        const int k = kS + dk * m;
+        const unsigned kl = (unsigned)(k * L + j) * 8u;
+        const lds_f64* tk = utab + k * TR;
+        if constexpr (PH == 2) {
+            if (2 * m == Ns || 2 * m == Ns + 1) __syncthreads();      // the partner wave's first-half stores
+        }
+        double jhalf = 0.0;
+        if constexpr (PH == 2) jhalf = at(Jnew, kl);
+        double I, Lam;
+        if (m == 0) {
+            I = Iu;
+            Lam = 0.0;
+        } else {
+            const Para r = parabolic_point_fast(Iu, S_u, d.S, has_d ? Sd : 0.0, dtau_u, has_d ? dtau_d : 1.0, has_d, etab);
+            I = r.I;
+            Lam = r.Lam;
+        }
+        const double Psi = Lam * d.rchi;
+        Iu = I;
+        S_u = d.S;
+        dtau_u = dtau_d;
+        if (m == Ns - 1 && dir == 1 && valid) p.Iout[((size_t)col * Nspect + la) * NR + mu] = I;
+        // angle quadrature: J (:640), Psibar and sum_mu w Psi* phi for the fast / linked continua
+        xrow[lane] = wmuh_l * I;
+        __builtin_amdgcn_wave_barrier();
+        double Jsum = xrow[j];
+#pragma unroll
+        for (int q = 1; q < NR; ++q) Jsum += xrow[q * L + j];
+        if (nF > 0) {
+            const double wP = wq_l * Psi;
+            __builtin_amdgcn_wave_barrier();
+            xrow[lane] = wP;
+            if constexpr (LK) {
+#pragma unroll
+                for (int u = 0; u < NL; ++u) xrow2[u * LSX_WAVE + lane] = wP * d.pv[u];
+            }
+            __builtin_amdgcn_wave_barrier();
+            double sPsi = xrow[j];
+#pragma unroll
+            for (int q = 1; q < NR; ++q) sPsi += xrow[q * L + j];
+            at(psibar, kl) = sPsi;
+            if constexpr (LK) {
+#pragma unroll
+                for (int u = 0; u < NL; ++u) {
+                    double sPP = xrow2[u * LSX_WAVE + j];
+#pragma unroll
+                    for (int q = 1; q < NR; ++q) sPP += xrow2[u * LSX_WAVE + q * L + j];
+                    at(ppsum, (unsigned)(u * plane) * 8u + kl) = sPP;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // Gamma integrands (rh_method.py:643-681), the level bookkeeping of :616-627 from the tile's (at most two) slots
+        double g1v[NS], g2v[NS];
+#pragma unroll
+        for (int u = 0; u < NPT; ++u) {
+            const bool line = u < NL;
+            const double Vij = line ? slots[u].cB * d.pv[u] : alv[u];
+            const double Vji = line ? slots[u].Vc * d.pv[u] : d.pv[u];
+            double etaA = d.eta[u], chi_i = d.ch[u], chi_j = -d.ch[u], U_j = d.Uji[u], U_i = 0.0;
+            if constexpr (NPT == 2) {
+                const int v = 1 - u;
+                if constexpr (TOPO == 1) { etaA += d.eta[v]; chi_i += d.ch[v]; }
+                else if constexpr (TOPO == 0) {
+                    const auto* rel = slots[u].rel[0];
+                    etaA = fma(rel[REL_EA], d.eta[v], etaA);
+                    chi_i = fma(rel[REL_CI], d.ch[v], chi_i);
+                    chi_j = fma(rel[REL_CJ], d.ch[v], chi_j);
+                    U_j = fma(rel[REL_UJ], d.Uji[v], U_j);
+                    U_i = rel[REL_UI] * d.Uji[v];
+                }
+            }
+            if constexpr (LK) {
+                if (line) {
+                    etaA += d.cr[u < NLK ? u : 0][0];
+                    chi_i += d.cr[u < NLK ? u : 0][1];
+                    if constexpr (NCR > 2) chi_j += d.cr[u < NLK ? u : 0][2];
+                }
+            }
+            const double wt = line ? wlv[u] * tk[3 * u + 2] : wlv[u];          // :451 (lines: x wphi), :455, :665
+            const double Ieff = I - Psi * etaA;                                // :652
+            g1v[u] = wt * ((d.Uji[u] + Vji * Ieff) - (chi_i * Psi) * U_j);      // :677
+            g2v[u] = wt * ((Vij * Ieff) - (chi_j * Psi) * U_i);                // :680
+        }
+        if constexpr (NPT == 1) {
+            const double t = reduce_pair(g1v[0], g2v[0]);
+            if (lane == 31) gpart[(0 * 2 + dir) * Ns + k] = t;
+            if (lane == 63) gpart[(1 * 2 + dir) * Ns + k] = t;
+        } else if constexpr (NPT == 2) {
+            const double t = reduce_quad(g1v[0], g2v[0], g1v[1], g2v[1]);      // lane 15: g1[0], 47: g2[0], 31: g1[1], 63: g2[1]
+            if ((lane & 15) == 15) {
+                const int q = ((lane >> 4) & 1) * 2 + (lane >> 5);            // 15 -> 0, 47 -> 1, 31 -> 2, 63 -> 3
+                gpart[(q * 2 + dir) * Ns + k] = t;
+            }
+        }
+        // J: the two directions meet at depth k at different steps
+        if constexpr (PH == 0) {
+            at(Jnew, kl) = Jsum;
+        } else if constexpr (PH == 1) {
+            if (lead) xwg[dir * LSX_WAVE + j] = Jsum;
+            __syncthreads();
+            if (lead && dir == 0) {
+                const double Jv = Jsum + xwg[LSX_WAVE + j];
+                at(Jnew, kl) = Jv;
+                dJ = nanmax(dJ, fabs(1.0 - d.jd * rcp(Jv)));
+            }
+        } else {
+            const double Jv = jhalf + Jsum;
+            at(Jnew, kl) = Jv;
+            dJ = nanmax(dJ, fabs(1.0 - d.jd * rcp(Jv)));
+        }
+    };
+    // step s (s >= 1): depth s's streams are in `cs`, the next depth's are requested into `ns`; depth s - 1 is finished
+    auto step = [&](const int s, auto phase_c, Str& cs, Str& ns) __attribute__((always_inline)) {
+        const int k = kS + dk * s;
+        if (s + 1 < Ns) stream_loads(k + dk, ns);
+        front(k, cs, dcur);
+        // optical depth of the interval between depths s - 1 and s along this ray: the table row "behind" depth s
+        const double dtau_d = (dprev.chi + dcur.chi) * ((utab + TR * dir)[k * TR + 3 * NPT] * zmu_l);
+        finish(s - 1, phase_c, dprev, dcur.S, dtau_d, true);
+        dprev = dcur;
+    };
+    {
+        // depth m is finished in step m + 1; m < nA: first visitor, m = nA (odd Nspace): the midpoint, then second visitor
+        const int nA = Ns / 2;
+        auto one = [&](int s, auto ph) __attribute__((always_inline)) { if (s & 1) step(s, ph, sB, sA); else step(s, ph, sA, sB); };
+        int s = 1;
+        for (; s <= nA; ++s) one(s, std::integral_constant<int, 0>{});                     // finishes m = 0 .. nA - 1
+        if (Ns & 1) { one(s, std::integral_constant<int, 1>{}); ++s; }                     // m = nA
+        for (; s < Ns; ++s) one(s, std::integral_constant<int, 2>{});                      // m up to Ns - 2
+        finish(Ns - 1, std::integral_constant<int, 2>{}, dprev, 0.0, 1.0, false);          // the end point: the linear rule with its own weights
+    }
+    const double dJw = wave_max_nan(lead ? dJ : 0.0);
+    if (lane == 0) p.dJpart[((size_t)col * ntile + tile_id) * 2 + dir] = dJw;
+}
+
 // One kernel per (NPT, NR, SCAL) class; the host launches the classes of a call on separate streams
 // so they share the machine (a class alone would leave a tail).
 // register budget per class: tiles without per-ray slots fit 5 waves/SIMD, the others 4 (more would spill)
@@ -1185,8 +1502,17 @@ lsx_sweep_kernel(const SweepParams p)
 
 // Small batches (a few columns) are latency bound: one launch that dispatches on the tile's class inside
 // beats five tiny launches on five streams.
+// The instances are CALLED, not inlined: each keeps the register allocation it has as a class kernel (inlined side by side
+// they shared one scalar register file: 320 scalar spills), and the call happens once per workgroup.
+template <int NPT, int NL, int NR, bool SCAL, bool LK, int TOPO = 0>
+__device__ __attribute__((noinline)) void sweep_tile_call(const SweepParams& p, const int vb, const int tile_id)
+{
+    sweep_tile<NPT, NL, NR, SCAL, LK, TOPO>(p, vb, tile_id);
+}
+// (at most 31 columns x tiles workgroups: occupancy is no concern, so the register allocator gets the whole file -- no vector
+// spills in the one kernel every single-column Context runs)
 template <int NR, bool SCAL>
-__global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(LSX_WAVES_PER_EU)))
+__global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(1, 2)))
 lsx_sweep_kernel_all(const SweepParams p)
 {
     const int vb = blockIdx.x;
@@ -1199,13 +1525,13 @@ lsx_sweep_kernel_all(const SweepParams p)
     }
     const int nP = (LSX_CONST(DevTile, p.tiles) + tile_id)->nP, nL = (LSX_CONST(DevTile, p.tiles) + tile_id)->nL;
     const bool lk = (LSX_CONST(DevTile, p.tiles) + tile_id)->nK > 0;
-    if (nP > p.static_max) { if (lk) sweep_tile<-1, 0, NR, SCAL, true>(p, vb, tile_id); else sweep_tile<-1, 0, NR, SCAL, false>(p, vb, tile_id); }
-    else if (nP == 0) sweep_tile<0, 0, NR, SCAL, false>(p, vb, tile_id);
-    else if (nP == 1 && nL == 1) { if (lk) sweep_tile<1, 1, NR, SCAL, true>(p, vb, tile_id); else sweep_tile<1, 1, NR, SCAL, false>(p, vb, tile_id); }
-    else if (nP == 2 && nL == 2) { if (lk) sweep_tile<2, 2, NR, SCAL, true>(p, vb, tile_id); else sweep_tile<2, 2, NR, SCAL, false>(p, vb, tile_id); }
-    else if (nP == 2 && nL == 1 && !lk) sweep_tile<2, 1, NR, SCAL, false>(p, vb, tile_id);
-    else if (lk) sweep_tile<-1, 0, NR, SCAL, true>(p, vb, tile_id);     // the remaining shapes take the generic path here (code size)
-    else sweep_tile<-1, 0, NR, SCAL, false>(p, vb, tile_id);
+    if (nP > p.static_max) { if (lk) sweep_tile_call<-1, 0, NR, SCAL, true>(p, vb, tile_id); else sweep_tile_call<-1, 0, NR, SCAL, false>(p, vb, tile_id); }
+    else if (nP == 0) sweep_tile_call<0, 0, NR, SCAL, false>(p, vb, tile_id);
+    else if (nP == 1 && nL == 1) { if (lk) sweep_tile_call<1, 1, NR, SCAL, true>(p, vb, tile_id); else sweep_tile_call<1, 1, NR, SCAL, false>(p, vb, tile_id); }
+    else if (nP == 2 && nL == 2) { if (lk) sweep_tile_call<2, 2, NR, SCAL, true>(p, vb, tile_id); else sweep_tile_call<2, 2, NR, SCAL, false>(p, vb, tile_id); }
+    else if (nP == 2 && nL == 1 && !lk) sweep_tile_call<2, 1, NR, SCAL, false>(p, vb, tile_id);
+    else if (lk) sweep_tile_call<-1, 0, NR, SCAL, true>(p, vb, tile_id);     // the remaining shapes take the generic path here (code size)
+    else sweep_tile_call<-1, 0, NR, SCAL, false>(p, vb, tile_id);
 }
 
 
@@ -1214,15 +1540,61 @@ template <int NR, bool SCAL>
 __global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(LSX_WAVES_PER_EU)))
 lsx_sweep_kernel_parabolic(const SweepParams p)
 {
+    // every tile of every column (fused launch: no tile list), or the tiles of one class that has no compile-time instance
     const int vb = blockIdx.x;
-    const int col = vb / p.ntile_total;
-    const int tile_id = vb - col * p.ntile_total;
+    const int col = vb / p.n_class_tiles;
+    const int tile_id = p.class_tiles ? LSX_CONST(int32_t, p.class_tiles)[vb - col * p.n_class_tiles] : vb - col * p.n_class_tiles;
     if (p.colmask && LSX_CONST(uint8_t, p.colmask)[col] == 0) {
-        const size_t tb = (size_t)vb * p.Nspace * p.L;
+        const size_t tb = ((size_t)col * p.ntile_total + tile_id) * p.Nspace * p.L;
         for (int e = threadIdx.x; e < p.Nspace * p.L; e += 2 * LSX_WAVE) p.Jnew_T[tb + e] = p.Jdag_T[tb + e];
         return;
     }
     sweep_tile_parabolic<NR, SCAL>(p, vb, tile_id);
+}
+
+// N4, compile-time classes: one kernel per (slots, lines, linked, relation), five rays
+template <int NPT, int NL, bool LK, int TOPO>
+__global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(2)))
+lsx_sweep_kernel_par(const SweepParams p)
+{
+    int vb;
+    {
+        const int nb = gridDim.x, x = blockIdx.x & 7, q = blockIdx.x >> 3;
+        const int nb8 = nb >> 3, rem = nb & 7;
+        vb = x * nb8 + (x < rem ? x : rem) + q;
+    }
+    const int col = vb / p.n_class_tiles;
+    const int tile_id = LSX_CONST(int32_t, p.class_tiles)[vb - col * p.n_class_tiles];
+    if (p.colmask && LSX_CONST(uint8_t, p.colmask)[col] == 0) {
+        const size_t tb = ((size_t)col * p.ntile_total + tile_id) * p.Nspace * p.L;
+        for (int e = threadIdx.x; e < p.Nspace * p.L; e += 2 * LSX_WAVE) p.Jnew_T[tb + e] = p.Jdag_T[tb + e];
+        return;
+    }
+    sweep_tile_par<NPT, NL, LSX_RS_RAYS, LK, TOPO>(p, vb, tile_id);
+}
+
+// the parabolic rule for one class: its compile-time instance where one exists (the shapes of LSX_RS_INSTANCES, five rays, one
+// scattering coefficient per depth), the generic instance on the class's tile list otherwise
+extern "C" hipError_t lsx_launch_sweep_par(const SweepParams* p, int code, int nblocks, size_t lds_bytes, hipStream_t st)
+{
+    const dim3 g(nblocks), b(2 * LSX_WAVE);
+    if (p->Nrays == LSX_RS_RAYS && !p->sca_per_lambda) {
+        switch (code) {
+#define LSX_X(NPT, NL, LK, TOPO) \
+        case lsx_class_code(NPT, NL, LK, TOPO): hipLaunchKernelGGL((lsx_sweep_kernel_par<NPT, NL, LK, TOPO>), g, b, lds_bytes, st, *p); return hipGetLastError();
+        LSX_RS_INSTANCES(LSX_X)
+#undef LSX_X
+        default: break;
+        }
+    }
+    if (!p->sca_per_lambda && p->Nrays == 5) hipLaunchKernelGGL((lsx_sweep_kernel_parabolic<5, false>), g, b, lds_bytes, st, *p);
+#ifndef LSX_ONLY_NR5
+    else if (!p->sca_per_lambda && p->Nrays == 3) hipLaunchKernelGGL((lsx_sweep_kernel_parabolic<3, false>), g, b, lds_bytes, st, *p);
+    else hipLaunchKernelGGL((lsx_sweep_kernel_parabolic<0, true>), g, b, lds_bytes, st, *p);
+#else
+    else return hipErrorNotSupported;
+#endif
+    return hipGetLastError();
 }
 
 template <int NR, bool SCAL>

@@ -13,7 +13,7 @@ import csv, glob, json, os, re, sys, collections
 
 
 def short(name):
-    m = re.search(r'(lsx_sweep_kernel(?:_all)?<[^>]*>)', name)
+    m = re.search(r'(lsx_sweep_(?:rs_)?kernel(?:_all)?<[^>]*>)', name)
     if m:
         return m.group(1).replace(' ', '')
     m = re.search(r'(k_\w+|__amd_\w+)', name)
@@ -31,7 +31,7 @@ def main():
         for r in rows:
             per[short(r['Kernel_Name'])].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
         out['kernels_avg_us'] = {k: {'calls': len(v), 'avg_us': round(sum(v) / len(v) / 1e3, 2)} for k, v in sorted(per.items())}
-        sw = sorted([r for r in rows if 'lsx_sweep_kernel' in r['Kernel_Name']], key=lambda r: int(r['Start_Timestamp']))
+        sw = sorted([r for r in rows if 'lsx_sweep_' in r['Kernel_Name']], key=lambda r: int(r['Start_Timestamp']))
         classes = sorted({short(r['Kernel_Name']) for r in sw})
         n = len(classes)
         spans = []
@@ -47,7 +47,7 @@ def main():
     for d in sorted(glob.glob(tag + '_pmc*')):
         for f in glob.glob(os.path.join(d, '*counter_collection.csv')):
             for r in csv.DictReader(open(f)):
-                if 'lsx_sweep_kernel' in r['Kernel_Name']:
+                if 'lsx_sweep_' in r['Kernel_Name']:
                     ctr[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
     if ctr:
         pc = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in ctr.items()}
@@ -104,9 +104,9 @@ def main():
             f64 = sum(tot.get('SQ_INSTS_VALU_%s_F64' % x, 0.0) for x in ('FMA', 'ADD', 'MUL', 'TRANS'))
             if f64:
                 fig['f64_share_of_valu_insts'] = f64 / tot['SQ_INSTS_VALU']
-        if 'SQ_ACTIVE_INST_VALU' in tot and tot.get('GRBM_GUI_ACTIVE'):
-            # all classes together: busy quad-cycles of every class over the cycles of every class (serialised passes)
-            fig['valu_busy_frac'] = tot['SQ_ACTIVE_INST_VALU'] * 4.0 / (nsimd * tot['GRBM_GUI_ACTIVE'] / 8.0)
+        # (round 2 quoted SQ_ACTIVE_INST_VALU * 4 / (SIMDs x GRBM cycles) as "VALU busy"; its sibling ratio for all instructions
+        # exceeds 1, so it is not a utilisation and is no longer published; the pipe estimate per class stays in
+        # sweep_binding_resource, the clock the chip actually holds is measured in the kernel: profiles/stamps.py)
         if fig:
             out['figures'] = fig
     cal = glob.glob(tag + '_calib/*counter_collection.csv')
@@ -124,7 +124,10 @@ def main():
             allfig = json.load(open(path))
         except Exception:
             allfig = {}
-        allfig[sys.argv[3]] = dict(out['figures'], source='rocprofv3 --pmc passes of `bench.py --workload %s` (profiles/collect.sh %s), '
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import srchash
+        allfig[sys.argv[3]] = dict(out['figures'], csrc_hash=srchash.csrc_hash(),
+                                   source='rocprofv3 --pmc passes of `bench.py --workload %s` (profiles/collect.sh %s), '
                                    'summed over the sweep classes of a call' % (sys.argv[3], os.path.basename(tag)))
         json.dump(allfig, open(path, 'w'), indent=1)
 
