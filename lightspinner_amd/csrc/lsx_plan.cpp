@@ -429,7 +429,8 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
     // ---- ray-serial sweep: five columns per wavefront, addressed as one base + 32-bit byte offsets
     {
         const size_t big = std::max(std::max(P.til_col, P.phi_col), std::max(std::max(P.corr_col, P.pp_col), (size_t)std::max(P.NLtot, std::max(P.Nlines, P.Ncont)) * Ns));
-        P.rs_ok = !opt.no_rs && P.Nrays == LSX_RS_RAYS && !P.sca_per_lambda && (LSX_RS_COLS + 1) * big * 8 < 0xffffffffull;
+        P.rs_ok = !opt.no_rs && P.Nrays == LSX_RS_RAYS && !P.sca_per_lambda && (LSX_RS_COLS + 1) * big * 8 < 0xffffffffull &&
+                  (size_t)lsx_rs_lds_doubles(2, Ns) * sizeof(double) <= 64 * 1024;      // (the operand table of a two-slot tile fits)
         P.rs_min_columns = opt.rs_min_columns;
         for (auto& k : P.plan_classes) k.rs = P.rs_ok && k.npt >= 0 && k.npt <= opt.rs_max_npt && lsx_rs_instance_exists(k.npt, k.nl, k.linked, k.topo);
     }

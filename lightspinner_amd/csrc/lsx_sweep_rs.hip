@@ -76,6 +76,11 @@ lsx_sweep_rs_kernel(const SweepParams p)
     const int lane = threadIdx.x & (LSX_WAVE - 1);
     const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0: down (toFrom False), 1: up (True)
     lds_f64* const red = etab + LSX_EXP_TAB + (size_t)dir * (NV + 1) * RROW;   // this wave's reduction rows (+ one for dJ)
+    // per-depth operands of the group's columns, staged once per workgroup: utab[c][k][TR] = per slot (lines: cB (n_i - g n_j),
+    // n_j Uc, wphi; continua: n_i, n_j, nStar_i / nStar_j), then the half length of the interval above depth k and the
+    // scattering coefficient (row Nspace of a column: zeros -- the up sweep reads the interval behind depth k from row k + 1)
+    constexpr int TR = 3 * NPT + 2;
+    lds_f64* const utab = etab + LSX_EXP_TAB + 2 * (NV + 1) * RROW + 2 * LSX_WAVE;
 
     // XCD-aware block -> (column group, tile): every XCD gets a contiguous range (speed only)
     int vb;
@@ -104,7 +109,38 @@ lsx_sweep_rs_kernel(const SweepParams p)
     const bool act = valid && live_col;
 
     etab[threadIdx.x] = p.exp2_tab[threadIdx.x];
+    {
+        const int Nsp = p.Nspace;
+        for (int e = threadIdx.x; e < NC * (Nsp + 1); e += 2 * LSX_WAVE) {
+            const int c = e / (Nsp + 1), k = e - c * (Nsp + 1);
+            const int colc = col0 + (c < ncg ? c : ncg - 1);
+            lds_f64* row = utab + (size_t)e * TR;
+            if (k == Nsp) {
+#pragma unroll
+                for (int t = 0; t < TR; ++t) row[t] = 0.0;
+                continue;
+            }
+            const double* ncolp = p.n + (size_t)colc * p.NLtot * Nsp;
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                const double ni = ncolp[(size_t)slots[u].li * Nsp + k], nj = ncolp[(size_t)slots[u].lj * Nsp + k];
+                if (u < NL) {
+                    row[3 * u + 0] = slots[u].cB * (ni - slots[u].g * nj);          // :279-280, :613
+                    row[3 * u + 1] = nj * slots[u].Uc;                               // eta = n_j Uji = (n_j Uc) phi, :281, :614
+                    row[3 * u + 2] = p.wphi[(size_t)colc * p.Nlines * Nsp + slots[u].wphi_off + k];
+                } else {
+                    row[3 * u + 0] = ni;
+                    row[3 * u + 1] = nj;
+                    row[3 * u + 2] = p.nsr[(size_t)colc * p.Ncont * Nsp + slots[u].base + k];   // g_ij = this x E, :453
+                }
+            }
+            const double* zc = p.height + (size_t)colc * Nsp;
+            row[3 * NPT + 0] = k > 0 ? 0.5 * fabs(zc[k - 1] - zc[k]) : 0.0;
+            row[3 * NPT + 1] = p.sca[(size_t)colc * Nsp + k];
+        }
+    }
     __syncthreads();
+    const lds_f64* const ucol = utab + (size_t)cc * (p.Nspace + 1) * TR;            // this lane's column
 
     // ---- per-lane bases: every stream of a column is addressed as (wave-uniform base of column col0) + 32-bit byte offset
     const size_t til_col = (size_t)ntile * Ns * LW;
@@ -123,18 +159,6 @@ lsx_sweep_rs_kernel(const SweepParams p)
     double* __restrict__ ppsum = LK ? p.Psi3_T + ((size_t)dir * p.ncol + col0) * p.pp_col_stride + tilep->pp_off : nullptr;
     const unsigned o_pp = LK ? (unsigned)((size_t)cc * p.pp_col_stride * 8u) + (unsigned)j * 8u : 0u;
     const size_t plane = (size_t)Ns * LW;
-    // per-depth operands of the lane's column (12 lanes share an address): populations, line normalisation / nStar ratio,
-    // height, scattering coefficient
-    const double* __restrict__ ncolb = p.n + (size_t)col0 * p.NLtot * Ns;
-    const unsigned o_n = (unsigned)((size_t)cc * p.NLtot * Ns * 8u);
-    const double* __restrict__ wphib = p.wphi + (size_t)col0 * p.Nlines * Ns;
-    const unsigned o_wphi = (unsigned)((size_t)cc * p.Nlines * Ns * 8u);
-    const double* __restrict__ nsrb = p.nsr + (size_t)col0 * p.Ncont * Ns;
-    const unsigned o_nsr = (unsigned)((size_t)cc * p.Ncont * Ns * 8u);
-    const double* __restrict__ zb = p.height + (size_t)col0 * Ns;
-    const double* __restrict__ scab = p.sca + (size_t)col0 * Ns;
-    const unsigned o_col = (unsigned)((size_t)cc * Ns * 8u);
-
     const int kS = dir ? Ns - 1 : 0;
     const int dk = dir ? -1 : 1;
     const bool compact = p.phi_compact != 0;
@@ -158,8 +182,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
         if (l >= 0 && l < slots[u].Nlam && p.active[slots[u].trans * Nspect + la] != 0) pact |= 1u << u;
     }
     unsigned phi_o[NS], phi_k[NS], phi_m[NS];       // lines: byte offset of (depth 0, ray 0), per depth, per ray
-    unsigned nio[NS], njo[NS], wo[NS];              // byte offsets of n_i, n_j and wphi / nStar ratio at depth 0
-    double wlam[NS], alv[NS], cB[NS], gq[NS], Vc[NS], Uc[NS];
+    double wlam[NS], alv[NS], cB[NS], Vc[NS], Uc[NS];
 #pragma unroll
     for (int u = 0; u < NPT; ++u) {
         const bool a = (pact >> u) & 1u;
@@ -173,38 +196,25 @@ lsx_sweep_rs_kernel(const SweepParams p)
         phi_o[u] = o_phi + (unsigned)(e0 * 8);
         phi_k[u] = (line && a) ? (unsigned)((compact ? 1 : NR) * len * 8) : 0u;
         phi_m[u] = (line && a && !compact) ? (unsigned)(len * 8) : 0u;
-        nio[u] = o_n + (unsigned)(slots[u].li * Ns * 8);
-        njo[u] = o_n + (unsigned)(slots[u].lj * Ns * 8);
-        wo[u] = line ? o_wphi + (unsigned)(slots[u].wphi_off * 8) : o_nsr + (unsigned)(slots[u].base * 8);
         wlam[u] = (a && act) ? (4.0 * kPi) * p.wl[slots[u].wl_off + l] : 0.0;   // :451/:455, :665 without the angle weight
         alv[u] = (a && !line) ? p.alpha[slots[u].wl_off + l] : 0.0;
-        cB[u] = slots[u].cB; gq[u] = slots[u].g; Vc[u] = slots[u].Vc; Uc[u] = slots[u].Uc;
-        if constexpr (NPT == 1) asm volatile("" : "+v"(cB[u]), "+v"(gq[u]), "+v"(Vc[u]), "+v"(Uc[u]));
+        cB[u] = slots[u].cB; Vc[u] = slots[u].Vc; Uc[u] = slots[u].Uc;
+        if constexpr (NPT == 1) asm volatile("" : "+v"(cB[u]), "+v"(Vc[u]), "+v"(Uc[u]));
     }
 
     // ---- one depth's operands ------------------------------------------------------------------------------------------
     struct Ops {
-        double bc, be, jd, E, zk, sc;
-        double ni[NS], nj[NS], w3[NS];       // populations; wphi (lines) | nStar_i / nStar_j (continua)
+        double bc, be, jd, E;
         double ph[NS][NR];                   // line profile per ray
         double cr[NLK][3];                   // linked tiles: the continua's share of atom.eta, atom.chi[i], atom.chi[j]
     };
     auto load_ops = [&](int kk, Ops& o) __attribute__((always_inline)) {
         const unsigned kt = o_til + (unsigned)(kk * LW) * 8u;
-        const unsigned kc = (unsigned)kk * 8u;
         o.jd = at(Jdag, kt);
         o.bc = at(bgchi, kt);
         o.be = at(bgeta, kt);
-        o.zk = at(zb, o_col + kc);
-        o.sc = at(scab, o_col + kc);
         o.E = 0.0;
         if constexpr (HASC) o.E = at(Eb, kt);
-#pragma unroll
-        for (int u = 0; u < NPT; ++u) {
-            o.ni[u] = at(ncolb, nio[u] + kc);
-            o.nj[u] = at(ncolb, njo[u] + kc);
-            o.w3[u] = u < NL ? at(wphib, wo[u] + kc) : at(nsrb, wo[u] + kc);
-        }
 #pragma unroll
         for (int u = 0; u < NL; ++u)
 #pragma unroll
@@ -218,15 +228,16 @@ lsx_sweep_rs_kernel(const SweepParams p)
         }
     };
     // total opacity of ray m from one depth's operands (rh_method.py:613, 279-285)
-    auto chi_of = [&](const Ops& o, int m) __attribute__((always_inline)) {
+    auto chi_of = [&](const Ops& o, int kk, int m) __attribute__((always_inline)) {
+        const lds_f64* tk = ucol + kk * TR;
         double c = o.bc;
 #pragma unroll
         for (int u = 0; u < NPT; ++u) {
-            if (u < NL) c = fma(cB[u] * (o.ni[u] - gq[u] * o.nj[u]), o.ph[u][m], c);
+            if (u < NL) c = fma(tk[3 * u + 0], o.ph[u][m], c);
             else {
                 const bool a = (pact >> u) & 1u;
-                const double Vji = a ? (o.w3[u] * o.E) * alv[u] : 0.0;
-                c += o.ni[u] * alv[u] - o.nj[u] * Vji;
+                const double Vji = a ? (tk[3 * u + 2] * o.E) * alv[u] : 0.0;
+                c += tk[3 * u + 0] * alv[u] - tk[3 * u + 1] * Vji;
             }
         }
         return c;
@@ -243,14 +254,13 @@ lsx_sweep_rs_kernel(const SweepParams p)
         const Ops &cur = opA, &nxt = opB;
         const auto* tcol = p.temperature + (size_t)col * Ns;
         const double B0 = planck(tcol[Ns - 2], wav), B1 = planck(tcol[Ns - 1], wav);
-        const double hz = 0.5 * fabs(cur.zk - nxt.zk);
+        const double hz = ucol[(kS + dk + 1) * TR + 3 * NPT];          // 0.5 |z[Ns - 2] - z[Ns - 1]|: the interval behind depth kS + dk
 #pragma unroll
         for (int m = 0; m < NR; ++m) {
-            const double dtau_uw = zmu[m] * (chi_of(cur, m) + chi_of(nxt, m)) * hz;
+            const double dtau_uw = zmu[m] * (chi_of(cur, kS, m) + chi_of(nxt, kS + dk, m)) * hz;
             Iu[m] = B1 - (B0 - B1) / dtau_uw;
         }
     }
-    double zprev = opA.zk;
     double dJ = 0.0;
 
     // Gamma integrands of the previous depth wait in this wave's reduction rows [value][lane]; lane (c, q) of the first
@@ -292,25 +302,27 @@ lsx_sweep_rs_kernel(const SweepParams p)
         }
 
         // ---- ray-independent part (rh_method.py:601-632): continuum slots, emissivity without the lines
-        const double hdz = 0.5 * fabs(zprev - cur.zk);
-        zprev = cur.zk;
-        double etaB = cur.be + cur.sc * cur.jd;
+        const lds_f64* tk = ucol + k * TR;                                 // this depth's row of the lane's column
+        const double hdz = (ucol + TR * dir)[k * TR + 3 * NPT];            // the interval behind this ray: row k (down) / k + 1 (up)
+        double etaB = cur.be + tk[3 * NPT + 1] * cur.jd;
         double chiB = cur.bc;
-        double X[NS], Vjc[NS], Ujc[NS], chic[NS], njUc[NS];  // lines: X = cB (n_i - g n_j), n_j Uc; continua: Vji, Uji, chi
+        double X[NS], Vjc[NS], Ujc[NS], chic[NS], njUc[NS], njc[NS], w3k[NS];   // lines: X = cB (n_i - g n_j), n_j Uc, wphi; continua: Vji, Uji, chi, n_j
 #pragma unroll
         for (int u = 0; u < NPT; ++u) {
+            w3k[u] = tk[3 * u + 2];
             if (u < NL) {
-                X[u] = cB[u] * (cur.ni[u] - gq[u] * cur.nj[u]);           // :279-280, :613
-                njUc[u] = cur.nj[u] * Uc[u];                              // eta = n_j Uji = (n_j Uc) phi, :281, :614
-                Vjc[u] = Ujc[u] = chic[u] = 0.0;
+                X[u] = tk[3 * u + 0];
+                njUc[u] = tk[3 * u + 1];
+                Vjc[u] = Ujc[u] = chic[u] = njc[u] = 0.0;
             } else {
                 const bool a = (pact >> u) & 1u;
                 X[u] = njUc[u] = 0.0;
-                Vjc[u] = a ? (cur.w3[u] * cur.E) * alv[u] : 0.0;          // g_ij alpha, :284-285, :453
+                njc[u] = tk[3 * u + 1];
+                Vjc[u] = a ? (w3k[u] * cur.E) * alv[u] : 0.0;             // g_ij alpha, :284-285, :453
                 Ujc[u] = u_la * Vjc[u];                                   // :286
-                chic[u] = cur.ni[u] * alv[u] - cur.nj[u] * Vjc[u];
+                chic[u] = tk[3 * u + 0] * alv[u] - njc[u] * Vjc[u];
                 chiB += chic[u];
-                etaB = fma(cur.nj[u], Ujc[u], etaB);
+                etaB = fma(njc[u], Ujc[u], etaB);
             }
         }
 
@@ -480,8 +492,8 @@ lsx_sweep_rs_kernel(const SweepParams p)
                 if (u < NL) {
                     chi[u] = X[u] * cur.ph[u][m];
                     Uji[u] = Uc[u] * cur.ph[u][m];                         // :281
-                    eta[u] = cur.nj[u] * Uji[u];                           // :614
-                } else { chi[u] = chic[u]; Uji[u] = Ujc[u]; eta[u] = cur.nj[u] * Ujc[u]; }
+                    eta[u] = njUc[u] * cur.ph[u][m];                       // :614
+                } else { chi[u] = chic[u]; Uji[u] = Ujc[u]; eta[u] = njc[u] * Ujc[u]; }
             }
 #pragma unroll
             for (int u = 0; u < NPT; ++u) {
@@ -544,7 +556,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
             // lanes (c, j) -> element c * 12 + j of the value's row (= the lane number); idle lanes park zeros
 #pragma unroll
             for (int u = 0; u < NPT; ++u) {
-                const double wt = u < NL ? wlam[u] * cur.w3[u] : wlam[u];      // lines: x wphi (rh_method.py:451); continua :455
+                const double wt = u < NL ? wlam[u] * w3k[u] : wlam[u];         // lines: x wphi (rh_method.py:451); continua :455
                 red[(2 * u) * RROW + lane] = wt * G1[u];
                 red[(2 * u + 1) * RROW + lane] = wt * G2[u];
             }
@@ -611,7 +623,7 @@ template <int NPT, int NL, bool LK, int TOPO>
 static hipError_t launch_rs(const SweepParams& p, int ngroups, hipStream_t st)
 {
     const dim3 g((unsigned)(ngroups * p.n_class_tiles)), b(2 * LSX_WAVE);
-    hipLaunchKernelGGL((lsx_sweep_rs_kernel<NPT, NL, LK, TOPO>), g, b, lsx_rs_lds_doubles(NPT) * sizeof(double), st, p);
+    hipLaunchKernelGGL((lsx_sweep_rs_kernel<NPT, NL, LK, TOPO>), g, b, lsx_rs_lds_doubles(NPT, p.Nspace) * sizeof(double), st, p);
     return hipGetLastError();
 }
 
