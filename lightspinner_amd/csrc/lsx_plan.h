@@ -126,10 +126,11 @@ inline bool lsx_rs_instance_exists(int npt, int nl, bool lk, int topo)
     }
 }
 // LDS doubles of a ray-serial workgroup: exp table, [2 waves][2 npt + 1] rows of 64 (parked Gamma integrands, dJ), [2][64] J
-// exchange, and the per-depth operand table of the group's columns [LSX_RS_COLS][Nspace + 1][3 npt + 2]
+// exchange, the per-depth operand table of the group's columns [LSX_RS_COLS][Nspace + 1][3 npt + 2], the parked Gamma totals
 constexpr int lsx_rs_lds_doubles(int npt, int Ns)
 {
-    return LSX_EXP_TAB + 2 * (2 * (npt > 0 ? npt : 1) + 1) * 64 + 2 * LSX_WAVE + LSX_RS_COLS * (Ns + 1) * (3 * npt + 2);
+    return LSX_EXP_TAB + 2 * (2 * (npt > 0 ? npt : 1) + 1) * 64 + 2 * LSX_WAVE + LSX_RS_COLS * (Ns + 1) * (3 * npt + 2) +
+           2 * LSX_RS_COLS * 2 * (npt > 0 ? npt : 1) * 64;        // + [2 waves][columns x values][64] parked Gamma totals
 }
 
 namespace lsxd {

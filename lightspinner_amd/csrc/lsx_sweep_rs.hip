@@ -264,11 +264,13 @@ lsx_sweep_rs_kernel(const SweepParams p)
     double dJ = 0.0;
 
     // Gamma integrands of the previous depth wait in this wave's reduction rows [value][lane]; lane (c, q) of the first
-    // NC x NV lanes adds up the 12 wavelengths of column c for value q and stores the total: one store per depth.
+    // NC x NV lanes adds up the 12 wavelengths of column c for value q and parks the total in entry (step mod 64) of its row
+    // park[c NV + q][64]; every 64 steps (and at the end) each row leaves as ONE coalesced store of 64 consecutive depths.
     const int o_c = lane / NV, o_q = lane - o_c * NV;
-    const bool own = lane < NC * NV && o_c < ncg && (p.colmask ? p.colmask[col0 + o_c] != 0 : true);
-    double* __restrict__ gown = p.Gpart + (((size_t)(col0 + (o_c < ncg ? o_c : 0)) * p.nslot_total + slot0) * 4 + (size_t)(o_q * 2 + dir)) * Ns;
-    auto flush = [&](int kprev) __attribute__((always_inline)) {
+    const bool own = lane < NC * NV;
+    lds_f64* const park = utab + (size_t)NC * (p.Nspace + 1) * TR + (size_t)dir * NC * NV * 64;
+    double* __restrict__ gbase = p.Gpart + (((size_t)col0 * p.nslot_total + slot0) * 4 + (size_t)dir) * Ns;      // + (c nslot 4 + q 2) Ns + k
+    auto flush = [&](int sprev) __attribute__((always_inline)) {         // the totals of step sprev (depth kS + dk sprev)
         if constexpr (NPT >= 1) {
             typedef double lds_pair __attribute__((ext_vector_type(2)));
             const auto* src = (const __attribute__((address_space(3))) lds_pair*)(red + o_q * RROW + (o_c < NC ? o_c : 0) * LW);
@@ -276,7 +278,20 @@ lsx_sweep_rs_kernel(const SweepParams p)
             double acc = v2.x + v2.y;
 #pragma unroll
             for (int e = 1; e < LW / 2; ++e) { v2 = src[e]; acc += v2.x + v2.y; }
-            if (own) gown[kprev] = acc;
+            const int e64 = sprev & 63;
+            if (own) park[lane * 64 + e64] = acc;
+            if (e64 == 63 || sprev == Ns - 1) {
+                __builtin_amdgcn_wave_barrier();
+                const int kk = kS + dk * (sprev - e64 + lane);             // the depth parked in entry `lane` of every row
+                if (lane <= e64) {
+                    for (int c = 0; c < ncg; ++c) {
+                        if (p.colmask && LSX_CONST(uint8_t, p.colmask)[col0 + c] == 0) continue;      // a frozen column keeps its slabs
+#pragma unroll
+                        for (int q = 0; q < NV; ++q) gbase[((size_t)c * p.nslot_total * 4 + (size_t)q * 2) * Ns + kk] = park[(c * NV + q) * 64 + lane];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     };
 
@@ -297,7 +312,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
         // the Gamma totals of the previous depth (their values were parked at the end of the previous step)
         if constexpr (!FIRST && NPT >= 1) {
             __builtin_amdgcn_wave_barrier();
-            flush(k - dk);
+            flush(s - 1);
             __builtin_amdgcn_wave_barrier();
         }
 
@@ -581,7 +596,13 @@ lsx_sweep_rs_kernel(const SweepParams p)
     {
         // tiles with at most one per-ray slot: the operand buffers swap roles, two steps per loop trip; two slots: one step per trip
         // and one copy of the operands per step (the two-step body of a two-slot tile needs more registers than there are)
+#if defined(LSX_RS_SWAP2)
+        constexpr bool SWAP = true;
+#elif defined(LSX_RS_NOSWAP)
+        constexpr bool SWAP = false;
+#else
         constexpr bool SWAP = NPT <= 1;
+#endif
         auto one = [&](int s, auto ph) __attribute__((always_inline)) {
             if constexpr (SWAP) { if (s & 1) step(s, ph, opB, opA); else step(s, ph, opA, opB); }
             else { step(s, ph, opA, opB); opA = opB; }
@@ -605,7 +626,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
         one(Ns - 1, std::integral_constant<int, 3>{});
         if constexpr (NPT >= 1) {
             __builtin_amdgcn_wave_barrier();
-            flush(kS + dk * (Ns - 1));
+            flush(Ns - 1);
         }
     }
     // dJ of every (column, tile, direction): the maximum over the column's wavelengths (NaN propagates, rh_method.py:706)

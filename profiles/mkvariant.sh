@@ -7,6 +7,7 @@
 set -e
 cd "$(dirname "$0")/../lightspinner_amd/csrc"
 NAME=$1; XF=$2; MODE=${3:-sweep}
+XD=$(for f in $XF; do case $f in -D*) echo -n "$f ";; esac; done)      # what the host-side plan needs of the flags
 make -s build/lsx_hip.o build/lsx_setup.o build/lsx_grid.o build/lsx_plan.o build/lsx_sweep.o build/lsx_sweep_rs.o
 mkdir -p ../../ab_so /tmp/lsxvar
 CF="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -DLSX_WAVES_PER_EU=4"
@@ -15,12 +16,12 @@ if [ "$MODE" = host ]; then
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../ab_so/$NAME.so /tmp/lsxvar/$NAME.o build/lsx_setup.o build/lsx_grid.o build/lsx_plan.o build/lsx_sweep.o build/lsx_sweep_rs.o
 elif [ "$MODE" = rs ]; then     # the ray-serial sweep (lsx_sweep_rs.hip) with the flags
   /opt/rocm/bin/hipcc $CF $XF -c lsx_sweep_rs.hip -o /tmp/lsxvar/$NAME.o
-  g++ -O2 -std=c++17 -fPIC $XF -c lsx_plan.cpp -o /tmp/lsxvar/${NAME}_plan.o
+  g++ -O2 -std=c++17 -fPIC $XD -c lsx_plan.cpp -o /tmp/lsxvar/${NAME}_plan.o
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../ab_so/$NAME.so build/lsx_hip.o build/lsx_setup.o build/lsx_grid.o /tmp/lsxvar/${NAME}_plan.o build/lsx_sweep.o /tmp/lsxvar/$NAME.o
 else
   ONLY="-DLSX_ONLY_NR5"; [ "$MODE" = full ] && ONLY=""
   /opt/rocm/bin/hipcc $CF $ONLY $XF -c lsx_sweep.hip -o /tmp/lsxvar/$NAME.o
-  g++ -O2 -std=c++17 -fPIC $XF -c lsx_plan.cpp -o /tmp/lsxvar/${NAME}_plan.o
+  g++ -O2 -std=c++17 -fPIC $XD -c lsx_plan.cpp -o /tmp/lsxvar/${NAME}_plan.o
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../ab_so/$NAME.so build/lsx_hip.o build/lsx_setup.o build/lsx_grid.o /tmp/lsxvar/${NAME}_plan.o /tmp/lsxvar/$NAME.o build/lsx_sweep_rs.o
 fi
 echo "built ab_so/$NAME.so"
