@@ -127,10 +127,11 @@ inline bool lsx_rs_instance_exists(int npt, int nl, bool lk, int topo)
 }
 // LDS doubles of a ray-serial workgroup: exp table, [2 waves][2 npt + 1] rows of 64 (parked Gamma integrands, dJ), [2][64] J
 // exchange, the per-depth operand table of the group's columns [LSX_RS_COLS][Nspace + 1][3 npt + 2], the parked Gamma totals
+constexpr int lsx_rs_park(int npt) { return npt >= 2 ? 16 : 64; }      // depths a row of parked Gamma totals holds (two slots: 16, for two workgroups more per CU)
 constexpr int lsx_rs_lds_doubles(int npt, int Ns)
 {
     return LSX_EXP_TAB + 2 * (2 * (npt > 0 ? npt : 1) + 1) * 64 + 2 * LSX_WAVE + LSX_RS_COLS * (Ns + 1) * (3 * npt + 2) +
-           2 * LSX_RS_COLS * 2 * (npt > 0 ? npt : 1) * 64;        // + [2 waves][columns x values][64] parked Gamma totals
+           2 * LSX_RS_COLS * 2 * (npt > 0 ? npt : 1) * lsx_rs_park(npt);   // + [2 waves][columns x values][entries] parked Gamma totals
 }
 
 namespace lsxd {
@@ -160,7 +161,7 @@ struct PlanOptions {           // diagnostic switches (lsx_create reads them fro
     int occ_wg = 0;            // LSX_OCC_WG: at most this many workgroups per CU (through the LDS request)
     bool no_rs = false;        // LSX_NO_RS: every class through lsx_sweep.hip (one ray per lane)
     int rs_min_columns = LSX_RS_MIN_COLUMNS;   // LSX_RS_MIN_COLUMNS: contexts with fewer columns keep one ray per lane (too few wavefronts otherwise)
-    int rs_max_npt = 1;        // LSX_RS_MAX_NPT: classes with more per-ray slots keep one ray per lane (measured: the two-slot ray-serial instances need 240+ registers and lose to lsx_sweep.hip at C3 sizes)
+    int rs_max_npt = 2;        // LSX_RS_MAX_NPT: classes with more per-ray slots keep one ray per lane (diagnostic: 1 leaves the two-slot tiles to lsx_sweep.hip)
 };
 
 // launch shapes of the kernels around the sweep, fixed when the plan is made so that no enqueue path can fail on them

@@ -360,7 +360,13 @@ int lsx_set_atmosphere(lsx_ctx* c, int32_t col0, int32_t ncol, const lsx_atmosph
     const int Ns = c->Nspace;
     const size_t nc = (size_t)c->ncol;
     int rc;
-    if (!c->d_vBroad && ((rc = dmalloc(&c->d_vBroad, nc * c->Natoms * Ns)) || (rc = dmalloc(&c->d_aDamp, nc * std::max(1, c->Nlines) * Ns)))) return rc;
+    // (either both exist or neither: a failed second allocation must not leave a half-made pair behind for the next call)
+    if (!c->d_vBroad || !c->d_aDamp) {
+        if (c->d_vBroad) { (void)hipFree(c->d_vBroad); c->d_vBroad = nullptr; }
+        if (c->d_aDamp) { (void)hipFree(c->d_aDamp); c->d_aDamp = nullptr; }
+        if ((rc = dmalloc(&c->d_vBroad, nc * c->Natoms * Ns))) return rc;
+        if ((rc = dmalloc(&c->d_aDamp, nc * std::max(1, c->Nlines) * Ns))) { (void)hipFree(c->d_vBroad); c->d_vBroad = nullptr; return rc; }
+    }
     // staging: ne, vturb, nHGround, vlos
     const size_t per = (size_t)4 * Ns;
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(ncol, ((size_t)32 << 20) / per));

@@ -264,11 +264,12 @@ lsx_sweep_rs_kernel(const SweepParams p)
     double dJ = 0.0;
 
     // Gamma integrands of the previous depth wait in this wave's reduction rows [value][lane]; lane (c, q) of the first
-    // NC x NV lanes adds up the 12 wavelengths of column c for value q and parks the total in entry (step mod 64) of its row
-    // park[c NV + q][64]; every 64 steps (and at the end) each row leaves as ONE coalesced store of 64 consecutive depths.
+    // NC x NV lanes adds up the 12 wavelengths of column c for value q and parks the total in entry (step mod PE) of its row
+    // park[c NV + q][PE]; every PE steps (and at the end) each row leaves as ONE coalesced store of PE consecutive depths.
     const int o_c = lane / NV, o_q = lane - o_c * NV;
     const bool own = lane < NC * NV;
-    lds_f64* const park = utab + (size_t)NC * (p.Nspace + 1) * TR + (size_t)dir * NC * NV * 64;
+    constexpr int PE = lsx_rs_park(NPT);
+    lds_f64* const park = utab + (size_t)NC * (p.Nspace + 1) * TR + (size_t)dir * NC * NV * PE;
     double* __restrict__ gbase = p.Gpart + (((size_t)col0 * p.nslot_total + slot0) * 4 + (size_t)dir) * Ns;      // + (c nslot 4 + q 2) Ns + k
     auto flush = [&](int sprev) __attribute__((always_inline)) {         // the totals of step sprev (depth kS + dk sprev)
         if constexpr (NPT >= 1) {
@@ -278,16 +279,16 @@ lsx_sweep_rs_kernel(const SweepParams p)
             double acc = v2.x + v2.y;
 #pragma unroll
             for (int e = 1; e < LW / 2; ++e) { v2 = src[e]; acc += v2.x + v2.y; }
-            const int e64 = sprev & 63;
-            if (own) park[lane * 64 + e64] = acc;
-            if (e64 == 63 || sprev == Ns - 1) {
+            const int e64 = sprev & (PE - 1);
+            if (own) park[lane * PE + e64] = acc;
+            if (e64 == PE - 1 || sprev == Ns - 1) {
                 __builtin_amdgcn_wave_barrier();
                 const int kk = kS + dk * (sprev - e64 + lane);             // the depth parked in entry `lane` of every row
                 if (lane <= e64) {
                     for (int c = 0; c < ncg; ++c) {
                         if (p.colmask && LSX_CONST(uint8_t, p.colmask)[col0 + c] == 0) continue;      // a frozen column keeps its slabs
 #pragma unroll
-                        for (int q = 0; q < NV; ++q) gbase[((size_t)c * p.nslot_total * 4 + (size_t)q * 2) * Ns + kk] = park[(c * NV + q) * 64 + lane];
+                        for (int q = 0; q < NV; ++q) gbase[((size_t)c * p.nslot_total * 4 + (size_t)q * 2) * Ns + kk] = park[(c * NV + q) * PE + lane];
                     }
                 }
                 __builtin_amdgcn_wave_barrier();

@@ -75,6 +75,7 @@ class MaxReducer:
             if on_device:               # HIP engine, CPU collective (gloo rehearsal): stage through a device scratch
                 if self._dev_scratch is None:
                     self._dev_scratch = torch.zeros(4, dtype=torch.float64, device='cuda')
+                    torch.cuda.synchronize()        # the fill runs on torch's stream, lsx_monitors on the engine's: order them once
                 eng.monitors_to(self._dev_scratch.data_ptr())
                 eng.sync()
                 self.buf.copy_(self._dev_scratch)

@@ -145,17 +145,18 @@ def test_profiles_must_be_set_before_a_formal_solution(hip_lib):
     e.close()
 
 
-@pytest.mark.parametrize('mode', ['default', 'ray-serial', 'ray-per-lane'])
+@pytest.mark.parametrize('mode', ['default', 'mixed', 'ray-per-lane'])
 @pytest.mark.parametrize('name,ncol,nuniq', [('falc_ca.npz', 1000, 8), ('falc_cah.npz', 1250, 10)])
 def test_full_size_batches_by_size_independent_properties(hip_lib, oracle_lib, monkeypatch, name, ncol, nuniq, mode):
     """BASELINE sizes (C3: 1000 CaII columns, C4: one GPU's 1250 Ca+H columns), where the oracle would take minutes:
     columns are independent 1-D problems, so a batch built from `nuniq` distinct columns repeated in a scrambled order must
     give every copy the bits its original gets in a small batch -- whatever its position, its neighbours, its place inside
     a five-column wavefront or the size of the grid; the small batch itself is checked against the oracle.
-    default (what a context of this size runs: the ray-serial kernel for tiles with at most one per-ray slot, one ray per
-    lane for the others) and ray-serial (every class that has a ray-serial instance): the small batch is 37 columns (seven
-    column groups and one of two) forced onto the same kernels; ray-per-lane (LSX_NO_RS): the small batch takes the fused
-    launch, the big one the per-class launches.  Also: a frozen column keeps its state bit for bit while its neighbours
+    default (what a context of this size runs: the ray-serial kernel for every class, all of which have at most two per-ray
+    slots here) and mixed (LSX_RS_MAX_NPT=1: ray-serial for tiles with at most one per-ray slot, one ray per lane for the
+    two-line tiles, side by side in one call): the small batch is 37 columns (seven column groups and one of two) forced
+    onto the same kernels; ray-per-lane (LSX_NO_RS): the small batch takes the fused launch, the big one the per-class
+    launches.  Also: a frozen column keeps its state bit for bit while its neighbours
     iterate (lsx_set_active_columns)."""
     ray_serial = mode != 'ray-per-lane'
     prob, base, raw = fixtures.load_problem_npz(golden(name), phi_compact=False)
@@ -167,8 +168,8 @@ def test_full_size_batches_by_size_independent_properties(hip_lib, oracle_lib, m
     pick = lambda idx: (type(blk).concatenate([blk.slice(int(q), int(q) + 1) for q in idx]), tuple(p[idx] for p in prof))
     if ray_serial:
         monkeypatch.setenv('LSX_RS_MIN_COLUMNS', '1')
-        if mode == 'ray-serial':
-            monkeypatch.setenv('LSX_RS_MAX_NPT', '2')
+        if mode == 'mixed':
+            monkeypatch.setenv('LSX_RS_MAX_NPT', '1')
     else:
         monkeypatch.setenv('LSX_NO_RS', '1')
     small = Engine(prob, nsmall, lib=hip_lib)
@@ -195,7 +196,7 @@ def test_full_size_batches_by_size_independent_properties(hip_lib, oracle_lib, m
     assert relerr(small.get(_capi.LSX_N)[first], ora.get(_capi.LSX_N)) < tol and relerr(small.get(_capi.LSX_I)[first], ora.get(_capi.LSX_I)) < tol
     table, fused = class_table(hip_lib, big)
     assert fused == 0 and all(launches == 6 for _, launches in table.values())
-    expect = {key: (ray_serial and (mode == 'ray-serial' or key[0] <= 1)) for key in table}
+    expect = {key: (ray_serial and (mode == 'default' or key[0] <= 1)) for key in table}
     assert class_table.ray_serial == expect, class_table.ray_serial
     if ray_serial:
         table, fused = class_table(hip_lib, small)
