@@ -595,14 +595,14 @@ lsx_sweep_rs_kernel(const SweepParams p)
         }
     };
     {
-        // tiles with at most one per-ray slot: the operand buffers swap roles, two steps per loop trip; two slots: one step per trip
-        // and one copy of the operands per step (the two-step body of a two-slot tile needs more registers than there are)
+        // the operand buffers swap roles, two steps per loop trip -- where the two-step body fits the register file; the other
+        // two-slot tiles take one step per trip and one copy of the operands per step
 #if defined(LSX_RS_SWAP2)
         constexpr bool SWAP = true;
 #elif defined(LSX_RS_NOSWAP)
         constexpr bool SWAP = false;
 #else
-        constexpr bool SWAP = NPT <= 1;
+        constexpr bool SWAP = NPT <= 1 || (!LK && TOPO != 0);      // (two lines with a known relation, no linked continua: 2 spilled registers)
 #endif
         auto one = [&](int s, auto ph) __attribute__((always_inline)) {
             if constexpr (SWAP) { if (s & 1) step(s, ph, opB, opA); else step(s, ph, opA, opB); }
