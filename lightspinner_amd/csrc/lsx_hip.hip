@@ -443,7 +443,9 @@ __global__ void __launch_bounds__(256) k_fast_prepass(const FastParams f)
                 if (u < nLc) {
                     cr[(size_t)(3 * u + 0) * plane] = EC[u];
                     cr[(size_t)(3 * u + 1) * plane] = XCi[u];
-                    cr[(size_t)(3 * u + 2) * plane] = XCj[u];
+                    // a tile with a single per-ray slot never reads atom.chi[j_line] (it multiplies atom.U[i_line], which only
+                    // another slot feeds): its third stream stays as lsx_create zeroed it
+                    if (tl.nP > 1) cr[(size_t)(3 * u + 2) * plane] = XCj[u];
                 }
         }
     }
@@ -1490,6 +1492,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     if (c->any_cont) TRY(dmalloc(&c->d_E, nc * c->til_col));
     if (c->corr_col) {
         TRY(dmalloc(&c->d_corr, nc * c->corr_col));
+        (void)hipMemsetAsync(c->d_corr, 0, nc * c->corr_col * 8, c->stream);
         TRY(dmalloc(&c->d_Psi3, 2 * nc * c->pp_col));
         (void)hipMemsetAsync(c->d_Psi3, 0, 2 * nc * c->pp_col * 8, c->stream);
     }

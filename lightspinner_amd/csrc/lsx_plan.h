@@ -127,10 +127,13 @@ inline bool lsx_rs_instance_exists(int npt, int nl, bool lk, int topo)
 }
 // LDS doubles of a ray-serial workgroup: exp table, [2 waves][2 npt + 1] rows of 64 (parked Gamma integrands, dJ), [2][64] J
 // exchange, the per-depth operand table of the group's columns [LSX_RS_COLS][Nspace + 1][3 npt + 2], the parked Gamma totals
+// doubles between two columns of the operand table: the five columns of a wavefront read the same row at once, so their
+// rows must not share LDS banks (a stride that is a multiple of 8 doubles would put columns 0 and 4 on the same banks)
+constexpr int lsx_rs_ucol_stride(int npt, int Ns) { return (Ns + 1) * (3 * npt + 2) + ((((Ns + 1) * (3 * npt + 2)) % 8) == 0 ? 1 : 0); }
 constexpr int lsx_rs_park(int npt) { return npt >= 2 ? 16 : 64; }      // depths a row of parked Gamma totals holds (two slots: 16, for two workgroups more per CU)
 constexpr int lsx_rs_lds_doubles(int npt, int Ns)
 {
-    return LSX_EXP_TAB + 2 * (2 * (npt > 0 ? npt : 1) + 1) * 64 + 2 * LSX_WAVE + LSX_RS_COLS * (Ns + 1) * (3 * npt + 2) +
+    return LSX_EXP_TAB + 2 * (2 * (npt > 0 ? npt : 1) + 1) * 64 + 2 * LSX_WAVE + LSX_RS_COLS * lsx_rs_ucol_stride(npt, Ns) +
            2 * LSX_RS_COLS * 2 * (npt > 0 ? npt : 1) * lsx_rs_park(npt);   // + [2 waves][columns x values][entries] parked Gamma totals
 }
 

@@ -111,10 +111,11 @@ lsx_sweep_rs_kernel(const SweepParams p)
     etab[threadIdx.x] = p.exp2_tab[threadIdx.x];
     {
         const int Nsp = p.Nspace;
+        const int ucs = lsx_rs_ucol_stride(NPT, Nsp);
         for (int e = threadIdx.x; e < NC * (Nsp + 1); e += 2 * LSX_WAVE) {
             const int c = e / (Nsp + 1), k = e - c * (Nsp + 1);
             const int colc = col0 + (c < ncg ? c : ncg - 1);
-            lds_f64* row = utab + (size_t)e * TR;
+            lds_f64* row = utab + (size_t)c * ucs + (size_t)k * TR;
             if (k == Nsp) {
 #pragma unroll
                 for (int t = 0; t < TR; ++t) row[t] = 0.0;
@@ -140,7 +141,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
         }
     }
     __syncthreads();
-    const lds_f64* const ucol = utab + (size_t)cc * (p.Nspace + 1) * TR;            // this lane's column
+    const lds_f64* const ucol = utab + (size_t)cc * lsx_rs_ucol_stride(NPT, p.Nspace);       // this lane's column
 
     // ---- per-lane bases: every stream of a column is addressed as (wave-uniform base of column col0) + 32-bit byte offset
     const size_t til_col = (size_t)ntile * Ns * LW;
@@ -269,7 +270,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
     const int o_c = lane / NV, o_q = lane - o_c * NV;
     const bool own = lane < NC * NV;
     constexpr int PE = lsx_rs_park(NPT);
-    lds_f64* const park = utab + (size_t)NC * (p.Nspace + 1) * TR + (size_t)dir * NC * NV * PE;
+    lds_f64* const park = utab + (size_t)NC * lsx_rs_ucol_stride(NPT, p.Nspace) + (size_t)dir * NC * NV * PE;
     double* __restrict__ gbase = p.Gpart + (((size_t)col0 * p.nslot_total + slot0) * 4 + (size_t)dir) * Ns;      // + (c nslot 4 + q 2) Ns + k
     auto flush = [&](int sprev) __attribute__((always_inline)) {         // the totals of step sprev (depth kS + dk sprev)
         if constexpr (NPT >= 1) {
