@@ -270,7 +270,7 @@ __global__ void k_gamma_finish(const FinishParams f)
     for (int e = 0; e < f.NL2tot; ++e) G[e * nt] = 0.0 + Cm[(size_t)e * Ns];     // Gamma = C, :587-590
     const double* P = f.Gpart + (size_t)col * f.nslot_total * 4 * Ns + k;
     // slabs in (tile, slot, entry, direction) order = slot-table order; the loads of several slots are in flight at once
-#pragma unroll 4
+#pragma unroll 8
     for (int u = 0; u < f.nslot_total; ++u) {
         const int ts = f.tile_slots[u];
         const bool fast = (ts >> 30) & 1;                    // fast continuum: one entry carries both directions
