@@ -1552,12 +1552,18 @@ lsx_sweep_kernel_parabolic(const SweepParams p)
     sweep_tile_parabolic<NR, SCAL>(p, vb, tile_id);
 }
 
+#ifndef LSX_PAR_WPE0
+#define LSX_PAR_WPE0 4
+#endif
 #ifndef LSX_PAR_WPE1
-#define LSX_PAR_WPE1 2
+#define LSX_PAR_WPE1 3
+#endif
+#ifndef LSX_PAR_WPE2
+#define LSX_PAR_WPE2 2
 #endif
 // N4, compile-time classes: one kernel per (slots, lines, linked, relation), five rays
 template <int NPT, int NL, bool LK, int TOPO>
-__global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(NPT <= 1 ? LSX_PAR_WPE1 : 2)))
+__global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(NPT == 0 ? LSX_PAR_WPE0 : NPT == 1 ? LSX_PAR_WPE1 : LSX_PAR_WPE2)))
 lsx_sweep_kernel_par(const SweepParams p)
 {
     int vb;

@@ -25,7 +25,9 @@ def load(eng, b, p, n):
     synth.load_columns(eng, b.slice(0, n), tuple(x[:n] for x in p))
 
 
+solver = os.environ.get('LSX_AB_SOLVER', 'linear')       # 'parabolic': time and check the N4 rule instead
 eng = Engine(prob, ncol, lib=lib)
+eng.set_formal_solver(solver)
 load(eng, blk, prof, ncol)
 for _ in range(3):
     drivers.mali_step(eng)
@@ -45,6 +47,7 @@ ora = oracle.load()
 nchk = 40
 e1, e2 = Engine(prob, nchk, lib=lib), Engine(prob, nchk, lib=ora)
 for e in (e1, e2):
+    e.set_formal_solver(solver)
     load(e, blk, prof, nchk)
 ora.dll.lsx_oracle_set_threads(e2._h, 16)
 e1.formal_sol_gamma(); e2.formal_sol_gamma()
@@ -56,5 +59,6 @@ for it in range(2, 8):
         if it > 3:
             e.stat_equil()
 en = relerr(e1.get(_capi.LSX_N), e2.get(_capi.LSX_N))
-print('%-22s %s ncol=%d sweep %.4f ms  fs %.4f ms  step %.4f ms | call1 J %.1e I %.1e Goff %.1e Gdiag %.1e | it7 n %.1e'
-      % (os.path.basename(so), wl, ncol, best[0], best[1], step, eJ, eI, off, diag, en))
+print('%-22s %s' % (os.path.basename(so), solver), end=' ')
+print('%s ncol=%d sweep %.4f ms  fs %.4f ms  step %.4f ms | call1 J %.1e I %.1e Goff %.1e Gdiag %.1e | it7 n %.1e'
+      % (wl, ncol, best[0], best[1], step, eJ, eI, off, diag, en))
