@@ -448,13 +448,16 @@ def main():
         if not args.no_single_column:
             p1, b1, r1 = fixtures.load_problem_npz(os.path.join(ROOT, 'tests', 'golden', 'falc_ca.npz'))
             e1 = Engine(p1, 1, device=local_rank, stream=ts.cuda_stream, lib=lib)
-            e1.set_columns(0, b1)
-            t0 = time.perf_counter()
-            h = drivers.iterate_mali_engine(e1)
-            t_c2 = time.perf_counter() - t0
+            t_runs = []
+            for _ in range(3):       # the first run pays for code objects and first launches; `seconds` is the best of the others
+                e1.set_columns(0, b1)
+                t0 = time.perf_counter()
+                h = drivers.iterate_mali_engine(e1)
+                t_runs.append(time.perf_counter() - t0)
+            t_c2 = min(t_runs[1:])
             nref = fixtures.pops_from_raw(r1, 'conv', p1)
             n1 = e1.get(_capi.LSX_N)[0]
-            single = dict(n_iter=h.n_iter, converged=h.converged, seconds=t_c2, mali_iters_per_sec=h.n_iter / t_c2,
+            single = dict(n_iter=h.n_iter, converged=h.converged, seconds=t_c2, seconds_first_run=t_runs[0], mali_iters_per_sec=h.n_iter / t_c2,
                           point_updates_per_sec=p1.work_units_per_column() * h.n_iter / t_c2,
                           max_dn_over_n_vs_ref=float(np.max(np.abs(n1 - nref) / np.abs(nref))),
                           max_dI_over_I_vs_ref=float(np.max(np.abs(e1.get(_capi.LSX_I)[0] - r1['conv_I']) / np.abs(r1['conv_I']))),

@@ -113,6 +113,7 @@ enum {
     LSX_GAMMA = 3,     /* [NL2tot][Nspace]  atom.Gamma[i][j][k], atoms concatenated   */
     LSX_DJ_COL = 4,    /* [1]  per-column max|1-Jdag/J| of the last FS call           */
     LSX_DPOPS_COL = 5, /* [1]  per-column max rel. population change of the last SE   */
+                       /*      (valid from that lsx_stat_equil until the next lsx_formal_sol_gamma, whose epilogue clears it) */
     LSX_NSTAR = 6,     /* [NLtot][Nspace]                                             */
     LSX_C = 7,         /* [NL2tot][Nspace]                                            */
     /* 8, 9: not assigned.  t.Rij / t.Rji (rh_method.py:691-692) are write-only state of the reference -- accumulated

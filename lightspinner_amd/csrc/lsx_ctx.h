@@ -49,7 +49,9 @@ struct lsx_ctx : lsxd::LsxPlan {        // the plan (lsx_plan.h: dimensions, tab
     uint8_t* d_active = nullptr;
     DevTrans* d_trans = nullptr;
     DevTile* d_tiles = nullptr;
-    int *d_tile_slots = nullptr, *d_Nlevel = nullptr, *d_lev2_off = nullptr;
+    int *d_tile_slots = nullptr, *d_Nlevel = nullptr, *d_lev2_off = nullptr, *d_fin_ptr = nullptr, *d_fin_idx = nullptr;
+    bool dp_zeroed = false;          // the Gamma epilogue has zeroed dPcol / the singular flag for the next stat_equil
+    bool opt_finish_big = false;     // LSX_FINISH_BIG=1: the many-column Gamma epilogue also for small batches (tests)
     // device: per column
     double *d_height = nullptr, *d_temperature = nullptr, *d_nStar = nullptr, *d_nTotal = nullptr, *d_n = nullptr,
            *d_C = nullptr, *d_Gamma = nullptr, *d_wphi = nullptr, *d_bgchi = nullptr, *d_bgeta = nullptr,

@@ -198,6 +198,18 @@ static __device__ __forceinline__ double fma3s(double a, double b_uniform, doubl
 #endif
 }
 
+// ... and with a wave-uniform addend (Horner steps: the coefficient sits in a scalar register pair)
+static __device__ __forceinline__ double fma3c(double a, double b, double c_uniform)
+{
+#ifndef LSX_NO_FMA3
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_uniform));
+    return d;
+#else
+    return fma(a, b, c_uniform);
+#endif
+}
+
 typedef __attribute__((address_space(3))) double lds_f64;   // LDS pointers carry their address space: ds_ instructions, no flat-pointer checks
 
 // exp(x) for the sweep (x = -dtau, -50 <= x <= -5e-4 where the value is used): x = (64 q + j) ln2/64 + r with
@@ -279,6 +291,9 @@ static __device__ __forceinline__ void w2(double dtau, double& w0, double& w1, c
 
 // Weights of the parabolic rule (include/lsx.h, N4): w_n = int_0^dtau t^n e^-t dt, n = 0, 1, 2; same regimes and the same
 // exponential as w2.
+// SCOEF: the series' coefficients as scalar operands of three-address fmas (no vector moves, 24 scalar registers held across the
+// depth loop -- for the instances that have them to spare); otherwise the compiler's choice (vector constants, v_fmac + moves)
+template <bool SCOEF = false>
 static __device__ __forceinline__ void w3(double dtau, double& w0, double& w1, double& w2q, const lds_f64* exp2_tab)
 {
     // Below dtau = 0.25 the closed forms cancel (oracle/lsx_oracle.c, w3: three twelve-term series there).  Here ONE series,
@@ -299,7 +314,24 @@ static __device__ __forceinline__ void w3(double dtau, double& w0, double& w1, d
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     if (__builtin_amdgcn_ballot_w64(small) != 0) {          // no lane in the series regime (deep layers): skip it
         const double x = dtau;
-        s2 = x * x * x * (1.0 / 3.0 + x * (-1.0 / 4.0 + x * (1.0 / 10.0 + x * (-1.0 / 36.0 + x * (1.0 / 168.0 + x * (-1.0 / 960.0 + x * (1.0 / 6480.0 + x * (-1.0 / 50400.0 + x * (1.0 / 443520.0 + x * (-1.0 / 4354560.0 + x * (1.0 / 47174400.0 + x * (-1.0 / 558835200.0))))))))))));
+        // sum_n (-1)^n x^(n+3) / (n! (n + 3)), twelve terms (x < 0.25: the next one is below 1e-19 of the first)
+        double t;
+        if constexpr (SCOEF) {
+            t = fma3c(x, -1.0 / 558835200.0, 1.0 / 47174400.0);
+            t = fma3c(x, t, -1.0 / 4354560.0);
+            t = fma3c(x, t, 1.0 / 443520.0);
+            t = fma3c(x, t, -1.0 / 50400.0);
+            t = fma3c(x, t, 1.0 / 6480.0);
+            t = fma3c(x, t, -1.0 / 960.0);
+            t = fma3c(x, t, 1.0 / 168.0);
+            t = fma3c(x, t, -1.0 / 36.0);
+            t = fma3c(x, t, 1.0 / 10.0);
+            t = fma3c(x, t, -1.0 / 4.0);
+            t = fma3c(x, t, 1.0 / 3.0);
+        } else {
+            t = 1.0 / 3.0 + x * (-1.0 / 4.0 + x * (1.0 / 10.0 + x * (-1.0 / 36.0 + x * (1.0 / 168.0 + x * (-1.0 / 960.0 + x * (1.0 / 6480.0 + x * (-1.0 / 50400.0 + x * (1.0 / 443520.0 + x * (-1.0 / 4354560.0 + x * (1.0 / 47174400.0 + x * (-1.0 / 558835200.0)))))))))));
+        }
+        s2 = (x * x) * (x * t);
         s1 = 0.5 * fma(x * x, e, s2);
         s0 = fma(x, e, s1);
     }
@@ -337,24 +369,31 @@ static __device__ __forceinline__ Para parabolic_point(double Iu, double S_u, do
     return r;
 }
 
-// the same point with the divisions as v_rcp_f64 + one Newton step (four reciprocals instead of nine divisions): the
-// compile-time tile classes of the parabolic rule (lsx_sweep.hip, sweep_tile_par); relative differences of a few 1e-15
-static __device__ __forceinline__ Para parabolic_point_fast(double Iu, double S_u, double S_k, double S_d, double dtau_u, double dtau_d, bool has_d,
-                                                            const lds_f64* etab)
+// the same point with the divisions as v_rcp_f64 + one Newton step: the compile-time tile classes of the parabolic rule
+// (lsx_sweep.hip, sweep_tile_par); relative differences of a few 1e-15.  Two reciprocals per point instead of nine divisions:
+// 1 / dtau_u is the previous point's 1 / dtau_d (handed over in `ru`, returned in `rd`), and the harmonic mean is taken over one
+// common denominator: with alpha = (u + 2 d) / (3 (u + d)), beta = (2 u + d) / (3 (u + d)),
+//   a = p q / (alpha q + beta p) = 3 (u + d) p q / D,   da/dS = (beta p^2 / d - alpha q^2 / u) / (alpha q + beta p)^2
+//                                                             = ((2 u + d) p^2 / d - (u + 2 d) q^2 / u) 3 (u + d) / D^2,
+//   D = (u + 2 d) q + (2 u + d) p      (p q > 0: both terms have one sign, D != 0)
+template <bool SCOEF>
+static __device__ __forceinline__ Para parabolic_point_fast(double Iu, double S_u, double S_k, double S_d, double dtau_u, double ru, double dtau_d,
+                                                            bool has_d, const lds_f64* etab, double& rd)
 {
     double w0, w1, w2q;
-    w3(dtau_u, w0, w1, w2q, etab);
-    const double ru = rcp(dtau_u);
+    w3<SCOEF>(dtau_u, w0, w1, w2q, etab);
     const double p = (S_u - S_k) * ru;
     double a = p, dadS = -ru;                                        // end point: the linear rule
+    rd = 1.0;
     if (has_d) {
-        const double rd = rcp(dtau_d);
+        rd = rcp(dtau_d);
         const double q = (S_k - S_d) * rd;
         if (p * q > 0.0) {
-            const double alpha = (1.0 + dtau_d * rcp(dtau_u + dtau_d)) * (1.0 / 3.0), beta = 1.0 - alpha;
-            const double rden = rcp(alpha * q + beta * p);
-            a = (p * q) * rden;
-            dadS = ((beta * p) * p * rd - (alpha * q) * q * ru) * (rden * rden);
+            const double sum = dtau_u + dtau_d, cu = sum + dtau_d, cd = sum + dtau_u;
+            const double rden = rcp(cu * q + cd * p);
+            const double t3 = (3.0 * sum) * rden;
+            a = (p * q) * t3;
+            dadS = ((cd * p) * p * rd - (cu * q) * q * ru) * (t3 * rden);
             if (fabs(a) > 2.0 * fabs(p)) { a = 2.0 * p; dadS = -2.0 * ru; }
         } else {
             a = 0.0;

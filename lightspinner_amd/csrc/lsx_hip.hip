@@ -249,6 +249,10 @@ struct FinishParams {
     double* Gamma;
     double* dJcol;
     const uint8_t* colmask;
+    double* dPcol;                      // zeroed here for the stat_equil that follows (its per-column maxima are atomic)
+    unsigned long long* singular;       // likewise
+    const int* fin_ptr;                 // [NL2tot + 1]  k_gamma_finish_small: the slabs that add up to one entry,
+    const int* fin_idx;                 //               as (slot * 4 + slab), in slot order
 };
 
 // Gamma = C + sum of the sweep's slabs in (tile, slot, entry, direction) order; then the
@@ -261,6 +265,8 @@ __global__ void k_gamma_finish(const FinishParams f)
     const long gid = (long)blockIdx.x * nt + tid;
     if (gid >= (long)f.ncol * Ns) return;
     const int col = gid / Ns, k = gid % Ns;
+    if (k == 0) f.dPcol[col] = 0.0;
+    if (gid == 0) *f.singular = 0ull;
     if (f.colmask && !f.colmask[col]) {
         if (k == 0) f.dJcol[col] = 0.0;
         return;
@@ -306,6 +312,68 @@ __global__ void k_gamma_finish(const FinishParams f)
             m = (v != v || m != m) ? __builtin_nan("") : fmax(m, v);
         }
         f.dJcol[col] = m;
+    }
+}
+
+// The same epilogue for small batches (fewer than 32 columns: the fused sweep launch), where k_gamma_finish is one long chain
+// of dependent adds per thread and nothing else runs: one wavefront per (column, depth), lane = Gamma entry.  The slabs of an
+// entry are listed in slot order (fin_ptr / fin_idx, made with the context), i.e. each entry is summed in exactly the order
+// k_gamma_finish sums it: the two kernels give the same bits.
+__global__ void __launch_bounds__(64) k_gamma_finish_small(const FinishParams f)
+{
+    extern __shared__ double sm[];                          // [NL2tot]
+    const int Ns = f.Nspace;
+    const int col = blockIdx.x / Ns, k = blockIdx.x - col * Ns;
+    const int lane = threadIdx.x;
+    if (k == 0 && lane == 0) {
+        f.dPcol[col] = 0.0;
+        if (col == 0) *f.singular = 0ull;
+    }
+    if (f.colmask && !f.colmask[col]) {
+        if (k == 0 && lane == 0) f.dJcol[col] = 0.0;
+        return;
+    }
+    const double* P = f.Gpart + (size_t)col * f.nslot_total * 4 * Ns + k;
+    const double* Cm = f.C + (size_t)col * f.NL2tot * Ns + k;
+    for (int e = lane; e < f.NL2tot; e += 64) {
+        double g = 0.0 + Cm[(size_t)e * Ns];                // Gamma = C, :587-590
+        const int b = f.fin_ptr[e], n = f.fin_ptr[e + 1];
+#pragma unroll 4
+        for (int i = b; i < n; ++i) g += P[(size_t)f.fin_idx[i] * Ns];
+        sm[e] = g;
+    }
+    __syncthreads();
+    double diag = 0.0;                                      // Gamma_ii = -sum_{l != i} Gamma_li, :698-703 (one level per lane)
+    int dpos = -1;
+    for (int a = 0, base = 0; a < f.Natoms; ++a) {
+        const int Nl = f.Nlevel[a];
+        const int i = lane - base;
+        if (i >= 0 && i < Nl) {
+            const double* Ga = sm + f.lev2_off[a];
+            double s = 0.0;
+            for (int l = 0; l < Nl; ++l) s += (l == i) ? 0.0 : Ga[l * Nl + i];
+            diag = -s;
+            dpos = f.lev2_off[a] + i * Nl + i;
+        }
+        base += Nl;
+    }
+    __syncthreads();
+    if (dpos >= 0) sm[dpos] = diag;
+    __syncthreads();
+    double* Gout = f.Gamma + (size_t)col * f.NL2tot * Ns + k;
+    for (int e = lane; e < f.NL2tot; e += 64) Gout[(size_t)e * Ns] = sm[e];
+    if (k == 0) {     // per-column dJ: max over the column's tiles, NaN propagating (rh_method.py:705-706)
+        double m = 0.0;
+        for (int t = lane; t < 2 * f.ntile; t += 64) {
+            const double v = f.dJpart[(size_t)col * 2 * f.ntile + t];
+            m = (v != v || m != m) ? __builtin_nan("") : fmax(m, v);
+        }
+#pragma unroll
+        for (int w = 1; w < 64; w <<= 1) {
+            const double o = __shfl_xor(m, w, 64);
+            m = (o != o || m != m) ? __builtin_nan("") : fmax(m, o);
+        }
+        if (lane == 0) f.dJcol[col] = m;
     }
 }
 
@@ -1342,7 +1410,7 @@ void lsx_destroy(lsx_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_wavelength, c->d_zmu, c->d_wmuh, c->d_wl, c->d_alpha, c->d_u_la, c->d_active, c->d_trans,
-                    c->d_tiles, c->d_slots, c->d_tile_slots, c->d_Nlevel, c->d_lev2_off, c->d_height,
+                    c->d_tiles, c->d_slots, c->d_tile_slots, c->d_fin_ptr, c->d_fin_idx, c->d_Nlevel, c->d_lev2_off, c->d_height,
                     c->d_temperature, c->d_nStar, c->d_nTotal, c->d_n, c->d_C, c->d_Gamma, c->d_wphi, c->d_bgchi,
                     c->d_bgeta, c->d_sca, c->d_phi, c->d_E, c->d_corr, c->d_Psi3, c->d_J[0], c->d_J[1], c->d_I, c->d_Gpart, c->d_dJpart,
                     c->d_res, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_fast_cols[0], c->d_fast_cols[1], c->d_fast_cols[2], c->d_fast_cols[3], c->d_fast_rest, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab, c->d_voigt_w, c->d_muz, c->d_wmu,
@@ -1419,6 +1487,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     c->opt_se_lds = getenv("LSX_SE_LDS") != nullptr;
     c->opt_trace_classes = getenv("LSX_TRACE_CLASSES") != nullptr;
     c->opt_serial = getenv("LSX_SERIAL") != nullptr;              // every class on the context's stream, one after the other
+    c->opt_finish_big = getenv("LSX_FINISH_BIG") != nullptr;      // the many-column Gamma epilogue also for small batches
     const int Ns = c->Nspace, Nspect = c->Nspect;
     double work_total = 0.0, work_seen = 0.0;
     for (auto& k : c->classes) work_total += k.work;
@@ -1446,6 +1515,26 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         std::vector<int> enc(c->tile_slots);
         for (size_t u = 0; u < enc.size(); ++u) enc[u] |= c->tile_slot_fast[u] ? (1 << 30) : 0;
         TRY(upload(&c->d_tile_slots, enc, c->stream));
+    }
+    {   // the slabs behind each Gamma entry, in slot order (k_gamma_finish_small): ij <- slabs 0, 1; ji <- slabs 2, 3; a fast
+        // continuum has one slab per entry
+        std::vector<std::vector<int>> lists((size_t)c->NL2tot);
+        for (size_t u = 0; u < c->tile_slots.size(); ++u) {
+            const DevTrans& tr = c->htrans[(size_t)c->tile_slots[u]];
+            const bool fast = c->tile_slot_fast[u];
+            lists[(size_t)tr.gam_ij].push_back((int)u * 4 + 0);
+            if (!fast) lists[(size_t)tr.gam_ij].push_back((int)u * 4 + 1);
+            lists[(size_t)tr.gam_ji].push_back((int)u * 4 + 2);
+            if (!fast) lists[(size_t)tr.gam_ji].push_back((int)u * 4 + 3);
+        }
+        std::vector<int> ptr((size_t)c->NL2tot + 1, 0), idx;
+        for (int e = 0; e < c->NL2tot; ++e) {
+            idx.insert(idx.end(), lists[(size_t)e].begin(), lists[(size_t)e].end());
+            ptr[(size_t)e + 1] = (int)idx.size();
+        }
+        if (idx.empty()) idx.push_back(0);
+        TRY(upload(&c->d_fin_ptr, ptr, c->stream));
+        TRY(upload(&c->d_fin_idx, idx, c->stream));
     }
     TRY(upload(&c->d_slots, c->slots, c->stream));
     TRY(upload(&c->d_Nlevel, c->Nlevel, c->stream));
@@ -1697,13 +1786,15 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
     // generic instance for every tile and takes the same route at any size
     const bool parabolic = c->solver == LSX_SOLVER_PARABOLIC;
     if (c->ncol < 32) {
-        if (has_fast) launch_prepass(c->stream, c->d_fast_tiles, c->fast_tiles.size());
-        const long nblocks = (long)c->tiles.size() * c->ncol;
-        p.class_tiles = nullptr;
-        p.n_class_tiles = (int)c->tiles.size();
         p.ncell_lev = S.fused_ncell_lev; p.ncell_atom = S.fused_ncell_atom;
         c->fused_launches++;
-        note(lsx_launch_sweep(&p, parabolic ? -4 : -2, (int)nblocks, S.fused_lds, c->stream));
+        const int code = parabolic ? -4 : -2;
+        // (measured: starting the tiles without fast continua on a second stream, ahead of the pre-pass, costs more in the
+        // fork and join than the 8 us it takes off the critical path: 4.62 against 4.40 ms for the 46 iterations of a FALC column)
+        if (has_fast) launch_prepass(c->stream, c->d_fast_tiles, c->fast_tiles.size());
+        p.class_tiles = nullptr;
+        p.n_class_tiles = (int)c->tiles.size();
+        note(lsx_launch_sweep(&p, code, (int)((long)c->tiles.size() * c->ncol), S.fused_lds, c->stream));
         if (has_fast) launch_fast_gamma(c->stream, c->fast_cols, c->d_fast_cols, c->d_fast_rest, c->fast_rest.size());
     } else {
         // The classes of one call run side by side on their own streams, forked from the context's stream and joined
@@ -1747,8 +1838,13 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
     f.nslot_total = (int)c->tile_slots.size(); f.Nlevel = c->d_Nlevel; f.lev2_off = c->d_lev2_off; f.tiles = c->d_tiles;
     f.tile_slots = c->d_tile_slots; f.trans = c->d_trans; f.C = c->d_C; f.Gpart = c->d_Gpart; f.dJpart = c->d_dJpart;
     f.Gamma = c->d_Gamma; f.dJcol = c->d_dJcol; f.colmask = c->d_colmask;
+    f.dPcol = c->d_dPcol; f.singular = c->d_singular; f.fin_ptr = c->d_fin_ptr; f.fin_idx = c->d_fin_idx;
     const long nthreads = (long)c->ncol * c->Nspace;
-    hipLaunchKernelGGL(k_gamma_finish, dim3((unsigned)((nthreads + S.finish_nt - 1) / S.finish_nt)), dim3(S.finish_nt), S.finish_lds, c->stream, f);
+    if (c->ncol < 32 && !c->opt_finish_big)
+        hipLaunchKernelGGL(k_gamma_finish_small, dim3((unsigned)nthreads), dim3(64), (size_t)c->NL2tot * sizeof(double), c->stream, f);
+    else
+        hipLaunchKernelGGL(k_gamma_finish, dim3((unsigned)((nthreads + S.finish_nt - 1) / S.finish_nt)), dim3(S.finish_nt), S.finish_lds, c->stream, f);
+    c->dp_zeroed = true;
     note(hipGetLastError());
     if (timed) note(hipEventRecord(c->ev2, c->stream));
     c->jcur ^= 1;
@@ -1795,7 +1891,10 @@ int lsx_stat_equil_async(lsx_ctx* c)
 {
     if (!c) return fail(LSX_EINVAL, "null ctx");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemsetAsync(c->d_dPcol, 0, ((size_t)c->ncol + 1) * 8, c->stream));     // dPcol and the singular flag behind it
+    // dPcol and the singular flag behind it start at zero: the Gamma epilogue of the formal solution has done that, unless
+    // this is a second stat_equil on the same Gamma
+    if (!c->dp_zeroed) HIPCHK(hipMemsetAsync(c->d_dPcol, 0, ((size_t)c->ncol + 1) * 8, c->stream));
+    c->dp_zeroed = false;
     const long nthreads = (long)c->ncol * c->Nspace;
     for (int a = 0; a < c->Natoms; ++a) {
         const int Nl = c->Nlevel[a];

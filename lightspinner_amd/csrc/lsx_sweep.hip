@@ -1314,7 +1314,7 @@ __device__ __forceinline__ void sweep_tile_par(const SweepParams& p, const int v
         const double B0 = planck(tcol[Ns - 2], wav), B1 = planck(tcol[Ns - 1], wav);
         Iu = B1 - (B0 - B1) / dtau_uw;
     }
-    double S_u = 0.0, dtau_u = 1.0;          // source function of the upwind depth, optical depth of the interval behind the local one
+    double S_u = 0.0, dtau_u = 1.0, rdt_u = 1.0;   // source function of the upwind depth, optical depth of the interval behind the local one and its reciprocal
     double dJ = 0.0;
 
     // finish depth m (this wave's m-th): formal solution, angle sums, Gamma integrands, J.  `d`: the depth's own values,
@@ -1329,12 +1329,13 @@ __device__ __forceinline__ void sweep_tile_par(const SweepParams& p, const int v
         }
         double jhalf = 0.0;
         if constexpr (PH == 2) jhalf = at(Jnew, kl);
-        double I, Lam;
+        double I, Lam, rdt_d;
         if (m == 0) {
             I = Iu;
             Lam = 0.0;
+            rdt_d = rcp(dtau_d);
         } else {
-            const Para r = parabolic_point_fast(Iu, S_u, d.S, has_d ? Sd : 0.0, dtau_u, has_d ? dtau_d : 1.0, has_d, etab);
+            const Para r = parabolic_point_fast<!LK>(Iu, S_u, d.S, has_d ? Sd : 0.0, dtau_u, rdt_u, has_d ? dtau_d : 1.0, has_d, etab, rdt_d);
             I = r.I;
             Lam = r.Lam;
         }
@@ -1342,6 +1343,7 @@ __device__ __forceinline__ void sweep_tile_par(const SweepParams& p, const int v
         Iu = I;
         S_u = d.S;
         dtau_u = dtau_d;
+        rdt_u = rdt_d;
         if (m == Ns - 1 && dir == 1 && valid) p.Iout[((size_t)col * Nspect + la) * NR + mu] = I;
         // angle quadrature: J (:640), Psibar and sum_mu w Psi* phi for the fast / linked continua
         xrow[lane] = wmuh_l * I;
@@ -1563,7 +1565,7 @@ lsx_sweep_kernel_parabolic(const SweepParams p)
 #endif
 // N4, compile-time classes: one kernel per (slots, lines, linked, relation), five rays
 template <int NPT, int NL, bool LK, int TOPO>
-__global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(NPT == 0 ? LSX_PAR_WPE0 : NPT == 1 ? LSX_PAR_WPE1 : LSX_PAR_WPE2)))
+__global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(NPT == 0 ? LSX_PAR_WPE0 : NPT == 1 ? (LK ? LSX_PAR_WPE1 : LSX_PAR_WPE1 + 1) : (LK ? LSX_PAR_WPE2 : LSX_PAR_WPE2 + 1))))
 lsx_sweep_kernel_par(const SweepParams p)
 {
     int vb;

@@ -210,6 +210,11 @@ lsx_sweep_rs_kernel(const SweepParams p)
         double cr[NLK][3];                   // linked tiles: the continua's share of atom.eta, atom.chi[i], atom.chi[j]
     };
     auto load_ops = [&](int kk, Ops& o) __attribute__((always_inline)) {
+#ifdef LSX_ABL_NOLOAD
+        // ablation build (profiles/r03_bound_evidence.md): every depth gets the operands of the middle one, fetched once; the
+        // values pass through an opaque move so that nothing computed from them leaves the loop
+        kk = Ns / 2;
+#endif
         const unsigned kt = o_til + (unsigned)(kk * LW) * 8u;
         o.jd = at(Jdag, kt);
         o.bc = at(bgchi, kt);
@@ -227,6 +232,13 @@ lsx_sweep_rs_kernel(const SweepParams p)
 #pragma unroll
                 for (int q = 0; q < NCR; ++q) o.cr[u][q] = at(corr, (unsigned)((3 * u + q) * plane) * 8u + kq);
         }
+#ifdef LSX_ABL_NOLOAD
+        asm volatile("" : "+v"(o.jd), "+v"(o.bc), "+v"(o.be), "+v"(o.E));
+#pragma unroll
+        for (int u = 0; u < NL; ++u)
+#pragma unroll
+            for (int m = 0; m < NR; ++m) asm volatile("" : "+v"(o.ph[u][m]));
+#endif
     };
     // total opacity of ray m from one depth's operands (rh_method.py:613, 279-285)
     auto chi_of = [&](const Ops& o, int kk, int m) __attribute__((always_inline)) {

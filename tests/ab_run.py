@@ -29,12 +29,18 @@ solver = os.environ.get('LSX_AB_SOLVER', 'linear')       # 'parabolic': time and
 eng = Engine(prob, ncol, lib=lib)
 eng.set_formal_solver(solver)
 load(eng, blk, prof, ncol)
-for _ in range(3):
-    drivers.mali_step(eng)
+time_only = os.environ.get('LSX_AB_TIME_ONLY') is not None    # ablation builds (wrong results by construction): formal solution only
+if not time_only:
+    for _ in range(3):
+        drivers.mali_step(eng)
 best = (1e9, 1e9)
 for _ in range(3):
     t, s = eng.time_formal_sol(2, 15)
     best = min(best, (s, t))
+if time_only:
+    print('%-22s %s %s ncol=%d sweep %.4f ms  fs %.4f ms  (formal solution only, results not checked)' % (os.path.basename(so), solver, wl, ncol, best[0], best[1]))
+    eng.close()
+    sys.exit(0)
 N = 30
 t0 = time.perf_counter()
 for _ in range(N):

@@ -128,6 +128,36 @@ def test_single_column_reaches_the_fused_kernel(hip_lib):
     e.close()
 
 
+@pytest.mark.parametrize('name,ncol', [('falc_ca.npz', 1), ('falc_cah.npz', 3)])
+def test_small_batch_gamma_epilogue_gives_the_bits_of_the_many_column_one(hip_lib, monkeypatch, name, ncol):
+    """fewer than 32 columns: the Gamma epilogue runs one wavefront per (column, depth) with one entry per lane
+    (k_gamma_finish_small); it sums every entry in the order the many-column kernel does, so Gamma, the monitors and the
+    populations after five iterations are the same bits.  A second stat_equil on the same Gamma (the epilogue has zeroed the
+    per-column maxima only once: the call has to do it itself) solves the same system again: it reports no change, not the
+    first call's."""
+    prob, base, raw = fixtures.load_problem_npz(golden(name), phi_compact=False)
+    blk, (aD, vB, vlos) = synth.perturbed_columns(prob, base, raw, ncol=ncol, seed=11, vlos_sigma=1.0e3)
+    out = []
+    for big in (False, True):
+        if big:
+            monkeypatch.setenv('LSX_FINISH_BIG', '1')
+        e = Engine(prob, ncol, lib=hip_lib)
+        e.set_columns(0, blk)
+        e.set_line_profiles(0, aD, vB, vlos)
+        mon = []
+        for it in range(5):
+            mon.append(e.formal_sol_gamma())
+            if it >= 2:
+                mon.append(e.stat_equil())
+        mon.append(e.stat_equil())                                  # twice on one Gamma
+        out.append((e.get(_capi.LSX_GAMMA), e.get(_capi.LSX_N), e.get(_capi.LSX_DJ_COL), e.get(_capi.LSX_DPOPS_COL), mon))
+        e.close()
+    for a, b in zip(out[0][:4], out[1][:4]):
+        assert np.array_equal(a, b)
+    assert out[0][4] == out[1][4]
+    assert out[0][4][-1] == 0.0 < out[0][4][-2]
+
+
 def test_profiles_must_be_set_before_a_formal_solution(hip_lib):
     """lsx_set_columns with phi == NULL leaves the profiles to lsx_set_line_profiles; a formal solution in between is
     refused instead of reading uninitialised memory"""
