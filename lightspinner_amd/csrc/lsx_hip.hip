@@ -758,7 +758,9 @@ __global__ void __launch_bounds__(NT) k_fast_gamma(const FastParams f)
 // arithmetic reads it from there.  Same terms, same order per wavelength as k_fast_gamma; the sum over the wavelengths
 // runs over the lane's pairs in ascending order, then lane 0 + lane 1.
 // (LSX_FAST_NQ, LSX_FGC_ROWS, LSX_FGC_MAXF: lsx_plan.h -- the plan sizes this kernel's LDS and decides which tiles it takes)
-template <int NLC>            // NLC: lines of the tile that linked continua feed (0: the tile has no linked continuum)
+// NPC: wavelength pairs per row known at compile time (6: twelve wavelengths, the five-ray tiling) -- the staging loop then has
+// three rounds, unrolled, with unconditional loads: all of a wave's loads are in flight together instead of round after round
+template <int NLC, int NPC>   // NLC: lines of the tile that linked continua feed (0: the tile has no linked continuum)
 __global__ void __launch_bounds__(256) k_fast_gamma_cols(const FastParams f)
 {
     constexpr bool LINKS = NLC > 0;
@@ -766,7 +768,7 @@ __global__ void __launch_bounds__(256) k_fast_gamma_cols(const FastParams f)
     extern __shared__ double sm[];
     const int t = f.fast_tiles[blockIdx.y];
     const DevTile tl = f.tiles[t];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, Ns = f.Nspace, L = f.L, NP = L / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, Ns = f.Nspace, L = NPC > 0 ? 2 * NPC : f.L, NP = NPC > 0 ? NPC : L / 2;
     const DevSlot* fs = f.slots + tl.slot0 + tl.nP;
     const DevSlot* ls = f.slots + tl.slot0;
     double* sA = sm;                                          // [q][j]{alpha, wlambda}, 0 where the continuum is inactive
@@ -787,52 +789,57 @@ __global__ void __launch_bounds__(256) k_fast_gamma_cols(const FastParams f)
     const size_t dstride = (size_t)f.ncol * f.ntile * Ns * L, pstride = (size_t)f.ncol * f.pp_col_stride, plane = (size_t)Ns * L;
     // ---- the wave's rows, global -> LDS: piece c = 16 bytes = wavelength pair c % NP of row c / NP
     const double2 zero2 = make_double2(0.0, 0.0);
-    for (int c = lane; c < R * NP; c += 64) {
+    auto stage = [&](const int c, auto masked) __attribute__((always_inline)) {
         const int r = c / NP, p = c - r * NP;
-        const long g = row0 + r;
-        double2 vJ = zero2, vP = zero2, vE = zero2, vL[NL1];
+        const long g0 = row0 + r;
+        // a row past the batch or of a frozen column reads the batch's last row (any valid address) and stores zeros; so do the pad
+        // wavelengths, which hold nothing defined
+        const unsigned g = (unsigned)(g0 < nrows ? g0 : nrows - 1);       // columns x depths < 2^31 (checked with the launch shapes)
+        const int col = (int)(g / (unsigned)Ns), k = (int)(g - (unsigned)col * (unsigned)Ns);
+        bool live = g0 < nrows;
+        if constexpr (decltype(masked)::value) {       // (an unconditional load, no short circuit: no branch between the rounds)
+            const bool on = f.colmask[col] != 0;
+            live = live & on;
+        }
+        const bool kx = live && 2 * p < tl.nla, ky = live && 2 * p + 1 < tl.nla;
+        const size_t o = ((size_t)((size_t)col * f.ntile + t) * Ns + k) * L + 2 * p;
+        const double2 vJ = *reinterpret_cast<const double2*>(f.J_T + o);
+        const double2 a = *reinterpret_cast<const double2*>(f.Psi2_T + o), b = *reinterpret_cast<const double2*>(f.Psi2_T + dstride + o);
+        const double2 vE = *reinterpret_cast<const double2*>(f.E_T + o);
+        double2 vL[NL1];
 #pragma unroll
-        for (int u = 0; u < NL1; ++u) vL[u] = zero2;
-        if (g < nrows) {
-            const int col = (int)(g / Ns), k = (int)(g - (long)col * Ns);
-            if (!f.colmask || f.colmask[col]) {
-                const size_t o = ((size_t)((size_t)col * f.ntile + t) * Ns + k) * L + 2 * p;
-                vJ = *reinterpret_cast<const double2*>(f.J_T + o);
-                const double2 a = *reinterpret_cast<const double2*>(f.Psi2_T + o), b = *reinterpret_cast<const double2*>(f.Psi2_T + dstride + o);
-                vP = make_double2(a.x + b.x, a.y + b.y);
-                vE = *reinterpret_cast<const double2*>(f.E_T + o);
-#pragma unroll
-                for (int u = 0; u < NL1; ++u)
-                    if (LINKS && u < nLc) {
-                        const double* pp = f.Psi3_T + (size_t)col * f.pp_col_stride + tl.pp_off + (size_t)u * plane + (size_t)k * L + 2 * p;
-                        const double2 x = *reinterpret_cast<const double2*>(pp), y = *reinterpret_cast<const double2*>(pp + pstride);
-                        vL[u] = make_double2(x.x + y.x, x.y + y.y);
-                    }
-                if (2 * p + 1 >= tl.nla) {                    // pad wavelengths hold nothing defined: zeros keep them out
-                    vJ.y = vP.y = vE.y = 0.0;
-#pragma unroll
-                    for (int u = 0; u < NL1; ++u) vL[u].y = 0.0;
-                    if (2 * p >= tl.nla) {
-                        vJ.x = vP.x = vE.x = 0.0;
-#pragma unroll
-                        for (int u = 0; u < NL1; ++u) vL[u].x = 0.0;
-                    }
-                }
+        for (int u = 0; u < NL1; ++u) {
+            vL[u] = zero2;
+            if (LINKS && u < nLc) {
+                const double* pp = f.Psi3_T + (size_t)col * f.pp_col_stride + tl.pp_off + (size_t)u * plane + (size_t)k * L + 2 * p;
+                const double2 x = *reinterpret_cast<const double2*>(pp), y = *reinterpret_cast<const double2*>(pp + pstride);
+                vL[u] = make_double2(x.x + y.x, x.y + y.y);
             }
         }
-        *reinterpret_cast<double2*>(sS + (size_t)c * 2) = vJ;
-        *reinterpret_cast<double2*>(sS + (size_t)R * L + (size_t)c * 2) = vP;
-        *reinterpret_cast<double2*>(sS + (size_t)2 * R * L + (size_t)c * 2) = vE;
+        *reinterpret_cast<double2*>(sS + (size_t)c * 2) = make_double2(kx ? vJ.x : 0.0, ky ? vJ.y : 0.0);
+        *reinterpret_cast<double2*>(sS + (size_t)R * L + (size_t)c * 2) = make_double2(kx ? a.x + b.x : 0.0, ky ? a.y + b.y : 0.0);
+        *reinterpret_cast<double2*>(sS + (size_t)2 * R * L + (size_t)c * 2) = make_double2(kx ? vE.x : 0.0, ky ? vE.y : 0.0);
 #pragma unroll
         for (int u = 0; u < NL1; ++u)
-            if (LINKS) *reinterpret_cast<double2*>(sS + (size_t)(3 + u) * R * L + (size_t)c * 2) = vL[u];
+            if (LINKS) *reinterpret_cast<double2*>(sS + (size_t)(3 + u) * R * L + (size_t)c * 2) = make_double2(kx ? vL[u].x : 0.0, ky ? vL[u].y : 0.0);
+    };
+    if constexpr (NPC > 0 && (R * NPC) % 64 == 0) {
+        if (f.colmask) {
+#pragma unroll
+            for (int it = 0; it < R * NPC / 64; ++it) stage(lane + 64 * it, std::true_type{});
+        } else {
+#pragma unroll
+            for (int it = 0; it < R * NPC / 64; ++it) stage(lane + 64 * it, std::false_type{});
+        }
+    } else {
+        for (int c = lane; c < R * NP; c += 64) { if (f.colmask) stage(c, std::true_type{}); else stage(c, std::false_type{}); }
     }
     __builtin_amdgcn_wave_barrier();                          // a wave's LDS operations complete in order
     // ---- arithmetic: lane = (row, h), h = which of the row's wavelength pairs
     const int r = lane >> 1, h = lane & 1;
     const long g = row0 + r;
     if (g >= nrows) return;
-    const int col = (int)(g / Ns), k = (int)(g - (long)col * Ns);
+    const int col = (int)((unsigned)g / (unsigned)Ns), k = (int)((unsigned)g - (unsigned)col * (unsigned)Ns);
     if (f.colmask && !f.colmask[col]) return;
     double sW = 0.0;
     for (int m = 0; m < f.Nrays; ++m) sW += 2.0 * f.wmuh[m] * (4.0 * M_PI);   // both directions
@@ -1463,6 +1470,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         if (prc) return fail(prc, "%s", perr.c_str());
     }
     if ((long)plan.tiles.size() * ncol > 0x7fffffffL) return fail(LSX_EUNSUPPORTED, "lsx_create: %zu tiles x %d columns exceed the grid", plan.tiles.size(), ncol);
+    if ((long)d->Nspace * ncol > 0x7fffffffL) return fail(LSX_EUNSUPPORTED, "lsx_create: %d depths x %d columns exceed 32-bit row indices", d->Nspace, ncol);
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(LSX_EDEVICE, "lsx_create: no HIP device visible (this library has no CPU path)");
@@ -1768,7 +1776,8 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
         FastParams fq = ff;
         fq.fast_tiles = d_list; fq.n_fast_tiles = (int)n;
         dim3 grid((unsigned)(((size_t)c->ncol * c->Nspace + 4 * LSX_FGC_ROWS - 1) / (4 * LSX_FGC_ROWS)), (unsigned)n);
-#define LSX_FC(NLCV) if (kLkLines[v] == NLCV) hipLaunchKernelGGL((k_fast_gamma_cols<NLCV>), grid, dim3(256), S.cols_lds[v], st, fq);
+#define LSX_FC(NLCV) if (kLkLines[v] == NLCV) { if (c->L == 12) hipLaunchKernelGGL((k_fast_gamma_cols<NLCV, 6>), grid, dim3(256), S.cols_lds[v], st, fq); \
+                                                else hipLaunchKernelGGL((k_fast_gamma_cols<NLCV, 0>), grid, dim3(256), S.cols_lds[v], st, fq); }
         LSX_FC(0) LSX_FC(1) LSX_FC(2)
 #undef LSX_FC
     };

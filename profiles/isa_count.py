@@ -30,7 +30,7 @@ def main():
     end = next(i for i in range(start + 1, len(lines)) if lines[i].startswith('.Lfunc_end'))
     body = lines[start:end]
     # inner loops: from "Inner Loop Header" label to the last line tagged "in Loop: Header=<that label>"
-    heads = [(i, re.match(r'\.(LBB\d+_\d+):', l).group(1)) for i, l in enumerate(body) if 'Inner Loop Header' in l]
+    heads = [(i, m.group(1)) for i, l in enumerate(body) if 'Inner Loop Header' in l for m in [re.match(r'\.(LBB\d+_\d+):', l)] if m]
     for hi, name in heads:
         last = hi
         for i in range(hi, len(body)):
