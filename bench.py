@@ -239,9 +239,10 @@ def roofline_block(eng, lib, prob, ncol, workload, kernel_reps):
                         insts_per_launch=fig['valu_insts_per_call_per_column'] * ncol,
                         source='%s (instruction counts from a builder-run rocprofv3 --pmc pass of this command at source hash %s, per '
                                'column; divided by the LIVE duration)' % (src, fig.get('csrc_hash')))
-    return dict(bound='hbm', kernel='the sweep of one formal solution: lsx_sweep_rs_kernel<slots,lines,linked,topo> (five columns per wavefront, '
-                                    'tiles with at most one per-ray slot) and lsx_sweep_kernel<slots,lines,rays,sca,linked,topo> (the others), one '
-                                    'instance per tile class, launched side by side; duration = span',
+    return dict(bound='hbm', kernel='the sweep of one formal solution: lsx_sweep_rs_kernel<slots,lines,linked,topo> (ray-serial, five columns per '
+                                    'wavefront: every tile class with at most two per-ray slots in contexts of >= 160 columns) and '
+                                    'lsx_sweep_kernel<slots,lines,rays,sca,linked,topo> (one ray per lane: the other classes and smaller contexts), '
+                                    'one instance per tile class, launched side by side; duration = span',
                 achieved=ach, peak=HBM_PEAK_GBPS, unit='GB/s', frac=ach / HBM_PEAK_GBPS, traffic=traffic,
                 traffic_stale=bool(stale) if fig else None,
                 traffic_source=('%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a builder run at source hash %s, (2*FETCH_SIZE + '
@@ -249,9 +250,11 @@ def roofline_block(eng, lib, prob, ncol, workload, kernel_reps):
                                 % (src, fig.get('csrc_hash'), '; STALE: the kernel sources have changed since, so the figure is withheld' if stale else ''))
                 if fig else None,
                 valu=valu, alg_bytes_per_launch=bsweep * ncol, avg_launch_ms=ms_sweep,
-                limited_by='not HBM: with its loads removed the sweep is 13-25 % faster, with 2 -> 5 waves per SIMD 1.4x; it runs on vector '
-                           'issue at the clock the chip holds under fp64 load (1.6 - 1.8 GHz) and on each wave\'s serial chain '
-                           '(profiles/r03_bound_evidence.md: in-kernel clock, per-segment stamps, occupancy sweep, no-load ablation)',
+                limited_by='not HBM: with its stream loads removed the ray-serial sweep is 10-15 % faster (no-load ablation). It holds 150-256 '
+                           'vector registers, i.e. two waves per SIMD; at that occupancy the vector pipe is about half busy (counter instruction '
+                           'mix x cycle costs / kernel cycles) and waves wait 40-48 % of their cycles: latency at two waves per SIMD. The '
+                           'one-ray-per-lane kernel it replaced sat on vector issue at the clock the chip holds under fp64 load (1.6-1.8 GHz) '
+                           '(profiles/r03_bound_evidence.md: in-kernel clock, stamps, occupancy sweep, ablations, class schedule)',
                 fs_call=dict(ms=ms_total, ms_sweep_kernel=ms_sweep, ms_epilogue_kernels=info(4), alg_bytes=balg * ncol,
                              achieved_GBps=balg * ncol / (ms_total * 1e-3) / 1e9,
                              frac=balg * ncol / (ms_total * 1e-3) / 1e9 / HBM_PEAK_GBPS),

@@ -632,6 +632,12 @@ lsx_sweep_rs_kernel(const SweepParams p)
             }
         };
         const int nA = Ns / 2;
+#ifdef LSX_CLOCK
+        // diagnostic build: the shader clock against the 100 MHz clock around the depth loop (the production instruction stream in
+        // between) -> p.debug, records as lsx_sweep.hip writes them (profiles/stamps.py): the clock the chip holds under this kernel
+        unsigned long long tk0, tr0, tk1, tr1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk0), "=s"(tr0)::"memory");
+#endif
         step(0, std::integral_constant<int, 4>{}, opA, opB);          // the ray's first point (depth 1 is already requested: its load is skipped there)
         if constexpr (!SWAP) opA = opB;
         run(1, nA, std::integral_constant<int, 0>{});
@@ -642,6 +648,16 @@ lsx_sweep_rs_kernel(const SweepParams p)
             __builtin_amdgcn_wave_barrier();
             flush(Ns - 1);
         }
+#ifdef LSX_CLOCK
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk1), "=s"(tr1)::"memory");
+        if (lane == 0 && dir == 0 && p.debug && col0 % 100 == 5) {      // the column groups that start at column 5, 105, ...
+            unsigned long long* D = (unsigned long long*)p.debug + (size_t)(((col0 / 100) * ntile + tile_id) & 1023) * 16;
+            for (int i = 0; i < 8; ++i) D[i] = 0;
+            D[7] = tk1 - tk0; D[1] = tr0;
+            D[8] = tile_id; D[9] = NPT; D[10] = nF; D[11] = col0; D[12] = NL; D[13] = LK; D[14] = TOPO;
+            D[15] = tr1 - tr0;
+        }
+#endif
     }
     // dJ of every (column, tile, direction): the maximum over the column's wavelengths (NaN propagates, rh_method.py:706)
     __builtin_amdgcn_wave_barrier();
