@@ -98,3 +98,74 @@ def test_toy_parity_parabolic_rule(hip_lib, oracle_lib, kw):
     assert off < 1e-10 and diag < 1e-11, (off, diag)
     dn = np.abs(h[-1]['n'] - o[-1]['n']) / np.abs(o[-1]['n']).max(axis=1, keepdims=True)
     assert dn.max() < 1e-8 and relerr(h[-1]['J'], o[-1]['J']) < 1e-8
+
+
+def _classes_on_ray_serial(lib, eng):
+    """-> [(slots, lines, linked, relation)] of the classes the context ran on the ray-serial kernel"""
+    import ctypes as C
+    f = lib.dll.lsx_hip_class_info
+    f.restype = C.c_int32
+    f.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
+    out = (C.c_int64 * 8)()
+    n = f(eng._h, -1, out)
+    rs = []
+    for i in range(n):
+        f(eng._h, i, out)
+        if out[6] and out[3] > 0:
+            rs.append((int(out[0]), int(out[1]), int(out[4]), int(out[5])))
+    return rs
+
+
+RS_CASES = [
+    dict(seed=11, Nrays=5, Nspace=82, Nspect=140, ncol=33, chain=False),        # 33 columns: six full groups of five and one of three
+    dict(seed=13, Nrays=5, Nspace=41, Nspect=120, ncol=34, multiplet=3),        # odd depth count: the two directions meet in one step
+    dict(seed=15, Nrays=5, Nspace=41, Nspect=120, ncol=37, multiplet=4),        # four-line multiplets (generic class beside the ray-serial ones)
+    dict(seed=21, Nrays=5, Nspace=3, Nspect=60, ncol=36),                       # the shortest column the rule allows
+    dict(seed=22, Nrays=5, Nspace=30, Nspect=90, ncol=41, phi_compact=True),    # ray-independent profiles
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kw', RS_CASES, ids=lambda k: '-'.join('%s%s' % (a[:3], b) for a, b in k.items()))
+def test_toy_parity_on_the_ray_serial_kernel(hip_lib, oracle_lib, monkeypatch, kw):
+    """the ray-serial sweep (production: contexts of >= 160 columns) forced onto small toy batches: ragged column groups (>= 32 columns: the per-class launch path), odd and
+    minimal depth counts, compact profiles, every tile shape the toy atoms produce with at most two per-ray slots; then the same
+    batch with every third column frozen (lsx_set_active_columns): frozen columns keep their J, I, Gamma and populations, the
+    others do not notice"""
+    monkeypatch.setenv('LSX_RS_MIN_COLUMNS', '1')
+    kw = dict(kw)
+    ncol = kw['ncol']
+    prob, block = toy_problem(**kw)
+    eh, eo = Engine(prob, ncol, lib=hip_lib), Engine(prob, ncol, lib=oracle_lib)
+    for e in (eh, eo):
+        e.set_columns(0, block)
+    tol = 2e-10 if kw.get('multiplet') else 1e-11
+    for it in range(6):
+        dh, do = eh.formal_sol_gamma(), eo.formal_sol_gamma()
+        if it == 0:
+            assert _classes_on_ray_serial(hip_lib, eh), 'no class of this problem ran on the ray-serial kernel'
+            assert relerr(eh.get(_capi.LSX_I), eo.get(_capi.LSX_I)) < tol and relerr(eh.get(_capi.LSX_J), eo.get(_capi.LSX_J)) < tol
+            off, diag = gamma_err(eh.get(_capi.LSX_GAMMA), eo.get(_capi.LSX_GAMMA), prob)
+            assert off < 1e-10 and diag < 1e-11, (off, diag)
+        assert abs(dh - do) <= 1e-7 * max(abs(do), 1e-3)
+        if it >= 2:
+            eh.stat_equil(); eo.stat_equil()
+    n_o = eo.get(_capi.LSX_N)
+    dn = np.abs(eh.get(_capi.LSX_N) - n_o) / np.abs(n_o).max(axis=1, keepdims=True)
+    assert dn.max() < 1e-8
+    # ---- every third column frozen
+    active = np.ones(ncol, dtype=bool)
+    active[::3] = False
+    before = {w: eh.get(w) for w in (_capi.LSX_J, _capi.LSX_N, _capi.LSX_GAMMA, _capi.LSX_I)}
+    for e in (eh, eo):
+        e.set_active_columns(active)
+        e.formal_sol_gamma(); e.stat_equil()
+    for w, v in before.items():
+        assert np.array_equal(eh.get(w)[~active], v[~active])
+    n_o = eo.get(_capi.LSX_N)
+    dn = np.abs(eh.get(_capi.LSX_N) - n_o) / np.abs(n_o).max(axis=1, keepdims=True)
+    # (J against the largest J of its column: the three-depth columns have mean intensities that pass through zero)
+    Jh, Jo = eh.get(_capi.LSX_J)[active], eo.get(_capi.LSX_J)[active]
+    dJ = np.abs(Jh - Jo).reshape(len(Jo), -1).max(axis=1) / np.abs(Jo).reshape(len(Jo), -1).max(axis=1)
+    assert dn.max() < 1e-8 and dJ.max() < 1e-7         # (after seven iterations; the single call above agrees to 1e-11)
+    eh.close(); eo.close()
