@@ -169,3 +169,19 @@ def test_toy_parity_on_the_ray_serial_kernel(hip_lib, oracle_lib, monkeypatch, k
     dJ = np.abs(Jh - Jo).reshape(len(Jo), -1).max(axis=1) / np.abs(Jo).reshape(len(Jo), -1).max(axis=1)
     assert dn.max() < 1e-8 and dJ.max() < 1e-7         # (after seven iterations; the single call above agrees to 1e-11)
     eh.close(); eo.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kw', RS_CASES[:3] + RS_CASES[4:], ids=lambda k: '-'.join('%s%s' % (a[:3], b) for a, b in k.items()))
+def test_toy_parity_parabolic_rule_compile_time_classes(hip_lib, oracle_lib, kw):
+    """five rays and >= 32 columns: the parabolic rule's compile-time tile classes (sweep_tile_par) on the toy topologies -- odd
+    depth counts, multiplets (whose four-slot tiles take the generic parabolic instance on their own tile list), compact profiles"""
+    prob, block = toy_problem(**kw)
+    h = _run(hip_lib, prob, block, 6, solver='parabolic')
+    o = _run(oracle_lib, prob, block, 6, solver='parabolic')
+    tol = 2e-10 if kw.get('multiplet') else 1e-11
+    assert relerr(h[0]['I'], o[0]['I']) < tol and relerr(h[0]['J'], o[0]['J']) < tol
+    off, diag = gamma_err(h[0]['G'], o[0]['G'], prob)
+    assert off < 1e-10 and diag < 1e-11, (off, diag)
+    dn = np.abs(h[-1]['n'] - o[-1]['n']) / np.abs(o[-1]['n']).max(axis=1, keepdims=True)
+    assert dn.max() < 1e-8 and relerr(h[-1]['J'], o[-1]['J']) < 1e-8
