@@ -268,15 +268,19 @@ def roofline_block(eng, lib, prob, ncol, workload, kernel_reps):
 
 def timed_steps(eng, reducer, nsteps, warmup, barrier):
     from lightspinner_amd import drivers
-    for _ in range(warmup):
-        drivers.mali_step(eng, True, reducer)
+    # drivers.mali_steps: the MALI loop as the product runs it -- the next iteration's formal solution is enqueued while the host
+    # waits for the monitors of the current one (exactly `nsteps` formal solutions and `nsteps` stat_equil calls inside the
+    # timed region, nothing enqueued beyond the last step)
+    for _ in drivers.mali_steps(eng, warmup, reducer):
+        pass
     barrier()
     per = []
-    t0 = time.perf_counter()
-    for _ in range(nsteps):
-        ta = time.perf_counter()
-        dJ, dP = drivers.mali_step(eng, True, reducer)
-        per.append(time.perf_counter() - ta)
+    t0 = ta = time.perf_counter()
+    dJ = dP = None
+    for dJ, dP in drivers.mali_steps(eng, nsteps, reducer):
+        tb = time.perf_counter()
+        per.append(tb - ta)
+        ta = tb
     barrier()
     return time.perf_counter() - t0, per, dJ, dP
 
@@ -480,7 +484,7 @@ def main():
                                   Nrays=prob.Nrays, profiles='compact (vlos=0)' if compact else 'ray dependent (vlos!=0)',
                                   columns='populations, rates and profiles derived by the library from each column\'s perturbed atmosphere' if t_chain is not None else 'input-level perturbations (BASELINE C3 / C4)',
                                   parallelism=parallelism_text(world, rehearsal)),
-                      step_ms=dict(stats_ms(per_step), note='host clock around each step on rank 0 (a step ends with the read-back of the monitors)'),
+                      step_ms=dict(stats_ms(per_step), note='host clock on rank 0 between the monitor read-backs of consecutive steps (the next step is already enqueued when a read-back is waited for)'),
                       mali_iters_per_sec=args.steps / dt, column_iters_per_sec=args.steps * ncol * world / dt,
                       last_dJ=dJ, last_dPops=dP,
                       roofline=roofline, cpu_baseline=cpu, falc_single_column=single,

@@ -234,6 +234,37 @@ int lsx_formal_sol_gamma_async(lsx_ctx* ctx);
 int lsx_stat_equil_async(lsx_ctx* ctx);
 int lsx_sync(lsx_ctx* ctx, double* dJ_max, double* dPops_max);
 
+/* ---- the MALI loop without a host round trip per iteration (test.py:20-29: `while dJ > 2e-3 or dPops > 1e-3`) ----------
+ * The reference decides after every iteration, on the host, whether to run another one.  Waiting for that decision leaves the
+ * GPU idle between iterations (and, over several GPUs, for the all-reduce of the monitors).  These entries let the caller
+ * enqueue the NEXT iteration's formal solution before the decision is known and take it back if the loop has ended:
+ *
+ *   lsx_formal_sol_gamma_async; [lsx_stat_equil_async]; lsx_sync_begin            -- iteration 1
+ *   repeat:  lsx_formal_sol_gamma_speculative                                      -- iteration i + 1, ahead of the decision
+ *            lsx_sync_end(&dJ, &dPops)                                             -- monitors of iteration i
+ *            converged?  lsx_discard_formal_sol; stop                              -- I, J, Gamma, monitors are iteration i's again
+ *            else        [lsx_stat_equil_async]; lsx_sync_begin                    -- iteration i + 1 goes on
+ *
+ * The results are those of the plain loop, bit for bit (tests/test_pipelined_loop.py).
+ * lsx_sync_begin: enqueue the read-back of the monitors of the calls enqueued so far (what lsx_sync would return); one at a time.
+ * lsx_sync_end: wait for THAT read-back only -- work enqueued behind it keeps running -- and return the maxima; LSX_ESINGULAR as
+ *   lsx_sync.  Without a pending lsx_sync_begin it is lsx_sync.
+ * lsx_formal_sol_gamma_speculative: lsx_formal_sol_gamma_async whose I, Gamma and monitors go to a second set of buffers (J is a
+ *   pair already), so that the previous call's remain available.  LSX_EUNSUPPORTED while columns are frozen
+ *   (lsx_set_active_columns).
+ * lsx_discard_formal_sol: undo the last call if it was speculative and nothing has been built on it (no lsx_stat_equil, no new
+ *   inputs since): lsx_get and the next calls see the previous formal solution.  LSX_EINVAL otherwise. */
+int lsx_sync_begin(lsx_ctx* ctx);
+int lsx_sync_end(lsx_ctx* ctx, double* dJ_max, double* dPops_max);
+int lsx_formal_sol_gamma_speculative(lsx_ctx* ctx);
+int lsx_discard_formal_sol(lsx_ctx* ctx);
+/* 1 if enqueueing ahead pays for this context, else 0.  HIP library: 1 for contexts whose formal solution is one launch chain
+ * on the context's own stream (fewer than 32 columns: the latency-bound case, a FALC column: 4.37 -> 3.91 ms for its 46
+ * iterations).  Larger contexts fork their tile classes onto several streams; enqueued ahead, that fork and the join become
+ * waits on PENDING events across hardware queues, measured at 80-100 us each on this runtime against the 20-50 us of idle time
+ * the look-ahead removes (1000 CaII columns: 1.44 against 1.10 ms per iteration), so 0.  The oracle computes synchronously: 0. */
+int lsx_prefers_lookahead(lsx_ctx* ctx);
+
 /* The convergence monitors of the most recent (enqueued) calls, reduced over this context's columns and left where the
  * caller's collective can take them without a host round trip: dst[0] = max dJ, dst[1] = max dPops, dst[2] = 1 if dJ is
  * NaN anywhere else 0 (MAX collectives do not order NaN; with the flag set dst[0] holds the maximum of the other

@@ -17,6 +17,7 @@ LSX_I, LSX_J, LSX_N, LSX_GAMMA, LSX_DJ_COL, LSX_DPOPS_COL, LSX_NSTAR, LSX_C, _, 
 LSX_SOLVER_LINEAR, LSX_SOLVER_PARABOLIC = 0, 1
 LSX_COLL_OMEGA, LSX_COLL_CI, LSX_COLL_CE = range(3)
 
+LSX_EINVAL, LSX_EDEVICE, LSX_ESINGULAR, LSX_EUNSUPPORTED = 1, 2, 3, 5
 ERRORS = {1: 'LSX_EINVAL', 2: 'LSX_EDEVICE', 3: 'LSX_ESINGULAR', 5: 'LSX_EUNSUPPORTED'}
 
 _dp = C.POINTER(C.c_double)
@@ -94,6 +95,7 @@ REQUIRED_SYMBOLS = (
     'lsx_piecewise_1d_impl', 'lsx_w2', 'lsx_monitors', 'lsx_set_atomic_data', 'lsx_set_atmosphere',
     'lsx_wavelength_grid', 'lsx_active_set', 'lsx_line_wavelength', 'lsx_continuum_alpha',
     'lsx_piecewise_parabolic_1d_impl', 'lsx_w3', 'lsx_set_formal_solver',
+    'lsx_sync_begin', 'lsx_sync_end', 'lsx_formal_sol_gamma_speculative', 'lsx_discard_formal_sol', 'lsx_prefers_lookahead',
 )
 
 
@@ -162,6 +164,11 @@ class LsxLibrary:
         d.lsx_line_wavelength.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32, _dp, ip]
         d.lsx_continuum_alpha.argtypes = [C.POINTER(LsxContinuumModel), C.c_int32, _dp, _dp]
         d.lsx_monitors.argtypes = [C.c_void_p, C.c_void_p]
+        d.lsx_sync_begin.argtypes = [C.c_void_p]
+        d.lsx_sync_end.argtypes = [C.c_void_p, _dp, _dp]
+        d.lsx_formal_sol_gamma_speculative.argtypes = [C.c_void_p]
+        d.lsx_discard_formal_sol.argtypes = [C.c_void_p]
+        d.lsx_prefers_lookahead.argtypes = [C.c_void_p]
         d.lsx_set_atomic_data.argtypes = [C.c_void_p, C.POINTER(LsxAtomicData)]
         d.lsx_set_atmosphere.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(LsxAtmosphere)]
         d.lsx_set_active_columns.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]

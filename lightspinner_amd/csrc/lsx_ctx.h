@@ -87,6 +87,13 @@ struct lsx_ctx : lsxd::LsxPlan {        // the plan (lsx_plan.h: dimensions, tab
     double last_dJ = 0.0, last_dP = 0.0;
     bool fs_pending = false, se_pending = false;
     hipEvent_t evA = nullptr, evB = nullptr;
+    // pipelined MALI loop (include/lsx.h: lsx_sync_begin / lsx_formal_sol_gamma_speculative / lsx_discard_formal_sol): the second set
+    // of the buffers a formal solution overwrites (J already is a pair), and the read-back in flight
+    double *d_I_alt = nullptr, *d_Gamma_alt = nullptr, *d_res_alt = nullptr;
+    bool spec_valid = false;         // the last formal solution was speculative and nothing has built on it: it can be discarded
+    bool spec_dp_zeroed = false;     // dp_zeroed as it was before that call
+    bool mon_outstanding = false, mon_fs = false, mon_se = false;
+    hipEvent_t ev_mon = nullptr;
 };
 
 namespace lsxd {

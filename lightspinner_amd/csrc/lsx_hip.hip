@@ -1437,6 +1437,9 @@ void lsx_destroy(lsx_ctx* c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (hipEvent_t e : {c->ev0, c->ev1, c->ev2})
         if (e) (void)hipEventDestroy(e);
+    if (c->ev_mon) (void)hipEventDestroy(c->ev_mon);
+    for (void* q : {(void*)c->d_I_alt, (void*)c->d_Gamma_alt, (void*)c->d_res_alt})
+        if (q) (void)hipFree(q);
     if (c->evA) (void)hipEventDestroy(c->evA);
     if (c->evB) (void)hipEventDestroy(c->evB);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -1638,6 +1641,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
 
 int lsx_set_columns(lsx_ctx* c, int32_t col0, int32_t ncol, const lsx_columns* s)
 {
+    if (c) c->spec_valid = false;         // new inputs: a speculative formal solution can no longer be discarded
     if (!c || !s || col0 < 0 || ncol < 1 || col0 + ncol > c->ncol) return fail(LSX_EINVAL, "lsx_set_columns: bad range");
     if (!s->height || !s->temperature || !s->nStar || !s->nTotal || !s->n || !s->C || !s->bg_chi || !s->bg_eta || !s->bg_sca ||
         (c->Nlines && ((s->phi == nullptr) != (s->wphi == nullptr))))
@@ -1710,7 +1714,17 @@ int lsx_set_columns(lsx_ctx* c, int32_t col0, int32_t ncol, const lsx_columns* s
     return LSX_OK;
 }
 
-static int enqueue_fs(lsx_ctx* c, bool timed)
+static void swap_result_buffers(lsx_ctx* c)
+{
+    std::swap(c->d_I, c->d_I_alt);
+    std::swap(c->d_Gamma, c->d_Gamma_alt);
+    std::swap(c->d_res, c->d_res_alt);
+    c->d_dJcol = c->d_res;
+    c->d_dPcol = c->d_res + c->ncol;
+    c->d_singular = reinterpret_cast<unsigned long long*>(c->d_res + 2 * (size_t)c->ncol);
+}
+
+static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
 {
     if (c->n_phi_set != (size_t)c->ncol) {
         size_t q = 0;
@@ -1719,6 +1733,25 @@ static int enqueue_fs(lsx_ctx* c, bool timed)
                                 "must be followed by lsx_set_line_profiles)", q);
     }
     HIPCHK(hipSetDevice(c->device));
+    if (speculative) {
+        // I, Gamma and the monitors of this call go to the second set of buffers (J is a pair anyway): the previous call's stay
+        // intact until lsx_discard_formal_sol or the next call
+        if (c->d_colmask) return fail(LSX_EUNSUPPORTED, "lsx_formal_sol_gamma_speculative: not with frozen columns (lsx_set_active_columns)");
+        if (!c->d_I_alt) {
+            const size_t nc = (size_t)c->ncol;
+            int rc = dmalloc(&c->d_I_alt, nc * c->Nspect * c->Nrays);
+            if (!rc) rc = dmalloc(&c->d_Gamma_alt, nc * c->NL2tot * c->Nspace);
+            if (!rc) rc = dmalloc(&c->d_res_alt, 2 * nc + 1);
+            if (rc) {
+                for (void* q : {(void*)c->d_I_alt, (void*)c->d_Gamma_alt, (void*)c->d_res_alt}) if (q) (void)hipFree(q);
+                c->d_I_alt = c->d_Gamma_alt = c->d_res_alt = nullptr;
+                return rc;
+            }
+        }
+        swap_result_buffers(c);
+        c->spec_dp_zeroed = c->dp_zeroed;
+    }
+    c->spec_valid = speculative;
     SweepParams p{};
     p.Nspace = c->Nspace; p.Nrays = c->Nrays; p.Nspect = c->Nspect; p.Natoms = c->Natoms; p.Ntrans = c->Ntrans;
     p.ncol = c->ncol; p.NLtot = c->NLtot; p.NL2tot = c->NL2tot; p.Nlines = c->Nlines;
@@ -1896,9 +1929,34 @@ int lsx_formal_sol_gamma_async(lsx_ctx* c)
     return enqueue_fs(c, false);
 }
 
+int lsx_formal_sol_gamma_speculative(lsx_ctx* c)
+{
+    if (!c) return fail(LSX_EINVAL, "null ctx");
+    return enqueue_fs(c, false, true);
+}
+
+int lsx_prefers_lookahead(lsx_ctx* c)
+{
+    return c && c->ncol < 32 && !c->d_colmask ? 1 : 0;      // the fused launch on the context's stream (enqueue_fs)
+}
+
+int lsx_discard_formal_sol(lsx_ctx* c)
+{
+    if (!c) return fail(LSX_EINVAL, "null ctx");
+    if (!c->spec_valid) return fail(LSX_EINVAL, "lsx_discard_formal_sol: the last call was not a speculative formal solution");
+    // (its kernels may still be running: everything that follows is ordered behind them on the context's stream)
+    swap_result_buffers(c);
+    c->jcur ^= 1;
+    c->dp_zeroed = c->spec_dp_zeroed;
+    c->fs_pending = false;
+    c->spec_valid = false;
+    return LSX_OK;
+}
+
 int lsx_stat_equil_async(lsx_ctx* c)
 {
     if (!c) return fail(LSX_EINVAL, "null ctx");
+    c->spec_valid = false;            // the populations now build on the last formal solution
     HIPCHK(hipSetDevice(c->device));
     // dPcol and the singular flag behind it start at zero: the Gamma epilogue of the formal solution has done that, unless
     // this is a second stat_equil on the same Gamma
@@ -1931,6 +1989,7 @@ int lsx_stat_equil_async(lsx_ctx* c)
 
 int lsx_set_active_columns(lsx_ctx* c, const uint8_t* active)
 {
+    if (c) c->spec_valid = false;         // new inputs: a speculative formal solution can no longer be discarded
     if (!c) return fail(LSX_EINVAL, "null ctx");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1947,41 +2006,87 @@ int lsx_set_active_columns(lsx_ctx* c, const uint8_t* active)
     return LSX_OK;
 }
 
+// the maxima of a read-back block (h_pinned): -> the singular flag
+static unsigned long long digest_monitors(lsx_ctx* c, bool fs, bool se)
+{
+    const size_t nc = (size_t)c->ncol;
+    unsigned long long sing = 0;
+    auto nanmax = [](const double* v, size_t n) {       // numpy max semantics: NaN wins (rh_method.py:706)
+        double m = 0.0;
+        for (size_t i = 0; i < n; ++i)
+            if (v[i] != v[i]) return v[i];
+            else if (v[i] > m) m = v[i];
+        return m;
+    };
+    if (fs) c->last_dJ = nanmax(c->h_pinned, nc);
+    if (se) {
+        c->last_dP = nanmax(c->h_pinned + nc, nc);      // the per-column values are never NaN (k_stat_equil)
+        memcpy(&sing, c->h_pinned + 2 * nc, sizeof sing);
+    }
+    return sing;
+}
+
+int lsx_sync_begin(lsx_ctx* c)
+{
+    if (!c) return fail(LSX_EINVAL, "null ctx");
+    if (c->mon_outstanding) return fail(LSX_EINVAL, "lsx_sync_begin: the previous read-back has not been collected (lsx_sync_end)");
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->ev_mon) HIPCHK(hipEventCreateWithFlags(&c->ev_mon, hipEventDisableTiming));
+    HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_res, (2 * (size_t)c->ncol + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipEventRecord(c->ev_mon, c->stream));
+    c->mon_fs = c->fs_pending; c->mon_se = c->se_pending;
+    c->fs_pending = c->se_pending = false;
+    c->mon_outstanding = true;
+    return LSX_OK;
+}
+
+static int singular_error(lsx_ctx* c, unsigned long long sing);
+
+int lsx_sync_end(lsx_ctx* c, double* dJ, double* dP)
+{
+    if (!c) return fail(LSX_EINVAL, "null ctx");
+    if (!c->mon_outstanding) return lsx_sync(c, dJ, dP);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventSynchronize(c->ev_mon));             // the read-back only: what was enqueued behind it keeps running
+    c->mon_outstanding = false;
+    const unsigned long long sing = digest_monitors(c, c->mon_fs, c->mon_se);
+    if (dJ) *dJ = c->last_dJ;
+    if (dP) *dP = c->last_dP;
+    return sing ? singular_error(c, sing) : LSX_OK;
+}
+
 int lsx_sync(lsx_ctx* c, double* dJ, double* dP)
 {
     if (!c) return fail(LSX_EINVAL, "null ctx");
     HIPCHK(hipSetDevice(c->device));
     unsigned long long sing = 0;
+    if (c->mon_outstanding) {                           // a read-back in flight: collect it first (its maxima are superseded below
+        HIPCHK(hipEventSynchronize(c->ev_mon));         // if later calls are pending)
+        c->mon_outstanding = false;
+        sing = digest_monitors(c, c->mon_fs, c->mon_se);
+    }
     if (c->fs_pending || c->se_pending) {
         const size_t nc = (size_t)c->ncol;
         HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_res, (2 * nc + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        auto nanmax = [](const double* v, size_t n) {       // numpy max semantics: NaN wins (rh_method.py:706)
-            double m = 0.0;
-            for (size_t i = 0; i < n; ++i)
-                if (v[i] != v[i]) return v[i];
-                else if (v[i] > m) m = v[i];
-            return m;
-        };
-        if (c->fs_pending) c->last_dJ = nanmax(c->h_pinned, nc);
-        if (c->se_pending) {
-            c->last_dP = nanmax(c->h_pinned + nc, nc);      // the per-column values are never NaN (k_stat_equil)
-            memcpy(&sing, c->h_pinned + 2 * nc, sizeof sing);
-        }
+        const unsigned long long s2 = digest_monitors(c, c->fs_pending, c->se_pending);
+        if (!sing) sing = s2;
         c->fs_pending = c->se_pending = false;
     } else {
         HIPCHK(hipStreamSynchronize(c->stream));
     }
     if (dJ) *dJ = c->last_dJ;
     if (dP) *dP = c->last_dP;
-    if (sing) {
-        const unsigned long long key = LSX_SING_BASE - sing;
-        const long gid = (long)(key >> 8);
-        return fail(LSX_ESINGULAR, "stat_equil: singular matrix at column %ld, depth %ld, atom %d (the first such system; cf. "
-                                   "LinAlgError at rh_method.py:739); its populations are left untouched",
-                    gid / c->Nspace, gid % c->Nspace, (int)(key & 0xff));
-    }
-    return LSX_OK;
+    return sing ? singular_error(c, sing) : LSX_OK;
+}
+
+static int singular_error(lsx_ctx* c, unsigned long long sing)
+{
+    const unsigned long long key = LSX_SING_BASE - sing;
+    const long gid = (long)(key >> 8);
+    return fail(LSX_ESINGULAR, "stat_equil: singular matrix at column %ld, depth %ld, atom %d (the first such system; cf. "
+                               "LinAlgError at rh_method.py:739); its populations are left untouched",
+                gid / c->Nspace, gid % c->Nspace, (int)(key & 0xff));
 }
 
 int lsx_monitors(lsx_ctx* c, double* dst)
@@ -2076,6 +2181,7 @@ int lsx_get(lsx_ctx* c, int32_t what, int32_t col0, int32_t ncol, double* dst, s
 
 int lsx_set(lsx_ctx* c, int32_t what, int32_t col0, int32_t ncol, const double* src, size_t nbytes)
 {
+    if (c) c->spec_valid = false;         // new inputs: a speculative formal solution can no longer be discarded
     if (!c || !src || col0 < 0 || ncol < 1 || col0 + ncol > c->ncol) return fail(LSX_EINVAL, "lsx_set: bad range");
     if (what != LSX_N && what != LSX_J) return fail(LSX_EINVAL, "lsx_set: only LSX_N and LSX_J are writable");
     HIPCHK(hipSetDevice(c->device));

@@ -64,24 +64,124 @@ def mali_step(engine, with_stat_equil=True, reducer=None):
     return dJ, (dP if with_stat_equil else None)
 
 
-def iterate_mali_engine(engine, reducer=None, dJ_tol=2e-3, dPops_tol=1e-3, n_lambda_only=3, max_iter=500, log=None) -> MaliHistory:
+def _begin(engine, reducer):
+    if reducer is not None:
+        reducer.engine_begin(engine)
+    else:
+        engine.sync_begin()
+
+
+def _end(engine, reducer):
+    return reducer.engine_end(engine) if reducer is not None else engine.sync_end()
+
+
+def mali_steps(engine, nsteps, reducer=None, n_lambda_only=0, first=1, lookahead=None):
+    """`nsteps` MALI iterations, yielding (dJ, dPops or None) after each, WITHOUT a host round trip between them: the next
+    iteration's formal solution is enqueued before the monitors of the current one are waited for (include/lsx.h, lsx_sync_begin /
+    lsx_sync_end), so the GPU goes from one iteration into the next while the host reads.  The iterations are numbered from
+    `first`; those with a number > n_lambda_only include stat_equil (test.py:27).  The caller consumes every step (no early
+    exit: nothing is rolled back here -- iterate_mali_engine does that).  lookahead (default: lsx_prefers_lookahead) False: the plain
+    sequence of mali_step calls."""
+    if nsteps < 1:
+        return
+    if lookahead is None:
+        lookahead = engine.prefers_lookahead()
+    if not lookahead:
+        for s in range(nsteps):
+            yield mali_step(engine, first + s > n_lambda_only, reducer)
+        return
+    i = first
+    engine.formal_sol_gamma_async()
+    se = i > n_lambda_only
+    if se:
+        engine.stat_equil_async()
+    _begin(engine, reducer)
+    for s in range(nsteps):
+        last = s == nsteps - 1
+        if not last:
+            engine.formal_sol_gamma_async()            # iteration i + 1: nothing to take back, so the plain call
+        dJ, dP = _end(engine, reducer)
+        yield dJ, (dP if se else None)
+        if not last:
+            i += 1
+            se = i > n_lambda_only
+            if se:
+                engine.stat_equil_async()
+            _begin(engine, reducer)
+
+
+def iterate_mali_engine(engine, reducer=None, dJ_tol=2e-3, dPops_tol=1e-3, n_lambda_only=3, max_iter=500, log=None,
+                        pipelined=None) -> MaliHistory:
     """iterate_mali (test.py:20-29) on an Engine with many columns, globally converged: the loop runs until the maxima
-    over all columns (and, with a reducer, over all ranks) are below the thresholds."""
+    over all columns (and, with a reducer, over all ranks) are below the thresholds.
+
+    pipelined (default: where the library says it pays, lsx_prefers_lookahead -- small contexts, e.g. a single column): iteration
+    i + 1's formal solution is enqueued speculatively before the monitors of iteration i are known and discarded if the loop ends
+    there (lsx_formal_sol_gamma_speculative / lsx_discard_formal_sol) -- the same iterations, the same results bit for bit, no
+    idle GPU between iterations."""
     h = MaliHistory()
-    dJ, dPops, i = 1.0, 1.0, 0
-    while dJ > dJ_tol or dPops > dPops_tol:
-        i += 1
-        dJ, dP = mali_step(engine, i > n_lambda_only, reducer)
-        if dP is not None:
-            dPops = dP
+    if pipelined is None:
+        pipelined = engine.prefers_lookahead()
+    if max_iter < 1:
+        return h
+
+    def record(i, dJ, dPops):
         h.dJ.append(dJ)
         h.dPops.append(dPops if i > n_lambda_only else float('nan'))
         if log:
             log('Iteration %.3d: dJ: %.2e, dPops: %s' % (i, dJ, 'Just iterating Jbar' if i <= n_lambda_only else '%.2e' % dPops))
         if not (np.isfinite(dJ) and np.isfinite(dPops)):
             h.nonfinite = True
-        if i >= max_iter:
+
+    dJ, dPops, i = 1.0, 1.0, 0
+    if not pipelined:
+        while dJ > dJ_tol or dPops > dPops_tol:
+            i += 1
+            dJ, dP = mali_step(engine, i > n_lambda_only, reducer)
+            if dP is not None:
+                dPops = dP
+            record(i, dJ, dPops)
+            if i >= max_iter:
+                break
+        h.converged = (dJ <= dJ_tol and dPops <= dPops_tol)
+        return h
+
+    i = 1
+    engine.formal_sol_gamma_async()
+    if i > n_lambda_only:
+        engine.stat_equil_async()
+    _begin(engine, reducer)
+    can_speculate = True
+    while True:
+        speculating = can_speculate and i < max_iter
+        if speculating:
+            try:
+                engine.formal_sol_gamma_speculative()          # iteration i + 1, ahead of the decision
+            except Exception as e:
+                from ._capi import LSX_EUNSUPPORTED
+                if getattr(e, 'code', None) != LSX_EUNSUPPORTED:
+                    _end(engine, reducer)
+                    raise
+                can_speculate = speculating = False             # frozen columns: the loop goes on without looking ahead
+        try:
+            dJ, dP = _end(engine, reducer)                      # monitors of iteration i
+        except Exception:
+            if speculating:
+                engine.discard_formal_sol()
+            raise
+        if i > n_lambda_only:
+            dPops = dP
+        record(i, dJ, dPops)
+        if not (dJ > dJ_tol or dPops > dPops_tol) or i >= max_iter:
+            if speculating:
+                engine.discard_formal_sol()                     # the loop ends with iteration i: its I, J, Gamma are the results
             break
+        i += 1
+        if not speculating:
+            engine.formal_sol_gamma_async()
+        if i > n_lambda_only:
+            engine.stat_equil_async()
+        _begin(engine, reducer)
     h.converged = (dJ <= dJ_tol and dPops <= dPops_tol)
     return h
 

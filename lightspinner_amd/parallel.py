@@ -44,6 +44,8 @@ class MaxReducer:
         self.stream = stream            # torch.cuda.Stream the engine launches on (its handle went to lsx_create)
         self.buf = torch.zeros(4, dtype=torch.float64, device=self.device)
         self._dev_scratch = None
+        self._pending = None            # engine_begin / engine_end: the result of an exchange that had nothing to overlap with
+        self._host4 = None
 
     def __call__(self, dJ: float, dPops: float):
         if not self.active:
@@ -86,6 +88,45 @@ class MaxReducer:
             if self.active:
                 self.dist.all_reduce(self.buf, op=self.dist.ReduceOp.MAX, group=self.group)
             out = self.buf.tolist()
+        if out[3] > 0:
+            from ._capi import LsxSingularError
+            raise LsxSingularError(3, 'stat_equil: singular matrix on some rank (cf. LinAlgError at rh_method.py:739)')
+        dJ = float('nan') if out[2] > 0 else out[0]
+        return dJ, out[1]
+
+
+    # ---- the same exchange split in two, for the loop without a host round trip per iteration (drivers.mali_steps /
+    # iterate_mali_engine): begin enqueues reduction, all-reduce and read-back behind the iteration's kernels, the caller then
+    # enqueues the next formal solution, end waits for the read-back only
+    def engine_begin(self, eng):
+        torch = self.torch
+        on_device = eng.lib.backend.startswith('hip')
+        if on_device and self.buf.is_cuda and self.stream is not None:
+            if self._host4 is None:
+                self._host4 = torch.empty(4, dtype=torch.float64).pin_memory()
+                self._ev = torch.cuda.Event()
+            with torch.cuda.stream(self.stream):
+                eng.monitors_to(self.buf.data_ptr())
+                if self.active:
+                    self.dist.all_reduce(self.buf, op=self.dist.ReduceOp.MAX, group=self.group)
+                self._host4.copy_(self.buf, non_blocking=True)
+                self._ev.record(self.stream)
+            self._pending = None
+        else:                           # nothing to overlap with (CPU collective, oracle, engine-owned stream): the plain exchange now
+            try:
+                self._pending = ('ok', self.engine(eng))
+            except Exception as e:      # raised where the plain loop would see it: at the end of the iteration
+                self._pending = ('err', e)
+
+    def engine_end(self, eng):
+        if self._pending is not None:
+            kind, val = self._pending
+            self._pending = None
+            if kind == 'err':
+                raise val
+            return val
+        self._ev.synchronize()
+        out = self._host4.tolist()
         if out[3] > 0:
             from ._capi import LsxSingularError
             raise LsxSingularError(3, 'stat_equil: singular matrix on some rank (cf. LinAlgError at rh_method.py:739)')

@@ -278,6 +278,29 @@ class Engine:
         self.lib.check(self.lib.dll.lsx_sync(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    # ---- the loop without a host round trip per iteration (include/lsx.h; drivers.iterate_mali_engine) ----
+    def sync_begin(self):
+        """enqueue the read-back of the monitors of the calls enqueued so far"""
+        self.lib.check(self.lib.dll.lsx_sync_begin(self._h))
+
+    def sync_end(self):
+        """-> (dJ, dPops) of that read-back; what was enqueued behind it keeps running"""
+        a, b = C.c_double(), C.c_double()
+        self.lib.check(self.lib.dll.lsx_sync_end(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def formal_sol_gamma_speculative(self):
+        """the next iteration's formal solution, enqueued before the monitors of this one are known"""
+        self.lib.check(self.lib.dll.lsx_formal_sol_gamma_speculative(self._h))
+
+    def prefers_lookahead(self) -> bool:
+        """whether enqueueing ahead pays for this context (include/lsx.h, lsx_prefers_lookahead)"""
+        return bool(self.lib.dll.lsx_prefers_lookahead(self._h))
+
+    def discard_formal_sol(self):
+        """take the speculative formal solution back: I, J, Gamma and the monitors are the previous call's again"""
+        self.lib.check(self.lib.dll.lsx_discard_formal_sol(self._h))
+
     def monitors_to(self, ptr):
         """lsx_monitors: (max dJ, max dPops, NaN flag, singular flag) of the enqueued calls -> 4 doubles at `ptr`
         (an int address: device memory for the HIP library -- e.g. tensor.data_ptr() -- host memory for the oracle)"""

@@ -58,6 +58,11 @@ struct lsx_ctx {
     /* per column, reference layouts */
     double *height, *temperature, *nStar, *nTotal, *n, *C, *bg_chi, *bg_eta, *bg_sca, *phi, *wphi;
     double *J, *I, *Gamma, *Rij, *Rji, *dJcol, *dPcol;
+    double* spec_save;        /* what a speculative formal solution overwrote (lsx_formal_sol_gamma_speculative), or NULL */
+    double spec_last_dJ;
+    int spec_valid;
+    double mon_dJ, mon_dP;    /* the maxima as they were at lsx_sync_begin */
+    int mon_set;
     long* sing_col; /* per column: (depth << 8 | atom) of its first singular system in the last stat_equil, or -1 */
     /* set-up chain: deep copy of the atomic data (lsx_set_atomic_data) and what lsx_set_atmosphere derives */
     int have_atomic_data;
@@ -152,7 +157,7 @@ void lsx_destroy(lsx_ctx* c)
     free(c->bg_chi); free(c->bg_eta); free(c->bg_sca); free(c->phi); free(c->wphi);
     free(c->colmask);
     free(c->J); free(c->I); free(c->Gamma); free(c->Rij); free(c->Rji); free(c->dJcol); free(c->dPcol); free(c->sing_col);
-    free_atomic_data(c); free(c->vBroad); free(c->aDamp);
+    free_atomic_data(c); free(c->vBroad); free(c->aDamp); free(c->spec_save);
     free(c);
 }
 
@@ -1129,6 +1134,7 @@ static double colmax(const double* v, int n)
 int lsx_formal_sol_gamma_async(lsx_ctx* c)
 {
     if (!c) return fail(LSX_EINVAL, "null ctx");
+    c->spec_valid = 0;
     size_t nd = fs_scratch_doubles(c);
 #ifdef _OPENMP
 #pragma omp parallel num_threads(c->nthreads)
@@ -1153,6 +1159,63 @@ int lsx_formal_sol_gamma(lsx_ctx* c, double* dJ)
     int rc = lsx_formal_sol_gamma_async(c);
     if (rc) return rc;
     if (dJ) *dJ = c->last_dJ;
+    return LSX_OK;
+}
+
+/* The pipelined-loop entries of the ABI (include/lsx.h).  The oracle computes synchronously, so a speculative formal solution
+ * simply keeps a copy of everything the call overwrites (J, I, Gamma, the accumulated Rij / Rji, the per-column dJ) and
+ * lsx_discard_formal_sol puts it back; lsx_sync_begin has nothing to enqueue and lsx_sync_end is lsx_sync. */
+static void spec_copy(lsx_ctx* c, int restore)
+{
+    const size_t nc = (size_t)c->ncol, Ns = (size_t)c->Nspace;
+    const size_t nt = (size_t)(c->Ntrans ? c->Ntrans : 1);
+    double* arr[6] = {c->J, c->I, c->Gamma, c->Rij, c->Rji, c->dJcol};
+    const size_t len[6] = {nc * c->Nspect * Ns, nc * c->Nspect * c->Nrays, nc * c->NL2tot * Ns, nc * nt * Ns, nc * nt * Ns, nc};
+    size_t tot = 0;
+    for (int i = 0; i < 6; ++i) tot += len[i];
+    if (!c->spec_save) c->spec_save = (double*)malloc(tot * 8);
+    double* q = c->spec_save;
+    for (int i = 0; i < 6; ++i) {
+        if (restore) memcpy(arr[i], q, len[i] * 8);
+        else memcpy(q, arr[i], len[i] * 8);
+        q += len[i];
+    }
+}
+
+int lsx_formal_sol_gamma_speculative(lsx_ctx* c)
+{
+    if (!c) return fail(LSX_EINVAL, "null ctx");
+    if (c->colmask) return fail(LSX_EUNSUPPORTED, "lsx_formal_sol_gamma_speculative: not with frozen columns (lsx_set_active_columns)");
+    spec_copy(c, 0);
+    c->spec_last_dJ = c->last_dJ;
+    int rc = lsx_formal_sol_gamma_async(c);
+    c->spec_valid = rc == LSX_OK;
+    return rc;
+}
+
+int lsx_discard_formal_sol(lsx_ctx* c)
+{
+    if (!c) return fail(LSX_EINVAL, "null ctx");
+    if (!c->spec_valid) return fail(LSX_EINVAL, "lsx_discard_formal_sol: the last call was not a speculative formal solution");
+    spec_copy(c, 1);
+    c->last_dJ = c->spec_last_dJ;
+    c->spec_valid = 0;
+    return LSX_OK;
+}
+
+int lsx_prefers_lookahead(lsx_ctx* c)
+{
+    (void)c;
+    return 0;
+}
+
+int lsx_sync_begin(lsx_ctx* c)
+{
+    if (!c) return fail(LSX_EINVAL, "null ctx");
+    if (c->mon_set) return fail(LSX_EINVAL, "lsx_sync_begin: the previous read-back has not been collected (lsx_sync_end)");
+    c->mon_dJ = c->last_dJ;
+    c->mon_dP = c->last_dP;
+    c->mon_set = 1;
     return LSX_OK;
 }
 
@@ -1234,6 +1297,7 @@ static int stat_equil_column(lsx_ctx* c, int col)
 int lsx_stat_equil_async(lsx_ctx* c)
 {
     if (!c) return fail(LSX_EINVAL, "null ctx");
+    c->spec_valid = 0;
     for (int a = 0; a < c->Natoms; ++a)
         if (c->Nlevel[a] > 32) return fail(LSX_EUNSUPPORTED, "oracle stat_equil: Nlevel > 32");
     int sing = 0;
@@ -1287,8 +1351,19 @@ int lsx_set_active_columns(lsx_ctx* c, const uint8_t* active)
 int lsx_sync(lsx_ctx* c, double* dJ, double* dP)
 {
     if (!c) return fail(LSX_EINVAL, "null ctx");
+    c->mon_set = 0;
     if (dJ) *dJ = c->last_dJ;
     if (dP) *dP = c->last_dP;
+    return LSX_OK;
+}
+
+int lsx_sync_end(lsx_ctx* c, double* dJ, double* dP)
+{
+    if (!c) return fail(LSX_EINVAL, "null ctx");
+    if (!c->mon_set) return lsx_sync(c, dJ, dP);
+    c->mon_set = 0;
+    if (dJ) *dJ = c->mon_dJ;
+    if (dP) *dP = c->mon_dP;
     return LSX_OK;
 }
 

@@ -89,7 +89,7 @@ def _worker_engine_path(rank, world, port, ncol_total, out_dir):
     first, n = shard_columns(ncol_total, rank, world)
     eng = Engine(prob, n, lib=lib)
     synth.load_columns(eng, *synth.perturbed_columns(prob, base, raw, ncol=n, seed=99, first=first))
-    h = drivers.iterate_mali_engine(eng, reducer=MaxReducer(), max_iter=7)
+    h = drivers.iterate_mali_engine(eng, reducer=MaxReducer(), max_iter=7, pipelined=True)     # the look-ahead loop over the ranks (engine_begin / engine_end) against the plain single-process loop below
     np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), first=first, n=eng.get(_capi.LSX_N), J=eng.get(_capi.LSX_J),
              dJ=np.array(h.dJ), dP=np.array(h.dPops))
     dist.barrier()
@@ -204,6 +204,18 @@ def test_max_reducer_over_rccl_single_rank():
             b = drivers.mali_step(e2, it > 3)
             assert a == b, (it, a, b)
         assert np.array_equal(e1.get(_capi.LSX_N), e2.get(_capi.LSX_N))
+        # the same exchange split in two (MaxReducer.engine_begin / engine_end): reduction, all-reduce and read-back are enqueued,
+        # the next formal solution goes out behind them, the host waits for the read-back only (drivers.mali_steps); and the
+        # whole loop with the look-ahead formal solution taken back at the end (drivers.iterate_mali_engine)
+        a = list(drivers.mali_steps(e1, 5, reducer=red, n_lambda_only=0, first=6, lookahead=True))
+        b = [drivers.mali_step(e2, True) for _ in range(5)]
+        assert a == b
+        assert np.array_equal(e1.get(_capi.LSX_N), e2.get(_capi.LSX_N)) and np.array_equal(e1.get(_capi.LSX_I), e2.get(_capi.LSX_I))
+        ha = drivers.iterate_mali_engine(e1, reducer=red, n_lambda_only=0, max_iter=40, pipelined=True)
+        hb = drivers.iterate_mali_engine(e2, n_lambda_only=0, max_iter=40, pipelined=False)
+        assert ha.converged and ha.dJ == hb.dJ and ha.dPops == hb.dPops
+        for w in (_capi.LSX_N, _capi.LSX_I, _capi.LSX_J, _capi.LSX_GAMMA):
+            assert np.array_equal(e1.get(w), e2.get(w))
         e3 = Engine(prob, 1, stream=ts.cuda_stream)            # singular system (Gamma still zero) -> LinAlgError on every rank
         e3.set_columns(0, base)
         e3.stat_equil_async()
