@@ -260,9 +260,10 @@ int lsx_formal_sol_gamma_speculative(lsx_ctx* ctx);
 int lsx_discard_formal_sol(lsx_ctx* ctx);
 /* 1 if enqueueing ahead pays for this context, else 0.  HIP library: 1 for contexts whose formal solution is one launch chain
  * on the context's own stream (fewer than 32 columns: the latency-bound case, a FALC column: 4.37 -> 3.91 ms for its 46
- * iterations).  Larger contexts fork their tile classes onto several streams; enqueued ahead, that fork and the join become
- * waits on PENDING events across hardware queues, measured at 80-100 us each on this runtime against the 20-50 us of idle time
- * the look-ahead removes (1000 CaII columns: 1.44 against 1.10 ms per iteration), so 0.  The oracle computes synchronously: 0. */
+ * iterations).  Larger contexts fork their tile classes onto several streams; enqueued ahead, the fork is a wait on a PENDING
+ * event across hardware queues, which costs what the host round trip it replaces costs (29 against 28 us from the read-back to
+ * the first sweep, 1000 CaII columns: 1.10 ms per iteration either way; with the default system-scope events it was 1.44), so 0.
+ * The oracle computes synchronously: 0. */
 int lsx_prefers_lookahead(lsx_ctx* ctx);
 
 /* The convergence monitors of the most recent (enqueued) calls, reduced over this context's columns and left where the

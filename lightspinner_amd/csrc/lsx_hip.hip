@@ -1550,6 +1550,10 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     TRY(upload(&c->d_slots, c->slots, c->stream));
     TRY(upload(&c->d_Nlevel, c->Nlevel, c->stream));
     TRY(upload(&c->d_lev2_off, c->lev2_off, c->stream));
+    // the fork / join events order kernels of THIS device only: a device-scope release when they are recorded, not the default
+    // system-scope fence (cache write-back and invalidation before every class starts and before the epilogue);
+    // LSX_SYSTEM_EVENTS=1: the default events (a measured alternative)
+    const unsigned kDevEvent = hipEventDisableTiming | (getenv("LSX_SYSTEM_EVENTS") ? 0u : (unsigned)hipEventReleaseToDevice);
     for (auto& k : c->classes) {
         TRY(upload(&k.d_tiles, k.tiles, c->stream));
         if (!k.fast_tiles.empty()) TRY(upload(&k.d_fast_tiles, k.fast_tiles, c->stream));
@@ -1568,9 +1572,9 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         // is bound by vector issue, so there is no idle resource for a favoured class to pick up; LSX_PRIO=1 restores the tiers)
         const int prio = getenv("LSX_PRIO") ? std::min(prio_lo, prio_hi + want) : prio_lo;
         if (c->opt_trace_classes) fprintf(stderr, "class npt=%d nl=%d: stream priority %d (range %d .. %d)\n", k.npt, k.nl, prio, prio_hi, prio_lo);
-        if (hipStreamCreateWithPriority(&k.stream, hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&k.done, hipEventDisableTiming) != hipSuccess) { lsx_destroy(c); return fail(LSX_EDEVICE, "class stream"); }
+        if (hipStreamCreateWithPriority(&k.stream, hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&k.done, kDevEvent) != hipSuccess) { lsx_destroy(c); return fail(LSX_EDEVICE, "class stream"); }
     }
-    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { lsx_destroy(c); return fail(LSX_EDEVICE, "hipEventCreate"); }
+    if (hipEventCreateWithFlags(&c->ev_fork, kDevEvent) != hipSuccess) { lsx_destroy(c); return fail(LSX_EDEVICE, "hipEventCreate"); }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess) { lsx_destroy(c); return fail(LSX_EDEVICE, "hipEventCreate"); }
     if (hipEventCreate(&c->evA) != hipSuccess || hipEventCreate(&c->evB) != hipSuccess) { lsx_destroy(c); return fail(LSX_EDEVICE, "hipEventCreate"); }
 
