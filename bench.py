@@ -268,9 +268,10 @@ def roofline_block(eng, lib, prob, ncol, workload, kernel_reps):
 
 def timed_steps(eng, reducer, nsteps, warmup, barrier):
     from lightspinner_amd import drivers
-    # drivers.mali_steps: the MALI loop as the product runs it -- the next iteration's formal solution is enqueued while the host
-    # waits for the monitors of the current one (exactly `nsteps` formal solutions and `nsteps` stat_equil calls inside the
-    # timed region, nothing enqueued beyond the last step)
+    # drivers.mali_steps: the MALI loop as the product runs it -- where the library says it pays (lsx_prefers_lookahead: small
+    # contexts) the next iteration's formal solution is enqueued while the host waits for the monitors of the current one, else
+    # the plain sequence; either way exactly `nsteps` formal solutions and `nsteps` stat_equil calls inside the timed region and
+    # nothing enqueued beyond the last step
     for _ in drivers.mali_steps(eng, warmup, reducer):
         pass
     barrier()
@@ -484,7 +485,9 @@ def main():
                                   Nrays=prob.Nrays, profiles='compact (vlos=0)' if compact else 'ray dependent (vlos!=0)',
                                   columns='populations, rates and profiles derived by the library from each column\'s perturbed atmosphere' if t_chain is not None else 'input-level perturbations (BASELINE C3 / C4)',
                                   parallelism=parallelism_text(world, rehearsal)),
-                      step_ms=dict(stats_ms(per_step), note='host clock on rank 0 between the monitor read-backs of consecutive steps (the next step is already enqueued when a read-back is waited for)'),
+                      step_ms=dict(stats_ms(per_step), note='host clock on rank 0 between the monitor read-backs of consecutive steps; loop: ' +
+                                   ('look-ahead (the next formal solution is enqueued before a read-back is waited for)' if eng.prefers_lookahead()
+                                    else 'plain (formal solution, stat_equil, read-back; lsx_prefers_lookahead = 0 for this context)')),
                       mali_iters_per_sec=args.steps / dt, column_iters_per_sec=args.steps * ncol * world / dt,
                       last_dJ=dJ, last_dPops=dP,
                       roofline=roofline, cpu_baseline=cpu, falc_single_column=single,
