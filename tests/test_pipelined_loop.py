@@ -89,6 +89,12 @@ def _discard_semantics(lib):
         e.discard_formal_sol()
     for w in RESULTS:
         assert np.array_equal(e.get(w), e2.get(w))
+    # one read-back in flight at a time; lsx_sync_end without one is lsx_sync
+    e.sync_begin()
+    with pytest.raises(_capi.LsxError, match='not been collected'):
+        e.sync_begin()
+    a = e.sync_end()
+    assert a == e.sync_end() == e.sync()
     # frozen columns: no speculation (the loop then simply does not look ahead)
     e.set_active_columns(np.array([True, False]))
     with pytest.raises(_capi.LsxError, match='frozen'):
