@@ -22,6 +22,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# hardware queues of the HIP runtime (read when it initialises; lightspinner_amd/__init__.py says why): set before anything imports
+# torch, recorded in the JSON line (config.runtime_env)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
@@ -484,7 +488,8 @@ def main():
                                   columns_per_gpu=ncol, columns_total=ncol * world, Nspace=prob.Nspace, Nspect=prob.Nspect,
                                   Nrays=prob.Nrays, profiles='compact (vlos=0)' if compact else 'ray dependent (vlos!=0)',
                                   columns='populations, rates and profiles derived by the library from each column\'s perturbed atmosphere' if t_chain is not None else 'input-level perturbations (BASELINE C3 / C4)',
-                                  parallelism=parallelism_text(world, rehearsal)),
+                                  parallelism=parallelism_text(world, rehearsal),
+                                  runtime_env=dict(GPU_MAX_HW_QUEUES=os.environ.get('GPU_MAX_HW_QUEUES'))),
                       step_ms=dict(stats_ms(per_step), note='host clock on rank 0 between the monitor read-backs of consecutive steps; loop: ' +
                                    ('look-ahead (the next formal solution is enqueued before a read-back is waited for)' if eng.prefers_lookahead()
                                     else 'plain (formal solution, stat_equil, read-back; lsx_prefers_lookahead = 0 for this context)')),
