@@ -172,6 +172,11 @@ def leg_oracle(path):
     e = Engine(prob, 3, lib=lib)
     synth.load_columns(e, blk, prof)            # lsx_set_line_profiles: the oracle's Voigt
     e.formal_sol_gamma(); e.stat_equil()
+    # the look-ahead loop: speculative formal solutions (a copy of everything they overwrite), the discard at the end
+    from lightspinner_amd import drivers
+    h = drivers.iterate_mali_engine(e, max_iter=6, pipelined=True)
+    assert h.n_iter == 6
+    e.formal_sol_gamma_speculative(); e.discard_formal_sol()
     e.close()
     for kw in (dict(seed=1), dict(seed=3, Nrays=5, Nspace=82, Nspect=130, sca_per_lambda=True), dict(seed=15, Nrays=5, Nspace=41, Nspect=120, multiplet=4)):
         prob, block = toy_problem(**kw)
