@@ -170,3 +170,19 @@ def test_header_is_plain_c_and_cxx():
         assert r.returncode == 0, r.stderr
     text = open(hdr).read()
     assert '#include <torch' not in text and '#include <hip' not in text and 'at::Tensor' not in text      # a stream is passed as void*
+
+
+def test_import_asks_for_eight_hardware_queues_unless_the_caller_has_chosen():
+    """lightspinner_amd/__init__.py: GPU_MAX_HW_QUEUES=8 (six tile classes on streams of their own) is a default, not an
+    override -- checked in fresh interpreters, without touching a GPU"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import os, lightspinner_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    for preset, expect in ((None, '8'), ('4', '4')):
+        env = {k: v for k, v in os.environ.items() if k != 'GPU_MAX_HW_QUEUES'}
+        if preset is not None:
+            env['GPU_MAX_HW_QUEUES'] = preset
+        out = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.strip() == expect
