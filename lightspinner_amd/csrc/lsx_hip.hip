@@ -20,6 +20,16 @@
 
 #include "lsx_ctx.h"
 
+// A context launches up to six tile classes on streams of their own; with the HIP runtime's default of four hardware queues two
+// of them wait for the others.  The runtime reads GPU_MAX_HW_QUEUES when it initialises, i.e. at the process's first
+// HIP call: asking for eight when this library is loaded covers hosts that bind the C ABI directly (the Python package does the
+// same at import).  A value the caller has set is left alone; LSX_KEEP_HW_QUEUES=1 keeps the runtime's default (measurements).
+namespace {
+struct HwQueueDefault {
+    HwQueueDefault() { if (!getenv("LSX_KEEP_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+} g_hw_queue_default;
+}
+
 namespace lsxd {
 thread_local std::string g_err;
 int fail(int code, const char* fmt, ...)
