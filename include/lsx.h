@@ -253,7 +253,11 @@ int lsx_sync(lsx_ctx* ctx, double* dJ_max, double* dPops_max);
  *   pair already), so that the previous call's remain available.  LSX_EUNSUPPORTED while columns are frozen
  *   (lsx_set_active_columns).
  * lsx_discard_formal_sol: undo the last call if it was speculative and nothing has been built on it (no lsx_stat_equil, no new
- *   inputs since): lsx_get and the next calls see the previous formal solution.  LSX_EINVAL otherwise. */
+ *   inputs since): lsx_get, lsx_sync and the next calls see the previous formal solution (an earlier call whose monitors nobody
+ *   has read is pending again).  LSX_EINVAL otherwise -- also while a read-back begun AFTER the speculative call is in flight
+ *   (lsx_sync_begin; collect it with lsx_sync_end first).
+ * Monitors are not lost between calls: a formal solution enqueued while a statistical equilibrium's maxima and singular flag
+ *   have not been read back (`FS; SE; FS; lsx_sync`, `SE_async; lsx_formal_sol_gamma(&dJ)`) leaves them in place. */
 int lsx_sync_begin(lsx_ctx* ctx);
 int lsx_sync_end(lsx_ctx* ctx, double* dJ_max, double* dPops_max);
 int lsx_formal_sol_gamma_speculative(lsx_ctx* ctx);
@@ -385,6 +389,25 @@ int lsx_w3(int32_t device, int32_t n, const double* dtau, double* w);
  * formal_solver.py:203-209 unchanged). */
 enum { LSX_SOLVER_LINEAR = 0, LSX_SOLVER_PARABOLIC = 1 };
 int lsx_set_formal_solver(lsx_ctx* ctx, int32_t solver);
+
+/* ---- which sweep kernel runs: part of the PROBLEM, not of the shard ("per-column results must be bitwise equal
+ * to the 1-GPU run"; response_fn.py:61-65 is one loop over all columns) ---------------------------------------------------
+ * The HIP library has two mappings of the formal solution onto the wavefront: one ray per lane (lsx_sweep.hip; the fused
+ * launch of small contexts and the per-class launches give the same bits) and the ray-serial mapping (lsx_sweep_rs.hip: a
+ * lane walks the five rays of one wavelength, five columns per wavefront).  They compute the same terms and associate the
+ * angle / wavelength sums differently: results agree to rounding (1e-13), not bit for bit.  Which one pays depends on how many
+ * columns there are, so LSX_SWEEP_AUTO decides by a column count: ray-serial from 160 columns on (if the context's shape
+ * admits it: five rays, wavelength-independent scattering), else one ray per lane; the parabolic rule (below) likewise takes its
+ * compile-time tile classes from 32 columns on and its generic instance below.
+ * `decide_for_columns` is that count: 0 = the context's own columns (the default), > 0 = decide as for a context of that many
+ * columns.  A driver that shards N columns over several contexts (ranks, GPUs, sub-batches) passes N to every one of them: every
+ * column then gets the bits it gets when all N sit in one context, whatever the shard sizes (tests/test_sharding_invariance.py).
+ * LSX_SWEEP_RAY_PER_LANE / LSX_SWEEP_RAY_SERIAL pin the mapping outright (LSX_EUNSUPPORTED if the context's shape does not
+ * admit the ray-serial kernel).  Takes effect from the next formal solution on.  The oracle accepts and ignores the call. */
+enum { LSX_SWEEP_AUTO = 0, LSX_SWEEP_RAY_PER_LANE = 1, LSX_SWEEP_RAY_SERIAL = 2 };
+int lsx_set_sweep_policy(lsx_ctx* ctx, int32_t policy, int32_t decide_for_columns);
+/* the mapping the next (linear-rule) formal solution will use: LSX_SWEEP_RAY_PER_LANE or LSX_SWEEP_RAY_SERIAL; the oracle: 0 */
+int32_t lsx_sweep_policy(const lsx_ctx* ctx);
 
 /* Measurement hooks (bench.py): time `reps` back-to-back FS calls with device events
  * on the context's stream.  ms_total = whole FS call (all kernels), ms_sweep = the

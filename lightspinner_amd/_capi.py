@@ -15,6 +15,7 @@ ABI_VERSION = 1
 # item selectors (include/lsx.h)
 LSX_I, LSX_J, LSX_N, LSX_GAMMA, LSX_DJ_COL, LSX_DPOPS_COL, LSX_NSTAR, LSX_C, _, _, LSX_PHI, LSX_WPHI, LSX_VBROAD, LSX_ADAMP = range(14)
 LSX_SOLVER_LINEAR, LSX_SOLVER_PARABOLIC = 0, 1
+LSX_SWEEP_AUTO, LSX_SWEEP_RAY_PER_LANE, LSX_SWEEP_RAY_SERIAL = 0, 1, 2      # include/lsx.h: lsx_set_sweep_policy
 LSX_COLL_OMEGA, LSX_COLL_CI, LSX_COLL_CE = range(3)
 
 LSX_EINVAL, LSX_EDEVICE, LSX_ESINGULAR, LSX_EUNSUPPORTED = 1, 2, 3, 5
@@ -96,6 +97,7 @@ REQUIRED_SYMBOLS = (
     'lsx_wavelength_grid', 'lsx_active_set', 'lsx_line_wavelength', 'lsx_continuum_alpha',
     'lsx_piecewise_parabolic_1d_impl', 'lsx_w3', 'lsx_set_formal_solver',
     'lsx_sync_begin', 'lsx_sync_end', 'lsx_formal_sol_gamma_speculative', 'lsx_discard_formal_sol', 'lsx_prefers_lookahead',
+    'lsx_set_sweep_policy', 'lsx_sweep_policy',
 )
 
 
@@ -158,6 +160,9 @@ class LsxLibrary:
         d.lsx_piecewise_parabolic_1d_impl.argtypes = [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.POINTER(C.c_int32), _dp, _dp, _dp,
                                                       _dp, _dp]
         d.lsx_set_formal_solver.argtypes = [C.c_void_p, C.c_int32]
+        d.lsx_set_sweep_policy.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        d.lsx_sweep_policy.argtypes = [C.c_void_p]
+        d.lsx_sweep_policy.restype = C.c_int32
         ip = C.POINTER(C.c_int32)
         d.lsx_wavelength_grid.argtypes = [C.c_int32, C.POINTER(LsxTransGrid), C.c_int32, _dp, C.c_double, C.c_int32, _dp, ip, ip, ip]
         d.lsx_active_set.argtypes = [C.c_int32, C.c_int32, ip, ip, C.POINTER(C.c_uint8)]

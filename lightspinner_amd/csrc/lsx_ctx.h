@@ -61,6 +61,8 @@ struct lsx_ctx : lsxd::LsxPlan {        // the plan (lsx_plan.h: dimensions, tab
     std::vector<uint8_t> phi_set;    // per column: line profiles have been handed over or built
     size_t n_phi_set = 0;
     int solver = 0;               // LSX_SOLVER_* (lsx_set_formal_solver)
+    int sweep_policy = LSX_SWEEP_AUTO;   // lsx_set_sweep_policy: which wavefront mapping the formal solution runs ...
+    int policy_columns = 0;              // ... and, under AUTO, the column count that decides (0: this context's own)
     bool opt_se_lds = false, opt_trace_classes = false, opt_serial = false;   // LSX_SE_LDS / LSX_TRACE_CLASSES / LSX_SERIAL, read once in lsx_create
     long fused_launches = 0;
     uint8_t* d_colmask = nullptr; // per-column activity, nullptr = all active
@@ -92,11 +94,31 @@ struct lsx_ctx : lsxd::LsxPlan {        // the plan (lsx_plan.h: dimensions, tab
     double *d_I_alt = nullptr, *d_Gamma_alt = nullptr, *d_res_alt = nullptr;
     bool spec_valid = false;         // the last formal solution was speculative and nothing has built on it: it can be discarded
     bool spec_dp_zeroed = false;     // dp_zeroed as it was before that call
+    bool spec_fs_pending = false;    // fs_pending likewise
+    double spec_last_dJ = 0.0;       // last_dJ likewise
+    bool mon_spec = false;           // the read-back in flight was begun while a speculative call could still be discarded
     bool mon_outstanding = false, mon_fs = false, mon_se = false;
     hipEvent_t ev_mon = nullptr;
 };
 
 namespace lsxd {
+
+// the column count the bit-relevant kernel choices are made for (include/lsx.h, lsx_set_sweep_policy)
+inline int policy_ncol(const lsx_ctx* c) { return c->policy_columns > 0 ? c->policy_columns : c->ncol; }
+// linear rule: the ray-serial mapping (classes that have an instance of it) or one ray per lane
+inline bool use_ray_serial(const lsx_ctx* c)
+{
+    if (!c->rs_ok || c->sweep_policy == LSX_SWEEP_RAY_PER_LANE) return false;
+    return c->sweep_policy == LSX_SWEEP_RAY_SERIAL || policy_ncol(c) >= c->rs_min_columns;
+}
+// one launch per tile class on forked streams (else: one fused launch on the context's stream).  For the linear rule the two
+// give the same bits per mapping, so the context's OWN size decides unless the ray-serial kernels run (they exist per class
+// only); the parabolic rule's compile-time classes and its generic instance differ in the last bits: the policy count decides.
+inline bool per_class_launches(const lsx_ctx* c)
+{
+    if (c->solver == LSX_SOLVER_PARABOLIC) return policy_ncol(c) >= 32;
+    return c->ncol >= 32 || use_ray_serial(c);
+}
 
 template <typename T>
 int dmalloc(T** p, size_t count)

@@ -22,12 +22,16 @@
 
 // A context launches up to six tile classes on streams of their own; with the HIP runtime's default of four hardware queues two
 // of them wait for the others.  The runtime reads GPU_MAX_HW_QUEUES when it initialises, i.e. at the process's first
-// HIP call: asking for eight when this library is loaded covers hosts that bind the C ABI directly (the Python package does the
-// same at import).  A value the caller has set is left alone; LSX_KEEP_HW_QUEUES=1 keeps the runtime's default (measurements).
-namespace {
-struct HwQueueDefault {
-    HwQueueDefault() { if (!getenv("LSX_KEEP_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "8", 0); }
-} g_hw_queue_default;
+// HIP call.  The library does NOT touch the process environment on its own (a dlopen'ed library that calls setenv races with the
+// host's other threads and changes every HIP user of the process): the Python package and bench.py set the default at import;
+// a host that binds the C ABI directly sets the variable itself or calls lsx_hip_request_hw_queues() before its first HIP call
+// (INTEGRATION.md 2).
+extern "C" int lsx_hip_request_hw_queues(int32_t n)
+{
+    if (n < 1 || n > 64) return LSX_EINVAL;
+    char buf[16];
+    snprintf(buf, sizeof buf, "%d", (int)n);
+    return setenv("GPU_MAX_HW_QUEUES", buf, 0) == 0 ? LSX_OK : LSX_EDEVICE;      // (a value the caller has set is left alone)
 }
 
 namespace lsxd {
@@ -259,8 +263,9 @@ struct FinishParams {
     double* Gamma;
     double* dJcol;
     const uint8_t* colmask;
-    double* dPcol;                      // zeroed here for the stat_equil that follows (its per-column maxima are atomic)
-    unsigned long long* singular;       // likewise
+    double* dPcol;                      // zeroed here for the stat_equil that follows (its per-column maxima are atomic) ...
+    unsigned long long* singular;       // likewise ...
+    int clear_dp;                       // ... unless a stat_equil's monitors are still waiting to be read back (0)
     const int* fin_ptr;                 // [NL2tot + 1]  k_gamma_finish_small: the slabs that add up to one entry,
     const int* fin_idx;                 //               as (slot * 4 + slab), in slot order
 };
@@ -275,8 +280,10 @@ __global__ void k_gamma_finish(const FinishParams f)
     const long gid = (long)blockIdx.x * nt + tid;
     if (gid >= (long)f.ncol * Ns) return;
     const int col = gid / Ns, k = gid % Ns;
-    if (k == 0) f.dPcol[col] = 0.0;
-    if (gid == 0) *f.singular = 0ull;
+    if (f.clear_dp) {
+        if (k == 0) f.dPcol[col] = 0.0;
+        if (gid == 0) *f.singular = 0ull;
+    }
     if (f.colmask && !f.colmask[col]) {
         if (k == 0) f.dJcol[col] = 0.0;
         return;
@@ -335,7 +342,7 @@ __global__ void __launch_bounds__(64) k_gamma_finish_small(const FinishParams f)
     const int Ns = f.Nspace;
     const int col = blockIdx.x / Ns, k = blockIdx.x - col * Ns;
     const int lane = threadIdx.x;
-    if (k == 0 && lane == 0) {
+    if (f.clear_dp && k == 0 && lane == 0) {
         f.dPcol[col] = 0.0;
         if (col == 0) *f.singular = 0ull;
     }
@@ -1507,6 +1514,11 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     }
     c->opt_se_lds = getenv("LSX_SE_LDS") != nullptr;
     c->opt_trace_classes = getenv("LSX_TRACE_CLASSES") != nullptr;
+    if (c->opt_trace_classes) {
+        const char* q = getenv("GPU_MAX_HW_QUEUES");
+        fprintf(stderr, "lsx_create: GPU_MAX_HW_QUEUES=%s at this point (%zu tile classes, each on a stream of its own; the runtime read the "
+                        "variable at the process's first HIP call)\n", q ? q : "(unset: the runtime's default of 4)", c->plan_classes.size());
+    }
     c->opt_serial = getenv("LSX_SERIAL") != nullptr;              // every class on the context's stream, one after the other
     c->opt_finish_big = getenv("LSX_FINISH_BIG") != nullptr;      // the many-column Gamma epilogue also for small batches
     const int Ns = c->Nspace, Nspect = c->Nspect;
@@ -1764,6 +1776,8 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
         }
         swap_result_buffers(c);
         c->spec_dp_zeroed = c->dp_zeroed;
+        c->spec_fs_pending = c->fs_pending;
+        c->spec_last_dJ = c->last_dJ;
     }
     c->spec_valid = speculative;
     SweepParams p{};
@@ -1841,7 +1855,8 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
     // small batches: one fused launch (n_class_tiles == ntile, identity tile list is not needed); the parabolic rule (N4) has one
     // generic instance for every tile and takes the same route at any size
     const bool parabolic = c->solver == LSX_SOLVER_PARABOLIC;
-    if (c->ncol < 32) {
+    const bool ray_serial = !parabolic && use_ray_serial(c);
+    if (!per_class_launches(c)) {
         p.ncell_lev = S.fused_ncell_lev; p.ncell_atom = S.fused_ncell_atom;
         c->fused_launches++;
         const int code = parabolic ? -4 : -2;
@@ -1873,7 +1888,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
                 const bool inst = c->Nrays == LSX_RS_RAYS && !c->sca_per_lambda && k.npt >= 0 && lsx_rs_instance_exists(k.npt, k.nl, k.linked, k.topo);
                 if (!inst) { p.ncell_lev = S.fused_ncell_lev; p.ncell_atom = S.fused_ncell_atom; }
                 note(lsx_launch_sweep_par(&p, inst ? k.code() : -1, (int)nblocks, inst ? k.lds_bytes : S.fused_lds, st));
-            } else if (k.rs && c->ncol >= c->rs_min_columns) note(lsx_launch_sweep_rs(&p, k.code(), st));       // five columns per wavefront
+            } else if (k.rs && ray_serial) note(lsx_launch_sweep_rs(&p, k.code(), st));       // five columns per wavefront
             else note(lsx_launch_sweep(&p, k.code(), (int)nblocks, k.lds_bytes, st));
             if (timed) {
                 if (!k.tdone) note(hipEventCreate(&k.tdone));
@@ -1895,17 +1910,23 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
     f.tile_slots = c->d_tile_slots; f.trans = c->d_trans; f.C = c->d_C; f.Gpart = c->d_Gpart; f.dJpart = c->d_dJpart;
     f.Gamma = c->d_Gamma; f.dJcol = c->d_dJcol; f.colmask = c->d_colmask;
     f.dPcol = c->d_dPcol; f.singular = c->d_singular; f.fin_ptr = c->d_fin_ptr; f.fin_idx = c->d_fin_idx;
+    // `FS; SE; FS; sync` (and `SE; formal_sol_gamma(&dJ)`): the statistical equilibrium's per-column maxima and its singular flag
+    // have not been read back yet -- they live in the block this epilogue would clear.  Then the epilogue leaves them alone and
+    // the next stat_equil clears them itself.  (A speculative call writes the second block: nothing pending there.)
+    f.clear_dp = (c->se_pending && !speculative) ? 0 : 1;
     const long nthreads = (long)c->ncol * c->Nspace;
     if (c->ncol < 32 && !c->opt_finish_big)
         hipLaunchKernelGGL(k_gamma_finish_small, dim3((unsigned)nthreads), dim3(64), (size_t)c->NL2tot * sizeof(double), c->stream, f);
     else
         hipLaunchKernelGGL(k_gamma_finish, dim3((unsigned)((nthreads + S.finish_nt - 1) / S.finish_nt)), dim3(S.finish_nt), S.finish_lds, c->stream, f);
-    c->dp_zeroed = true;
+    c->dp_zeroed = f.clear_dp != 0;
     note(hipGetLastError());
     if (timed) note(hipEventRecord(c->ev2, c->stream));
     c->jcur ^= 1;
     c->fs_pending = true;
-    if (lerr != hipSuccess) return fail(lerr == hipErrorNotSupported ? LSX_EUNSUPPORTED : LSX_EDEVICE, "formal_sol_gamma: a launch failed: %s", hipGetErrorString(lerr));
+    // (LSX_EDEVICE whatever the HIP error: shapes were checked when the context was made, and LSX_EUNSUPPORTED from the speculative
+    // entry means "refused, nothing enqueued" to the drivers)
+    if (lerr != hipSuccess) return fail(LSX_EDEVICE, "formal_sol_gamma: a launch failed: %s", hipGetErrorString(lerr));
     return LSX_OK;
 }
 
@@ -1951,18 +1972,22 @@ int lsx_formal_sol_gamma_speculative(lsx_ctx* c)
 
 int lsx_prefers_lookahead(lsx_ctx* c)
 {
-    return c && c->ncol < 32 && !c->d_colmask ? 1 : 0;      // the fused launch on the context's stream (enqueue_fs)
+    return c && !per_class_launches(c) && !c->d_colmask ? 1 : 0;      // the fused launch on the context's stream (enqueue_fs)
 }
 
 int lsx_discard_formal_sol(lsx_ctx* c)
 {
     if (!c) return fail(LSX_EINVAL, "null ctx");
     if (!c->spec_valid) return fail(LSX_EINVAL, "lsx_discard_formal_sol: the last call was not a speculative formal solution");
+    if (c->mon_outstanding && c->mon_spec)
+        return fail(LSX_EINVAL, "lsx_discard_formal_sol: a read-back begun after the speculative call is in flight (lsx_sync_end first: "
+                                "it would report the discarded call's monitors)");
     // (its kernels may still be running: everything that follows is ordered behind them on the context's stream)
     swap_result_buffers(c);
     c->jcur ^= 1;
     c->dp_zeroed = c->spec_dp_zeroed;
-    c->fs_pending = false;
+    c->fs_pending = c->spec_fs_pending;      // an earlier formal solution whose monitors nobody has read yet is pending again
+    c->last_dJ = c->spec_last_dJ;            // (and lsx_sync reports the accepted call's dJ, whether or not the discarded one's was read)
     c->spec_valid = false;
     return LSX_OK;
 }
@@ -2048,6 +2073,7 @@ int lsx_sync_begin(lsx_ctx* c)
     if (!c->ev_mon) HIPCHK(hipEventCreateWithFlags(&c->ev_mon, hipEventDisableTiming));
     HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_res, (2 * (size_t)c->ncol + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipEventRecord(c->ev_mon, c->stream));
+    c->mon_spec = c->spec_valid;      // this read-back carries a speculative call's monitors: collect it before discarding that call
     c->mon_fs = c->fs_pending; c->mon_se = c->se_pending;
     c->fs_pending = c->se_pending = false;
     c->mon_outstanding = true;
@@ -2353,6 +2379,24 @@ int lsx_w3(int32_t device, int32_t n, const double* dtau, double* w)
     return LSX_OK;
 }
 
+int lsx_set_sweep_policy(lsx_ctx* c, int32_t policy, int32_t decide_for_columns)
+{
+    if (!c || policy < LSX_SWEEP_AUTO || policy > LSX_SWEEP_RAY_SERIAL || decide_for_columns < 0)
+        return fail(LSX_EINVAL, "lsx_set_sweep_policy: bad argument");
+    if (policy == LSX_SWEEP_RAY_SERIAL && !c->rs_ok)
+        return fail(LSX_EUNSUPPORTED, "lsx_set_sweep_policy: this context's shape has no ray-serial kernel (it needs %d rays, a "
+                                      "wavelength-independent scattering coefficient and column blocks within 32-bit offsets)", LSX_RS_RAYS);
+    c->spec_valid = false;            // a speculative formal solution was made under the old policy: it stands
+    c->sweep_policy = policy;
+    c->policy_columns = decide_for_columns;
+    return LSX_OK;
+}
+
+int32_t lsx_sweep_policy(const lsx_ctx* c)
+{
+    return c && use_ray_serial(c) ? LSX_SWEEP_RAY_SERIAL : LSX_SWEEP_RAY_PER_LANE;
+}
+
 int lsx_set_formal_solver(lsx_ctx* c, int32_t solver)
 {
     if (!c || (solver != LSX_SOLVER_LINEAR && solver != LSX_SOLVER_PARABOLIC)) return fail(LSX_EINVAL, "lsx_set_formal_solver: bad argument");
@@ -2398,7 +2442,7 @@ int lsx_time_formal_sol(lsx_ctx* c, int32_t warmup, int32_t reps, double* ms_tot
         // the sweep: from the fork to the end of the last class (the classes run side by side; the fast-continuum
         // pre-pass and epilogue run next to them and are not part of this figure unless they delay a class)
         HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        if (c->ncol >= 32) {
+        if (per_class_launches(c)) {
             float mx = 0.f;
             for (auto& k : c->classes)
                 if (k.tdone) {
@@ -2450,7 +2494,7 @@ int32_t lsx_hip_class_info(const lsx_ctx* c, int32_t idx, int64_t* out)
     if (out && idx >= 0 && idx < (int)c->classes.size()) {
         const SweepClass& k = c->classes[idx];
         out[0] = k.npt; out[1] = k.nl; out[2] = (int64_t)k.tiles.size(); out[3] = k.launches; out[4] = k.linked ? 1 : 0; out[5] = k.topo;
-        out[6] = (k.rs && c->ncol >= c->rs_min_columns) ? 1 : 0;
+        out[6] = (k.rs && c->solver != LSX_SOLVER_PARABOLIC && use_ray_serial(c)) ? 1 : 0;
     }
     return (int32_t)c->classes.size();
 }

@@ -25,11 +25,15 @@
 // ---- the compiled instances of lsx_sweep_kernel<NPT, NL, NR, SCAL, LK, TOPO> (per-ray slots, lines among them, linked
 // continua, two-line relation): ONE list.  lsx_sweep.hip expands it into the launch switch, the plan asks it before it
 // files a tile under a class; a tile whose shape has no instance runs the generic one (runtime slot loops).
+// Shapes the plan can never make are not on the list (round 4, tests/test_instance_ledger.py): a per-ray continuum needs a
+// line of its own atom in the tile, so there is no tile with per-ray slots and no line (1,0) (2,0); and if one continuum of an
+// atom is per-ray all of that atom's continua in the tile are, so a tile whose only line belongs to that atom has no linked
+// continuum left: (2,1,linked) (3,1,linked).
 #define LSX_SWEEP_INSTANCES(X)                                                                                   \
-    X(0, 0, false, 0) X(1, 0, false, 0) X(1, 1, false, 0) X(2, 0, false, 0) X(2, 1, false, 0) X(2, 2, false, 0)  \
+    X(0, 0, false, 0) X(1, 1, false, 0) X(2, 1, false, 0) X(2, 2, false, 0)                                      \
     X(3, 1, false, 0) X(3, 2, false, 0) X(3, 3, false, 0)                                                        \
     X(4, 1, false, 0) X(4, 2, false, 0) X(4, 3, false, 0) X(4, 4, false, 0)                                      \
-    X(1, 1, true, 0) X(2, 1, true, 0) X(2, 2, true, 0) X(3, 1, true, 0) X(3, 2, true, 0) X(3, 3, true, 0)        \
+    X(1, 1, true, 0) X(2, 2, true, 0) X(3, 2, true, 0) X(3, 3, true, 0)                                          \
     X(2, 2, false, 1) X(2, 2, false, 2) X(2, 2, true, 1) X(2, 2, true, 2)
 // launch code of a class: >= 0 a compiled instance; -1 generic, -3 generic with linked continua, -2 fused small-batch
 // kernel, -4 parabolic rule (N4)
@@ -105,8 +109,8 @@ constexpr SweepLds lsx_sweep_lds(int npt, bool linked, int Ns, int ncell_lev, in
 #define LSX_RS_COLS 5
 #define LSX_RS_MIN_COLUMNS 160         // default of PlanOptions::rs_min_columns
 #define LSX_RS_INSTANCES(X)                                                                                      \
-    X(0, 0, false, 0) X(1, 0, false, 0) X(1, 1, false, 0) X(2, 0, false, 0) X(2, 1, false, 0) X(2, 2, false, 0)  \
-    X(1, 1, true, 0) X(2, 1, true, 0) X(2, 2, true, 0)                                                           \
+    X(0, 0, false, 0) X(1, 1, false, 0) X(2, 1, false, 0) X(2, 2, false, 0)                                      \
+    X(1, 1, true, 0) X(2, 2, true, 0)                                                                            \
     X(2, 2, false, 1) X(2, 2, false, 2) X(2, 2, true, 1) X(2, 2, true, 2)
 #ifndef LSX_RS_WPE1
 #define LSX_RS_WPE1 2

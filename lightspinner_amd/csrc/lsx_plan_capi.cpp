@@ -177,6 +177,37 @@ int lsx_plan_probe(const lsx_problem* d, uint32_t option_bits, int64_t* summary,
     return LSX_OK;
 }
 
+// The compiled template instances, from the lists the kernels are instantiated from (lsx_plan.h): which = 0 the one-ray-per-lane
+// sweep (LSX_SWEEP_INSTANCES), 1 the ray-serial sweep = the parabolic rule's compile-time classes (LSX_RS_INSTANCES).  -> count;
+// codes[i] = lsx_class_code(per-ray slots, lines, linked, two-line relation).  tests/test_instance_ledger.py: every instance that
+// is compiled must be planned -- and run against the oracle -- by some GPU test.
+int32_t lsx_plan_instances(int32_t which, int32_t* codes, int32_t max)
+{
+    std::vector<int32_t> v;
+#define LSX_X(NPT, NL, LK, TOPO) v.push_back(lsx_class_code(NPT, NL, LK, TOPO));
+    if (which == 0) { LSX_SWEEP_INSTANCES(LSX_X) }
+    else if (which == 1) { LSX_RS_INSTANCES(LSX_X) }
+#undef LSX_X
+    for (int32_t i = 0; codes && i < (int32_t)v.size() && i < max; ++i) codes[i] = v[i];
+    return (int32_t)v.size();
+}
+
+// the ray-serial eligibility of a problem's classes: -> number of classes; out[c][2] = class code, 1 if the class has a
+// ray-serial instance AND the context's shape admits the kernel (five rays, wavelength-independent scattering, 32-bit offsets)
+int32_t lsx_plan_rs_classes(const lsx_problem* d, int32_t* out, int32_t max)
+{
+    PlanOptions opt;
+    LsxPlan P;
+    std::string e;
+    if (plan_build(d, opt, &P, &e) != LSX_OK) return -1;
+    int32_t n = 0;
+    for (auto& k : P.plan_classes) {
+        if (out && n < max) { out[2 * n] = k.code(); out[2 * n + 1] = k.rs ? 1 : 0; }
+        ++n;
+    }
+    return n;
+}
+
 } // extern "C"
 
 // what lsx_grid.cpp expects from the runtime (the product defines these in lsx_hip.hip)

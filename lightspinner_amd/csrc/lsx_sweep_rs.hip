@@ -293,7 +293,14 @@ lsx_sweep_rs_kernel(const SweepParams p)
 #pragma unroll
             for (int e = 1; e < LW / 2; ++e) { v2 = src[e]; acc += v2.x + v2.y; }
             const int e64 = sprev & (PE - 1);
+#ifdef LSX_RS_FLUSH2
+            // every lane writes: the lanes that own no (column, value) pair put their sum into the wave's dJ row, which is only
+            // read after the last step has overwritten it -- no branch around the reads and the adds, so they can be scheduled
+            // into the ray-independent part of the step
+            *(own ? &park[lane * PE + e64] : &red[NV * RROW + lane]) = acc;
+#else
             if (own) park[lane * PE + e64] = acc;
+#endif
             if (e64 == PE - 1 || sprev == Ns - 1) {
                 __builtin_amdgcn_wave_barrier();
                 const int kk = kS + dk * (sprev - e64 + lane);             // the depth parked in entry `lane` of every row
@@ -325,9 +332,13 @@ lsx_sweep_rs_kernel(const SweepParams p)
         if constexpr (SECOND) jhalf = at(Jnew, kt);
         // the Gamma totals of the previous depth (their values were parked at the end of the previous step)
         if constexpr (!FIRST && NPT >= 1) {
+#ifdef LSX_RS_FLUSH2
+            flush(s - 1);
+#else
             __builtin_amdgcn_wave_barrier();
             flush(s - 1);
             __builtin_amdgcn_wave_barrier();
+#endif
         }
 
         // ---- ray-independent part (rh_method.py:601-632): continuum slots, emissivity without the lines
@@ -574,7 +585,9 @@ lsx_sweep_rs_kernel(const SweepParams p)
         }
 
         // ---- the wavelength's sums leave: Psibar, Psi* phi, the Gamma integrands (parked for the lane reduction), J
+#ifndef LSX_ABL_NOSTORE
         if (nF > 0 && act) at(psibar, kt) = Pacc;
+#endif
         if constexpr (LK) {
             if (act) {
 #pragma unroll
@@ -591,7 +604,11 @@ lsx_sweep_rs_kernel(const SweepParams p)
             }
         }
         if constexpr (PH == 0) {
+#ifdef LSX_ABL_NOSTORE
+            if (valid && Jacc == 1.2345) at(Jnew, kt) = Jacc;
+#else
             if (valid) at(Jnew, kt) = live_col ? Jacc : cur.jd;           // first visitor stores its half (frozen: J moves over)
+#endif
         } else if constexpr (PH == 1) {                                   // odd Nspace: both waves are at the same depth
             lds_f64* const xwg = etab + LSX_EXP_TAB + 2 * (NV + 1) * RROW;
             xwg[dir * LSX_WAVE + lane] = Jacc;
@@ -603,7 +620,11 @@ lsx_sweep_rs_kernel(const SweepParams p)
             }
         } else {
             const double Jv = jhalf + Jacc;
+#ifdef LSX_ABL_NOSTORE
+            if (valid && Jv == 1.2345) at(Jnew, kt) = Jv;
+#else
             if (valid) at(Jnew, kt) = live_col ? Jv : cur.jd;
+#endif
             if (act) dJ = nanmax(dJ, fabs(1.0 - cur.jd * rcp(Jv)));             // :705
         }
     };
@@ -625,6 +646,9 @@ lsx_sweep_rs_kernel(const SweepParams p)
             int s = s0;
             if constexpr (SWAP) {
                 if (s < s1 && (s & 1)) { step(s, ph, opB, opA); ++s; }
+#ifdef LSX_RS_PREWAIT
+                __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): no load is pending on any path into the loop
+#endif
                 for (; s + 1 < s1; s += 2) { step(s, ph, opA, opB); step(s + 1, ph, opB, opA); }
                 if (s < s1) step(s, ph, opA, opB);
             } else {

@@ -160,9 +160,19 @@ def iterate_mali_engine(engine, reducer=None, dJ_tol=2e-3, dPops_tol=1e-3, n_lam
             except Exception as e:
                 from ._capi import LSX_EUNSUPPORTED
                 if getattr(e, 'code', None) != LSX_EUNSUPPORTED:
-                    _end(engine, reducer)
+                    # a failed enqueue: collect the read-back in flight, take back whatever part of the call was enqueued
+                    # (the library has already switched buffers), and let the caller see the error
+                    try:
+                        _end(engine, reducer)
+                    finally:
+                        try:
+                            engine.discard_formal_sol()
+                        except Exception:
+                            pass
                     raise
-                can_speculate = speculating = False             # frozen columns: the loop goes on without looking ahead
+                # LSX_EUNSUPPORTED is the library's refusal BEFORE anything is enqueued (frozen columns): the loop goes on
+                # without looking ahead
+                can_speculate = speculating = False
         try:
             dJ, dP = _end(engine, reducer)                      # monitors of iteration i
         except Exception:

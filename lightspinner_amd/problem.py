@@ -174,7 +174,11 @@ class ColumnBlock:
 class Engine:
     """One lsx_ctx.  `lib=None` binds the HIP backend (and raises if it is not built)."""
 
-    def __init__(self, problem: Problem, ncol: int, device: int = 0, stream: Optional[int] = None, lib=None):
+    def __init__(self, problem: Problem, ncol: int, device: int = 0, stream: Optional[int] = None, lib=None,
+                 policy_columns: Optional[int] = None, sweep_policy: str = 'auto'):
+        """policy_columns: the column count of the WHOLE problem this engine holds a shard of (None: its own `ncol`).  The HIP
+        library picks its sweep kernel by a column count; a driver that splits N columns over several engines passes N to all
+        of them, so that every column gets the bits it gets when all N sit in one engine (include/lsx.h, lsx_set_sweep_policy)."""
         self.lib = lib if lib is not None else _capi.load_hip_library()
         self.problem = problem
         self.ncol = int(ncol)
@@ -182,6 +186,8 @@ class Engine:
         cprob, self._keep = problem.to_c()
         self.lib.check(self.lib.dll.lsx_create(C.byref(cprob), self.ncol, int(device),
                                                C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        if policy_columns is not None or sweep_policy != 'auto':
+            self.set_sweep_policy(sweep_policy, policy_columns)
 
     def close(self):
         if getattr(self, '_h', None) is not None and self._h:
@@ -245,6 +251,16 @@ class Engine:
         """'linear' (the reference's piecewise_linear_1d, default) or 'parabolic' (monotonic piecewise parabolic, include/lsx.h N4)"""
         kind = {'linear': _capi.LSX_SOLVER_LINEAR, 'parabolic': _capi.LSX_SOLVER_PARABOLIC}[solver]
         self.lib.check(self.lib.dll.lsx_set_formal_solver(self._h, kind))
+
+    def set_sweep_policy(self, policy='auto', decide_for_columns=None):
+        """'auto' (by column count: `decide_for_columns`, default this engine's own), 'ray-per-lane' or 'ray-serial'"""
+        kind = {'auto': _capi.LSX_SWEEP_AUTO, 'ray-per-lane': _capi.LSX_SWEEP_RAY_PER_LANE,
+                'ray-serial': _capi.LSX_SWEEP_RAY_SERIAL}[policy]
+        self.lib.check(self.lib.dll.lsx_set_sweep_policy(self._h, kind, int(decide_for_columns or 0)))
+
+    def sweep_policy(self) -> str:
+        """the mapping the next linear-rule formal solution runs ('oracle' for the CPU restatement, which has one code path)"""
+        return {0: 'oracle', 1: 'ray-per-lane', 2: 'ray-serial'}[int(self.lib.dll.lsx_sweep_policy(self._h))]
 
     def set_active_columns(self, mask=None):
         """freeze columns whose mask entry is False (None: all active)"""

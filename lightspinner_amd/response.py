@@ -103,7 +103,8 @@ def run_response_function(prob: Problem, base: ColumnBlock, fixture: dict, ks, l
     cols = [apply_delta(prob, base, deltas_of(fixture, k, tag), k, start_n=n_base) for k, tag in jobs[first:first + count]]
     if cols:
         batch = ColumnBlock.concatenate(cols)
-        eng = Engine(prob, batch.ncol, device=device, lib=lib, stream=stream)
+        # the kernel choice belongs to the problem -- all 2 len(ks) perturbed columns -- not to this rank's shard of it
+        eng = Engine(prob, batch.ncol, device=device, lib=lib, stream=stream, policy_columns=len(jobs))
         for a in range(0, batch.ncol, 64):
             eng.set_columns(a, batch.slice(a, min(batch.ncol, a + 64)))
         n_iter = drivers.iterate_mali_columns(eng, log=log, all_done=all_done)

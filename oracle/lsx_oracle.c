@@ -62,7 +62,7 @@ struct lsx_ctx {
     double spec_last_dJ;
     int spec_valid;
     double mon_dJ, mon_dP;    /* the maxima as they were at lsx_sync_begin */
-    int mon_set;
+    int mon_set, mon_spec;
     long* sing_col; /* per column: (depth << 8 | atom) of its first singular system in the last stat_equil, or -1 */
     /* set-up chain: deep copy of the atomic data (lsx_set_atomic_data) and what lsx_set_atmosphere derives */
     int have_atomic_data;
@@ -1197,6 +1197,9 @@ int lsx_discard_formal_sol(lsx_ctx* c)
 {
     if (!c) return fail(LSX_EINVAL, "null ctx");
     if (!c->spec_valid) return fail(LSX_EINVAL, "lsx_discard_formal_sol: the last call was not a speculative formal solution");
+    if (c->mon_set && c->mon_spec)
+        return fail(LSX_EINVAL, "lsx_discard_formal_sol: a read-back begun after the speculative call is in flight (lsx_sync_end first: "
+                                "it would report the discarded call's monitors)");
     spec_copy(c, 1);
     c->last_dJ = c->spec_last_dJ;
     c->spec_valid = 0;
@@ -1216,6 +1219,7 @@ int lsx_sync_begin(lsx_ctx* c)
     c->mon_dJ = c->last_dJ;
     c->mon_dP = c->last_dP;
     c->mon_set = 1;
+    c->mon_spec = c->spec_valid;      /* (as the HIP library: collect this read-back before discarding the call it reports) */
     return LSX_OK;
 }
 
@@ -1334,6 +1338,21 @@ int lsx_set_formal_solver(lsx_ctx* c, int32_t solver)
     if (!c || (solver != LSX_SOLVER_LINEAR && solver != LSX_SOLVER_PARABOLIC)) return fail(LSX_EINVAL, "lsx_set_formal_solver: bad argument");
     c->solver = solver;
     return LSX_OK;
+}
+
+/* include/lsx.h: the choice between the HIP library's two wavefront mappings.  The oracle has one code path: it checks the
+ * arguments like the HIP library does and changes nothing. */
+int lsx_set_sweep_policy(lsx_ctx* c, int32_t policy, int32_t decide_for_columns)
+{
+    if (!c || policy < LSX_SWEEP_AUTO || policy > LSX_SWEEP_RAY_SERIAL || decide_for_columns < 0)
+        return fail(LSX_EINVAL, "lsx_set_sweep_policy: bad argument");
+    return LSX_OK;
+}
+
+int32_t lsx_sweep_policy(const lsx_ctx* c)
+{
+    (void)c;
+    return 0;
 }
 
 int lsx_set_active_columns(lsx_ctx* c, const uint8_t* active)

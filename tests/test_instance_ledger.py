@@ -1,0 +1,102 @@
+"""Ledger of the compiled sweep instances (CPU side; the GPU side is tests/test_instances_gpu.py, the shared data
+tests/instance_cases.py): an instance that lsx_plan.h lists is compiled into the product and can be dispatched to, so some GPU parity
+test has to plan it.  The plans come from the product's own planner (lsx_plan.cpp built into liblsx_host.so, `make host`)."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden
+import instance_cases as ic
+from lightspinner_amd import fixtures
+
+CSRC = os.path.join(ROOT, 'lightspinner_amd', 'csrc')
+pytestmark = pytest.mark.skipif(shutil.which('g++') is None, reason='no host compiler')
+
+
+@pytest.fixture(scope='module')
+def host():
+    subprocess.check_call(['make', '-s', '-C', CSRC, 'host'])
+    from san_driver import HostOnly
+    h = HostOnly(os.path.join(CSRC, 'liblsx_host.so'))
+    h.dll.lsx_plan_instances.restype = C.c_int32
+    h.dll.lsx_plan_instances.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.c_int32]
+    h.dll.lsx_plan_rs_classes.restype = C.c_int32
+    return h
+
+
+def _instances(host, which):
+    buf = (C.c_int32 * 64)()
+    n = host.dll.lsx_plan_instances(which, buf, 64)
+    assert 0 < n <= 64
+    return [ic.decode(int(buf[i])) for i in range(n)]
+
+
+def _planned(host, prob, bits=0):
+    rc, msg, s, tiles = host.probe(prob, bits)
+    assert rc == 0, msg
+    return {ic.decode(int(t[6])) for t in tiles}
+
+
+def _rs_classes(host, prob):
+    p, keep = prob.to_c()
+    out = (C.c_int32 * 128)()
+    n = host.dll.lsx_plan_rs_classes(C.byref(p), out, 64)
+    assert n > 0
+    return {ic.decode(int(out[2 * i])) for i in range(n) if out[2 * i + 1]}
+
+
+def test_every_compiled_instance_is_planned_by_a_gpu_parity_test(host):
+    lane, serial = _instances(host, 0), _instances(host, 1)
+    assert set(serial) <= set(lane) and all(k[0] <= 2 for k in serial)
+    # ---- what the GPU suite's problems plan
+    by_case = {}
+    for name, ncol, Ns, compact in ic.CASES:
+        prob, _ = ic.build(name, 2, Ns, compact)
+        got = _planned(host, prob)
+        assert set(ic.EXPECT[name]) <= got, (name, sorted(got))
+        by_case[name] = (got, _rs_classes(host, prob))
+    # the reference's own problems (tests/test_production_classes.py: both kernels; the parabolic rule: tests/parabolic_cases.py)
+    for fx in ('falc_ca.npz', 'falc_cah.npz'):
+        prob, base, raw = fixtures.load_problem_npz(golden(fx), phi_compact=False)
+        by_case[fx] = (_planned(host, prob), _rs_classes(host, prob))
+    lane_hit = set().union(*(g for g, _ in by_case.values()))
+    serial_hit = set().union(*(r for _, r in by_case.values()))
+    assert [k for k in lane if k not in lane_hit] == [], 'one-ray-per-lane instances no GPU test plans'
+    # the ray-serial kernel and the parabolic rule's compile-time classes share their list (lsx_plan.h)
+    assert [k for k in serial if k not in serial_hit] == [], 'ray-serial / parabolic instances no GPU test plans'
+    # every class a case reaches on the ray-serial kernel has an instance there (nothing falls through to a wrong one)
+    assert serial_hit <= set(serial)
+    # the generic instances (runtime slot loops), with and without linked continua
+    assert {(-1, 0, 0, 0), (-1, 0, 1, 0)} <= lane_hit
+
+
+def test_shapes_without_an_instance_cannot_be_planned(host):
+    """the shapes dropped from the lists in round 4 -- (1,0) (2,0): per-ray slots without a line; (2,1,linked) (3,1,linked): linked
+    continua beside a single line whose atom has a per-ray continuum -- do not occur in any plan: 400 random transition tables,
+    the reference's problems, the toy topologies, with and without linking"""
+    from san_driver import random_problem
+    from toy import toy_problem
+    rng = np.random.default_rng(2024)
+    lane = set(_instances(host, 0))
+    seen = set()
+    probs = [random_problem(rng) for _ in range(400)]
+    probs += [toy_problem(seed=s, Nrays=5, Nspect=120, ncol=1, **kw)[0] for s, kw in ((1, {}), (2, dict(chain=False)), (3, dict(multiplet=3)), (4, dict(multiplet=4)))]
+    probs += [fixtures.load_problem_npz(golden(fx), phi_compact=False)[0] for fx in ('falc_ca.npz', 'falc_cah.npz')]
+    for prob in probs:
+        for bits in (0, 1, 4):          # default, LSX_NO_LINKED, LSX_NO_TOPO
+            rc, msg, s, tiles = host.probe(prob, bits)
+            if rc != 0:
+                assert rc in (1, 5), msg
+                continue
+            for t in tiles:
+                nP, nL, nK = int(t[2]), int(t[4]), int(t[5])
+                assert not (nP > 0 and nL == 0), 'per-ray slots without a line'
+                assert not (nK > 0 and nL == 1 and nP > 1), 'linked continua beside one line and its atom\'s per-ray continua'
+                k = ic.decode(int(t[6]))
+                seen.add(k)
+                assert k[0] < 0 or k in lane, k
+    assert len(seen) >= 12

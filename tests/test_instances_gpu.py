@@ -1,0 +1,77 @@
+"""GPU side of the instance ledger (tests/instance_cases.py, tests/test_instance_ledger.py): every topology case on
+  lane      the one-ray-per-lane kernels (lsx_sweep.hip), one launch per tile class
+  serial    the ray-serial kernels (lsx_sweep_rs.hip) for the classes that have an instance there, one ray per lane for the rest
+  parabolic the parabolic rule's compile-time tile classes (sweep_tile_par) and its generic instance
+against the oracle on the same columns (rh_method.py:595-692, formal_solver.py:14-212; the topologies: rh_method.py:606-627,
+654-681 on atoms shaped like rh_atoms.py:194, :355), and the classes that ran are the ones the case is in the ledger for.
+
+Tolerances as tests/test_toy_topologies.py: one formal solution 1e-11 on I, J (2e-10 where the case has an interval just above the
+5e-4 switch of w2), off-diagonal Gamma 1e-10, diagonal 1e-11 of its column's largest entry; populations after six
+iterations 1e-8 of the depth's largest population."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import relerr, gamma_err
+import instance_cases as ic
+from lightspinner_amd import _capi
+from lightspinner_amd.problem import Engine
+
+pytestmark = pytest.mark.gpu
+
+
+def classes_run(lib, eng):
+    """-> {(slots, lines, linked, relation): (launches, on the ray-serial kernel)}, fused launches"""
+    f = lib.dll.lsx_hip_class_info
+    f.restype = C.c_int32
+    f.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
+    out = (C.c_int64 * 8)()
+    n = f(eng._h, -1, out)
+    fused = int(out[0])
+    table = {}
+    for i in range(n):
+        f(eng._h, i, out)
+        table[(int(out[0]), int(out[1]), int(out[4]), int(out[5]))] = (int(out[3]), bool(out[6]))
+    return table, fused
+
+
+@pytest.mark.parametrize('mode', ['lane', 'serial', 'parabolic'])
+@pytest.mark.parametrize('case', ic.CASES, ids=[c[0] for c in ic.CASES])
+def test_case_meets_the_oracle(hip_lib, oracle_lib, case, mode):
+    name, ncol, Ns, compact = case
+    prob, block = ic.build(name, ncol, Ns, compact)
+    eh = Engine(prob, ncol, lib=hip_lib, sweep_policy='ray-serial' if mode == 'serial' else 'ray-per-lane')
+    eo = Engine(prob, ncol, lib=oracle_lib)
+    oracle_lib.dll.lsx_oracle_set_threads(eo._h, 8)
+    for e in (eh, eo):
+        e.set_columns(0, block)
+        e.set_formal_solver('parabolic' if mode == 'parabolic' else 'linear')
+    # (crowd: one up-going ray of column 30 has an interval at dtau = 5.0e-4 (1 + 3e-4), where w1 = (1 - e) - dtau e cancels to
+    # dtau^2 / 2 and the two libraries' exp() differ by one ulp: 2.2e-10 on that ray's emergent intensity -- the same value on
+    # both kernels --, 1.4e-13 on J)
+    tol = 5e-10 if name == 'crowd' else 2e-10
+    for it in range(6):
+        dh, do = eh.formal_sol_gamma(), eo.formal_sol_gamma()
+        if it == 0:
+            eI, eJ = relerr(eh.get(_capi.LSX_I), eo.get(_capi.LSX_I)), relerr(eh.get(_capi.LSX_J), eo.get(_capi.LSX_J))
+            off, diag = gamma_err(eh.get(_capi.LSX_GAMMA), eo.get(_capi.LSX_GAMMA), prob)
+            assert eI < tol and eJ < tol and off < 1e-10 and diag < 1e-11, (eI, eJ, off, diag)
+        assert abs(dh - do) <= 1e-7 * max(abs(do), 1e-3)
+        if it >= 2:
+            ph, po = eh.stat_equil(), eo.stat_equil()
+            assert abs(ph - po) <= 1e-6 * max(abs(po), 1e-3)
+    n_o = eo.get(_capi.LSX_N)
+    dn = np.abs(eh.get(_capi.LSX_N) - n_o) / np.abs(n_o).max(axis=1, keepdims=True)
+    assert dn.max() < 1e-8 and relerr(eh.get(_capi.LSX_J), eo.get(_capi.LSX_J)) < 1e-7
+    # ---- the ledger: the expected classes ran, each on the kernel this mode is about
+    table, fused = classes_run(hip_lib, eh)
+    assert fused == 0
+    for key in ic.EXPECT[name]:
+        assert key in table and table[key][0] == 6, (key, table)
+    serial = {k for k, (_, rs) in table.items() if rs}
+    if mode == 'serial':
+        assert serial == {k for k in table if 0 <= k[0] <= 2}, (serial, table)      # every class with at most two per-ray slots
+    else:
+        assert not serial
+    eh.close(); eo.close()

@@ -1,0 +1,115 @@
+""""per-column results must be bitwise equal to the 1-GPU run (same kernel, same per-column reduction order)" --
+response_fn.py:61-65 is ONE loop over the 2 x 82 perturbed atmospheres, however many GPUs share it.
+
+The HIP library has two wavefront mappings of the formal solution (one ray per lane / ray-serial) that associate the angle and
+wavelength sums differently, and it picks one by a column count.  That count belongs to the problem, not to the shard: a driver
+that splits N columns over several contexts passes N to every one of them (lsx_set_sweep_policy, Engine(policy_columns=N));
+C5's 164 columns then get the same bits in ONE context (what one GPU runs: ray-serial, 164 >= 160) and in contexts of 21 / 20
+columns (what eight GPUs run; by their own size they would take the fused one-ray-per-lane launch)."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from lightspinner_amd import fixtures, synth, Engine, _capi, drivers, response
+from lightspinner_amd.parallel import shard_columns
+from lightspinner_amd.problem import ColumnBlock
+
+
+def test_policy_entry_points_on_the_oracle(oracle_lib):
+    """the ABI is shared: the oracle checks the arguments and has one code path"""
+    prob, base, raw = fixtures.load_problem_npz(golden('falc_ca.npz'))
+    e = Engine(prob, 2, lib=oracle_lib, policy_columns=164)
+    assert e.sweep_policy() == 'oracle'
+    e.set_sweep_policy('ray-serial')
+    e.set_sweep_policy('ray-per-lane', 7)
+    with pytest.raises(_capi.LsxError):
+        e.lib.check(e.lib.dll.lsx_set_sweep_policy(e._h, 3, 0))
+    with pytest.raises(_capi.LsxError):
+        e.lib.check(e.lib.dll.lsx_set_sweep_policy(e._h, 0, -1))
+    e.close()
+
+
+def _c5_columns():
+    p = golden('rf_ca_inputs.npz')
+    prob, base, raw = fixtures.load_problem_npz(golden('falc_ca.npz'))
+    fx = dict(np.load(p))
+    rf = dict(np.load(golden('rf_ca.npz')))
+    jobs = [(k, tag) for k in range(prob.Nspace) for tag in ('p', 'm')]
+    cols = [response.apply_delta(prob, base, response.deltas_of(fx, k, tag), k, start_n=rf['base_n']) for k, tag in jobs]
+    return prob, ColumnBlock.concatenate(cols)
+
+
+def _solve(lib, prob, batch, **kw):
+    eng = Engine(prob, batch.ncol, lib=lib, **kw)
+    for a in range(0, batch.ncol, 64):
+        eng.set_columns(a, batch.slice(a, min(batch.ncol, a + 64)))
+    policy = eng.sweep_policy()
+    n_iter = drivers.iterate_mali_columns(eng)
+    out = dict(I=eng.get(_capi.LSX_I), n=eng.get(_capi.LSX_N), J=eng.get(_capi.LSX_J), n_iter=n_iter, policy=policy)
+    eng.close()
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world', [2, 8])
+def test_c5_columns_get_the_same_bits_in_one_context_and_in_shards(hip_lib, world):
+    prob, batch = _c5_columns()
+    N = batch.ncol
+    assert N == 164
+    one = _solve(hip_lib, prob, batch)
+    assert one['policy'] == 'ray-serial'                   # 164 >= LSX_RS_MIN_COLUMNS
+    shards = []
+    for rank in range(world):
+        first, count = shard_columns(N, rank, world)
+        assert count in (N // world, N // world + 1)
+        s = _solve(hip_lib, prob, batch.slice(first, first + count), policy_columns=N)
+        assert s['policy'] == 'ray-serial', (rank, count)
+        shards.append(s)
+    for key in ('I', 'n', 'J', 'n_iter'):
+        assert np.array_equal(np.concatenate([s[key] for s in shards]), one[key]), key
+    # the counterpart: left to its own size a shard of 20 / 21 columns takes the other mapping (what round 3 did on 8 GPUs)
+    first, count = shard_columns(N, world - 1, world)
+    own = Engine(prob, count, lib=hip_lib)
+    assert own.sweep_policy() == ('ray-per-lane' if count < 160 else 'ray-serial')
+    own.close()
+
+
+@pytest.mark.gpu
+def test_pinned_mappings_and_the_counts_that_decide(hip_lib):
+    prob, base, raw = fixtures.load_problem_npz(golden('falc_ca.npz'), phi_compact=False)
+    blk, prof = synth.perturbed_columns(prob, base, raw, ncol=12, seed=3, vlos_sigma=2.0e3)
+    res = {}
+    for name, kw in (('own', {}), ('as-1000', dict(policy_columns=1000)), ('serial', dict(sweep_policy='ray-serial')),
+                     ('lane-as-1000', dict(sweep_policy='ray-per-lane', policy_columns=1000))):
+        e = Engine(prob, 12, lib=hip_lib, **kw)
+        synth.load_columns(e, blk, prof)
+        pol = e.sweep_policy()
+        for it in range(1, 6):
+            e.formal_sol_gamma()
+            if it > 3:
+                e.stat_equil()
+        res[name] = (pol, e.get(_capi.LSX_I), e.get(_capi.LSX_N), e.get(_capi.LSX_GAMMA))
+        e.close()
+    assert [res[k][0] for k in ('own', 'as-1000', 'serial', 'lane-as-1000')] == ['ray-per-lane', 'ray-serial', 'ray-serial', 'ray-per-lane']
+    for q in (1, 2, 3):
+        assert np.array_equal(res['as-1000'][q], res['serial'][q])
+        assert np.array_equal(res['own'][q], res['lane-as-1000'][q])
+    # the two mappings agree to rounding, not bit for bit (include/lsx.h; five iterations, two of them with stat_equil: 1e-11)
+    d = np.max(np.abs(res['own'][1] - res['serial'][1]) / np.abs(res['serial'][1]))
+    assert 0.0 < d < 1e-9
+    # the parabolic rule takes its compile-time tile classes from 32 columns on: the same knob
+    out = []
+    for kw in ({}, dict(policy_columns=12)):
+        e = Engine(prob, 40, lib=hip_lib, **kw)
+        e.set_formal_solver('parabolic')
+        b40, p40 = synth.perturbed_columns(prob, base, raw, ncol=40, seed=3, vlos_sigma=2.0e3)
+        synth.load_columns(e, b40, p40)
+        e.formal_sol_gamma()
+        out.append(e.get(_capi.LSX_I)[:12])
+        e.close()
+    e = Engine(prob, 12, lib=hip_lib)
+    e.set_formal_solver('parabolic')
+    synth.load_columns(e, blk, prof)
+    e.formal_sol_gamma()
+    assert np.array_equal(e.get(_capi.LSX_I), out[1])      # 12 columns alone = the first 12 of 40 decided as for 12
+    e.close()

@@ -27,17 +27,6 @@ def toy_problem(seed=0, Nspace=37, Nrays=3, Nspect=90, ncol=3, sca_per_lambda=Fa
     """dead_level: atom 1 gets a fourth level that no radiative transition touches and no collision populates
     (only collisions out of it): statistical equilibrium drives it to exactly 0, so the next stat_equil sees
     0/0 = NaN in its relative change (the case rh_method.py:741's builtin max drops)."""
-    rng = np.random.default_rng(seed)
-    wavelength = np.sort(rng.uniform(90.0, 900.0, Nspect))
-    wavelength[1:] += np.arange(1, Nspect) * 1e-3          # strictly increasing
-    muz, wmu = _gl(Nrays)
-
-    def rng_range(lo_frac, hi_frac):
-        a = int(lo_frac * Nspect)
-        b = max(a + 3, int(hi_frac * Nspect))
-        return a, min(b, Nspect) - a
-
-    trans = []
     # atom 0: 5 levels.  lines 0-1 and 0-2 overlap; continua 1->4, 2->4 (simple set), and with chain=True a
     # "continuum" 0->1 whose upper level is the lower level of 1->4, and 3->4 that overlaps the lines
     specs0 = [('l', 0, 1, 0.30, 0.52), ('l', 0, 2, 0.45, 0.70), ('l', 1, 3, 0.80, 0.93),
@@ -54,7 +43,28 @@ def toy_problem(seed=0, Nspace=37, Nrays=3, Nspect=90, ncol=3, sca_per_lambda=Fa
     # atom 1: continua only, 3 levels
     specs1 = [('c', 0, 2, 0.00, 0.35), ('c', 1, 2, 0.10, 0.75)]
     Nlevel = [6 if multiplet else 5, 4 if dead_level else 3]
-    for atom, specs in enumerate((specs0, specs1)):
+    return spec_problem([(Nlevel[0], specs0), (Nlevel[1], specs1)], seed=seed, Nspace=Nspace, Nrays=Nrays, Nspect=Nspect, ncol=ncol,
+                        sca_per_lambda=sca_per_lambda, phi_compact=phi_compact, dead_atom=1 if dead_level else None)
+
+
+def spec_problem(atoms, seed=0, Nspace=37, Nrays=5, Nspect=240, ncol=3, sca_per_lambda=False, phi_compact=False, dead_atom=None):
+    """atoms: [(Nlevel, [(kind 'l' | 'c', lower level, upper level, blue end, red end as fractions of the spectrum), ...]), ...]:
+    any level topology -- which transitions overlap in wavelength and which levels they share decides the tile classes the plan
+    makes (lsx_plan.cpp), i.e. which template instances of the sweep kernels a problem reaches (tests/instance_cases.py)."""
+    rng = np.random.default_rng(seed)
+    wavelength = np.sort(rng.uniform(90.0, 900.0, Nspect))
+    wavelength[1:] += np.arange(1, Nspect) * 1e-3          # strictly increasing
+    muz, wmu = _gl(Nrays)
+
+    def rng_range(lo_frac, hi_frac):
+        a = int(lo_frac * Nspect)
+        b = max(a + 3, int(hi_frac * Nspect))
+        return a, min(b, Nspect) - a
+
+    trans = []
+    Nlevel = [int(nl) for nl, _ in atoms]
+    dead_level = dead_atom is not None
+    for atom, (_, specs) in enumerate(atoms):
         for kind, i, j, lo, hi in specs:
             Nblue, Nlam = rng_range(lo, hi)
             if kind == 'l':
@@ -73,7 +83,7 @@ def toy_problem(seed=0, Nspace=37, Nrays=3, Nspect=90, ncol=3, sca_per_lambda=Fa
     for t, tr in enumerate(trans):
         active[t, tr.Nblue:tr.Nblue + tr.Nlambda] = 1
     prob = Problem(Nspace=Nspace, wavelength=wavelength, muz=muz, wmu=wmu, Nlevel=Nlevel, trans=trans, active=active,
-                   sca_per_lambda=sca_per_lambda, phi_compact=phi_compact, atom_names=['X', 'Y'])
+                   sca_per_lambda=sca_per_lambda, phi_compact=phi_compact, atom_names=['X', 'Y', 'Z', 'W'][:len(Nlevel)])
 
     Ns = Nspace
     NLtot, NL2tot = prob.NLtot, prob.NL2tot
@@ -86,7 +96,7 @@ def toy_problem(seed=0, Nspace=37, Nrays=3, Nspect=90, ncol=3, sca_per_lambda=Fa
         temperature = 4500.0 + 5000.0 * depth ** 2 + 3000.0 * (1 - depth) ** 8 + rng.uniform(-50, 50, Ns)
         ntot = 1e14 * np.exp(9.0 * depth)                   # m^-3
         nStar = np.zeros((NLtot, Ns))
-        nTotal = np.zeros((2, Ns))
+        nTotal = np.zeros((len(Nlevel), Ns))
         o = 0
         for a, nl in enumerate(Nlevel):
             frac = np.array([10.0 ** (-1.2 * l) for l in range(nl)])[:, None] * (1.0 + 0.3 * rng.uniform(-1, 1, (nl, Ns)))
@@ -105,7 +115,7 @@ def toy_problem(seed=0, Nspace=37, Nrays=3, Nspect=90, ncol=3, sca_per_lambda=Fa
             Ca = 10.0 ** rng.uniform(1.0, 4.0, (nl, nl, Ns)) * (ntot / ntot[-1]) ** 0.5
             for l in range(nl):
                 Ca[l, l] = 0.0
-            if dead_level and a == 1:
+            if dead_level and a == dead_atom:
                 Ca[nl - 1, :] = 0.0                         # C[to][from]: nothing goes INTO the last level
             C[o:o + nl * nl] = Ca.reshape(nl * nl, Ns)
             o += nl * nl
