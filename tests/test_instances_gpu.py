@@ -47,9 +47,9 @@ def test_case_meets_the_oracle(hip_lib, oracle_lib, case, mode):
     for e in (eh, eo):
         e.set_columns(0, block)
         e.set_formal_solver('parabolic' if mode == 'parabolic' else 'linear')
-    # (crowd: one up-going ray of column 30 has an interval at dtau = 5.0e-4 (1 + 3e-4), where w1 = (1 - e) - dtau e cancels to
-    # dtau^2 / 2 and the two libraries' exp() differ by one ulp: 2.2e-10 on that ray's emergent intensity -- the same value on
-    # both kernels --, 1.4e-13 on J)
+    # (crowd: measured 2.17e-10 on the emergent intensity of one ray -- the same value on both kernels -- with J at 1.4e-13 and
+    # Gamma at 5e-15: the signature of an interval just above the 5e-4 switch of w2, where w1 = (1 - e) - dtau e cancels to
+    # dtau^2 / 2 and a 1-ulp difference between the two libraries' exp() is up to 1e-9 of that ray's contribution)
     tol = 5e-10 if name == 'crowd' else 2e-10
     for it in range(6):
         dh, do = eh.formal_sol_gamma(), eo.formal_sol_gamma()
