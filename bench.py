@@ -28,8 +28,11 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
+HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (the spec peak the roofline fraction is priced against)
+HBM_MEASURED_GBPS = 6290.0        # the guide's measured achievable streaming rate (reported beside it: frac_of_measured_peak)
 N_SIMD, CLOCK_HZ = 1024, 2.4e9    # 256 CUs x 4 SIMD-32, max clock
+HELD_CLOCK_HZ = 1.9e9             # the clock the chip holds under the ray-serial sweep (in-kernel s_memtime / s_memrealtime: 1.85-1.92 GHz
+                                  # on C3, 2.03-2.13 on C4; profiles/r03_bound_evidence.md 7)
 VALU_PEAK = N_SIMD * CLOCK_HZ / 4.0   # wave64 fp64 VALU instructions per second (4 cycles each)
 
 
@@ -180,6 +183,26 @@ def cpu_baseline(prob, batch, prof, seconds_target=12.0):
     nsample = min(batch.ncol, 4 * cores)
     eng = Engine(prob, nsample, lib=lib)
     load_columns(eng, batch.slice(0, nsample), None if prof is None else tuple(None if p is None else p[:nsample] for p in prof))
+    # one thread on the SINGLE FALC CaII column (the reference's own case, test.py), beside the batch figures
+    single = None
+    try:
+        from lightspinner_amd import fixtures
+        p1, b1, _ = fixtures.load_problem_npz(os.path.join(ROOT, 'tests', 'golden', 'falc_ca.npz'))
+        e1 = Engine(p1, 1, lib=lib)
+        e1.set_columns(0, b1)
+        lib.check(lib.dll.lsx_oracle_set_threads(e1._h, 1))
+        e1.formal_sol_gamma()
+        t0 = time.perf_counter()
+        n1 = 0
+        while time.perf_counter() - t0 < 1.5:
+            e1.formal_sol_gamma(); e1.stat_equil()
+            n1 += 1
+        dt1 = time.perf_counter() - t0
+        e1.close()
+        single = dict(value=p1.work_units_per_column() * n1 / dt1, mali_iters_per_sec=n1 / dt1, iters=n1, seconds=dt1, threads=1,
+                      sample='the single FALC CaII column (82 depth x 287 wavelengths x 5 rays x 2), FS + SE per iteration, one thread')
+    except Exception as e:                       # the batch figures below do not depend on it
+        single = dict(error=str(e))
     out = {}
     for label, nthreads in (('1thread', 1), ('allcores', cores)):
         lib.check(lib.dll.lsx_oracle_set_threads(eng._h, nthreads))
@@ -199,7 +222,9 @@ def cpu_baseline(prob, batch, prof, seconds_target=12.0):
     return dict(value=out['allcores']['value'], unit='point-updates/s', cores=cores, kind='port',
                 sample='%d columns of the same workload x %d MALI iterations (FS+SE), OpenMP over columns; '
                        'single thread: %.4g point-updates/s' % (nsample, out['allcores']['iters'], out['1thread']['value']),
-                value_1thread=out['1thread']['value'])
+                value_1thread=out['1thread']['value'], host_cpu_count=os.cpu_count(),
+                cores_note='threads used = min(os.cpu_count(), LSX_CPU_THREADS or 16): the GPU box gives one GPU 16 cores of its host',
+                single_column_1thread=single)
 
 
 def profile_figures(workload):
@@ -236,18 +261,23 @@ def roofline_block(eng, lib, prob, ncol, workload, kernel_reps):
         if fig.get('valu_insts_per_call_per_column') is not None:
             rate = fig['valu_insts_per_call_per_column'] * ncol / (ms_sweep * 1e-3)
             valu = dict(achieved=rate, peak=VALU_PEAK, unit='wave64 VALU instructions/s', frac=rate / VALU_PEAK,
-                        peak_definition='1024 SIMDs x 2.4 GHz / 4 cycles: the issue rate of fp64 VALU instructions at the MAXIMUM clock. '
-                                        'The chip holds 1.6 - 1.8 GHz under this kernel (in-kernel s_memtime / s_memrealtime, '
-                                        'profiles/r03_bound_evidence.md), so the share of the issue rate actually available is frac x 2.4 / clock',
+                        frac_at_held_clock=rate / (N_SIMD * HELD_CLOCK_HZ / 4.0), held_clock_GHz=HELD_CLOCK_HZ / 1e9,
+                        peak_definition='peak / frac: 1024 SIMDs x 2.4 GHz / 4 cycles, the issue rate of fp64 VALU instructions at the MAXIMUM clock; '
+                                        'frac_at_held_clock: the same at the 1.9 GHz the chip holds under this kernel (in-kernel s_memtime / '
+                                        's_memrealtime: 1.85-1.92 GHz on C3, 2.03-2.13 on C4; profiles/r03_bound_evidence.md 7)',
                         f64_share_of_valu_insts=fig.get('f64_share_of_valu_insts'),
                         insts_per_launch=fig['valu_insts_per_call_per_column'] * ncol,
                         source='%s (instruction counts from a builder-run rocprofv3 --pmc pass of this command at source hash %s, per '
                                'column; divided by the LIVE duration)' % (src, fig.get('csrc_hash')))
-    return dict(bound='hbm', kernel='the sweep of one formal solution: lsx_sweep_rs_kernel<slots,lines,linked,topo> (ray-serial, five columns per '
+    return dict(bound='hbm', bound_means='the roofline the metric is DEFINED on (BASELINE.json north_star: fraction of the HBM roofline); what the '
+                                         'kernel actually waits for is in `limited_by` / `binding`',
+                binding='latency at two waves per SIMD (neither HBM nor vector issue is saturated)',
+                kernel='the sweep of one formal solution: lsx_sweep_rs_kernel<slots,lines,linked,topo> (ray-serial, five columns per '
                                     'wavefront: every tile class with at most two per-ray slots in contexts of >= 160 columns) and '
                                     'lsx_sweep_kernel<slots,lines,rays,sca,linked,topo> (one ray per lane: the other classes and smaller contexts), '
                                     'one instance per tile class, launched side by side; duration = span',
-                achieved=ach, peak=HBM_PEAK_GBPS, unit='GB/s', frac=ach / HBM_PEAK_GBPS, traffic=traffic,
+                achieved=ach, peak=HBM_PEAK_GBPS, unit='GB/s', frac=ach / HBM_PEAK_GBPS, frac_of_measured_peak=ach / HBM_MEASURED_GBPS,
+                measured_peak=HBM_MEASURED_GBPS, traffic=traffic,
                 traffic_stale=bool(stale) if fig else None,
                 traffic_source=('%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a builder run at source hash %s, (2*FETCH_SIZE + '
                                 'WRITE_SIZE)*1024 per call per column x columns; not measured in this run%s'
@@ -261,7 +291,8 @@ def roofline_block(eng, lib, prob, ncol, workload, kernel_reps):
                            '(profiles/r03_bound_evidence.md: in-kernel clock, stamps, occupancy sweep, ablations, class schedule)',
                 fs_call=dict(ms=ms_total, ms_sweep_kernel=ms_sweep, ms_epilogue_kernels=info(4), alg_bytes=balg * ncol,
                              achieved_GBps=balg * ncol / (ms_total * 1e-3) / 1e9,
-                             frac=balg * ncol / (ms_total * 1e-3) / 1e9 / HBM_PEAK_GBPS),
+                             frac=balg * ncol / (ms_total * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             frac_of_measured_peak=balg * ncol / (ms_total * 1e-3) / 1e9 / HBM_MEASURED_GBPS),
                 point_updates_per_sec_kernel=prob.work_units_per_column() * ncol / (ms_sweep * 1e-3),
                 tiles_per_column=info(1), wavelengths_per_tile=info(3), lds_bytes_per_workgroup=info(2),
                 slab_bytes_per_column=info(5),
@@ -303,6 +334,7 @@ def measure_share(workload, ncol, local_rank, lib, torch, steps=40, warmup=3, ke
     eng = Engine(prob, ncol, device=local_rank, stream=ts.cuda_stream, lib=lib)
     load_columns(eng, batch, prof)
     del batch
+    policy = eng.sweep_policy()
     dt, per, dJ, dP = timed_steps(eng, None, steps, warmup, torch.cuda.synchronize)
     units = prob.work_units_per_column() * ncol * steps
     roof = roofline_block(eng, lib, prob, ncol, workload, kernel_reps)
@@ -311,7 +343,7 @@ def measure_share(workload, ncol, local_rank, lib, torch, steps=40, warmup=3, ke
                          % (ncol, prob.Nspect),
                 columns=ncol, steps=steps, value=units / dt, unit='point-updates/s', ms_per_step=dt / steps * 1e3,
                 step_ms=stats_ms(per), last_dJ=dJ, last_dPops=dP, sweep_span_ms=roof['avg_launch_ms'], roofline=roof,
-                generate_s=t_gen)
+                generate_s=t_gen, sweep_policy=policy)
 
 
 def dry_run(args, rank, world):
@@ -414,7 +446,8 @@ def main():
     torch, dist, dev, local_rank, rehearsal = init_gpu(local_rank, world)
     lib = _capi.load_hip_library()
     ts = torch.cuda.Stream()                      # the engine launches on this stream; so does the collective (MaxReducer)
-    eng = Engine(prob, ncol, device=local_rank, stream=ts.cuda_stream, lib=lib)
+    # the sweep kernel is chosen for the WHOLE problem (all ranks' columns), not for this rank's shard of it (lsx_set_sweep_policy)
+    eng = Engine(prob, ncol, device=local_rank, stream=ts.cuda_stream, lib=lib, policy_columns=ncol * world)
     t0 = time.time()
     load_columns(eng, batch, prof)
     t_up = time.time() - t0
@@ -488,7 +521,7 @@ def main():
                                   columns_per_gpu=ncol, columns_total=ncol * world, Nspace=prob.Nspace, Nspect=prob.Nspect,
                                   Nrays=prob.Nrays, profiles='compact (vlos=0)' if compact else 'ray dependent (vlos!=0)',
                                   columns='populations, rates and profiles derived by the library from each column\'s perturbed atmosphere' if t_chain is not None else 'input-level perturbations (BASELINE C3 / C4)',
-                                  parallelism=parallelism_text(world, rehearsal),
+                                  parallelism=parallelism_text(world, rehearsal), sweep_policy=eng.sweep_policy(),
                                   runtime_env=dict(GPU_MAX_HW_QUEUES=os.environ.get('GPU_MAX_HW_QUEUES'))),
                       step_ms=dict(stats_ms(per_step), note='host clock on rank 0 between the monitor read-backs of consecutive steps; loop: ' +
                                    ('look-ahead (the next formal solution is enqueued before a read-back is waited for)' if eng.prefers_lookahead()
@@ -506,6 +539,22 @@ def main():
     del batch
     if rank == 0 and world == 1 and args.workload == 'c3' and not args.no_c4_share:
         result['c4_share'] = measure_share('c4', 1250, local_rank, lib, torch)
+    if rank == 0:
+        # short keys LAST, so that they survive a reader that keeps only the tail of the line: the headline workload and, at N = 1,
+        # the north-star workload's per-GPU share (BASELINE.json: 10^4 Ca+H columns over 8 GPUs), each with its roofline fractions
+        r = result['roofline']
+        result['summary'] = dict(workload=args.workload, ms_per_step=result['ms_per_step'], sweep_ms=r['avg_launch_ms'], sweep_frac=r['frac'],
+                                 fs_call_ms=r['fs_call']['ms'], fs_call_frac=r['fs_call']['frac'], frac_of_measured_peak=r['frac_of_measured_peak'])
+        c4 = result.get('c4_share')
+        if c4:
+            q = c4['roofline']
+            result['c4_ms_per_step'] = c4['ms_per_step']
+            result['c4_updates_per_s'] = c4['value']
+            result['c4_fs_call_ms'] = q['fs_call']['ms']
+            result['c4_sweep_ms'] = q['avg_launch_ms']
+            result['c4_sweep_frac'] = q['frac']
+            result['c4_fs_call_frac'] = q['fs_call']['frac']
+        result['c3_sweep_frac' if args.workload == 'c3' else 'sweep_frac'] = r['frac']
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -138,7 +138,8 @@ constexpr int lsx_rs_park(int npt) { return npt >= 2 ? 16 : 64; }      // depths
 constexpr int lsx_rs_lds_doubles(int npt, int Ns)
 {
     return LSX_EXP_TAB + 2 * (2 * (npt > 0 ? npt : 1) + 1) * 64 + 2 * LSX_WAVE + LSX_RS_COLS * lsx_rs_ucol_stride(npt, Ns) +
-           2 * LSX_RS_COLS * 2 * (npt > 0 ? npt : 1) * lsx_rs_park(npt);   // + [2 waves][columns x values][entries] parked Gamma totals
+           2 * LSX_RS_COLS * 2 * (npt > 0 ? npt : 1) * lsx_rs_park(npt) +  // + [2 waves][columns x values][entries] parked Gamma totals
+           2 * LSX_RS_RAYS + 2;                                            // + the angle quadrature (two-slot instances read it from here)
 }
 
 namespace lsxd {

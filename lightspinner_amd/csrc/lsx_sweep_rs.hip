@@ -166,15 +166,25 @@ lsx_sweep_rs_kernel(const SweepParams p)
     const double wav = p.wavelength[la];
     const double u_la = p.u_la[la];
     // angle quadrature: wave-uniform
-    double zmu[NR], wmuh[NR];
+    // two-slot instances: the ten quadrature constants live in LDS behind the parked totals and are read where they are used
+    // (broadcast reads with immediate offsets): twenty vector registers less in the instances that sit at the 256-register limit
+    constexpr bool QLDS = NPT >= 2;
+    lds_f64* const qtab = utab + (size_t)NC * lsx_rs_ucol_stride(NPT, p.Nspace) + (size_t)2 * NC * NV * lsx_rs_park(NPT);
+    if (QLDS && threadIdx.x < 2 * NR) qtab[threadIdx.x] = threadIdx.x < NR ? LSX_CONST(double, p.zmu)[threadIdx.x] : LSX_CONST(double, p.wmuh)[threadIdx.x - NR];
+    double zmu_r[NR], wmuh_r[NR];
 #pragma unroll
     for (int m = 0; m < NR; ++m) {
-        zmu[m] = LSX_CONST(double, p.zmu)[m];
-        wmuh[m] = LSX_CONST(double, p.wmuh)[m];                       // w_mu / 2; the 4 pi of rh_method.py:661-665 goes into wlam
+        zmu_r[m] = LSX_CONST(double, p.zmu)[m];
+        wmuh_r[m] = LSX_CONST(double, p.wmuh)[m];                     // w_mu / 2; the 4 pi of rh_method.py:661-665 goes into wlam
         // kept in vector registers (the kernel has them to spare at two waves per SIMD; its scalar registers are what runs out)
-        asm volatile("" : "+v"(zmu[m]), "+v"(wmuh[m]));
+        if constexpr (!QLDS) asm volatile("" : "+v"(zmu_r[m]), "+v"(wmuh_r[m]));
     }
+    auto zmu_of = [&](int m) __attribute__((always_inline)) { return QLDS ? (double)qtab[m] : zmu_r[m]; };
+    auto wmuh_of = [&](int m) __attribute__((always_inline)) { return QLDS ? (double)qtab[NR + m] : wmuh_r[m]; };
+#define zmu(m) zmu_of(m)
+#define wmuh(m) wmuh_of(m)
 
+    if constexpr (QLDS) __syncthreads();
     // ---- per-slot lane constants
     unsigned pact = 0;
 #pragma unroll
@@ -270,7 +280,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
         const double hz = ucol[(kS + dk + 1) * TR + 3 * NPT];          // 0.5 |z[Ns - 2] - z[Ns - 1]|: the interval behind depth kS + dk
 #pragma unroll
         for (int m = 0; m < NR; ++m) {
-            const double dtau_uw = zmu[m] * (chi_of(cur, kS, m) + chi_of(nxt, kS + dk, m)) * hz;
+            const double dtau_uw = zmu(m) * (chi_of(cur, kS, m) + chi_of(nxt, kS + dk, m)) * hz;
             Iu[m] = B1 - (B0 - B1) / dtau_uw;
         }
     }
@@ -293,14 +303,10 @@ lsx_sweep_rs_kernel(const SweepParams p)
 #pragma unroll
             for (int e = 1; e < LW / 2; ++e) { v2 = src[e]; acc += v2.x + v2.y; }
             const int e64 = sprev & (PE - 1);
-#ifdef LSX_RS_FLUSH2
             // every lane writes: the lanes that own no (column, value) pair put their sum into the wave's dJ row, which is only
             // read after the last step has overwritten it -- no branch around the reads and the adds, so they can be scheduled
             // into the ray-independent part of the step
             *(own ? &park[lane * PE + e64] : &red[NV * RROW + lane]) = acc;
-#else
-            if (own) park[lane * PE + e64] = acc;
-#endif
             if (e64 == PE - 1 || sprev == Ns - 1) {
                 __builtin_amdgcn_wave_barrier();
                 const int kk = kS + dk * (sprev - e64 + lane);             // the depth parked in entry `lane` of every row
@@ -332,13 +338,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
         if constexpr (SECOND) jhalf = at(Jnew, kt);
         // the Gamma totals of the previous depth (their values were parked at the end of the previous step)
         if constexpr (!FIRST && NPT >= 1) {
-#ifdef LSX_RS_FLUSH2
             flush(s - 1);
-#else
-            __builtin_amdgcn_wave_barrier();
-            flush(s - 1);
-            __builtin_amdgcn_wave_barrier();
-#endif
         }
 
         // ---- ray-independent part (rh_method.py:601-632): continuum slots, emissivity without the lines
@@ -385,7 +385,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
             if constexpr (FIRST) {
                 dt[m] = 1.0;
             } else {
-                const double dtau = (chi_prev[m] + chiTot) * (hdz * zmu[m]);
+                const double dtau = (chi_prev[m] + chiTot) * (hdz * zmu(m));
                 // formal_solver.py:138-139: the end point re-uses the PREVIOUS interval's w (and S[kEnd - dk]) with the fresh dS, dtau
                 dt[m] = LAST ? dtau_prev[m] : dtau;
                 dtau_prev[m] = dtau;
@@ -398,7 +398,9 @@ lsx_sweep_rs_kernel(const SweepParams p)
 #pragma unroll
             for (int m = 0; m < NR; ++m) {
                 m_small |= __builtin_amdgcn_fcmp(dt[m], 5e-4, 4 /* ordered < */);
-                m_mid |= __builtin_amdgcn_ballot_w64(!(dt[m] < 5e-4 || dt[m] > 50.0));
+                // two compares straight into lane masks (the ballot of a boolean expression materialises it first: five vector
+                // instructions per ray); unordered-or predicates: a NaN takes the exponential's path, as !(dt < 5e-4 || dt > 50) did
+                m_mid |= __builtin_amdgcn_fcmp(dt[m], 5e-4, 11 /* unordered or >= */) & __builtin_amdgcn_fcmp(dt[m], 50.0, 13 /* unordered or <= */);
             }
             if (m_mid != 0) {
                 // (saturated lanes need no select: for dtau > 50 the formulae give exactly (1, 1); lsx_dev.h, w2)
@@ -422,8 +424,8 @@ lsx_sweep_rs_kernel(const SweepParams p)
                 }
 #pragma unroll
                 for (int m = 0; m < NR; ++m) {
-                    double t = fma3s(r[m], 1.0 / 720.0, 1.0 / 120.0);
-                    t = fma3(r[m], t, 1.0 / 24.0);
+                    // |r| <= ln2 / 128: the r^6 / 720 term is 3.5e-17 of the result, a third of an ulp -- left out
+                    double t = fma3s(r[m], 1.0 / 120.0, 1.0 / 24.0);
                     t = fma3(r[m], t, 1.0 / 6.0);
                     t = fma(r[m], t, 0.5);
                     r[m] = fma(r[m] * r[m], t, r[m]);                                       // exp(r) - 1
@@ -486,8 +488,8 @@ lsx_sweep_rs_kernel(const SweepParams p)
             if constexpr (LAST) {
                 if (dir == 1 && act) p.Iout[((size_t)col * Nspect + la) * NR + m] = I;      // emergent intensity, :638
             }
-            Jacc = fma(wmuh[m], I, Jacc);                                  // :640
-            const double wP = wmuh[m] * Psi;                               // (x 4 pi where the sums leave)
+            Jacc = fma(wmuh(m), I, Jacc);                                  // :640
+            const double wP = wmuh(m) * Psi;                               // (x 4 pi where the sums leave)
             Pacc += wP;
             if constexpr (LK) {
 #pragma unroll
@@ -520,7 +522,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
                         Ie[u] = fma(-cur.cr[u < NLK ? u : 0][0], Psi, Ie[u]);
                         tv[u] = fma(-cur.cr[u < NLK ? u : 0][1], Psi, tv[u]);
                     }
-                    const double wph = wmuh[m] * cur.ph[u][m];
+                    const double wph = wmuh(m) * cur.ph[u][m];
                     G2[u] = fma(wph, Ie[u], G2[u]);                 // sum w phi Ieff
                     G1[u] = fma(wph, tv[u], G1[u]);                 // sum w phi (1 - Psi* chi_i)
                 }
@@ -565,8 +567,8 @@ lsx_sweep_rs_kernel(const SweepParams p)
                 double g1 = (Uji[u] + Vji * Ieff) - (chi_i * Psi) * U_j;        // :677
                 double g2 = Vij * Ieff;                                        // :680
                 if constexpr (NPT == 2 && TOPO == 0) g2 -= (chi_j * Psi) * U_i;
-                G1[u] = fma(wmuh[m], g1, G1[u]);                               // w_mu / 2 (:661); 4 pi and the wavelength weight below
-                G2[u] = fma(wmuh[m], g2, G2[u]);
+                G1[u] = fma(wmuh(m), g1, G1[u]);                               // w_mu / 2 (:661); 4 pi and the wavelength weight below
+                G2[u] = fma(wmuh(m), g2, G2[u]);
             }
             }
         }
@@ -586,7 +588,11 @@ lsx_sweep_rs_kernel(const SweepParams p)
 
         // ---- the wavelength's sums leave: Psibar, Psi* phi, the Gamma integrands (parked for the lane reduction), J
 #ifndef LSX_ABL_NOSTORE
-        if (nF > 0 && act) at(psibar, kt) = Pacc;
+        // lanes without a wavelength of their own shadow a real lane and hold its values: they store the same bits to the same
+        // address, so the store needs no lane mask (no branch around it: the compiler counts it when it places its waits -- loads and
+        // stores retire in issue order, a wait for the next depth's operands waits for every store before them); the
+        // Psibar of a frozen column is read by nobody (the fast-continuum kernels skip frozen columns)
+        if (nF > 0) at(psibar, kt) = Pacc;
 #endif
         if constexpr (LK) {
             if (act) {
@@ -607,7 +613,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
 #ifdef LSX_ABL_NOSTORE
             if (valid && Jacc == 1.2345) at(Jnew, kt) = Jacc;
 #else
-            if (valid) at(Jnew, kt) = live_col ? Jacc : cur.jd;           // first visitor stores its half (frozen: J moves over)
+            at(Jnew, kt) = live_col ? Jacc : cur.jd;                      // first visitor stores its half (frozen: J moves over; no lane mask, see Psibar)
 #endif
         } else if constexpr (PH == 1) {                                   // odd Nspace: both waves are at the same depth
             lds_f64* const xwg = etab + LSX_EXP_TAB + 2 * (NV + 1) * RROW;
@@ -623,7 +629,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
 #ifdef LSX_ABL_NOSTORE
             if (valid && Jv == 1.2345) at(Jnew, kt) = Jv;
 #else
-            if (valid) at(Jnew, kt) = live_col ? Jv : cur.jd;
+            at(Jnew, kt) = live_col ? Jv : cur.jd;
 #endif
             if (act) dJ = nanmax(dJ, fabs(1.0 - cur.jd * rcp(Jv)));             // :705
         }
@@ -646,9 +652,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
             int s = s0;
             if constexpr (SWAP) {
                 if (s < s1 && (s & 1)) { step(s, ph, opB, opA); ++s; }
-#ifdef LSX_RS_PREWAIT
                 __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): no load is pending on any path into the loop
-#endif
                 for (; s + 1 < s1; s += 2) { step(s, ph, opA, opB); step(s + 1, ph, opB, opA); }
                 if (s < s1) step(s, ph, opA, opB);
             } else {
@@ -693,6 +697,9 @@ lsx_sweep_rs_kernel(const SweepParams p)
         p.dJpart[((size_t)(col0 + lane) * ntile + tile_id) * 2 + dir] = m;
     }
 }
+
+#undef zmu
+#undef wmuh
 
 template <int NPT, int NL, bool LK, int TOPO>
 static hipError_t launch_rs(const SweepParams& p, int ngroups, hipStream_t st)
