@@ -52,6 +52,9 @@ struct lsx_ctx : lsxd::LsxPlan {        // the plan (lsx_plan.h: dimensions, tab
     int *d_tile_slots = nullptr, *d_Nlevel = nullptr, *d_lev2_off = nullptr, *d_fin_ptr = nullptr, *d_fin_idx = nullptr;
     bool dp_zeroed = false;          // the Gamma epilogue has zeroed dPcol / the singular flag for the next stat_equil
     bool opt_finish_big = false;     // LSX_FINISH_BIG=1: the many-column Gamma epilogue also for small batches (tests)
+    bool opt_fused_epilogue = false; // LSX_FUSED_EPILOGUE=1: the fused launch also runs its fast tiles' Gamma epilogue (measured: slower, see enqueue_fs)
+    int opt_abl_fast = 0;            // LSX_ABL_FUSED_FAST: timing ablations of the fused launch's fast-continuum work
+    bool opt_no_fused_fast = false;  // LSX_NO_FUSED_FAST=1: small batches launch the fast-continuum kernels around the fused sweep (tests)
     // device: per column
     double *d_height = nullptr, *d_temperature = nullptr, *d_nStar = nullptr, *d_nTotal = nullptr, *d_n = nullptr,
            *d_C = nullptr, *d_Gamma = nullptr, *d_wphi = nullptr, *d_bgchi = nullptr, *d_bgeta = nullptr,

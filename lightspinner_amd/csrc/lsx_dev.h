@@ -157,6 +157,8 @@ struct SweepParams {
     double* debug;              // diagnostic builds only
     int32_t static_max;         // fused launch: tiles with more per-ray slots than this take the generic path
     const double* exp2_tab;     // [64][2]: 2^(j/64) as a (head, tail) pair, for the sweep's exp(-dtau)
+    int32_t fused_fast;         // fused small-batch launch: the workgroup of a tile with fast continua runs the tile's pre-pass before and
+    int32_t nF_max;             // its Gamma epilogue after the sweep itself (lsx_fast.h); nF_max: the pre-pass's LDS layout
 };
 
 // ---- device functions shared by the sweep kernel and the stand-alone formal solver -------------------------

@@ -482,6 +482,18 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
         for (int q = -1; q <= npt_max; ++q)
             S.fused_lds = std::max(S.fused_lds, (size_t)lsx_sweep_lds(q, P.corr_col > 0, Ns, S.fused_ncell_lev, S.fused_ncell_atom).total * sizeof(double));
         if (S.fused_lds > 64 * 1024) return perr(err, LSX_EUNSUPPORTED, "lsx_create: the fused sweep launch needs %zu B of LDS", S.fused_lds);
+        // the fused launch takes over the fast-continuum work of its tiles (lsx_sweep.hip: lsx_sweep_kernel_all<5, false>) where every
+        // fast tile has the column-mapped epilogue with at most two linked lines, twelve wavelengths per tile, and a column's operands
+        // fit the pre-pass's LDS in one piece; its two waves then need the larger of the three LDS layouts
+        if (!P.fast_tiles.empty()) {
+            bool ok = P.Nrays == 5 && !P.sca_per_lambda && P.L == 12 && P.fast_rest.empty() && P.fast_cols[3].empty() && S.prepass_seg >= Ns;
+            size_t need = std::max(S.fused_lds, S.prepass_lds);
+            for (int v = 0; v < 3; ++v)
+                if (!P.fast_cols[v].empty())
+                    need = std::max(need, ((size_t)2 * LSX_FGC_MAXF * P.L + P.L + (size_t)2 * (3 + kLkLines[v]) * LSX_FGC_ROWS * P.L) * sizeof(double));
+            S.fused_fast = ok && need <= 64 * 1024;
+            S.fused_fast_lds = need;
+        }
     }
     return LSX_OK;
 }

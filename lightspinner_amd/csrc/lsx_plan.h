@@ -179,6 +179,7 @@ struct LaunchShapes {
     size_t cols_lds[3] = {0, 0, 0};                              // k_fast_gamma_cols<0, 1, 2>
     int finish_nt = 128; size_t finish_lds = 0;                   // k_gamma_finish
     size_t fused_lds = 0; int fused_ncell_lev = 1, fused_ncell_atom = 1;   // fused small-batch / parabolic launch
+    bool fused_fast = false; size_t fused_fast_lds = 0;          // the fused launch runs pre-pass and Gamma epilogue of its fast tiles itself
 };
 
 struct LsxPlan {

@@ -37,6 +37,7 @@
 #include <type_traits>
 #include "lsx_dev.h"
 #include "lsx_plan.h"
+#include "lsx_fast.h"
 
 namespace {
 
@@ -1513,6 +1514,20 @@ __device__ __attribute__((noinline)) void sweep_tile_call(const SweepParams& p, 
 }
 // (at most 31 columns x tiles workgroups: occupancy is no concern, so the register allocator gets the whole file -- no vector
 // spills in the one kernel every single-column Context runs)
+// the fast-continuum kernels' view of a sweep launch's parameters (lsx_fast.h; the fused launch only)
+static __device__ __forceinline__ FastParams fast_params_of(const SweepParams& p)
+{
+    FastParams f{};
+    f.Nspace = p.Nspace; f.Nspect = p.Nspect; f.Nrays = p.Nrays; f.ncol = p.ncol; f.ntile = p.ntile_total; f.L = p.L; f.NLtot = p.NLtot;
+    f.Natoms = p.Natoms; f.nslot_total = p.nslot_total; f.tiles = p.tiles; f.slots = p.slots; f.active = p.active; f.alpha = p.alpha;
+    f.wl = p.wl; f.u_la = p.u_la; f.wmuh = p.wmuh; f.n = p.n; f.nsr = p.nsr; f.E_T = p.E_T; f.Ncont = p.Ncont; f.nF_max = p.nF_max;
+    f.seg_depths = p.Nspace; f.bgchi_T = p.bgchi_T; f.bgeta_T = p.bgeta_T;
+    f.bgxchi_T = const_cast<double*>(p.bgxchi_T); f.bgxeta_T = const_cast<double*>(p.bgxeta_T); f.corr_T = const_cast<double*>(p.corr_T);
+    f.corr_col_stride = p.corr_col_stride; f.pp_col_stride = p.pp_col_stride; f.J_T = p.Jnew_T; f.Psi2_T = p.Psi2_T; f.Psi3_T = p.Psi3_T;
+    f.Gpart = p.Gpart; f.colmask = p.colmask;
+    return f;
+}
+
 template <int NR, bool SCAL>
 __global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(1, 2)))
 lsx_sweep_kernel_all(const SweepParams p)
@@ -1525,6 +1540,19 @@ lsx_sweep_kernel_all(const SweepParams p)
         for (int e = threadIdx.x; e < p.Nspace * p.L; e += 2 * LSX_WAVE) p.Jnew_T[tb + e] = p.Jdag_T[tb + e];
         return;
     }
+    // A single column (any batch below 32) is latency bound: three launches in a row -- pre-pass of the tiles with fast continua,
+    // sweep, their Gamma epilogue -- cost 8 + 54 + 9 us for FALC CaII, although only three short continuum tiles need the first and
+    // the last.  Here the workgroup of such a tile does both itself, around its own sweep: the line tiles next to it take longer
+    // anyway.  The same device functions as the stand-alone kernels (lsx_fast.h): the same bits.
+    extern __shared__ __attribute__((aligned(16))) double lds_fast[];
+    const bool fast_here = NR == 5 && !SCAL && p.fused_fast != 0 && (LSX_CONST(DevTile, p.tiles) + tile_id)->nF > 0;
+    if constexpr (NR == 5 && !SCAL) {
+        if (fast_here) {
+            const FastParams f = fast_params_of(p);
+            if (!(p.fused_fast & 2)) fast_prepass_tile<false, 2 * LSX_WAVE>(f, tile_id, (size_t)col, lds_fast);
+            __syncthreads();                 // (the workgroup's own global writes are visible to it behind the barrier)
+        }
+    }
     const int nP = (LSX_CONST(DevTile, p.tiles) + tile_id)->nP, nL = (LSX_CONST(DevTile, p.tiles) + tile_id)->nL;
     const bool lk = (LSX_CONST(DevTile, p.tiles) + tile_id)->nK > 0;
     if (nP > p.static_max) { if (lk) sweep_tile_call<-1, 0, NR, SCAL, true>(p, vb, tile_id); else sweep_tile_call<-1, 0, NR, SCAL, false>(p, vb, tile_id); }
@@ -1534,6 +1562,20 @@ lsx_sweep_kernel_all(const SweepParams p)
     else if (nP == 2 && nL == 1 && !lk) sweep_tile_call<2, 1, NR, SCAL, false>(p, vb, tile_id);
     else if (lk) sweep_tile_call<-1, 0, NR, SCAL, true>(p, vb, tile_id);     // the remaining shapes take the generic path here (code size)
     else sweep_tile_call<-1, 0, NR, SCAL, false>(p, vb, tile_id);
+    if constexpr (NR == 5 && !SCAL) {
+        if (fast_here && !(p.fused_fast & 4)) {       // J, Psibar and Psi* phi of this (tile, column) are complete: both directions are this workgroup's waves
+            __syncthreads();
+            const FastParams f = fast_params_of(p);
+            const auto* tp = LSX_CONST(DevTile, p.tiles) + tile_id;
+            const int nlc = tp->nK > 0 ? tp->nL : 0;            // lines the linked continua feed: 0, 1 or 2 (the host checked)
+            const long r0 = (long)col * p.Nspace, r1 = r0 + p.Nspace;
+            for (long rb = r0; rb < r1; rb += 2 * LSX_FGC_ROWS) {
+                if (nlc == 0) fast_gamma_cols_rows<0, 6, 2>(f, tile_id, rb, r1, lds_fast);
+                else if (nlc == 1) fast_gamma_cols_rows<1, 6, 2>(f, tile_id, rb, r1, lds_fast);
+                else fast_gamma_cols_rows<2, 6, 2>(f, tile_id, rb, r1, lds_fast);
+            }
+        }
+    }
 }
 
 

@@ -64,28 +64,26 @@ import math
 
 import pytest
 
+from conftest import REHEARSALS, rehearsal_output
+
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('args', [['--columns', '200', '--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--no-single-column'],
-                                  ['--workload', 'c5']], ids=['c3-columns', 'c5-response-function'])
-def test_two_rank_rehearsal_on_one_gpu(args):
+@pytest.mark.parametrize('which', list(REHEARSALS))
+def test_two_rank_rehearsal_on_one_gpu(which):
     """SURVEY 8e while no multi-GPU node is at hand: the N > 1 flow of bench.py end to end on ONE GPU -- the launcher parent (which
-    has touched no GPU) starts two ranks, both on GPU 0, exchanging over gloo (LSX_BENCH_REHEARSE=1; RCCL refuses two ranks on one
+    touches no GPU) starts two ranks, both on GPU 0, exchanging over gloo (LSX_BENCH_REHEARSE=1; RCCL refuses two ranks on one
     device); rank 0 prints ONE JSON line, labelled as a rehearsal.  C3: 200 columns per rank, the all-reduce(MAX) of the monitors
     per iteration; C5: the 164 perturbed columns of the response function sharded 82 / 82, per-column convergence, all_done = AND over
-    ranks, the intensities gathered -- and the same rf as the reference at its three depths."""
-    env = dict(os.environ, LSX_BENCH_REHEARSE='1')
-    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
-        env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + args, capture_output=True, text=True,
-                         timeout=600, cwd=ROOT, env=env)
-    assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    ranks, the intensities gathered -- and the same rf as the reference at its three depths.
+    (The two commands are started by tests/conftest.py when collection ends, before this process initialises the GPU.)"""
+    rc, out, err = rehearsal_output(which)
+    assert rc == 0, err[-3000:]
+    lines = [l for l in out.splitlines() if l.strip()]
     assert len(lines) == 1, lines
     r = json.loads(lines[0])
     assert r['rehearsal'] is True and r['backend'] == 'gloo' and r['n_gpus'] == 2
     assert math.isfinite(r['value']) and r['value'] > 0 and math.isfinite(r['ms_per_step'])
-    if '--workload' in args:
+    if which.startswith('c5'):
         assert r['response_function']['max_abs_err_vs_reference_rf_over_max'] < 1e-5
         assert r['scaling'] == 'strong'
     else:

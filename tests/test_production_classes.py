@@ -245,3 +245,36 @@ def test_full_size_batches_by_size_independent_properties(hip_lib, oracle_lib, m
     assert not np.array_equal(n1[mask], n0[mask])
     big.set_active_columns(None)
     small.close(); big.close(); ora.close()
+
+
+@pytest.mark.parametrize('name,ncol', [('falc_ca.npz', 1), ('falc_cah.npz', 3), ('falc_cah.npz', 31)])
+def test_fused_launch_runs_the_fast_continuum_work_itself_with_the_same_bits(hip_lib, monkeypatch, name, ncol):
+    """fewer than 32 columns: the workgroup of a tile with fast continua runs the tile's pre-pass itself, before its own sweep, inside
+    the ONE fused launch (lsx_sweep.hip, lsx_fast.h) instead of a launch in front of it (LSX_NO_FUSED_FAST=1 restores that; with
+    LSX_FUSED_EPILOGUE=1 the Gamma epilogue runs inside as well): the same device functions, the same bits -- J, I, Gamma, populations
+    and monitors after five iterations, Ca+H with linked continua (one and two lines per tile) included"""
+    prob, base, raw = fixtures.load_problem_npz(golden(name), phi_compact=False)
+    blk, (aD, vB, vlos) = synth.perturbed_columns(prob, base, raw, ncol=ncol, seed=21, vlos_sigma=1.5e3)
+    out = []
+    for leg in ('default', 'separate', 'epilogue-inside'):      # default: the pre-pass inside the fused launch, the epilogue a launch of its own
+        monkeypatch.delenv('LSX_NO_FUSED_FAST', raising=False)
+        monkeypatch.delenv('LSX_FUSED_EPILOGUE', raising=False)
+        if leg == 'separate':
+            monkeypatch.setenv('LSX_NO_FUSED_FAST', '1')
+        if leg == 'epilogue-inside':
+            monkeypatch.setenv('LSX_FUSED_EPILOGUE', '1')       # (measured slower: the epilogue then extends the longest workgroups)
+        e = Engine(prob, ncol, lib=hip_lib)
+        e.set_columns(0, blk)
+        e.set_line_profiles(0, aD, vB, vlos)
+        mon = []
+        for it in range(5):
+            mon.append(e.formal_sol_gamma())
+            if it >= 2:
+                mon.append(e.stat_equil())
+        out.append(([e.get(w) for w in (_capi.LSX_J, _capi.LSX_I, _capi.LSX_GAMMA, _capi.LSX_N, _capi.LSX_DJ_COL)], mon))
+        assert class_table(hip_lib, e)[1] == 5          # five fused launches either way
+        e.close()
+    for other in out[1:]:
+        for a, b in zip(out[0][0], other[0]):
+            assert np.array_equal(a, b)
+        assert out[0][1] == other[1]
