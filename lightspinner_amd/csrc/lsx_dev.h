@@ -157,9 +157,28 @@ struct SweepParams {
     double* debug;              // diagnostic builds only
     int32_t static_max;         // fused launch: tiles with more per-ray slots than this take the generic path
     const double* exp2_tab;     // [64][2]: 2^(j/64) as a (head, tail) pair, for the sweep's exp(-dtau)
+    int32_t phi_G;              // columns per group of the line-profile store (phi_elem below): 5 where the ray-serial sweep can run, else 1
     int32_t fused_fast;         // fused small-batch launch: the workgroup of a tile with fast continua runs the tile's pre-pass before and
     int32_t nF_max;             // its Gamma epilogue after the sweep itself (lsx_fast.h); nF_max: the pre-pass's LDS layout
 };
+
+// ---- the line-profile store phi_T --------------------------------------------------------------------------------------------
+// Per (tile, line) block and column the profile is [dir][k][mu][l < len] (x = (dir Nspace + k) Nrays + mu is the block's row; compact
+// profiles: x = k).  The ray-serial sweep reads row x of FIVE consecutive columns with one load per wavefront, so the store
+// interleaves the columns of a group of G = 5 inside every block row: [group]{block: [x][c < G][l < len]} -- the five 96-byte pieces
+// of a load are one contiguous run of G len doubles, and a wavefront's whole depth step is one run of Nrays G len doubles (2400 B)
+// instead of five runs a column apart.  G = 1 (contexts whose shape excludes the ray-serial sweep) is the plain per-column store.
+// base: the block's offset in a column's own numbering (DevSlot.base); col_stride: doubles per column (LsxPlan.phi_col; its last
+// two doubles per column stay zero: where lanes outside a line's range point their loads -- element G col_stride - 1 of a group).
+#ifdef __HIPCC__
+#define LSX_HD __host__ __device__
+#else
+#define LSX_HD
+#endif
+static LSX_HD inline size_t phi_elem(size_t col, int G, size_t col_stride, size_t base, size_t x, int len, int l)
+{
+    return (col / G) * G * col_stride + (size_t)G * (base + x * len) + (col % G) * len + l;
+}
 
 // ---- device functions shared by the sweep kernel and the stand-alone formal solver -------------------------
 #ifdef __HIPCC__

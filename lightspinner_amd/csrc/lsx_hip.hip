@@ -78,37 +78,50 @@ constexpr double kHC = kHPlanck * kCLight;
 
 
 // ------------------------------------------------------------------------------- kernels
+// where a (tile, line) block of the line-profile store lives (lsx_dev.h, phi_elem): columns col0 + blockIdx.y of the context
+struct PhiBlock {
+    double* store;          // phi_T
+    size_t col_stride;      // doubles per column
+    size_t col0;            // first column of this launch
+    size_t base;            // the block's offset in a column's own numbering
+    int G;                  // columns per group
+};
+
 // one (tile, line) block of the profile: in [col][lt][mu][dir][k] (rows lt0 .. lt0+len of the line)
-//   ->  out [col]{block: [dir][k][mu][l<len]}     (compact: pass Nrays = 1, ndir = 1)
-__global__ void k_pack_phi(const double* __restrict__ in, double* __restrict__ out, int lt0, int len, int Nrays, int ndir,
-                           int Ns, size_t in_col_stride, size_t out_col_stride)
+//   ->  the block's rows [dir][k][mu] x [l<len] in the store     (compact: pass Nrays = 1, ndir = 1)
+__global__ void k_pack_phi(const double* __restrict__ in, const PhiBlock out, int lt0, int len, int Nrays, int ndir,
+                           int Ns, size_t in_col_stride)
 {
     const size_t col = blockIdx.y;
     const size_t total = (size_t)len * Nrays * ndir * Ns;
     for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
         size_t r = o;
         const int l = r % len; r /= len;
+        const size_t x = r;                      // (d Ns + k) Nrays + mu
         const int mu = r % Nrays; r /= Nrays;
         const int k = r % Ns; r /= Ns;
         const int d = (int)r;
-        out[col * out_col_stride + o] = in[col * in_col_stride + (((size_t)(lt0 + l) * Nrays + mu) * ndir + d) * Ns + k];
+        out.store[phi_elem(out.col0 + col, out.G, out.col_stride, out.base, x, len, l)] =
+            in[col * in_col_stride + (((size_t)(lt0 + l) * Nrays + mu) * ndir + d) * Ns + k];
     }
 }
 
 
 // inverse of k_pack_phi (lsx_get of LSX_PHI)
-__global__ void k_unpack_phi(const double* __restrict__ in, double* __restrict__ out, int lt0, int len, int Nrays, int ndir,
-                             int Ns, size_t in_col_stride, size_t out_col_stride)
+__global__ void k_unpack_phi(const PhiBlock in, double* __restrict__ out, int lt0, int len, int Nrays, int ndir,
+                             int Ns, size_t out_col_stride)
 {
     const size_t col = blockIdx.y;
     const size_t total = (size_t)len * Nrays * ndir * Ns;
     for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
         size_t r = o;
         const int l = r % len; r /= len;
+        const size_t x = r;
         const int mu = r % Nrays; r /= Nrays;
         const int k = r % Ns; r /= Ns;
         const int d = (int)r;
-        out[col * out_col_stride + (((size_t)(lt0 + l) * Nrays + mu) * ndir + d) * Ns + k] = in[col * in_col_stride + o];
+        out[col * out_col_stride + (((size_t)(lt0 + l) * Nrays + mu) * ndir + d) * Ns + k] =
+            in.store[phi_elem(in.col0 + col, in.G, in.col_stride, in.base, x, len, l)];
     }
 }
 
@@ -158,8 +171,8 @@ struct VoigtParams {
     const double* vlos;         // [nb][Ns] or null
 };
 
-// compute_phi (rh_method.py:228-239) straight into one (tile, line) block of phi_T: [dir][k][mu][l<len]
-__global__ void k_voigt_block(const VoigtParams q, double* __restrict__ out, size_t out_col_stride, int first, int len,
+// compute_phi (rh_method.py:228-239) straight into one (tile, line) block of phi_T: rows [dir][k][mu] x [l<len]
+__global__ void k_voigt_block(const VoigtParams q, const PhiBlock out, int first, int len,
                               int line, int atom, double lambda0)
 {
     const size_t col = blockIdx.y;
@@ -175,7 +188,7 @@ __global__ void k_voigt_block(const VoigtParams q, double* __restrict__ out, siz
         const double vl = (q.vlos && q.ndir == 2) ? q.vlos[col * q.Ns + k] : 0.0;
         const double v = (q.wavelength[first + l] - lambda0) * kCLight / (vb * lambda0);          // :234
         const double vk = v + (d ? 1.0 : -1.0) * (q.muz[mu] * vl / vb);                            // :231, :237-238
-        out[col * out_col_stride + o] = dev_voigt(ad, vk, q.W) / (sqrt(M_PI) * vb);                // :239
+        out.store[phi_elem(out.col0 + col, out.G, out.col_stride, out.base, o / len, len, l)] = dev_voigt(ad, vk, q.W) / (sqrt(M_PI) * vb);     // :239
     }
 }
 
@@ -1052,7 +1065,7 @@ int profiles_from_device(lsx_ctx* c, size_t cc, size_t nb, const double* dA, con
         const DevTrans& h = c->htrans[sl.trans];
         const size_t total = (size_t)sl.len * R * D * Ns;
         dim3 grid((unsigned)std::min<size_t>((total + 255) / 256, 256), (unsigned)nb);
-        hipLaunchKernelGGL(k_voigt_block, grid, dim3(256), 0, c->stream, q, c->d_phi + cc * c->phi_col + sl.base, c->phi_col,
+        hipLaunchKernelGGL(k_voigt_block, grid, dim3(256), 0, c->stream, q, PhiBlock{c->d_phi, c->phi_col, cc, (size_t)sl.base, c->phi_group},
                            sl.first, sl.len, h.line_idx, h.atom, h.lambda0);
         HIPCHK(hipGetLastError());
     }
@@ -1137,6 +1150,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         opt.order_by_cost = (e = getenv("LSX_ORDER")) && std::string(e) == "cost";
         opt.occ_wg = (e = getenv("LSX_OCC_WG")) ? atoi(e) : 0;
         opt.no_rs = getenv("LSX_NO_RS") != nullptr;
+        opt.no_phi_group = (e = getenv("LSX_PHI_GROUP")) && atoi(e) == 1;
         if ((e = getenv("LSX_RS_MIN_COLUMNS"))) opt.rs_min_columns = atoi(e);
         if ((e = getenv("LSX_RS_MAX_NPT"))) opt.rs_max_npt = atoi(e);
     }
@@ -1273,8 +1287,10 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     TRY(dmalloc(&c->d_bgchi, nc * c->til_col));
     TRY(dmalloc(&c->d_bgeta, nc * c->til_col));
     TRY(dmalloc(&c->d_sca, nc * c->sca_col));
-    TRY(dmalloc(&c->d_phi, nc * c->phi_col));
-    if (c->phi_col) (void)hipMemsetAsync(c->d_phi, 0, nc * c->phi_col * sizeof(double), c->stream);
+    // (whole column groups: the store interleaves the columns of a group, lsx_dev.h phi_elem)
+    const size_t nc_phi = (nc + c->phi_group - 1) / c->phi_group * c->phi_group;
+    TRY(dmalloc(&c->d_phi, nc_phi * c->phi_col));
+    if (c->phi_col) (void)hipMemsetAsync(c->d_phi, 0, nc_phi * c->phi_col * sizeof(double), c->stream);
     if (c->any_cont) TRY(dmalloc(&c->d_E, nc * c->til_col));
     if (c->corr_col) {
         TRY(dmalloc(&c->d_corr, nc * c->corr_col));
@@ -1378,8 +1394,8 @@ int lsx_set_columns(lsx_ctx* c, int32_t col0, int32_t ncol, const lsx_columns* s
                 const size_t in_off = (size_t)h.phi_off * R * D * Ns;
                 const size_t total = (size_t)sl.len * R * D * Ns;
                 dim3 grid((unsigned)std::min<size_t>((total + 255) / 256, 256), (unsigned)nb);
-                hipLaunchKernelGGL(k_pack_phi, grid, dim3(256), 0, c->stream, c->d_stage + in_off, c->d_phi + cc * c->phi_col + sl.base,
-                                   sl.first - h.Nblue, sl.len, R, D, Ns, c->phi_in_col, c->phi_col);
+                hipLaunchKernelGGL(k_pack_phi, grid, dim3(256), 0, c->stream, c->d_stage + in_off, PhiBlock{c->d_phi, c->phi_col, cc, (size_t)sl.base, c->phi_group},
+                                   sl.first - h.Nblue, sl.len, R, D, Ns, c->phi_in_col);
                 HIPCHK(hipGetLastError());
             }
         }
@@ -1448,6 +1464,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
     p.L = c->L;
     p.wavelength = c->d_wavelength; p.zmu = c->d_zmu; p.wmuh = c->d_wmuh; p.wl = c->d_wl; p.alpha = c->d_alpha;
     p.u_la = c->d_u_la; p.active = c->d_active; p.tiles = c->d_tiles; p.slots = c->d_slots;
+    p.phi_G = c->phi_group;
     p.phi_col_stride = (int64_t)c->phi_col; p.corr_col_stride = (int64_t)c->corr_col; p.pp_col_stride = (int64_t)c->pp_col;
     p.height = c->d_height; p.temperature = c->d_temperature; p.n = c->d_n; p.wphi = c->d_wphi;
     p.bgchi_T = c->d_bgchi; p.bgeta_T = c->d_bgeta; p.bgxchi_T = c->d_bgxchi; p.bgxeta_T = c->d_bgxeta; p.Psi2_T = c->d_Psi2; p.sca = c->d_sca; p.phi_T = c->d_phi; p.nsr = c->d_nsr; p.Ncont = c->Ncont; p.E_T = c->d_E; p.corr_T = c->d_corr; p.Psi3_T = c->d_Psi3;
@@ -1863,8 +1880,8 @@ int lsx_get(lsx_ctx* c, int32_t what, int32_t col0, int32_t ncol, double* dst, s
                 const DevTrans& h = c->htrans[sl.trans];
                 const size_t total = (size_t)sl.len * R * D * Ns;
                 dim3 grid((unsigned)std::min<size_t>((total + 255) / 256, 256), (unsigned)nb);
-                hipLaunchKernelGGL(k_unpack_phi, grid, dim3(256), 0, c->stream, c->d_phi + (col0 + b0) * c->phi_col + sl.base,
-                                   c->d_stage + (size_t)h.phi_off * R * D * Ns, sl.first - h.Nblue, sl.len, R, D, (int)Ns, c->phi_col, c->phi_in_col);
+                hipLaunchKernelGGL(k_unpack_phi, grid, dim3(256), 0, c->stream, PhiBlock{c->d_phi, c->phi_col, (size_t)col0 + b0, (size_t)sl.base, c->phi_group},
+                                   c->d_stage + (size_t)h.phi_off * R * D * Ns, sl.first - h.Nblue, sl.len, R, D, (int)Ns, c->phi_in_col);
                 HIPCHK(hipGetLastError());
             }
             HIPCHK(hipMemcpyAsync(dst + b0 * per, c->d_stage, nb * per * 8, hipMemcpyDeviceToHost, c->stream));

@@ -432,6 +432,7 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
         P.rs_ok = !opt.no_rs && P.Nrays == LSX_RS_RAYS && !P.sca_per_lambda && (LSX_RS_COLS + 1) * big * 8 < 0xffffffffull &&
                   (size_t)lsx_rs_lds_doubles(2, Ns) * sizeof(double) <= 64 * 1024;      // (the operand table of a two-slot tile fits)
         P.rs_min_columns = opt.rs_min_columns;
+        P.phi_group = (P.rs_ok && !opt.no_phi_group) ? LSX_RS_COLS : 1;
         for (auto& k : P.plan_classes) k.rs = P.rs_ok && k.npt >= 0 && k.npt <= opt.rs_max_npt && lsx_rs_instance_exists(k.npt, k.nl, k.linked, k.topo);
     }
 

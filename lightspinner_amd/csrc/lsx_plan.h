@@ -169,6 +169,7 @@ struct PlanOptions {           // diagnostic switches (lsx_create reads them fro
     int occ_wg = 0;            // LSX_OCC_WG: at most this many workgroups per CU (through the LDS request)
     bool no_rs = false;        // LSX_NO_RS: every class through lsx_sweep.hip (one ray per lane)
     int rs_min_columns = LSX_RS_MIN_COLUMNS;   // LSX_RS_MIN_COLUMNS: contexts with fewer columns keep one ray per lane (too few wavefronts otherwise)
+    bool no_phi_group = false; // LSX_PHI_GROUP=1: the plain per-column profile store also where the ray-serial sweep can run (measurements)
     int rs_max_npt = 2;        // LSX_RS_MAX_NPT: classes with more per-ray slots keep one ray per lane (diagnostic: 1 leaves the two-slot tiles to lsx_sweep.hip)
 };
 
@@ -205,6 +206,7 @@ struct LsxPlan {
     // per-column strides in doubles
     size_t phi_col = 0, phi_in_col = 0, corr_col = 0, pp_col = 0, sca_col = 0, til_col = 0;
     LaunchShapes shapes;
+    int phi_group = 1;         // columns per group of the line-profile store (lsx_dev.h, phi_elem): LSX_RS_COLS where rs_ok
     bool rs_ok = false;        // the context's shape admits the ray-serial sweep (rays, scattering, 32-bit offsets over a column group)
     int rs_min_columns = LSX_RS_MIN_COLUMNS;
 };

@@ -221,7 +221,8 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
     double* __restrict__ Jnew = p.Jnew_T + tbase;
     const bool sca_l = SCAL && p.sca_per_lambda;
     const double* __restrict__ sca = sca_l ? p.sca + tbase : p.sca + (size_t)col * Ns;
-    const double* __restrict__ phi_col = p.phi_T + (size_t)col * p.phi_col_stride;
+    const int PG = p.phi_G, cphi = col % PG;                       // the grouped line-profile store (lsx_dev.h, phi_elem)
+    const double* __restrict__ phi_col = p.phi_T + (size_t)(col - cphi) * p.phi_col_stride;      // the group's first element
     const double* __restrict__ Eb = p.E_T + tbase;                    // Boltzmann factor of the continuum g_ij, [k][j]
     const auto* nsr_col = LSX_CONST(double, p.nsr + (size_t)col * p.Ncont * Ns);
     // linked continua: the tile's blocks of the correction streams [line][3][k][j] and of the Psi* phi sums [line][k][j]
@@ -300,8 +301,8 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             const int lb = a ? la - slots[u].first : 0;      // position inside the (tile, transition) block
             (void)Nlam;
             // lines: the lane's element of depth 0; a lane outside the line's range reads the column's zero pad at every depth
-            idx0[u] = line ? (a ? slots[u].base + raysel * len + lb : (int)p.phi_col_stride - 1) : 0;      // continua read the tile's shared E stream
-            kstr[u] = (line && a) ? kmul * len : 0;
+            idx0[u] = line ? (a ? PG * (slots[u].base + raysel * len) + cphi * len + lb : PG * (int)p.phi_col_stride - 1) : 0;      // continua read the tile's shared E stream
+            kstr[u] = (line && a) ? PG * kmul * len : 0;
             wlv[u] = (a && valid) ? wq_l * p.wl[slots[u].wl_off + l] : 0.0;                // :451/:455, :665
             alv[u] = (a && !line) ? p.alpha[slots[u].wl_off + l] : 0.0;
         }
@@ -318,7 +319,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
             const int l = a ? la - sl.Nblue : 0;
             const int lb = a ? la - sl.first : 0;
             if (sl.flags & SLOT_LINE) {
-                const double pv = a ? phi_col[sl.base + (kk * kmul + raysel) * sl.len + lb] : 0.0;
+                const double pv = a ? phi_col[PG * (sl.base + (kk * kmul + raysel) * sl.len) + cphi * sl.len + lb] : 0.0;
                 c += (sl.cB * (ni - sl.g * nj)) * pv;
             } else {
                 const double g = a ? nsr_col[sl.base + kk] * Eb[kk * L + j] : 0.0;
@@ -535,7 +536,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                 const int l = a ? la - sl.Nblue : 0;
                 double v, alf = 0.0;
                 if (sl.flags & SLOT_LINE) {
-                    v = a ? phi_col[sl.base + (k * kmul + raysel) * sl.len + (la - sl.first)] : 0.0;
+                    v = a ? phi_col[PG * (sl.base + (k * kmul + raysel) * sl.len) + cphi * sl.len + (la - sl.first)] : 0.0;
                 } else {
                     v = a ? nsr_col[sl.base + k] * at(Eb, kl) : 0.0;
                     alf = a ? p.alpha[sl.wl_off + l] : 0.0;
@@ -800,7 +801,7 @@ __device__ __forceinline__ void sweep_tile(const SweepParams& p, const int vb, c
                 double wla = a ? p.wl[sl.wl_off + l] : 0.0;
                 double pv, Vij, Uji, chi;
                 if (sl.flags & SLOT_LINE) {
-                    pv = a ? phi_col[sl.base + (k * kmul + raysel) * sl.len + (la - sl.first)] : 0.0; // L1/L2 hit
+                    pv = a ? phi_col[PG * (sl.base + (k * kmul + raysel) * sl.len) + cphi * sl.len + (la - sl.first)] : 0.0; // L1/L2 hit
                     Vij = sl.cB * pv;
                     Uji = sl.Uc * pv;
                     chi = (sl.cB * (ni - sl.g * nj)) * pv;
@@ -939,7 +940,8 @@ __device__ __forceinline__ void sweep_tile_parabolic(const SweepParams& p, const
     double* __restrict__ Jnew = p.Jnew_T + tbase;
     const bool sca_l = SCAL && p.sca_per_lambda;
     const double* __restrict__ sca = sca_l ? p.sca + tbase : p.sca + (size_t)col * Ns;
-    const double* __restrict__ phi_col = p.phi_T + (size_t)col * p.phi_col_stride;
+    const int PG = p.phi_G, cphi = col % PG;                       // the grouped line-profile store (lsx_dev.h, phi_elem)
+    const double* __restrict__ phi_col = p.phi_T + (size_t)(col - cphi) * p.phi_col_stride;      // the group's first element
     const double* __restrict__ Eb = p.E_T + tbase;
     const auto* nsr_col = LSX_CONST(double, p.nsr + (size_t)col * p.Ncont * Ns);
     const size_t plane = (size_t)Ns * L;
@@ -973,7 +975,7 @@ __device__ __forceinline__ void sweep_tile_parabolic(const SweepParams& p, const
         const int l = a ? la - sl.Nblue : 0;
         v.wla = a ? p.wl[sl.wl_off + l] : 0.0;
         if (sl.flags & SLOT_LINE) {
-            v.pv = a ? phi_col[sl.base + (k * kmul + raysel) * sl.len + (la - sl.first)] : 0.0;
+            v.pv = a ? phi_col[PG * (sl.base + (k * kmul + raysel) * sl.len) + cphi * sl.len + (la - sl.first)] : 0.0;
             v.Vij = sl.cB * v.pv;
             v.Uji = sl.Uc * v.pv;
             v.chi = (sl.cB * (ni - sl.g * nj)) * v.pv;
@@ -1189,7 +1191,8 @@ __device__ __forceinline__ void sweep_tile_par(const SweepParams& p, const int v
     double* __restrict__ psibar = p.Psi2_T + ((size_t)dir * p.ncol * ntile) * Ns * L + tbase;
     const double* __restrict__ Jdag = p.Jdag_T + tbase;
     double* __restrict__ Jnew = p.Jnew_T + tbase;
-    const double* __restrict__ phi_col = p.phi_T + (size_t)col * p.phi_col_stride;
+    const int PG = p.phi_G, cphi = col % PG;                       // the grouped line-profile store (lsx_dev.h, phi_elem)
+    const double* __restrict__ phi_col = p.phi_T + (size_t)(col - cphi) * p.phi_col_stride;      // the group's first element
     const double* __restrict__ Eb = p.E_T + tbase;
     const size_t plane = (size_t)Ns * L;
     const double* __restrict__ corr = LK ? p.corr_T + (size_t)col * p.corr_col_stride + tilep->corr_off : nullptr;
@@ -1243,8 +1246,8 @@ __device__ __forceinline__ void sweep_tile_par(const SweepParams& p, const int v
         const bool line = u < NL;
         const int len = slots[u].len;
         const int lb = a ? la - slots[u].first : 0;
-        idx0[u] = line ? (a ? slots[u].base + raysel * len + lb : (int)p.phi_col_stride - 1) : 0;
-        kstr[u] = (line && a) ? kmul * len : 0;
+        idx0[u] = line ? (a ? PG * (slots[u].base + raysel * len) + cphi * len + lb : PG * (int)p.phi_col_stride - 1) : 0;
+        kstr[u] = (line && a) ? PG * kmul * len : 0;
         wlv[u] = (a && valid) ? wq_l * p.wl[slots[u].wl_off + l] : 0.0;
         alv[u] = (a && !line) ? p.alpha[slots[u].wl_off + l] : 0.0;
     }

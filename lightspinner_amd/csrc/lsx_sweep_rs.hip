@@ -153,8 +153,15 @@ lsx_sweep_rs_kernel(const SweepParams p)
     double* __restrict__ Jnew = p.Jnew_T + tb0;
     double* __restrict__ psibar = p.Psi2_T + ((size_t)dir * p.ncol * ntile) * Ns * LW + tb0;
     const double* __restrict__ Eb = p.E_T + tb0;
+    // the line-profile store interleaves the columns of a group inside every block row (lsx_dev.h, phi_elem): with G = NC the five
+    // columns of this wavefront are ONE group, and row x of a block is one contiguous run [c < NC][l < len] for the whole wavefront
+    const int PG = p.phi_G;                                          // NC, or 1: the plain per-column store (LSX_PHI_GROUP=1)
     const double* __restrict__ phi0 = p.phi_T + (size_t)col0 * p.phi_col_stride;
-    const unsigned o_phi = (unsigned)((size_t)cc * p.phi_col_stride * 8u);
+#ifdef LSX_ABL_PHI_ONECOL
+    const int cphi = 0;              // ablation build (wrong results): the five columns of a wavefront read the FIRST column's profiles
+#else
+    const int cphi = cc;
+#endif
     const double* __restrict__ corr = LK ? p.corr_T + (size_t)col0 * p.corr_col_stride + tilep->corr_off : nullptr;
     const unsigned o_corr = LK ? (unsigned)((size_t)cc * p.corr_col_stride * 8u) + (unsigned)j * 8u : 0u;
     double* __restrict__ ppsum = LK ? p.Psi3_T + ((size_t)dir * p.ncol + col0) * p.pp_col_stride + tilep->pp_off : nullptr;
@@ -203,10 +210,15 @@ lsx_sweep_rs_kernel(const SweepParams p)
         const int lb = a ? la - slots[u].first : 0;
         // element ((dir Ns + k) Nrays + mu) len + lb of the (tile, line) block (compact: k len + lb); a lane outside the line's
         // range reads the column's zero pad at every depth and ray
-        const long e0 = line ? (a ? (long)slots[u].base + (compact ? 0L : (long)dir * Ns * NR * len) + lb : (long)p.phi_col_stride - 1) : 0L;
-        phi_o[u] = o_phi + (unsigned)(e0 * 8);
-        phi_k[u] = (line && a) ? (unsigned)((compact ? 1 : NR) * len * 8) : 0u;
-        phi_m[u] = (line && a && !compact) ? (unsigned)(len * 8) : 0u;
+        // grouped store: element PG (base + x len) + c len + l of the group (x = (dir Ns + k) NR + mu); plain store (PG = 1): the
+        // column's own base + x len + l.  A lane outside the line's range reads a zero pad at every depth and ray: the last
+        // element of the group (of its column)
+        const long xl0 = (long)slots[u].base + (compact ? 0L : (long)dir * Ns * NR * len);
+        const long e0 = !line ? 0L : PG > 1 ? (a ? (long)PG * xl0 + (long)cphi * len + lb : (long)PG * p.phi_col_stride - 1)
+                                            : (long)cphi * p.phi_col_stride + (a ? xl0 + lb : (long)p.phi_col_stride - 1);
+        phi_o[u] = (unsigned)(e0 * 8);
+        phi_k[u] = (line && a) ? (unsigned)(PG * (compact ? 1 : NR) * len * 8) : 0u;
+        phi_m[u] = (line && a && !compact) ? (unsigned)(PG * len * 8) : 0u;
         wlam[u] = (a && act) ? (4.0 * kPi) * p.wl[slots[u].wl_off + l] : 0.0;   // :451/:455, :665 without the angle weight
         alv[u] = (a && !line) ? p.alpha[slots[u].wl_off + l] : 0.0;
         cB[u] = slots[u].cB; Vc[u] = slots[u].Vc; Uc[u] = slots[u].Uc;
@@ -595,13 +607,11 @@ lsx_sweep_rs_kernel(const SweepParams p)
         // address, so the store needs no lane mask (no branch around it: the compiler counts it when it places its waits -- loads and
         // stores retire in issue order, a wait for the next depth's operands waits for every store before them); the
         // Psibar of a frozen column is read by nobody (the fast-continuum kernels skip frozen columns)
-        if (nF > 0) at(psibar, kt) = Pacc;
+        if (LK || nF > 0) at(psibar, kt) = Pacc;      // (a tile with linked continua has fast continua: no test at all in those instances)
 #endif
-        if constexpr (LK) {
-            if (act) {
+        if constexpr (LK) {       // (no lane mask either: shadow lanes repeat their lane's store, a frozen column's sums are read by nobody)
 #pragma unroll
-                for (int u = 0; u < NL; ++u) at(ppsum, (unsigned)(u * plane) * 8u + o_pp + (unsigned)(k * LW) * 8u) = PP[u];
-            }
+            for (int u = 0; u < NL; ++u) at(ppsum, (unsigned)(u * plane) * 8u + o_pp + (unsigned)(k * LW) * 8u) = PP[u];
         }
         if constexpr (NPT >= 1) {
             // lanes (c, j) -> element c * 12 + j of the value's row (= the lane number); idle lanes park zeros
