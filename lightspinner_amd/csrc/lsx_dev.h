@@ -106,6 +106,10 @@ struct DevTile {            // L consecutive wavelengths (L = 64 / Nrays) of one
     int32_t nK;             // linked continua among the nF fast ones
     int32_t corr_off;       // nK > 0: element offset of the tile's [nL][3][Nspace][L] block inside a column of corr_T
     int32_t pp_off;         // nK > 0: element offset of the tile's [nL][Nspace][L] block inside a column of Psi3_T
+    int32_t nX;             // nK > 0: nL correction slots behind the tile's nP + nF slots -- Gpart slabs (one entry per rate, like a fast
+                            // continuum's) in which the fast-continuum epilogue leaves what the linked continua add to each LINE's
+                            // rates where the sweep does not apply it itself (ray-serial instances, lsx_fast.h); zeros otherwise
+    int32_t pad_;
 };
 
 struct SweepParams {

@@ -43,6 +43,11 @@ struct FastParams {
     const double* Psi3_T;       // [dir][col]{tile: [line][k][j]}
     double* Gpart;
     const uint8_t* colmask;
+    // what the linked continua add to the rates of the tile's LINES (rh_method.py:616-627 through :652, :677-681): the sweep applies
+    // it ray by ray from the pre-pass's correction streams, or -- epi_corr, the ray-serial instances -- the column-mapped epilogue
+    // applies it from the sums it has anyway (fast_gamma_cols_rows) and the pre-pass writes no correction streams
+    int epi_corr, Nlines;
+    const double* wphi;         // [col][Nlines][k]
 };
 
 // effective background of the tiles that have fast continua: bgx = bg + sum over the tile's fast continua; for the
@@ -134,7 +139,7 @@ static __device__ __forceinline__ void fast_prepass_tile(const FastParams& f, co
         const size_t o = tb + (size_t)k * f.L + j;
         f.bgxchi_T[o] = chi;
         f.bgxeta_T[o] = eta;
-        if (nLc > 0) {
+        if (nLc > 0 && !f.epi_corr) {
             double* cr = f.corr_T + col * f.corr_col_stride + tl.corr_off + (size_t)k * f.L + j;
 #pragma unroll
             for (int u = 0; u < LSX_MAX_TILE_LINES; ++u)
@@ -179,7 +184,8 @@ static __device__ __forceinline__ void fast_gamma_cols_rows(const FastParams& f,
     const DevSlot* ls = f.slots + tl.slot0;
     double* sA = sm;                                          // [q][j]{alpha, wlambda}, 0 where the continuum is inactive
     double* sU = sA + (size_t)2 * LSX_FGC_MAXF * L;            // [j] 2hc/lambda^3
-    double* sS = sU + L + (size_t)wv * NST * R * L;           // this wave's streams: [J | Psibar | E | PsiPhi_u][row][j]
+    double* sLW = sU + L;                                      // [u < 2][j] the linked lines' wavelength weights (0 outside the line)
+    double* sS = sLW + 2 * L + (size_t)wv * NST * R * L;      // this wave's streams: [J | Psibar | E | PsiPhi_u][row][j]
     for (int e = tid; e < tl.nF * L; e += NT) {
         const int q = e / L, jj = e - q * L, lq = tl.la0 + min(jj, tl.nla - 1), lt = lq - fs[q].Nblue;
         const bool a = jj < tl.nla && lt >= 0 && lt < fs[q].Nlam && f.active[(size_t)fs[q].trans * f.Nspect + lq] != 0;
@@ -187,6 +193,17 @@ static __device__ __forceinline__ void fast_gamma_cols_rows(const FastParams& f,
         sA[e * 2 + 1] = a ? f.wl[fs[q].wl_off + lt] : 0.0;
     }
     for (int e = tid; e < L; e += NT) sU[e] = f.u_la[tl.la0 + min(e, tl.nla - 1)];
+    if constexpr (LINKS) {
+        for (int e = tid; e < 2 * L; e += NT) {
+            const int u = e / L, jj = e - u * L, lq = tl.la0 + min(jj, tl.nla - 1);
+            double w = 0.0;
+            if (u < min(tl.nL, NLC)) {
+                const int lt = lq - ls[u].Nblue;
+                if (jj < tl.nla && lt >= 0 && lt < ls[u].Nlam && f.active[(size_t)ls[u].trans * f.Nspect + lq] != 0) w = f.wl[ls[u].wl_off + lt];
+            }
+            sLW[e] = w;
+        }
+    }
     __syncthreads();
     const long row0 = row_begin + (long)wv * R;               // first (column, depth) row of this wave
     if (row0 >= nrows) return;
@@ -263,6 +280,12 @@ static __device__ __forceinline__ void fast_gamma_cols_rows(const FastParams& f,
         }
     }
     const double* srow = sS + (size_t)r * L;
+    // what the linked continua add to line u's rates, summed over this lane's wavelengths: dA = sum w_line EC sPP, dB = sum w_line XC_i sPP
+    // (EC, XC_i: the continua's share of atom.eta and atom.chi[i_line]; the sweep's own terms are phi [Uc (1 - Psi* chi_i) + Vc Ieff],
+    // cB phi Ieff with Ieff = I - Psi* eta: the shares enter as -EC sum_mu w Psi* phi and -XC_i sum_mu w Psi* phi)
+    double dA[NL1], dB[NL1];
+#pragma unroll
+    for (int u = 0; u < NL1; ++u) dA[u] = dB[u] = 0.0;
     for (int q0 = 0; q0 < tl.nF;) {                           // one atom at a time
         const int atom = fs[q0].atom;
         int q1 = q0;
@@ -324,13 +347,14 @@ static __device__ __forceinline__ void fast_gamma_cols_rows(const FastParams& f,
                         if (lk0 & (1u << (8 * u))) le += teta[u];
                 }
                 // rh_method.py:284-286, 453-455, 613-614 for the atom's continua; atom.chi[j], atom.U[j], atom.eta of :616-627
-#ifndef LSX_FGC_UNFACTORED
                 // The same terms with the common factors taken out (round 4: 10 instead of 21 fp64 instructions per (depth, wavelength,
                 // continuum) in a kernel that runs on the vector pipe).  With g = (nStar_i / nStar_j) E:
                 //   Vji = g alpha,  Uji = u Vji,  chi = alpha (n_i - n_j g) = alpha h,   U_a[j] = u sum g alpha,  eta_a = u sum n_j g alpha
                 //   w [(Uji sW + Vji sIe) - chi U_a[j] sPsi] = (w alpha) [g (u sW + sIe) - h (U_a[j] sPsi)],     w [alpha sIe] = (w alpha) sIe
                 // -- no difference is formed that the reference's own expression does not form.
-                double g[LSX_FAST_NQ], hq[LSX_FAST_NQ], Usum = 0.0, Esum = 0.0, Csum = 0.0;
+                double g[LSX_FAST_NQ], hq[LSX_FAST_NQ], Usum = 0.0, Esum = 0.0, Csum = 0.0, XCi[NL1];
+#pragma unroll
+                for (int u = 0; u < NL1; ++u) XCi[u] = 0.0;
 #pragma unroll
                 for (int q = 0; q < LSX_FAST_NQ; ++q) {
                     g[q] = hq[q] = 0.0;
@@ -341,10 +365,27 @@ static __device__ __forceinline__ void fast_gamma_cols_rows(const FastParams& f,
                         hq[q] = ni[q] - ng;
                         Usum = fma(g[q], alf, Usum);
                         Esum = fma(ng, alf, Esum);
-                        if constexpr (LINKS) Csum = fma(hq[q], alf, Csum);      // = -atom.chi[j]
+                        if constexpr (LINKS) {
+                            Csum = fma(hq[q], alf, Csum);                       // = -atom.chi[j]
+                            const unsigned lkq = fs[q0 + q].lkbits;             // (wave-uniform)
+#pragma unroll
+                            for (int u = 0; u < NL1; ++u)
+                                if (lkq & (2u << (8 * u))) XCi[u] = fma(hq[q], alf, XCi[u]);      // chi of the continua on line u's lower level
+                        }
                     }
                 }
                 const double U_j = ula * Usum, etaA = ula * Esum;
+                if constexpr (LINKS) {
+                    if (f.epi_corr) {
+#pragma unroll
+                        for (int u = 0; u < NL1; ++u)
+                            if (lk0 & (1u << (8 * u))) {                        // line u belongs to this atom: its EC is this atom's eta
+                                const double t = sLW[u * L + jw] * (w ? L2[u].y : L2[u].x);
+                                dA[u] = fma(t, etaA, dA[u]);
+                                dB[u] = fma(t, XCi[u], dB[u]);
+                            }
+                    }
+                }
                 const double sIe = (sI - etaA * sPsi) - le;
                 const double T = fma(ula, sW, sIe), UP = U_j * sPsi;
 #pragma unroll
@@ -362,35 +403,6 @@ static __device__ __forceinline__ void fast_gamma_cols_rows(const FastParams& f,
                         }
                     }
                 }
-#else
-                double Vji[LSX_FAST_NQ], chi[LSX_FAST_NQ], chi_j = 0.0, U_j = 0.0, etaA = 0.0;
-#pragma unroll
-                for (int q = 0; q < LSX_FAST_NQ; ++q) {
-                    Vji[q] = chi[q] = 0.0;
-                    if (q < nq) {
-                        const double alf = sA[(size_t)((q0 + q) * L + jw) * 2];
-                        Vji[q] = (nr[q] * E) * alf;
-                        const double Uji = ula * Vji[q];
-                        chi[q] = ni[q] * alf - nj[q] * Vji[q];
-                        chi_j -= chi[q];
-                        U_j += Uji;
-                        etaA += nj[q] * Uji;
-                    }
-                }
-                const double sIe = (sI - etaA * sPsi) - le;
-#pragma unroll
-                for (int q = 0; q < LSX_FAST_NQ; ++q) {
-                    if (q < nq) {
-                        const unsigned lk = fs[q0 + q].lkbits;
-                        const double2 A = *reinterpret_cast<const double2*>(sA + (size_t)((q0 + q) * L + jw) * 2);
-                        const double Uji = ula * Vji[q];
-                        const double cU = (chi[q] * U_j) * sPsi + line_chi(lk) * U_j;
-                        const double cU2 = chi_j * line_U(lk);
-                        a1[q] += A.y * ((Uji * sW + Vji[q] * sIe) - cU);
-                        a2[q] += A.y * ((A.x * sIe) - cU2);
-                    }
-                }
-#endif
             }
         }
 #pragma unroll
@@ -405,6 +417,28 @@ static __device__ __forceinline__ void fast_gamma_cols_rows(const FastParams& f,
             }
         }
         q0 = q1;
+    }
+    if constexpr (LINKS) {
+        // the correction slots of the tile's lines (DevTile.nX): what the linked continua add to Gamma[i][j] and Gamma[j][i] of line u,
+        // -wphi [Uc dB + Vc dA] and -wphi cB dA (the sweep's wavelength weight is 4 pi w_line wphi; the 4 pi sits in sPP); zeros where
+        // the sweep has applied the corrections itself
+#pragma unroll
+        for (int u = 0; u < NL1; ++u) {
+            if (u < nLc) {
+                double x1 = 0.0, x2 = 0.0;
+                if (f.epi_corr) {
+                    const double wp = f.wphi[((size_t)col * f.Nlines) * Ns + ls[u].wphi_off + k];
+                    x1 = -wp * fma(ls[u].Uc, dB[u], ls[u].Vc * dA[u]);
+                    x2 = -wp * (ls[u].cB * dA[u]);
+                }
+                const double s1 = x1 + dpp_f64<0xB1, 0xf>(x1), s2 = x2 + dpp_f64<0xB1, 0xf>(x2);
+                if (h == 0) {
+                    double* gp = f.Gpart + (((size_t)col * f.nslot_total + tl.slot0 + tl.nP + tl.nF + u) * 4) * (size_t)Ns + k;
+                    gp[0] = s1;
+                    gp[2 * (size_t)Ns] = s2;
+                }
+            }
+        }
     }
 }
 

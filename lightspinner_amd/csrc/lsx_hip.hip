@@ -591,6 +591,14 @@ __global__ void __launch_bounds__(NT) k_fast_gamma(const FastParams f)
                 g[2 * (size_t)Ns] = s2;
             }
         };
+        // the correction slots of the tile's lines (DevTile.nX) belong to the column-mapped epilogue (lsx_fast.h); the tiles this
+        // kernel takes get their linked corrections in the sweep: zeros here
+        if (last_lane && k < Ns)
+            for (int x = 0; x < tl.nX; ++x) {
+                double* g = f.Gpart + ((col * f.nslot_total + tl.slot0 + tl.nP + tl.nF + x) * 4) * (size_t)Ns + k;
+                g[0] = 0.0;
+                g[2 * (size_t)Ns] = 0.0;
+            }
         if (tl.fast_simple) {
             for (int q0 = 0; q0 < tl.nF;) {                 // one atom at a time
                 const int atom = fs[q0].atom;
@@ -1482,12 +1490,14 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
         ff.bgchi_T = c->d_bgchi; ff.bgeta_T = c->d_bgeta;
         ff.bgxchi_T = c->d_bgxchi; ff.bgxeta_T = c->d_bgxeta; ff.J_T = c->d_J[c->jcur ^ 1]; ff.Psi2_T = c->d_Psi2;
         ff.Gpart = c->d_Gpart; ff.colmask = c->d_colmask;
+        ff.epi_corr = 0; ff.Nlines = c->Nlines; ff.wphi = c->d_wphi;
     }
     // launch shapes (rows per pass, staged depths, LDS bytes): fixed and checked when the plan was made (lsx_plan.cpp)
     const LaunchShapes& S = c->shapes;
     const int LP = S.rows_lp;
-    auto launch_prepass = [&](hipStream_t st, const int* d_list, size_t n) {
+    auto launch_prepass = [&](hipStream_t st, const int* d_list, size_t n, bool epi = false) {
         FastParams fq = ff;
+        fq.epi_corr = epi ? 1 : 0;
         fq.fast_tiles = d_list; fq.n_fast_tiles = (int)n;
         fq.seg_depths = S.prepass_seg;
         dim3 grid((unsigned)n, (unsigned)c->ncol);
@@ -1510,8 +1520,9 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
 #undef LSX_FG
     };
     // the column-mapped kernel: two lanes per (column, depth), blocks of 256 over the columns' depths x the tiles
-    auto launch_fast_cols = [&](hipStream_t st, const int* d_list, size_t n, int v) {
+    auto launch_fast_cols = [&](hipStream_t st, const int* d_list, size_t n, int v, bool epi) {
         FastParams fq = ff;
+        fq.epi_corr = epi ? 1 : 0;
         fq.fast_tiles = d_list; fq.n_fast_tiles = (int)n;
         dim3 grid((unsigned)(((size_t)c->ncol * c->Nspace + 4 * LSX_FGC_ROWS - 1) / (4 * LSX_FGC_ROWS)), (unsigned)n);
 #define LSX_FC(NLCV) if (kLkLines[v] == NLCV) { if (c->L == 12) hipLaunchKernelGGL((k_fast_gamma_cols<NLCV, 6>), grid, dim3(256), S.cols_lds[v], st, fq); \
@@ -1519,9 +1530,9 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
         LSX_FC(0) LSX_FC(1) LSX_FC(2)
 #undef LSX_FC
     };
-    auto launch_fast_gamma = [&](hipStream_t st, const std::vector<int>* cols, int* const* d_cols, const int* d_rest, size_t nrest) {
+    auto launch_fast_gamma = [&](hipStream_t st, const std::vector<int>* cols, int* const* d_cols, const int* d_rest, size_t nrest, bool epi = false) {
         for (int v = 0; v < 3; ++v)
-            if (!cols[v].empty()) launch_fast_cols(st, d_cols[v], cols[v].size(), v);
+            if (!cols[v].empty()) launch_fast_cols(st, d_cols[v], cols[v].size(), v, epi);
         if (nrest) launch_fast_rows(st, d_rest, nrest);
     };
     // From here on nothing returns before the class streams have been joined back and jcur / fs_pending advanced: a launch
@@ -1564,7 +1575,11 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
         for (auto& k : c->classes) {
             hipStream_t st = fork ? k.stream : c->stream;
             if (fork) note(hipStreamWaitEvent(st, c->ev_fork, 0));
-            if (!k.fast_tiles.empty()) launch_prepass(st, k.d_fast_tiles, k.fast_tiles.size());
+            // a class of line tiles with linked continua on the ray-serial kernel: the sweep reads no correction streams, the pre-pass
+            // writes none, the column-mapped epilogue applies the corrections to the lines' rates (lsx_fast.h; the plan has checked
+            // that every tile of the class takes that epilogue)
+            const bool epi = k.lk_epi && k.rs && ray_serial;
+            if (!k.fast_tiles.empty()) launch_prepass(st, k.d_fast_tiles, k.fast_tiles.size(), epi);
             const long nblocks = (long)k.tiles.size() * c->ncol;
             p.class_tiles = k.d_tiles;
             p.n_class_tiles = (int)k.tiles.size();
@@ -1582,7 +1597,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
                 if (!k.tdone) note(hipEventCreate(&k.tdone));
                 if (k.tdone) note(hipEventRecord(k.tdone, st));
             }
-            if (!k.fast_tiles.empty()) launch_fast_gamma(st, k.fast_cols, k.d_fast_cols, k.d_fast_rest, k.fast_rest.size());
+            if (!k.fast_tiles.empty()) launch_fast_gamma(st, k.fast_cols, k.d_fast_cols, k.d_fast_rest, k.fast_rest.size(), epi);
             if (fork) {
                 note(hipEventRecord(k.done, st));
                 note(hipStreamWaitEvent(c->stream, k.done, 0));

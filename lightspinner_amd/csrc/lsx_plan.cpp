@@ -312,6 +312,18 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
             P.tile_slots.push_back(t);
             P.tile_slot_fast.push_back((sl.flags & SLOT_FAST) ? 1 : 0);
         }
+        // correction slots of a tile with linked continua: one per line, carrying the line's transition so that the Gamma
+        // epilogue adds their slabs to the line's rates; not a transition of their own (no wavelengths, no profile block)
+        tl.nX = tl.nK > 0 ? tl.nL : 0;
+        for (int x = 0; x < tl.nX; ++x) {
+            const DevTrans& h = P.htrans[lines[x]];
+            DevSlot sl{};
+            sl.flags = SLOT_FAST;
+            sl.li = h.li; sl.lj = h.lj; sl.atom = h.atom; sl.trans = lines[x];
+            P.slots.push_back(sl);
+            P.tile_slots.push_back(lines[x]);
+            P.tile_slot_fast.push_back(1);
+        }
         if (tl.nF > 0) {
             P.fast_tiles.push_back((int)P.tiles.size());
             P.nF_max = std::max(P.nF_max, tl.nF);
@@ -331,7 +343,7 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
                 group_max = std::max(group_max, group);
             }
             const int lkn = tl.nK > 0 ? (int)lines.size() : 0;       // lines the linked continua feed
-            const size_t lds_cols = ((size_t)2 * LSX_FGC_MAXF * P.L + P.L + (size_t)4 * (3 + lkn) * LSX_FGC_ROWS * P.L) * sizeof(double);
+            const size_t lds_cols = ((size_t)2 * LSX_FGC_MAXF * P.L + (size_t)3 * P.L + (size_t)4 * (3 + lkn) * LSX_FGC_ROWS * P.L) * sizeof(double);
             const bool cols = simple && group_max <= LSX_FAST_NQ && (int)fast.size() <= LSX_FGC_MAXF && P.L % 2 == 0 && lkn <= 2 && lds_cols <= 64 * 1024 && !opt.fast_rows;
             tl.fast_simple = simple ? (cols ? 2 : 1) : 0;
             if (!simple) P.fast_generic = true;
@@ -433,7 +445,16 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
                   (size_t)lsx_rs_lds_doubles(2, Ns) * sizeof(double) <= 64 * 1024;      // (the operand table of a two-slot tile fits)
         P.rs_min_columns = opt.rs_min_columns;
         P.phi_group = (P.rs_ok && !opt.no_phi_group) ? LSX_RS_COLS : 1;
-        for (auto& k : P.plan_classes) k.rs = P.rs_ok && k.npt >= 0 && k.npt <= opt.rs_max_npt && lsx_rs_instance_exists(k.npt, k.nl, k.linked, k.topo);
+        for (auto& k : P.plan_classes) {
+            k.rs = P.rs_ok && k.npt >= 0 && k.npt <= opt.rs_max_npt && lsx_rs_instance_exists(k.npt, k.nl, k.linked, k.topo);
+            // The ray-serial instances for line-only tiles with linked continua (one line; two lines with a known relation) do not
+            // read the continua's corrections: the column-mapped fast-continuum epilogue applies them to the lines' rates
+            // (lsx_fast.h).  A class with a tile that epilogue cannot take keeps one ray per lane.
+            k.lk_epi = k.linked && k.npt >= 1 && k.nl == k.npt && (k.npt == 1 || k.topo != 0);
+            if (k.rs && k.lk_epi)
+                for (int t : k.tiles)
+                    if (P.tiles[t].fast_simple != 2) k.rs = false;
+        }
     }
 
     // ---- launch shapes of the kernels around the sweep: decided (and refused) here, not inside a half-enqueued call
@@ -460,7 +481,7 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
         S.rows_lds = (per_depth * S.rows_seg + fixed_for(S.rows_nt)) * sizeof(double);
         if (!P.fast_rest.empty() && S.rows_lds > 64 * 1024) return perr(err, LSX_EUNSUPPORTED, "lsx_create: the fast-continuum epilogue needs %zu B of LDS", S.rows_lds);
         for (int v = 0; v < 3; ++v) {
-            S.cols_lds[v] = ((size_t)2 * LSX_FGC_MAXF * P.L + P.L + (size_t)4 * (3 + kLkLines[v]) * LSX_FGC_ROWS * P.L) * sizeof(double);
+            S.cols_lds[v] = ((size_t)2 * LSX_FGC_MAXF * P.L + (size_t)3 * P.L + (size_t)4 * (3 + kLkLines[v]) * LSX_FGC_ROWS * P.L) * sizeof(double);
             if (!P.fast_cols[v].empty() && S.cols_lds[v] > 64 * 1024) return perr(err, LSX_EUNSUPPORTED, "lsx_create: the fast-continuum epilogue (column mapped) needs %zu B of LDS", S.cols_lds[v]);
         }
     }
@@ -491,7 +512,7 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
             size_t need = std::max(S.fused_lds, S.prepass_lds);
             for (int v = 0; v < 3; ++v)
                 if (!P.fast_cols[v].empty())
-                    need = std::max(need, ((size_t)2 * LSX_FGC_MAXF * P.L + P.L + (size_t)2 * (3 + kLkLines[v]) * LSX_FGC_ROWS * P.L) * sizeof(double));
+                    need = std::max(need, ((size_t)2 * LSX_FGC_MAXF * P.L + (size_t)3 * P.L + (size_t)2 * (3 + kLkLines[v]) * LSX_FGC_ROWS * P.L) * sizeof(double));
             S.fused_fast = ok && need <= 64 * 1024;
             S.fused_fast_lds = need;
         }

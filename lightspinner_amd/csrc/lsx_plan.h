@@ -157,6 +157,7 @@ struct PlanClass {             // tiles that run the same kernel instantiation
     size_t lds_bytes = 0;
     double work = 0.0;         // estimated share of the call (launch order; stream priority tiers under LSX_PRIO)
     bool rs = false;           // the class has a ray-serial instance (lsx_sweep_rs.hip); lsx_create decides by the column count
+    bool lk_epi = false;       // ... whose linked corrections the fast-continuum epilogue applies (lsx_fast.h), not the sweep
     int code() const { return npt >= 0 ? lsx_class_code(npt, nl, linked, topo) : (linked ? -3 : -1); }
 };
 

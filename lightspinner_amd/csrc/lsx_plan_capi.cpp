@@ -59,7 +59,13 @@ void verify(const LsxPlan& P, Checker& ck)
         if (tl.la0 != la || tl.nla < 1 || tl.nla > L) ck.fail("tile %ld: la0 %ld nla %ld", (long)ti, tl.la0, tl.nla);
         la += tl.nla;
         if (tl.slot0 != slot) ck.fail("tile %ld: slot0 %ld, expected %ld", (long)ti, tl.slot0, slot);
-        slot += tl.nP + tl.nF;
+        slot += tl.nP + tl.nF + tl.nX;
+        if (tl.nX != (tl.nK > 0 ? tl.nL : 0)) ck.fail("tile %ld: correction slots", (long)ti);
+        for (int x = 0; x < tl.nX && slot <= (int)P.slots.size(); ++x) {
+            const int q = tl.slot0 + tl.nP + tl.nF + x;
+            if (P.tile_slots[q] != P.tile_slots[tl.slot0 + x] || !P.tile_slot_fast[q] || P.slots[q].len != 0 || (P.slots[q].flags & SLOT_LINE))
+                ck.fail("tile %ld: correction slot %ld", (long)ti, x);
+        }
         if (slot > (int)P.slots.size()) { ck.fail("tile %ld: slots run past the table", (long)ti); return; }
         if (tl.nL > tl.nP || tl.nK > tl.nF || tl.nP > LSX_MAX_PER_RAY || tl.nF > LSX_MAX_FAST) ck.fail("tile %ld: counts", (long)ti);
         if (tile_class[ti] < 0) { ck.fail("tile %ld is in no class", (long)ti); return; }

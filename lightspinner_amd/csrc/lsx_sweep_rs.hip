@@ -73,6 +73,12 @@ lsx_sweep_rs_kernel(const SweepParams p)
     constexpr int NLK = (LK && NL > 0) ? NL : 1;
     constexpr int NCR = NPT == 1 ? 2 : 3;                            // a single slot never reads atom.chi[j_line]
     constexpr bool FACT = NPT >= 1 && NL == NPT && (NPT == 1 || TOPO != 0);    // factored Gamma integrands (step, pass C)
+    // Linked continua add ray-independent shares EC, XC_i to atom.eta and atom.chi[i_line] (rh_method.py:616-627).  In the factored
+    // integrands they enter as -EC sum_mu w Psi* phi and -XC_i sum_mu w Psi* phi -- products of a (depth, wavelength) quantity with the
+    // sum this kernel stores for the fast-continuum epilogue anyway -- so the epilogue adds them to the line's rates (lsx_fast.h,
+    // correction slots) and these instances read NO correction streams: two loads per line, wavelength and depth less, and the
+    // pre-pass writes none.  (The unfactored instance <2,2,true,0> applies them ray by ray, like the one-ray-per-lane kernels.)
+    constexpr bool CORR = LK && !FACT;
     const int lane = threadIdx.x & (LSX_WAVE - 1);
     const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0: down (toFrom False), 1: up (True)
     lds_f64* const red = etab + LSX_EXP_TAB + (size_t)dir * (NV + 1) * RROW;   // this wave's reduction rows (+ one for dJ)
@@ -162,8 +168,8 @@ lsx_sweep_rs_kernel(const SweepParams p)
 #else
     const int cphi = cc;
 #endif
-    const double* __restrict__ corr = LK ? p.corr_T + (size_t)col0 * p.corr_col_stride + tilep->corr_off : nullptr;
-    const unsigned o_corr = LK ? (unsigned)((size_t)cc * p.corr_col_stride * 8u) + (unsigned)j * 8u : 0u;
+    const double* __restrict__ corr = CORR ? p.corr_T + (size_t)col0 * p.corr_col_stride + tilep->corr_off : nullptr;
+    const unsigned o_corr = CORR ? (unsigned)((size_t)cc * p.corr_col_stride * 8u) + (unsigned)j * 8u : 0u;
     double* __restrict__ ppsum = LK ? p.Psi3_T + ((size_t)dir * p.ncol + col0) * p.pp_col_stride + tilep->pp_off : nullptr;
     const unsigned o_pp = LK ? (unsigned)((size_t)cc * p.pp_col_stride * 8u) + (unsigned)j * 8u : 0u;
     const size_t plane = (size_t)Ns * LW;
@@ -229,7 +235,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
     struct Ops {
         double bc, be, jd, E;
         double ph[NS][NR];                   // line profile per ray
-        double cr[NLK][3];                   // linked tiles: the continua's share of atom.eta, atom.chi[i], atom.chi[j]
+        double cr[CORR ? NLK : 1][CORR ? 3 : 1];   // <2,2,true,0>: the continua's share of atom.eta, atom.chi[i], atom.chi[j]
     };
     auto load_ops = [&](int kk, Ops& o) __attribute__((always_inline)) {
 #ifdef LSX_ABL_NOLOAD
@@ -247,7 +253,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
         for (int u = 0; u < NL; ++u)
 #pragma unroll
             for (int m = 0; m < NR; ++m) o.ph[u][m] = at(phi0, phi_o[u] + (unsigned)kk * phi_k[u] + (unsigned)m * phi_m[u]);
-        if constexpr (LK) {
+        if constexpr (CORR) {
             const unsigned kq = o_corr + (unsigned)(kk * LW) * 8u;
 #pragma unroll
             for (int u = 0; u < NL; ++u)
@@ -533,10 +539,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
                 }
 #pragma unroll
                 for (int u = 0; u < NPT; ++u) {
-                    if constexpr (LK) {                             // + the linked continua's share of atom.eta, atom.chi[i]
-                        Ie[u] = fma(-cur.cr[u < NLK ? u : 0][0], Psi, Ie[u]);
-                        tv[u] = fma(-cur.cr[u < NLK ? u : 0][1], Psi, tv[u]);
-                    }
+                    // (+ the linked continua's share of atom.eta, atom.chi[i]: applied by the epilogue, see CORR above)
                     const double wph = wmuh(m) * cur.ph[u][m];
                     G2[u] = fma(wph, Ie[u], G2[u]);                 // sum w phi Ieff
                     G1[u] = fma(wph, tv[u], G1[u]);                 // sum w phi (1 - Psi* chi_i)
@@ -571,7 +574,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
                         U_i = rel[REL_UI] * Uji[v];
                     }
                 }
-                if constexpr (LK) {
+                if constexpr (CORR) {
                     if (line) {
                         etaA += cur.cr[u < NLK ? u : 0][0];
                         chi_i += cur.cr[u < NLK ? u : 0][1];
