@@ -288,7 +288,10 @@ def roofline_block(eng, lib, prob, ncol, workload, kernel_reps):
                            'vector registers, i.e. two waves per SIMD; at that occupancy the vector pipe is about half busy (counter instruction '
                            'mix x cycle costs / kernel cycles) and waves wait 40-48 % of their cycles: latency at two waves per SIMD. The '
                            'one-ray-per-lane kernel it replaced sat on vector issue at the clock the chip holds under fp64 load (1.6-1.8 GHz) '
-                           '(profiles/r03_bound_evidence.md: in-kernel clock, stamps, occupancy sweep, ablations, class schedule)',
+                           '(profiles/r03_bound_evidence.md: in-kernel clock, stamps, occupancy sweep, ablations, class schedule). Round 4 '
+                           '(profiles/r04_bound_evidence.md): without its J / Psibar stores it is 7-10 % faster, with a fifth of the profile bytes '
+                           '15-18 %: memory queueing latency against one depth of prefetch; a third wave per SIMD fits neither the register file nor, '
+                           'beside the per-depth operand table, the LDS',
                 fs_call=dict(ms=ms_total, ms_sweep_kernel=ms_sweep, ms_epilogue_kernels=info(4), alg_bytes=balg * ncol,
                              achieved_GBps=balg * ncol / (ms_total * 1e-3) / 1e9,
                              frac=balg * ncol / (ms_total * 1e-3) / 1e9 / HBM_PEAK_GBPS,
