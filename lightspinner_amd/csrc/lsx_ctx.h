@@ -49,7 +49,7 @@ struct lsx_ctx : lsxd::LsxPlan {        // the plan (lsx_plan.h: dimensions, tab
     uint8_t* d_active = nullptr;
     DevTrans* d_trans = nullptr;
     DevTile* d_tiles = nullptr;
-    int *d_tile_slots = nullptr, *d_Nlevel = nullptr, *d_lev2_off = nullptr, *d_fin_ptr = nullptr, *d_fin_idx = nullptr;
+    int *d_tile_slots = nullptr, *d_Nlevel = nullptr, *d_lev2_off = nullptr, *d_fin_ptr = nullptr, *d_fin_idx = nullptr, *d_atom_ptr = nullptr, *d_atom_slots = nullptr;
     bool dp_zeroed = false;          // the Gamma epilogue has zeroed dPcol / the singular flag for the next stat_equil
     bool opt_finish_big = false;     // LSX_FINISH_BIG=1: the many-column Gamma epilogue also for small batches (tests)
     bool opt_fused_epilogue = false; // LSX_FUSED_EPILOGUE=1: the fused launch also runs its fast tiles' Gamma epilogue (measured: slower, see enqueue_fs)

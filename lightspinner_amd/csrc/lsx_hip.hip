@@ -282,33 +282,42 @@ struct FinishParams {
     int clear_dp;                       // ... unless a stat_equil's monitors are still waiting to be read back (0)
     const int* fin_ptr;                 // [NL2tot + 1]  k_gamma_finish_small: the slabs that add up to one entry,
     const int* fin_idx;                 //               as (slot * 4 + slab), in slot order
+    const int* atom_ptr;                // [Natoms + 1]  k_gamma_finish: the slots of one atom's transitions, in slot order
+    const int* atom_slots;
 };
 
 // Gamma = C + sum of the sweep's slabs in (tile, slot, entry, direction) order; then the
-// diagonal (rh_method.py:587-590, 698-703).  One thread per (column, depth).
+// diagonal (rh_method.py:587-590, 698-703).  One thread per (column, depth, ATOM) (blockIdx.y = atom, round 4): a thread keeps only
+// its atom's Nlevel^2 entries in LDS and walks only its atom's slots (lists made with the context, in slot order: every entry is
+// summed in the order it always was -- the same bits), so a two-atom problem has twice the resident waves (Ca+H: 37 kB of LDS per 128
+// threads instead of per 64) and half the chain per thread: C4 0.33 -> see DESIGN.md 4.3.
 __global__ void k_gamma_finish(const FinishParams f)
 {
     extern __shared__ double sm[];
     const int Ns = f.Nspace;
     const int tid = threadIdx.x, nt = blockDim.x;
+    const int atom = blockIdx.y;
     const long gid = (long)blockIdx.x * nt + tid;
     if (gid >= (long)f.ncol * Ns) return;
     const int col = gid / Ns, k = gid % Ns;
-    if (f.clear_dp) {
+    if (f.clear_dp && atom == 0) {
         if (k == 0) f.dPcol[col] = 0.0;
         if (gid == 0) *f.singular = 0ull;
     }
     if (f.colmask && !f.colmask[col]) {
-        if (k == 0) f.dJcol[col] = 0.0;
+        if (k == 0 && atom == 0) f.dJcol[col] = 0.0;
         return;
     }
-    double* G = sm + tid;                                   // thread-private Gamma: G[e * nt]
-    const double* Cm = f.C + (size_t)col * f.NL2tot * Ns + k;
-    for (int e = 0; e < f.NL2tot; ++e) G[e * nt] = 0.0 + Cm[(size_t)e * Ns];     // Gamma = C, :587-590
+    const int Nl = f.Nlevel[atom], off2 = f.lev2_off[atom], Nl2 = Nl * Nl;
+    double* G = sm + tid;                                   // thread-private Gamma of this atom: G[e * nt]
+    const double* Cm = f.C + ((size_t)col * f.NL2tot + off2) * Ns + k;
+    for (int e = 0; e < Nl2; ++e) G[e * nt] = 0.0 + Cm[(size_t)e * Ns];     // Gamma = C, :587-590
     const double* P = f.Gpart + (size_t)col * f.nslot_total * 4 * Ns + k;
     // slabs in (tile, slot, entry, direction) order = slot-table order; the loads of several slots are in flight at once
+    const int s0 = f.atom_ptr[atom], s1 = f.atom_ptr[atom + 1];
 #pragma unroll 8
-    for (int u = 0; u < f.nslot_total; ++u) {
+    for (int v = s0; v < s1; ++v) {
+        const int u = f.atom_slots[v];
         const int ts = f.tile_slots[u];
         const bool fast = (ts >> 30) & 1;                    // fast continuum: one entry carries both directions
         const DevTrans& tr = f.trans[ts & 0x3fffffff];
@@ -316,27 +325,24 @@ __global__ void k_gamma_finish(const FinishParams f)
         // (unconditional loads, so that the loads of several slots stay in flight together: a fast slot re-reads its first entries)
         const double q0 = q[0], r1 = q[fast ? 0 : (size_t)Ns], q2 = q[(size_t)2 * Ns], r3 = q[(size_t)(fast ? 2 : 3) * Ns];
         const double q1 = fast ? 0.0 : r1, q3 = fast ? 0.0 : r3;
-        double gij = G[tr.gam_ij * nt], gji = G[tr.gam_ji * nt];
+        const int eij = tr.gam_ij - off2, eji = tr.gam_ji - off2;
+        double gij = G[eij * nt], gji = G[eji * nt];
         gij += q0;
         gij += q1;
         gji += q2;
         gji += q3;
-        G[tr.gam_ij * nt] = gij;
-        G[tr.gam_ji * nt] = gji;
+        G[eij * nt] = gij;
+        G[eji * nt] = gji;
     }
-    double* Gout = f.Gamma + (size_t)col * f.NL2tot * Ns + k;
-    for (int a = 0; a < f.Natoms; ++a) {
-        const int Nl = f.Nlevel[a];
-        double* Ga = G + f.lev2_off[a] * nt;
-        for (int i = 0; i < Nl; ++i) Ga[(i * Nl + i) * nt] = 0.0;
-        for (int i = 0; i < Nl; ++i) {                       // Gamma_ii = -sum_{l != i} Gamma_li, :698-703
-            double s = 0.0;
-            for (int l = 0; l < Nl; ++l) s += Ga[(l * Nl + i) * nt];
-            Ga[(i * Nl + i) * nt] = -s;
-        }
+    double* Gout = f.Gamma + ((size_t)col * f.NL2tot + off2) * Ns + k;
+    for (int i = 0; i < Nl; ++i) G[(i * Nl + i) * nt] = 0.0;
+    for (int i = 0; i < Nl; ++i) {                           // Gamma_ii = -sum_{l != i} Gamma_li, :698-703
+        double s = 0.0;
+        for (int l = 0; l < Nl; ++l) s += G[(l * Nl + i) * nt];
+        G[(i * Nl + i) * nt] = -s;
     }
-    for (int e = 0; e < f.NL2tot; ++e) Gout[(size_t)e * Ns] = G[e * nt];
-    if (k == 0) { // per-column dJ: max over the column's tiles, NaN propagating (rh_method.py:705-706)
+    for (int e = 0; e < Nl2; ++e) Gout[(size_t)e * Ns] = G[e * nt];
+    if (k == 0 && atom == 0) { // per-column dJ: max over the column's tiles, NaN propagating (rh_method.py:705-706)
         double m = 0.0;
         for (int t = 0; t < 2 * f.ntile; ++t) {
             const double v = f.dJpart[(size_t)col * 2 * f.ntile + t];
@@ -1112,7 +1118,7 @@ void lsx_destroy(lsx_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_wavelength, c->d_zmu, c->d_wmuh, c->d_wl, c->d_alpha, c->d_u_la, c->d_active, c->d_trans,
-                    c->d_tiles, c->d_slots, c->d_tile_slots, c->d_fin_ptr, c->d_fin_idx, c->d_Nlevel, c->d_lev2_off, c->d_height,
+                    c->d_tiles, c->d_slots, c->d_tile_slots, c->d_fin_ptr, c->d_fin_idx, c->d_atom_ptr, c->d_atom_slots, c->d_Nlevel, c->d_lev2_off, c->d_height,
                     c->d_temperature, c->d_nStar, c->d_nTotal, c->d_n, c->d_C, c->d_Gamma, c->d_wphi, c->d_bgchi,
                     c->d_bgeta, c->d_sca, c->d_phi, c->d_E, c->d_corr, c->d_Psi3, c->d_J[0], c->d_J[1], c->d_I, c->d_Gpart, c->d_dJpart,
                     c->d_res, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_fast_cols[0], c->d_fast_cols[1], c->d_fast_cols[2], c->d_fast_cols[3], c->d_fast_rest, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab, c->d_voigt_w, c->d_muz, c->d_wmu,
@@ -1250,6 +1256,16 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         if (idx.empty()) idx.push_back(0);
         TRY(upload(&c->d_fin_ptr, ptr, c->stream));
         TRY(upload(&c->d_fin_idx, idx, c->stream));
+        // k_gamma_finish: the slots of each atom's transitions, in slot order
+        std::vector<int> aptr((size_t)c->Natoms + 1, 0), aslots;
+        for (int a = 0; a < c->Natoms; ++a) {
+            for (size_t u = 0; u < c->tile_slots.size(); ++u)
+                if (c->htrans[(size_t)c->tile_slots[u]].atom == a) aslots.push_back((int)u);
+            aptr[(size_t)a + 1] = (int)aslots.size();
+        }
+        if (aslots.empty()) aslots.push_back(0);
+        TRY(upload(&c->d_atom_ptr, aptr, c->stream));
+        TRY(upload(&c->d_atom_slots, aslots, c->stream));
     }
     TRY(upload(&c->d_slots, c->slots, c->stream));
     TRY(upload(&c->d_Nlevel, c->Nlevel, c->stream));
@@ -1612,7 +1628,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
     f.nslot_total = (int)c->tile_slots.size(); f.Nlevel = c->d_Nlevel; f.lev2_off = c->d_lev2_off; f.tiles = c->d_tiles;
     f.tile_slots = c->d_tile_slots; f.trans = c->d_trans; f.C = c->d_C; f.Gpart = c->d_Gpart; f.dJpart = c->d_dJpart;
     f.Gamma = c->d_Gamma; f.dJcol = c->d_dJcol; f.colmask = c->d_colmask;
-    f.dPcol = c->d_dPcol; f.singular = c->d_singular; f.fin_ptr = c->d_fin_ptr; f.fin_idx = c->d_fin_idx;
+    f.dPcol = c->d_dPcol; f.singular = c->d_singular; f.fin_ptr = c->d_fin_ptr; f.fin_idx = c->d_fin_idx; f.atom_ptr = c->d_atom_ptr; f.atom_slots = c->d_atom_slots;
     // `FS; SE; FS; sync` (and `SE; formal_sol_gamma(&dJ)`): the statistical equilibrium's per-column maxima and its singular flag
     // have not been read back yet -- they live in the block this epilogue would clear.  Then the epilogue leaves them alone and
     // the next stat_equil clears them itself.  (A speculative call writes the second block: nothing pending there.)
@@ -1621,7 +1637,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
     if (c->ncol < 32 && !c->opt_finish_big)
         hipLaunchKernelGGL(k_gamma_finish_small, dim3((unsigned)nthreads), dim3(64), (size_t)c->NL2tot * sizeof(double), c->stream, f);
     else
-        hipLaunchKernelGGL(k_gamma_finish, dim3((unsigned)((nthreads + S.finish_nt - 1) / S.finish_nt)), dim3(S.finish_nt), S.finish_lds, c->stream, f);
+        hipLaunchKernelGGL(k_gamma_finish, dim3((unsigned)((nthreads + S.finish_nt - 1) / S.finish_nt), (unsigned)c->Natoms), dim3(S.finish_nt), S.finish_lds, c->stream, f);
     c->dp_zeroed = f.clear_dp != 0;
     note(hipGetLastError());
     if (timed) note(hipEventRecord(c->ev2, c->stream));

@@ -485,9 +485,12 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
             if (!P.fast_cols[v].empty() && S.cols_lds[v] > 64 * 1024) return perr(err, LSX_EUNSUPPORTED, "lsx_create: the fast-continuum epilogue (column mapped) needs %zu B of LDS", S.cols_lds[v]);
         }
     }
+    // k_gamma_finish: one thread per (column, depth, atom) with the atom's Nlevel^2 entries in LDS
+    size_t nl2max = 1;
+    for (int a = 0; a < P.Natoms; ++a) nl2max = std::max(nl2max, (size_t)P.Nlevel[a] * P.Nlevel[a]);
     S.finish_nt = 128;
-    while (S.finish_nt > 32 && (size_t)P.NL2tot * S.finish_nt * sizeof(double) > 48 * 1024) S.finish_nt >>= 1;
-    S.finish_lds = (size_t)P.NL2tot * S.finish_nt * sizeof(double);
+    while (S.finish_nt > 32 && nl2max * S.finish_nt * sizeof(double) > 48 * 1024) S.finish_nt >>= 1;
+    S.finish_lds = nl2max * S.finish_nt * sizeof(double);
     if (S.finish_lds > 64 * 1024) return perr(err, LSX_EUNSUPPORTED, "lsx_create: the Gamma epilogue needs %zu B of LDS", S.finish_lds);
     for (int a = 0; a < P.Natoms; ++a) {       // k_stat_equil: atoms with more than 8 levels keep their system in LDS
         const int Nl = P.Nlevel[a];
