@@ -1508,15 +1508,19 @@ lsx_sweep_kernel(const SweepParams p)
 
 // Small batches (a few columns) are latency bound: one launch that dispatches on the tile's class inside
 // beats five tiny launches on five streams.
-// The instances are CALLED, not inlined: each keeps the register allocation it has as a class kernel (inlined side by side
-// they shared one scalar register file: 320 scalar spills), and the call happens once per workgroup.
+// The instances are INLINED into the one kernel, side by side behind the dispatch: no call frame (the called form kept 400 bytes of
+// stack per lane for the callee-saved registers), and the scalar registers the instances compete for spill into vector lanes
+// (383 `v_writelane`s, no memory) -- at the one or two waves per SIMD this kernel runs with there are vector registers to spare.
+// Measured on the single FALC column: formal solution 83.6 -> 78.8 us, MALI iteration 79.0 -> 74.4 us
+// (profiles/r04/c2_instances_inlined.txt).  LSX_TILE_CALL='__attribute__((noinline))' builds the called form.
+#ifndef LSX_TILE_CALL
+#define LSX_TILE_CALL __attribute__((always_inline))
+#endif
 template <int NPT, int NL, int NR, bool SCAL, bool LK, int TOPO = 0>
-__device__ __attribute__((noinline)) void sweep_tile_call(const SweepParams& p, const int vb, const int tile_id)
+__device__ LSX_TILE_CALL void sweep_tile_call(const SweepParams& p, const int vb, const int tile_id)
 {
     sweep_tile<NPT, NL, NR, SCAL, LK, TOPO>(p, vb, tile_id);
 }
-// (at most 31 columns x tiles workgroups: occupancy is no concern, so the register allocator gets the whole file -- no vector
-// spills in the one kernel every single-column Context runs)
 // the fast-continuum kernels' view of a sweep launch's parameters (lsx_fast.h; the fused launch only)
 static __device__ __forceinline__ FastParams fast_params_of(const SweepParams& p)
 {
