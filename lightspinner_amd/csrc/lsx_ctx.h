@@ -108,7 +108,7 @@ namespace lsxd {
 
 // the column count the bit-relevant kernel choices are made for (include/lsx.h, lsx_set_sweep_policy)
 inline int policy_ncol(const lsx_ctx* c) { return c->policy_columns > 0 ? c->policy_columns : c->ncol; }
-// linear rule: the ray-serial mapping (classes that have an instance of it) or one ray per lane
+// the ray-serial mapping (classes that have an instance of it for the context's rule) or one ray per lane
 inline bool use_ray_serial(const lsx_ctx* c)
 {
     if (!c->rs_ok || c->sweep_policy == LSX_SWEEP_RAY_PER_LANE) return false;
@@ -119,7 +119,7 @@ inline bool use_ray_serial(const lsx_ctx* c)
 // only); the parabolic rule's compile-time classes and its generic instance differ in the last bits: the policy count decides.
 inline bool per_class_launches(const lsx_ctx* c)
 {
-    if (c->solver == LSX_SOLVER_PARABOLIC) return policy_ncol(c) >= 32;
+    if (c->solver == LSX_SOLVER_PARABOLIC) return policy_ncol(c) >= 32 || use_ray_serial(c);
     return c->ncol >= 32 || use_ray_serial(c);
 }
 

@@ -65,6 +65,7 @@ using namespace lsxd;
 extern "C" hipError_t lsx_launch_sweep(const SweepParams*, int, int, size_t, hipStream_t);
 // launcher defined in lsx_sweep_rs.hip (ray-serial instances)
 extern "C" hipError_t lsx_launch_sweep_rs(const SweepParams*, int, hipStream_t);
+extern "C" hipError_t lsx_launch_sweep_rs_par(const SweepParams*, int, hipStream_t);     // N4 (lsx_sweep_rs.hip built with LSX_RS_PARABOLIC_TU)
 // the parabolic rule (N4) for one class: compile-time instance or the generic one on the class's tile list (lsx_sweep.hip)
 extern "C" hipError_t lsx_launch_sweep_par(const SweepParams*, int, int, size_t, hipStream_t);
 
@@ -1562,6 +1563,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
     // generic instance for every tile and takes the same route at any size
     const bool parabolic = c->solver == LSX_SOLVER_PARABOLIC;
     const bool ray_serial = !parabolic && use_ray_serial(c);
+    const bool ray_serial_par = parabolic && use_ray_serial(c);
     if (!per_class_launches(c)) {
         p.ncell_lev = S.fused_ncell_lev; p.ncell_atom = S.fused_ncell_atom;
         c->fused_launches++;
@@ -1596,14 +1598,16 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
             // a class of line tiles with linked continua on the ray-serial kernel: the sweep reads no correction streams, the pre-pass
             // writes none, the column-mapped epilogue applies the corrections to the lines' rates (lsx_fast.h; the plan has checked
             // that every tile of the class takes that epilogue)
-            const bool epi = k.lk_epi && k.rs && ray_serial;
+            const bool rs_here = (k.rs && ray_serial) || (k.rsp && ray_serial_par);
+            const bool epi = k.lk_epi && rs_here;
             if (!k.fast_tiles.empty()) launch_prepass(st, k.d_fast_tiles, k.fast_tiles.size(), epi);
             const long nblocks = (long)k.tiles.size() * c->ncol;
             p.class_tiles = k.d_tiles;
             p.n_class_tiles = (int)k.tiles.size();
             p.ncell_lev = k.npt >= 0 ? 0 : k.ncell_lev; p.ncell_atom = k.npt >= 0 ? 0 : k.ncell_atom; p.nstash = 0;
             k.launches++;
-            if (parabolic) {
+            if (k.rsp && ray_serial_par) note(lsx_launch_sweep_rs_par(&p, k.code(), st));     // N4, five columns per wavefront
+            else if (parabolic) {
                 // a class with a compile-time instance of the rule runs it on its own LDS layout; every other class runs the
                 // generic instance (level / atom cells, the fused launch's layout) on the class's tile list
                 const bool inst = c->Nrays == LSX_RS_RAYS && !c->sca_per_lambda && k.npt >= 0 && lsx_rs_instance_exists(k.npt, k.nl, k.linked, k.topo);
@@ -2215,7 +2219,7 @@ int32_t lsx_hip_class_info(const lsx_ctx* c, int32_t idx, int64_t* out)
     if (out && idx >= 0 && idx < (int)c->classes.size()) {
         const SweepClass& k = c->classes[idx];
         out[0] = k.npt; out[1] = k.nl; out[2] = (int64_t)k.tiles.size(); out[3] = k.launches; out[4] = k.linked ? 1 : 0; out[5] = k.topo;
-        out[6] = (k.rs && c->solver != LSX_SOLVER_PARABOLIC && use_ray_serial(c)) ? 1 : 0;
+        out[6] = ((c->solver == LSX_SOLVER_PARABOLIC ? k.rsp : k.rs) && use_ray_serial(c)) ? 1 : 0;
     }
     return (int32_t)c->classes.size();
 }

@@ -454,6 +454,8 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
             if (k.rs && k.lk_epi)
                 for (int t : k.tiles)
                     if (P.tiles[t].fast_simple != 2) k.rs = false;
+            k.rsp = k.rs && lsx_rsp_instance_exists(k.npt, k.nl, k.linked, k.topo) &&
+                    (size_t)lsx_rs_lds_doubles(k.npt, Ns, true) * sizeof(double) <= 64 * 1024;
         }
     }
 

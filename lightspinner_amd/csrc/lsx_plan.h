@@ -112,6 +112,8 @@ constexpr SweepLds lsx_sweep_lds(int npt, bool linked, int Ns, int ncell_lev, in
     X(0, 0, false, 0) X(1, 1, false, 0) X(2, 1, false, 0) X(2, 2, false, 0)                                      \
     X(1, 1, true, 0) X(2, 2, true, 0)                                                                            \
     X(2, 2, false, 1) X(2, 2, false, 2) X(2, 2, true, 1) X(2, 2, true, 2)
+// ... and for the parabolic rule (N4): line-only classes whose Gamma integrands factor (one line; two lines that share one level)
+#define LSX_RSP_INSTANCES(X) X(0, 0, false, 0) X(1, 1, false, 0) X(1, 1, true, 0)
 #ifndef LSX_RS_WPE1
 #define LSX_RS_WPE1 2
 #endif
@@ -129,17 +131,32 @@ inline bool lsx_rs_instance_exists(int npt, int nl, bool lk, int topo)
     default: return false;
     }
 }
+inline bool lsx_rsp_instance_exists(int npt, int nl, bool lk, int topo)
+{
+    switch (lsx_class_code(npt, nl, lk, topo)) {
+#define LSX_X(NPT, NL, LK, TOPO) case lsx_class_code(NPT, NL, LK, TOPO):
+        LSX_RSP_INSTANCES(LSX_X)
+#undef LSX_X
+        return npt >= 0;
+    default: return false;
+    }
+}
 // LDS doubles of a ray-serial workgroup: exp table, [2 waves][2 npt + 1] rows of 64 (parked Gamma integrands, dJ), [2][64] J
 // exchange, the per-depth operand table of the group's columns [LSX_RS_COLS][Nspace + 1][3 npt + 2], the parked Gamma totals
 // doubles between two columns of the operand table: the five columns of a wavefront read the same row at once, so their
 // rows must not share LDS banks (a stride that is a multiple of 8 doubles would put columns 0 and 4 on the same banks)
 constexpr int lsx_rs_ucol_stride(int npt, int Ns) { return (Ns + 1) * (3 * npt + 2) + ((((Ns + 1) * (3 * npt + 2)) % 8) == 0 ? 1 : 0); }
-constexpr int lsx_rs_park(int npt) { return npt >= 2 ? 16 : 64; }      // depths a row of parked Gamma totals holds (two slots: 16, for two workgroups more per CU)
-constexpr int lsx_rs_lds_doubles(int npt, int Ns)
+// (the parabolic instances park 16 depths in every class: they need the LDS for the lane-private cells below)
+constexpr int lsx_rs_park(int npt, bool par = false) { return (npt >= 2 || par) ? 16 : 64; }      // depths a row of parked Gamma totals holds (two slots: 16, for two workgroups more per CU)
+// parabolic instances: rows of 64 lane-private cells per wave -- 1 / opacity, opacity and the line profiles of the rays at the point
+// that waits for its downwind neighbour
+constexpr int lsx_rs_par_rows(int npt) { return LSX_RS_RAYS * (2 + npt); }
+constexpr int lsx_rs_lds_doubles(int npt, int Ns, bool par = false)
 {
     return LSX_EXP_TAB + 2 * (2 * (npt > 0 ? npt : 1) + 1) * 64 + 2 * LSX_WAVE + LSX_RS_COLS * lsx_rs_ucol_stride(npt, Ns) +
-           2 * LSX_RS_COLS * 2 * (npt > 0 ? npt : 1) * lsx_rs_park(npt) +  // + [2 waves][columns x values][entries] parked Gamma totals
-           2 * LSX_RS_RAYS + 2;                                            // + the angle quadrature (two-slot instances read it from here)
+           2 * LSX_RS_COLS * 2 * (npt > 0 ? npt : 1) * lsx_rs_park(npt, par) +  // + [2 waves][columns x values][entries] parked Gamma totals
+           2 * LSX_RS_RAYS + 2 +                                            // + the angle quadrature (two-slot instances read it from here)
+           (par ? 2 * lsx_rs_par_rows(npt) * LSX_WAVE : 0);
 }
 
 namespace lsxd {
@@ -157,6 +174,7 @@ struct PlanClass {             // tiles that run the same kernel instantiation
     size_t lds_bytes = 0;
     double work = 0.0;         // estimated share of the call (launch order; stream priority tiers under LSX_PRIO)
     bool rs = false;           // the class has a ray-serial instance (lsx_sweep_rs.hip); lsx_create decides by the column count
+    bool rsp = false;          // ... and a ray-serial instance of the parabolic rule (N4; LSX_RSP_INSTANCES)
     bool lk_epi = false;       // ... whose linked corrections the fast-continuum epilogue applies (lsx_fast.h), not the sweep
     int code() const { return npt >= 0 ? lsx_class_code(npt, nl, linked, topo) : (linked ? -3 : -1); }
 };

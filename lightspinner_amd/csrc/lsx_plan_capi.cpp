@@ -193,13 +193,15 @@ int32_t lsx_plan_instances(int32_t which, int32_t* codes, int32_t max)
 #define LSX_X(NPT, NL, LK, TOPO) v.push_back(lsx_class_code(NPT, NL, LK, TOPO));
     if (which == 0) { LSX_SWEEP_INSTANCES(LSX_X) }
     else if (which == 1) { LSX_RS_INSTANCES(LSX_X) }
+    else if (which == 2) { LSX_RSP_INSTANCES(LSX_X) }        // the ray-serial instances of the parabolic rule
 #undef LSX_X
     for (int32_t i = 0; codes && i < (int32_t)v.size() && i < max; ++i) codes[i] = v[i];
     return (int32_t)v.size();
 }
 
 // the ray-serial eligibility of a problem's classes: -> number of classes; out[c][2] = class code, 1 if the class has a
-// ray-serial instance AND the context's shape admits the kernel (five rays, wavelength-independent scattering, 32-bit offsets)
+// ray-serial instance AND the context's shape admits the kernel (five rays, wavelength-independent scattering, 32-bit offsets),
+// + 2 if it has one for the parabolic rule as well
 int32_t lsx_plan_rs_classes(const lsx_problem* d, int32_t* out, int32_t max)
 {
     PlanOptions opt;
@@ -208,7 +210,7 @@ int32_t lsx_plan_rs_classes(const lsx_problem* d, int32_t* out, int32_t max)
     if (plan_build(d, opt, &P, &e) != LSX_OK) return -1;
     int32_t n = 0;
     for (auto& k : P.plan_classes) {
-        if (out && n < max) { out[2 * n] = k.code(); out[2 * n + 1] = k.rs ? 1 : 0; }
+        if (out && n < max) { out[2 * n] = k.code(); out[2 * n + 1] = (k.rs ? 1 : 0) | (k.rsp ? 2 : 0); }
         ++n;
     }
     return n;

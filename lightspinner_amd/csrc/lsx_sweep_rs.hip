@@ -60,9 +60,19 @@ constexpr int RROW = 64;               // doubles per row of the reduction buffe
 } // namespace
 
 // NPT per-ray slots (0 .. 2), NL of them lines (they come first), LK: the tile has linked continua, TOPO: relation of the two
-// slots of a two-line tile (lsx_sweep.hip).
-template <int NPT, int NL, bool LK, int TOPO>
-__global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(LSX_RS_WPE(NPT, LK))))
+// slots of a two-line tile (lsx_sweep.hip).  PAR: the monotonic piecewise-parabolic rule (N4, include/lsx.h) instead of the
+// reference's piecewise-linear one -- the same mapping, the formal solution one depth behind the opacities (see `pstep`).
+// The parabolic instances run ONE wave per SIMD: a lane carries five more doubles of recurrence state per wavelength than under the
+// linear rule and the compiler's schedule of the five interleaved rays needs 310-320 registers (256 + 55..59 accumulation registers
+// as spill space, no scratch).  At two waves per SIMD (256 registers) the same source spills 50-60 registers to scratch; the reloads
+// sit between the stream loads and the waits, so every wait for a reload also waits for the next depth's operands: measured
+// slower than one wave per SIMD whenever the spills land inside the step (C3 / C4 formal solution 3.30 / 14.4 ms against
+// 2.12 / 7.92), equal at best (profiles/r04/n4_ray_serial_waves_per_simd.txt).
+#ifndef LSX_RSP_WPE
+#define LSX_RSP_WPE 1
+#endif
+template <int NPT, int NL, bool LK, int TOPO, bool PAR>
+__global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(PAR ? LSX_RSP_WPE : LSX_RS_WPE(NPT, LK))))
 lsx_sweep_rs_kernel(const SweepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
@@ -181,8 +191,8 @@ lsx_sweep_rs_kernel(const SweepParams p)
     // angle quadrature: wave-uniform
     // two-slot instances: the ten quadrature constants live in LDS behind the parked totals and are read where they are used
     // (broadcast reads with immediate offsets): twenty vector registers less in the instances that sit at the 256-register limit
-    constexpr bool QLDS = NPT >= 2;
-    lds_f64* const qtab = utab + (size_t)NC * lsx_rs_ucol_stride(NPT, p.Nspace) + (size_t)2 * NC * NV * lsx_rs_park(NPT);
+    constexpr bool QLDS = NPT >= 2 || PAR;
+    lds_f64* const qtab = utab + (size_t)NC * lsx_rs_ucol_stride(NPT, p.Nspace) + (size_t)2 * NC * NV * lsx_rs_park(NPT, PAR);
     if (QLDS && threadIdx.x < 2 * NR) qtab[threadIdx.x] = threadIdx.x < NR ? LSX_CONST(double, p.zmu)[threadIdx.x] : LSX_CONST(double, p.wmuh)[threadIdx.x - NR];
     double zmu_r[NR], wmuh_r[NR];
 #pragma unroll
@@ -228,7 +238,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
         wlam[u] = (a && act) ? (4.0 * kPi) * p.wl[slots[u].wl_off + l] : 0.0;   // :451/:455, :665 without the angle weight
         alv[u] = (a && !line) ? p.alpha[slots[u].wl_off + l] : 0.0;
         cB[u] = slots[u].cB; Vc[u] = slots[u].Vc; Uc[u] = slots[u].Uc;
-        if constexpr (NPT == 1) asm volatile("" : "+v"(cB[u]), "+v"(Vc[u]), "+v"(Uc[u]));
+        if constexpr (NPT == 1 && !PAR) asm volatile("" : "+v"(cB[u]), "+v"(Vc[u]), "+v"(Uc[u]));
     }
 
     // ---- one depth's operands ------------------------------------------------------------------------------------------
@@ -309,7 +319,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
     // park[c NV + q][PE]; every PE steps (and at the end) each row leaves as ONE coalesced store of PE consecutive depths.
     const int o_c = lane / NV, o_q = lane - o_c * NV;
     const bool own = lane < NC * NV;
-    constexpr int PE = lsx_rs_park(NPT);
+    constexpr int PE = lsx_rs_park(NPT, PAR);
     lds_f64* const park = utab + (size_t)NC * lsx_rs_ucol_stride(NPT, p.Nspace) + (size_t)dir * NC * NV * PE;
     double* __restrict__ gbase = p.Gpart + (((size_t)col0 * p.nslot_total + slot0) * 4 + (size_t)dir) * Ns;      // + (c nslot 4 + q 2) Ns + k
     auto flush = [&](int sprev) __attribute__((always_inline)) {         // the totals of step sprev (depth kS + dk sprev)
@@ -340,6 +350,326 @@ lsx_sweep_rs_kernel(const SweepParams p)
         }
     };
 
+    if constexpr (PAR) {
+    // ---- N4: the monotonic piecewise-parabolic rule (include/lsx.h; lsx_dev.h, parabolic_point_fast; the one-ray-per-lane form is
+    // sweep_tile_par of lsx_sweep.hip).  Point m needs the source function and the optical depth of its DOWNWIND interval, so step s
+    // (depth k = kS + dk s) builds opacity, emissivity and source function of depth k from the operands requested one step ago and
+    // then finishes point m = s - 1: formal solution, angle sums, Gamma integrands, J.  What a lane carries from step to step per ray:
+    // I and the upwind difference quotient of point m - 1, and of point m its source function, opacity, 1 / opacity, the optical
+    // depth of the upwind interval and its reciprocal; per wavelength: point m's line profiles (a copy of the operand registers:
+    // the buffer they arrived in takes the request for depth k + 1) and J-dagger.
+    static_assert(NPT == NL && (NPT == 0 || FACT) && !CORR, "ray-serial parabolic instances: line-only tiles with factored Gamma integrands");
+    // 1 / opacity and the line profiles of point m are only read when the point is finished: they wait in lane-private LDS cells (one
+    // row of 64 per value and wave, behind the angle quadrature) instead of twenty to thirty vector registers
+    double pu[NR], S_c[NR], dtau_u[NR], ru[NR];       // (+ Iu: the intensity of point m - 1)
+    double jd_c;
+    // (volatile: the compiler must not carry a parked value from its store to the next step's load in a register -- that is what the
+    // cells are there to avoid)
+    volatile lds_f64* const cell = qtab + 2 * NR + 2 + (size_t)dir * lsx_rs_par_rows(NPT) * LSX_WAVE + lane;      // row r: cell[r * 64]
+    auto rchi_c = [&](int m) __attribute__((always_inline)) -> volatile lds_f64& { return cell[m * LSX_WAVE]; };
+    auto chi_c = [&](int m) __attribute__((always_inline)) -> volatile lds_f64& { return cell[(NR + m) * LSX_WAVE]; };
+    auto ph_c = [&](int u, int m) __attribute__((always_inline)) -> volatile lds_f64& { return cell[(2 * NR + u * NR + m) * LSX_WAVE]; };
+    {   // point 0's own values (the boundary condition above has read the same operands)
+        const lds_f64* tk = ucol + kS * TR;
+        const double etaB = opA.be + tk[3 * NPT + 1] * opA.jd;
+#pragma unroll
+        for (int m = 0; m < NR; ++m) {
+            double chiTot = opA.bc, etaTot = etaB;
+#pragma unroll
+            for (int u = 0; u < NL; ++u) {
+                chiTot = fma(tk[3 * u + 0], opA.ph[u][m], chiTot);
+                etaTot = fma(tk[3 * u + 1], opA.ph[u][m], etaTot);
+                ph_c(u, m) = opA.ph[u][m];
+            }
+            chi_c(m) = chiTot;
+            const double rc = rcp(chiTot);
+            rchi_c(m) = rc;
+            S_c[m] = etaTot * rc;                                         // :632
+            pu[m] = 0.0; dtau_u[m] = 1.0; ru[m] = 1.0;
+        }
+        jd_c = opA.jd;
+    }
+    // One point, ray by ray: `ray(m, I, Psi)` hands over the formal solution of ray m at point mpt; the angle sums, the Gamma integrands and
+    // the stores follow (rh_method.py:638-681, as pass C of the linear step).  The per-ray values die inside the loop: nothing of a ray
+    // but its recurrence state outlives its turn.
+    auto point = [&](const int mpt, auto phase_c, auto last_c, const double jhalf, auto&& ray) __attribute__((always_inline)) {
+        constexpr int PH = decltype(phase_c)::value;              // 0 first visitor, 1 midpoint, 2 second visitor
+        constexpr bool LASTPT = decltype(last_c)::value;
+        const int km = kS + dk * mpt;
+        const unsigned kt = o_til + (unsigned)(km * LW) * 8u;
+        const lds_f64* tm = ucol + km * TR;
+        double X[NS], njUc[NS], w3k[NS];
+#pragma unroll
+        for (int u = 0; u < NPT; ++u) { X[u] = tm[3 * u + 0]; njUc[u] = tm[3 * u + 1]; w3k[u] = tm[3 * u + 2]; }
+        double Jacc = 0.0, Pacc = 0.0, PP[NLK], G1[NS], G2[NS];
+#pragma unroll
+        for (int u = 0; u < NLK; ++u) PP[u] = 0.0;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) G1[u] = G2[u] = 0.0;
+#pragma unroll
+        for (int m = 0; m < NR; ++m) {
+            double phm[NS];
+#pragma unroll
+            for (int u = 0; u < NL; ++u) phm[u] = ph_c(u, m);
+            double I, Psi;
+            ray(m, I, Psi, phm);
+            if constexpr (LASTPT) {
+                if (dir == 1 && act) p.Iout[((size_t)col * Nspect + la) * NR + m] = I;      // emergent intensity, :638
+            }
+            Jacc = fma(wmuh(m), I, Jacc);                                  // :640
+            const double wP = wmuh(m) * Psi;
+            Pacc += wP;
+            if constexpr (LK) {
+#pragma unroll
+                for (int u = 0; u < NL; ++u) PP[u] = fma(wP, phm[u], PP[u]);
+            }
+            if constexpr (NPT >= 1) {       // the factored integrands (see the linear step)
+                double qv[NS], Ie[NS], tv[NS];
+#pragma unroll
+                for (int u = 0; u < NPT; ++u) qv[u] = Psi * phm[u];
+                if constexpr (NPT == 2 && TOPO == 1) {
+                    const double Ic = fma(-njUc[1], qv[1], fma(-njUc[0], qv[0], I));
+                    const double tc = fma(-X[1], qv[1], fma(-X[0], qv[0], 1.0));
+                    Ie[0] = Ie[1] = Ic;
+                    tv[0] = tv[1] = tc;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < NPT; ++u) {
+                        Ie[u] = fma(-njUc[u], qv[u], I);            // Ieff = I - Psi* eta, :652
+                        tv[u] = fma(-X[u], qv[u], 1.0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NPT; ++u) {
+                    const double wph = wmuh(m) * phm[u];
+                    G2[u] = fma(wph, Ie[u], G2[u]);
+                    G1[u] = fma(wph, tv[u], G1[u]);
+                }
+            }
+        }
+        if constexpr (NPT >= 1) {
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                const double A = G2[u], B = G1[u];
+                G1[u] = fma(Uc[u], B, Vc[u] * A);                   // :677
+                G2[u] = cB[u] * A;                                  // :680
+            }
+        }
+        Pacc *= 4.0 * kPi;
+        if constexpr (LK) {
+#pragma unroll
+            for (int u = 0; u < NL; ++u) PP[u] *= 4.0 * kPi;
+        }
+        // (stores without lane masks: see the linear step)
+        if (LK || nF > 0) at(psibar, kt) = Pacc;
+        if constexpr (LK) {
+#pragma unroll
+            for (int u = 0; u < NL; ++u) at(ppsum, (unsigned)(u * plane) * 8u + o_pp + (unsigned)(km * LW) * 8u) = PP[u];
+        }
+        if constexpr (NPT >= 1) {
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                const double wt = wlam[u] * w3k[u];                             // lines: x wphi (rh_method.py:451)
+                red[(2 * u) * RROW + lane] = wt * G1[u];
+                red[(2 * u + 1) * RROW + lane] = wt * G2[u];
+            }
+        }
+        if constexpr (PH == 0) {
+            at(Jnew, kt) = live_col ? Jacc : jd_c;
+        } else if constexpr (PH == 1) {
+            lds_f64* const xwg = etab + LSX_EXP_TAB + 2 * (NV + 1) * RROW;
+            xwg[dir * LSX_WAVE + lane] = Jacc;
+            __syncthreads();
+            if (dir == 0 && valid) {
+                const double Jv = Jacc + xwg[LSX_WAVE + lane];
+                at(Jnew, kt) = live_col ? Jv : jd_c;
+                if (live_col) dJ = nanmax(dJ, fabs(1.0 - jd_c * rcp(Jv)));      // :705
+            }
+        } else {
+            const double Jv = jhalf + Jacc;
+            at(Jnew, kt) = live_col ? Jv : jd_c;
+            if (act) dJ = nanmax(dJ, fabs(1.0 - jd_c * rcp(Jv)));               // :705
+        }
+    };
+    // the three moments w_n = int_0^dtau t^n e^-t dt of the upwind intervals (lsx_dev.h, w3: the same regimes, the same exponential, ONE
+    // series and the downward recurrence).  Ahead of the ray loop, for the five rays together: e^-dtau and -- where some lane of the
+    // wavefront is below dtau = 0.25 -- the series of the second moment; `moments` forms the weights of one ray from the two when its
+    // turn comes (both forms and three selects: a ray's weights never wait in registers for the other rays' turns).
+    auto exps = [&](double (&ev)[NR], double (&s2)[NR]) __attribute__((always_inline)) {
+        unsigned long long m_nl = 0, m_small = 0;
+#pragma unroll
+        for (int m = 0; m < NR; ++m) {
+            m_small |= __builtin_amdgcn_fcmp(dtau_u[m], 0.25, 4 /* ordered < */);
+            m_nl |= __builtin_amdgcn_fcmp(dtau_u[m], 50.0, 13 /* unordered or <= */);
+        }
+        if (m_nl != 0) {
+            // (saturated lanes need no select: for dtau > 50 the closed forms give exactly (1, 1, 2))
+            double r[NR], th[NR], tl[NR];
+            int ki[NR];
+#pragma unroll
+            for (int m = 0; m < NR; ++m) {
+                const double dc = min_noquiet(dtau_u[m], 700.0);
+                const double kf = __builtin_rint(-dc * 0x1.71547652b82fep+6);       // 64 / ln2
+                r[m] = fma(kf, -0x1.62e42fef80000p-7, -dc);
+                r[m] = fma(kf, -0x1.1cf79abc9e3b4p-42, r[m]);
+                ki[m] = (int)kf;
+            }
+#pragma unroll
+            for (int m = 0; m < NR; ++m) {
+                const lds_f64* e = etab + 2 * (ki[m] & 63);
+                th[m] = e[0];
+                tl[m] = e[1];
+            }
+#pragma unroll
+            for (int m = 0; m < NR; ++m) {
+                double t = fma3s(r[m], 1.0 / 720.0, 1.0 / 120.0);
+                t = fma3(r[m], t, 1.0 / 24.0);
+                t = fma3(r[m], t, 1.0 / 6.0);
+                t = fma(r[m], t, 0.5);
+                r[m] = fma(r[m] * r[m], t, r[m]);                                       // exp(r) - 1
+            }
+#pragma unroll
+            for (int m = 0; m < NR; ++m) ev[m] = ldexp(fma(th[m], r[m], tl[m]) + th[m], ki[m] >> 6);
+        } else {
+#pragma unroll
+            for (int m = 0; m < NR; ++m) ev[m] = 0.0;
+        }
+        if (m_small != 0) {
+            // sum_n (-1)^n x^(n+3) / (n! (n + 3)), twelve terms (x < 0.25: the next one is below 1e-19 of the first); the coefficients
+            // as scalar operands: each is used by the five rays in turn
+            double t[NR];
+#pragma unroll
+            for (int m = 0; m < NR; ++m) t[m] = fma3c(dtau_u[m], -1.0 / 558835200.0, 1.0 / 47174400.0);
+#define LSX_HORNER(C) _Pragma("unroll") for (int m = 0; m < NR; ++m) t[m] = fma3c(dtau_u[m], t[m], C);
+            LSX_HORNER(-1.0 / 4354560.0) LSX_HORNER(1.0 / 443520.0) LSX_HORNER(-1.0 / 50400.0) LSX_HORNER(1.0 / 6480.0) LSX_HORNER(-1.0 / 960.0)
+            LSX_HORNER(1.0 / 168.0) LSX_HORNER(-1.0 / 36.0) LSX_HORNER(1.0 / 10.0) LSX_HORNER(-1.0 / 4.0) LSX_HORNER(1.0 / 3.0)
+#undef LSX_HORNER
+#pragma unroll
+            for (int m = 0; m < NR; ++m) s2[m] = (dtau_u[m] * dtau_u[m]) * (dtau_u[m] * t[m]);
+        } else {
+#pragma unroll
+            for (int m = 0; m < NR; ++m) s2[m] = 0.0;
+        }
+    };
+    auto moments = [&](const double x, const double e, const double s2, double& w0, double& w1, double& w2q) __attribute__((always_inline)) {
+        const double dc = min_noquiet(x, 700.0);
+        const double a0 = 1.0 - e, a1 = a0 - dc * e, a2 = 2.0 * a1 - (dc * dc) * e;
+        const double s1 = 0.5 * fma(x * x, e, s2), s0 = fma(x, e, s1);
+        const bool small = x < 0.25;
+        w0 = small ? s0 : a0;
+        w1 = small ? s1 : a1;
+        w2q = small ? s2 : a2;
+    };
+    // step s >= 1: depth k = kS + dk s from `cur`, the request for depth k + 1 into `nxt`, point s - 1 finished
+    auto pstep = [&](const int s, auto phase_c, auto flags_c, Ops& cur, Ops& nxt) __attribute__((always_inline)) {
+        constexpr int PH = decltype(phase_c)::value;             // of the FINISHED point
+        constexpr bool FIRSTPT = (decltype(flags_c)::value & 1) != 0, NOREQ = (decltype(flags_c)::value & 2) != 0;
+        const int k = kS + dk * s, mpt = s - 1;
+        if constexpr (PH == 2) {
+            if (2 * mpt == Ns || 2 * mpt == Ns + 1) __syncthreads();   // the partner wave's first-half stores
+        }
+        double jhalf = 0.0;
+        if constexpr (PH == 2) jhalf = at(Jnew, o_til + (unsigned)((k - dk) * LW) * 8u);
+        if constexpr (!FIRSTPT && NPT >= 1) flush(mpt - 1);
+        const lds_f64* tk = ucol + k * TR;
+        const double hdz = (ucol + TR * dir)[k * TR + 3 * NPT];            // the interval between points m and m + 1: row k (down) / k + 1 (up)
+        const double etaB = cur.be + tk[3 * NPT + 1] * cur.jd, chiB = cur.bc, jd_k = cur.jd;
+        double Xk[NS], njk[NS];
+#pragma unroll
+        for (int u = 0; u < NPT; ++u) { Xk[u] = tk[3 * u + 0]; njk[u] = tk[3 * u + 1]; }
+        if constexpr (!NOREQ) load_ops(k + dk, nxt);
+        double ev[NR], s2[NR];
+        if constexpr (!FIRSTPT) exps(ev, s2);
+        point(mpt, phase_c, std::false_type{}, jhalf, [&](const int m, double& I, double& Psi, const double (&)[NS]) __attribute__((always_inline)) {
+            // depth k: opacity, source function, the optical depth of the interval (m, m + 1) and its reciprocal (one v_rcp for both divisions)
+            double chiTot = chiB, etaTot = etaB;
+#pragma unroll
+            for (int u = 0; u < NL; ++u) {
+                chiTot = fma(Xk[u], cur.ph[u][m], chiTot);
+                etaTot = fma(njk[u], cur.ph[u][m], etaTot);
+            }
+            const double dtd = (chi_c(m) + chiTot) * (hdz * zmu(m));
+            const double rcd = rcp(chiTot * dtd);
+            const double rchi_k = rcd * dtd, rd = rcd * chiTot;
+            const double S_k = etaTot * rchi_k;
+            const double q = (S_c[m] - S_k) * rd;
+            if constexpr (FIRSTPT) {
+                I = Iu[m];
+                Psi = 0.0;
+            } else {
+                // (lsx_dev.h, parabolic_point_fast: the same expressions; the upwind quotient is the previous point's downwind one)
+                const double pp = pu[m];
+                const double sum = dtau_u[m] + dtd, cu = sum + dtd, cd = sum + dtau_u[m];
+                const double rden = rcp(cu * q + cd * pp);
+                const double t3 = (3.0 * sum) * rden;
+                double a = (pp * q) * t3;
+                double dadS = ((cd * pp) * pp * rd - (cu * q) * q * ru[m]) * (t3 * rden);
+                const bool big = fabs(a) > 2.0 * fabs(pp);
+                a = big ? 2.0 * pp : a;
+                dadS = big ? -2.0 * ru[m] : dadS;
+                const bool mono = pp * q > 0.0;
+                a = mono ? a : 0.0;
+                dadS = mono ? dadS : 0.0;
+                const double b = (pp - a) * ru[m];
+                double w0, w1, w2q;
+                moments(dtau_u[m], ev[m], s2[m], w0, w1, w2q);
+                I = Iu[m] * (1.0 - w0) + w0 * S_c[m] + w1 * a + w2q * b;
+                const double Lam = w0 + (w1 - w2q * ru[m]) * dadS - (w2q * ru[m]) * ru[m];
+                Psi = Lam * rchi_c(m);
+            }
+            // depth k becomes point m + 1
+            Iu[m] = I;
+            pu[m] = q;
+            S_c[m] = S_k;
+            chi_c(m) = chiTot;
+            rchi_c(m) = rchi_k;
+            dtau_u[m] = dtd;
+            ru[m] = rd;
+#pragma unroll
+            for (int u = 0; u < NL; ++u) ph_c(u, m) = cur.ph[u][m];
+        });
+        jd_c = jd_k;
+    };
+    {
+        typedef std::integral_constant<int, 0> F0;
+        typedef std::integral_constant<int, 1> F1;
+        typedef std::integral_constant<int, 2> F2;
+        auto one = [&](int s, auto ph, auto fl) __attribute__((always_inline)) { if (s & 1) pstep(s, ph, fl, opB, opA); else pstep(s, ph, fl, opA, opB); };
+        auto run = [&](int s0, int s1, auto ph) __attribute__((always_inline)) {           // steps [s0, s1) of one phase
+            int s = s0;
+            if (s < s1 && (s & 1)) { pstep(s, ph, F0{}, opB, opA); ++s; }
+            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): no load is pending on any path into the loop
+            for (; s + 1 < s1; s += 2) { pstep(s, ph, F0{}, opA, opB); pstep(s + 1, ph, F0{}, opB, opA); }
+            if (s < s1) pstep(s, ph, F0{}, opA, opB);
+        };
+        // point m is finished in step m + 1: m < nA first visitor, m = nA (odd Nspace) the midpoint, then second visitor
+        const int nA = Ns / 2;
+        one(1, std::integral_constant<int, 0>{}, F1{});                              // point 0: the boundary value (depth 1 is already requested... and 2 is now)
+        run(2, nA + 1, std::integral_constant<int, 0>{});
+        if (Ns & 1) one(nA + 1, std::integral_constant<int, 1>{}, F0{});
+        run(nA + 1 + (Ns & 1), Ns - 1, std::integral_constant<int, 2>{});
+        one(Ns - 1, std::integral_constant<int, 2>{}, F2{});                         // finishes point Ns - 2; nothing left to request
+        // the end point: the linear rule with its own weights (no downwind neighbour)
+        {
+            const int mpt = Ns - 1;
+            if (2 * mpt == Ns || 2 * mpt == Ns + 1) __syncthreads();
+            const double jhalf = at(Jnew, o_til + (unsigned)((kS + dk * mpt) * LW) * 8u);
+            if constexpr (NPT >= 1) flush(mpt - 1);
+            double ev[NR], s2[NR];
+            exps(ev, s2);
+            point(mpt, std::integral_constant<int, 2>{}, std::true_type{}, jhalf, [&](const int m, double& I, double& Psi, const double (&)[NS]) __attribute__((always_inline)) {
+                double w0, w1, w2q;
+                moments(dtau_u[m], ev[m], s2[m], w0, w1, w2q);
+                I = Iu[m] * (1.0 - w0) + w0 * S_c[m] + w1 * pu[m];
+                Psi = (w0 - w1 * ru[m]) * rchi_c(m);
+            });
+        }
+        if constexpr (NPT >= 1) {
+            __builtin_amdgcn_wave_barrier();
+            flush(Ns - 1);
+        }
+    }
+    } else {
     // `cur` holds the operands of this step's depth (requested one step ago), the next depth's are requested into `nxt`: the
     // two buffers swap roles from step to step (even steps: cur = opA), so nothing is copied
     auto step = [&](const int s, auto phase_c, Ops& cur, Ops& nxt) __attribute__((always_inline)) {
@@ -703,6 +1033,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
         }
 #endif
     }
+    }
     // dJ of every (column, tile, direction): the maximum over the column's wavelengths (NaN propagates, rh_method.py:706)
     __builtin_amdgcn_wave_barrier();
     red[NV * RROW + lane] = act ? dJ : 0.0;
@@ -717,23 +1048,38 @@ lsx_sweep_rs_kernel(const SweepParams p)
 #undef zmu
 #undef wmuh
 
-template <int NPT, int NL, bool LK, int TOPO>
+template <int NPT, int NL, bool LK, int TOPO, bool PAR>
 static hipError_t launch_rs(const SweepParams& p, int ngroups, hipStream_t st)
 {
     const dim3 g((unsigned)(ngroups * p.n_class_tiles)), b(2 * LSX_WAVE);
-    hipLaunchKernelGGL((lsx_sweep_rs_kernel<NPT, NL, LK, TOPO>), g, b, lsx_rs_lds_doubles(NPT, p.Nspace) * sizeof(double), st, p);
+    hipLaunchKernelGGL((lsx_sweep_rs_kernel<NPT, NL, LK, TOPO, PAR>), g, b, lsx_rs_lds_doubles(NPT, p.Nspace, PAR) * sizeof(double), st, p);
     return hipGetLastError();
 }
 
-// the ray-serial instance of a class (code = lsx_class_code of the class), NC columns per wavefront
+// the ray-serial instance of a class (code = lsx_class_code of the class), NC columns per wavefront.  This file is compiled twice
+// (Makefile): as it is for the reference's piecewise-linear rule, and with LSX_RS_PARABOLIC_TU for the parabolic instances (N4).
+#ifndef LSX_RS_PARABOLIC_TU
 extern "C" hipError_t lsx_launch_sweep_rs(const SweepParams* p, int code, hipStream_t st)
 {
     if (p->Nrays != LSX_RS_RAYS || p->sca_per_lambda || p->L != LW) return hipErrorNotSupported;
     const int ngroups = (p->ncol + NC - 1) / NC;
     switch (code) {
-#define LSX_X(NPT, NL, LK, TOPO) case lsx_class_code(NPT, NL, LK, TOPO): return launch_rs<NPT, NL, LK, TOPO>(*p, ngroups, st);
+#define LSX_X(NPT, NL, LK, TOPO) case lsx_class_code(NPT, NL, LK, TOPO): return launch_rs<NPT, NL, LK, TOPO, false>(*p, ngroups, st);
         LSX_RS_INSTANCES(LSX_X)
 #undef LSX_X
     default: return hipErrorNotSupported;
     }
 }
+#else
+extern "C" hipError_t lsx_launch_sweep_rs_par(const SweepParams* p, int code, hipStream_t st)
+{
+    if (p->Nrays != LSX_RS_RAYS || p->sca_per_lambda || p->L != LW) return hipErrorNotSupported;
+    const int ngroups = (p->ncol + NC - 1) / NC;
+    switch (code) {
+#define LSX_X(NPT, NL, LK, TOPO) case lsx_class_code(NPT, NL, LK, TOPO): return launch_rs<NPT, NL, LK, TOPO, true>(*p, ngroups, st);
+        LSX_RSP_INSTANCES(LSX_X)
+#undef LSX_X
+    default: return hipErrorNotSupported;
+    }
+}
+#endif

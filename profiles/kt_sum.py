@@ -4,7 +4,7 @@ import csv, collections, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ncall = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 def short(n):
-    m = re.search(r'(lsx_sweep_(?:rs_)?kernel(?:_all)?<[^>]*>)', n)
+    m = re.search(r'(lsx_sweep_(?:rs_)?kernel(?:_all|_parabolic|_par)?<[^>]*>)', n)
     if m: return m.group(1).replace(' ', '')
     m = re.search(r'(k_\w+(<[^>]*>)?)', n); return m.group(1) if m else n[:30]
 per = collections.defaultdict(list)

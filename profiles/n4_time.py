@@ -10,9 +10,12 @@ prob, base, raw = fixtures.load_problem_npz(os.path.join(ROOT, 'tests', 'golden'
 blk, prof = synth.perturbed_columns(prob, base, raw, ncol=ncol)
 eng = Engine(prob, ncol)
 synth.load_columns(eng, blk, prof)
-for rule in ('linear', 'parabolic', 'linear'):
+# (the parabolic rule on the ray-serial kernels where a class has an instance there, and -- 'parabolic/lane' -- on one ray per lane only)
+for rule, policy in (('linear', 'auto'), ('parabolic', 'auto'), ('parabolic', 'ray-per-lane'), ('linear', 'auto')):
+    synth.load_columns(eng, blk, prof)        # every configuration from the same starting populations
     eng.set_formal_solver(rule)
+    eng.set_sweep_policy(policy)
     for _ in range(3):
         eng.formal_sol_gamma(); eng.stat_equil()
     t, s = eng.time_formal_sol(2, 10)
-    print('%s %-9s ncol=%d  formal solution %.3f ms' % (wl, rule, ncol, t))
+    print('%s %-9s %-12s ncol=%d  formal solution %.3f ms' % (wl, rule, policy, ncol, t))

@@ -14,6 +14,10 @@ prob, base, raw = fixtures.load_problem_npz('tests/golden/falc_cah.npz' if wl ==
 blk, prof = synth.perturbed_columns(prob, base, raw, ncol=ncol)
 eng = Engine(prob, ncol)
 synth.load_columns(eng, blk, prof)
+if os.environ.get('LSX_STEP_SOLVER'):      # 'parabolic' (N4); with LSX_FS_ONLY=1: the strongly perturbed ensemble does not converge under that rule
+    eng.set_formal_solver(os.environ['LSX_STEP_SOLVER'])
+if os.environ.get('LSX_STEP_POLICY'):
+    eng.set_sweep_policy(os.environ['LSX_STEP_POLICY'])
 fs_only = os.environ.get('LSX_FS_ONLY') == '1'      # ablation variants (meaningless results): formal solutions only
 se = (lambda: None) if fs_only else eng.stat_equil_async
 for _ in range(3):

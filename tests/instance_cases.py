@@ -84,3 +84,6 @@ EXPECT = {
     'triplet': [(3, 3, 1, 0)],
     'crowd': [(-1, 0, 0, 0), (-1, 0, 1, 0)],
 }
+# the classes that have a ray-serial instance of the parabolic rule (lsx_plan.h, LSX_RSP_INSTANCES; the CPU ledger checks the two lists
+# against each other): mode 'parabolic-serial' of tests/test_instances_gpu.py expects exactly these on the ray-serial kernel
+PARABOLIC_SERIAL = [(0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 0)]

@@ -41,12 +41,12 @@ def _planned(host, prob, bits=0):
     return {ic.decode(int(t[6])) for t in tiles}
 
 
-def _rs_classes(host, prob):
+def _rs_classes(host, prob, bit=1):
     p, keep = prob.to_c()
     out = (C.c_int32 * 128)()
     n = host.dll.lsx_plan_rs_classes(C.byref(p), out, 64)
     assert n > 0
-    return {ic.decode(int(out[2 * i])) for i in range(n) if out[2 * i + 1]}
+    return {ic.decode(int(out[2 * i])) for i in range(n) if out[2 * i + 1] & bit}
 
 
 def test_every_compiled_instance_is_planned_by_a_gpu_parity_test(host):
@@ -58,13 +58,18 @@ def test_every_compiled_instance_is_planned_by_a_gpu_parity_test(host):
         prob, _ = ic.build(name, 2, Ns, compact)
         got = _planned(host, prob)
         assert set(ic.EXPECT[name]) <= got, (name, sorted(got))
-        by_case[name] = (got, _rs_classes(host, prob))
+        by_case[name] = (got, _rs_classes(host, prob), _rs_classes(host, prob, 2))
     # the reference's own problems (tests/test_production_classes.py: both kernels; the parabolic rule: tests/parabolic_cases.py)
     for fx in ('falc_ca.npz', 'falc_cah.npz'):
         prob, base, raw = fixtures.load_problem_npz(golden(fx), phi_compact=False)
-        by_case[fx] = (_planned(host, prob), _rs_classes(host, prob))
-    lane_hit = set().union(*(g for g, _ in by_case.values()))
-    serial_hit = set().union(*(r for _, r in by_case.values()))
+        by_case[fx] = (_planned(host, prob), _rs_classes(host, prob), _rs_classes(host, prob, 2))
+    lane_hit = set().union(*(g for g, _, _ in by_case.values()))
+    serial_hit = set().union(*(r for _, r, _ in by_case.values()))
+    # the ray-serial instances of the parabolic rule (tests/test_instances_gpu.py, mode 'parabolic-serial'): a subset of the ray-serial list
+    par_serial = _instances(host, 2)
+    assert set(par_serial) <= set(serial) and set(par_serial) == set(ic.PARABOLIC_SERIAL)
+    par_hit = set().union(*(r for _, _, r in by_case.values()))
+    assert [k for k in par_serial if k not in par_hit] == [] and par_hit <= set(par_serial)
     assert [k for k in lane if k not in lane_hit] == [], 'one-ray-per-lane instances no GPU test plans'
     # the ray-serial kernel and the parabolic rule's compile-time classes share their list (lsx_plan.h)
     assert [k for k in serial if k not in serial_hit] == [], 'ray-serial / parabolic instances no GPU test plans'

@@ -2,6 +2,7 @@
   lane      the one-ray-per-lane kernels (lsx_sweep.hip), one launch per tile class
   serial    the ray-serial kernels (lsx_sweep_rs.hip) for the classes that have an instance there, one ray per lane for the rest
   parabolic the parabolic rule's compile-time tile classes (sweep_tile_par) and its generic instance
+  parabolic-serial  the parabolic rule on the ray-serial kernels (lsx_sweep_rs.hip, PAR) for the classes that have an instance there
 against the oracle on the same columns (rh_method.py:595-692, formal_solver.py:14-212; the topologies: rh_method.py:606-627,
 654-681 on atoms shaped like rh_atoms.py:194, :355), and the classes that ran are the ones the case is in the ledger for.
 
@@ -36,17 +37,17 @@ def classes_run(lib, eng):
     return table, fused
 
 
-@pytest.mark.parametrize('mode', ['lane', 'serial', 'parabolic'])
+@pytest.mark.parametrize('mode', ['lane', 'serial', 'parabolic', 'parabolic-serial'])
 @pytest.mark.parametrize('case', ic.CASES, ids=[c[0] for c in ic.CASES])
 def test_case_meets_the_oracle(hip_lib, oracle_lib, case, mode):
     name, ncol, Ns, compact = case
     prob, block = ic.build(name, ncol, Ns, compact)
-    eh = Engine(prob, ncol, lib=hip_lib, sweep_policy='ray-serial' if mode == 'serial' else 'ray-per-lane')
+    eh = Engine(prob, ncol, lib=hip_lib, sweep_policy='ray-serial' if mode.endswith('serial') else 'ray-per-lane')
     eo = Engine(prob, ncol, lib=oracle_lib)
     oracle_lib.dll.lsx_oracle_set_threads(eo._h, 8)
     for e in (eh, eo):
         e.set_columns(0, block)
-        e.set_formal_solver('parabolic' if mode == 'parabolic' else 'linear')
+        e.set_formal_solver('parabolic' if mode.startswith('parabolic') else 'linear')
     # (crowd: measured 2.17e-10 on the emergent intensity of one ray -- the same value on both kernels -- with J at 1.4e-13 and
     # Gamma at 5e-15: the signature of an interval just above the 5e-4 switch of w2, where w1 = (1 - e) - dtau e cancels to
     # dtau^2 / 2 and a 1-ulp difference between the two libraries' exp() is up to 1e-9 of that ray's contribution)
@@ -72,6 +73,8 @@ def test_case_meets_the_oracle(hip_lib, oracle_lib, case, mode):
     serial = {k for k, (_, rs) in table.items() if rs}
     if mode == 'serial':
         assert serial == {k for k in table if 0 <= k[0] <= 2}, (serial, table)      # every class with at most two per-ray slots
+    elif mode == 'parabolic-serial':
+        assert serial == {k for k in table if k in ic.PARABOLIC_SERIAL}, (serial, table)
     else:
         assert not serial
     eh.close(); eo.close()

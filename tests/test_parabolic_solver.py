@@ -53,17 +53,22 @@ def test_context_with_the_parabolic_rule_on_hip(hip_lib, oracle_lib):
 
 
 @pytest.mark.gpu
-def test_parabolic_rule_on_production_shapes(hip_lib, oracle_lib):
-    """Ca+H with a line-of-sight velocity, 36 columns (> 32: the size at which the linear rule switches to per-class
-    launches): linked continua, two-line tiles and cells all go through the one parabolic instance"""
+@pytest.mark.parametrize('fixture, policy', [('falc_cah.npz', 'ray-per-lane'), ('falc_cah.npz', 'ray-serial'), ('falc_ca.npz', 'ray-serial')])
+def test_parabolic_rule_on_production_shapes(hip_lib, oracle_lib, fixture, policy):
+    """Ca+H (and CaII) with a line-of-sight velocity, 36 columns (> 32: the size at which the linear rule switches to per-class
+    launches): linked continua, two-line tiles and cells.  'ray-per-lane': the compile-time classes of sweep_tile_par and the
+    generic instance; 'ray-serial': the classes that have a ray-serial instance of the rule (lsx_sweep_rs.hip, PAR: continuum-only
+    tiles, one line, one line with linked continua -- whose corrections the epilogue applies) run it, the others stay on one ray per
+    lane; 36 columns = seven full five-column wavefronts and a ragged one."""
+    import ctypes as C
     import numpy as np
     from conftest import golden, relerr, gamma_err
     from lightspinner_amd import fixtures, synth, Engine, _capi
-    prob, base, raw = fixtures.load_problem_npz(golden('falc_cah.npz'), phi_compact=False)
+    prob, base, raw = fixtures.load_problem_npz(golden(fixture), phi_compact=False)
     blk, prof = synth.perturbed_columns(prob, base, raw, ncol=36, seed=4, vlos_sigma=2.0e3)
     engs = []
     for lib in (hip_lib, oracle_lib):
-        e = Engine(prob, 36, lib=lib)
+        e = Engine(prob, 36, lib=lib, sweep_policy=policy)
         synth.load_columns(e, blk, prof)
         e.set_formal_solver('parabolic')
         engs.append(e)
@@ -78,3 +83,16 @@ def test_parabolic_rule_on_production_shapes(hip_lib, oracle_lib):
         if it > 3:
             assert hip.stat_equil() == pytest.approx(ora.stat_equil(), rel=1e-6)
     assert relerr(hip.get(_capi.LSX_N), ora.get(_capi.LSX_N)) < 1e-8
+    # which classes ran on the ray-serial kernel
+    f = hip_lib.dll.lsx_hip_class_info
+    f.restype = C.c_int32
+    f.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
+    out = (C.c_int64 * 8)()
+    serial = set()
+    for i in range(f(hip._h, -1, out)):
+        f(hip._h, i, out)
+        assert int(out[3]) == 5
+        if out[6]:
+            serial.add((int(out[0]), int(out[1]), int(out[4]), int(out[5])))
+    want = {'ray-per-lane': set(), 'falc_cah.npz': {(0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 0)}, 'falc_ca.npz': {(0, 0, 0, 0), (1, 1, 0, 0)}}
+    assert serial == want[policy if policy == 'ray-per-lane' else fixture], serial

@@ -75,6 +75,34 @@ def test_c5_columns_get_the_same_bits_in_one_context_and_in_shards(hip_lib, worl
 
 
 @pytest.mark.gpu
+def test_c5_columns_under_the_parabolic_rule_get_the_same_bits_in_shards(hip_lib):
+    """N4: the parabolic rule has a ray-serial instance for some classes and one ray per lane for the others; the same count decides,
+    so the 164 columns get the same bits in one context and in eight contexts of 21 / 20 (three accelerated iterations)"""
+    prob, batch = _c5_columns()
+    N, world = batch.ncol, 8
+
+    def run(b, **kw):
+        eng = Engine(prob, b.ncol, lib=hip_lib, **kw)
+        for a in range(0, b.ncol, 64):
+            eng.set_columns(a, b.slice(a, min(b.ncol, a + 64)))
+        eng.set_formal_solver('parabolic')
+        for _ in range(3):
+            eng.formal_sol_gamma(); eng.stat_equil()
+        out = dict(I=eng.get(_capi.LSX_I), n=eng.get(_capi.LSX_N), J=eng.get(_capi.LSX_J), G=eng.get(_capi.LSX_GAMMA))
+        eng.close()
+        return out
+
+    one = run(batch)
+    shards = [run(batch.slice(*(lambda f, n: (f, f + n))(*shard_columns(N, r, world))), policy_columns=N) for r in range(world)]
+    for key in ('I', 'n', 'J', 'G'):
+        assert np.array_equal(np.concatenate([s[key] for s in shards]), one[key]), key
+    # ... and not the bits of the other mapping (the ray-serial instances did run)
+    lane = run(batch, sweep_policy='ray-per-lane')
+    d = np.abs(lane['J'] - one['J']).max() / np.abs(one['J']).max()
+    assert 0 < d < 1e-9
+
+
+@pytest.mark.gpu
 def test_pinned_mappings_and_the_counts_that_decide(hip_lib):
     prob, base, raw = fixtures.load_problem_npz(golden('falc_ca.npz'), phi_compact=False)
     blk, prof = synth.perturbed_columns(prob, base, raw, ncol=12, seed=3, vlos_sigma=2.0e3)
