@@ -191,7 +191,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
     // angle quadrature: wave-uniform
     // two-slot instances: the ten quadrature constants live in LDS behind the parked totals and are read where they are used
     // (broadcast reads with immediate offsets): twenty vector registers less in the instances that sit at the 256-register limit
-    constexpr bool QLDS = NPT >= 2 || PAR;
+    constexpr bool QLDS = NPT >= 2 || (PAR && LSX_RSP_WPE >= 2);
     lds_f64* const qtab = utab + (size_t)NC * lsx_rs_ucol_stride(NPT, p.Nspace) + (size_t)2 * NC * NV * lsx_rs_park(NPT, PAR);
     if (QLDS && threadIdx.x < 2 * NR) qtab[threadIdx.x] = threadIdx.x < NR ? LSX_CONST(double, p.zmu)[threadIdx.x] : LSX_CONST(double, p.wmuh)[threadIdx.x - NR];
     double zmu_r[NR], wmuh_r[NR];
@@ -359,16 +359,21 @@ lsx_sweep_rs_kernel(const SweepParams p)
     // depth of the upwind interval and its reciprocal; per wavelength: point m's line profiles (a copy of the operand registers:
     // the buffer they arrived in takes the request for depth k + 1) and J-dagger.
     static_assert(NPT == NL && (NPT == 0 || FACT) && !CORR, "ray-serial parabolic instances: line-only tiles with factored Gamma integrands");
-    // 1 / opacity and the line profiles of point m are only read when the point is finished: they wait in lane-private LDS cells (one
-    // row of 64 per value and wave, behind the angle quadrature) instead of twenty to thirty vector registers
+    // 1 / opacity, opacity and the line profiles of point m.  At one wave per SIMD (the default, see LSX_RSP_WPE) they stay in registers:
+    // a lone wave waits out every LDS round trip.  A build for two waves per SIMD (LSX_RSP_WPE=2) parks them in lane-private LDS cells
+    // (one row of 64 per value and wave, behind the angle quadrature; volatile: a parked value must not travel from its store to the
+    // next step's load in a register) -- twenty to thirty registers less, which was not enough (profiles/r04_bound_evidence.md 4).
+    constexpr bool CELLS = LSX_RSP_WPE >= 2;
     double pu[NR], S_c[NR], dtau_u[NR], ru[NR];       // (+ Iu: the intensity of point m - 1)
     double jd_c;
-    // (volatile: the compiler must not carry a parked value from its store to the next step's load in a register -- that is what the
-    // cells are there to avoid)
+    double rchi_r[NR], chi_r[NR], ph_r[NS][NR];
     volatile lds_f64* const cell = qtab + 2 * NR + 2 + (size_t)dir * lsx_rs_par_rows(NPT) * LSX_WAVE + lane;      // row r: cell[r * 64]
-    auto rchi_c = [&](int m) __attribute__((always_inline)) -> volatile lds_f64& { return cell[m * LSX_WAVE]; };
-    auto chi_c = [&](int m) __attribute__((always_inline)) -> volatile lds_f64& { return cell[(NR + m) * LSX_WAVE]; };
-    auto ph_c = [&](int u, int m) __attribute__((always_inline)) -> volatile lds_f64& { return cell[(2 * NR + u * NR + m) * LSX_WAVE]; };
+    auto rchi_c = [&](int m) __attribute__((always_inline)) { if constexpr (CELLS) return (double)cell[m * LSX_WAVE]; else return rchi_r[m]; };
+    auto chi_c = [&](int m) __attribute__((always_inline)) { if constexpr (CELLS) return (double)cell[(NR + m) * LSX_WAVE]; else return chi_r[m]; };
+    auto ph_c = [&](int u, int m) __attribute__((always_inline)) { if constexpr (CELLS) return (double)cell[(2 * NR + u * NR + m) * LSX_WAVE]; else return ph_r[u][m]; };
+    auto set_rchi = [&](int m, double v) __attribute__((always_inline)) { if constexpr (CELLS) cell[m * LSX_WAVE] = v; else rchi_r[m] = v; };
+    auto set_chi = [&](int m, double v) __attribute__((always_inline)) { if constexpr (CELLS) cell[(NR + m) * LSX_WAVE] = v; else chi_r[m] = v; };
+    auto set_ph = [&](int u, int m, double v) __attribute__((always_inline)) { if constexpr (CELLS) cell[(2 * NR + u * NR + m) * LSX_WAVE] = v; else ph_r[u][m] = v; };
     {   // point 0's own values (the boundary condition above has read the same operands)
         const lds_f64* tk = ucol + kS * TR;
         const double etaB = opA.be + tk[3 * NPT + 1] * opA.jd;
@@ -379,11 +384,11 @@ lsx_sweep_rs_kernel(const SweepParams p)
             for (int u = 0; u < NL; ++u) {
                 chiTot = fma(tk[3 * u + 0], opA.ph[u][m], chiTot);
                 etaTot = fma(tk[3 * u + 1], opA.ph[u][m], etaTot);
-                ph_c(u, m) = opA.ph[u][m];
+                set_ph(u, m, opA.ph[u][m]);
             }
-            chi_c(m) = chiTot;
+            set_chi(m, chiTot);
             const double rc = rcp(chiTot);
-            rchi_c(m) = rc;
+            set_rchi(m, rc);
             S_c[m] = etaTot * rc;                                         // :632
             pu[m] = 0.0; dtau_u[m] = 1.0; ru[m] = 1.0;
         }
@@ -552,6 +557,9 @@ lsx_sweep_rs_kernel(const SweepParams p)
         }
     };
     auto moments = [&](const double x, const double e, const double s2, double& w0, double& w1, double& w2q) __attribute__((always_inline)) {
+        // (the closed forms exactly as lsx_dev.h, w3, and the oracle form them: `I_u (1 - w0)` is the attenuated upwind intensity, and at
+        // large dtau it inherits the rounding of w0 = 1 - e -- measured: w0 formed as w1 + dtau e instead, equal to 1e-16, moves J by
+        // 1.5e-8 (CaII) / 1.5e-3 (Ca+H) of its value at far-UV wavelengths where that term is all there is)
         const double dc = min_noquiet(x, 700.0);
         const double a0 = 1.0 - e, a1 = a0 - dc * e, a2 = 2.0 * a1 - (dc * dc) * e;
         const double s1 = 0.5 * fma(x * x, e, s2), s0 = fma(x, e, s1);
@@ -621,12 +629,12 @@ lsx_sweep_rs_kernel(const SweepParams p)
             Iu[m] = I;
             pu[m] = q;
             S_c[m] = S_k;
-            chi_c(m) = chiTot;
-            rchi_c(m) = rchi_k;
+            set_chi(m, chiTot);
+            set_rchi(m, rchi_k);
             dtau_u[m] = dtd;
             ru[m] = rd;
 #pragma unroll
-            for (int u = 0; u < NL; ++u) ph_c(u, m) = cur.ph[u][m];
+            for (int u = 0; u < NL; ++u) set_ph(u, m, cur.ph[u][m]);
         });
         jd_c = jd_k;
     };
