@@ -96,3 +96,40 @@ def test_parabolic_rule_on_production_shapes(hip_lib, oracle_lib, fixture, polic
             serial.add((int(out[0]), int(out[1]), int(out[4]), int(out[5])))
     want = {'ray-per-lane': set(), 'falc_cah.npz': {(0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 0)}, 'falc_ca.npz': {(0, 0, 0, 0), (1, 1, 0, 0)}}
     assert serial == want[policy if policy == 'ray-per-lane' else fixture], serial
+
+
+@pytest.mark.gpu
+def test_parabolic_ray_serial_positions_and_frozen_columns(hip_lib):
+    """the ray-serial instances of the rule share a wavefront between five columns: a column's bits do not depend on where it sits in
+    the batch or on its neighbours (every original column appears several times at random positions of a ragged batch), and a frozen
+    column (lsx_set_active_columns) keeps J and populations bit for bit while its wavefront's other columns iterate"""
+    import numpy as np
+    from conftest import golden
+    from lightspinner_amd import fixtures, synth, Engine, _capi
+    prob, base, raw = fixtures.load_problem_npz(golden('falc_cah.npz'), phi_compact=False)
+    nuniq, ncol = 9, 43
+    blk, prof = synth.perturbed_columns(prob, base, raw, ncol=nuniq, seed=12, vlos_sigma=2.0e3)
+    src = np.concatenate([np.arange(nuniq), np.random.default_rng(8).integers(0, nuniq, ncol - nuniq)])
+    pick = lambda idx: (type(blk).concatenate([blk.slice(int(q), int(q) + 1) for q in idx]), tuple(p[idx] for p in prof))
+    eng = Engine(prob, ncol, lib=hip_lib, sweep_policy='ray-serial')
+    synth.load_columns(eng, *pick(src))
+    eng.set_formal_solver('parabolic')
+    for it in range(3):
+        eng.formal_sol_gamma()
+        if it:
+            eng.stat_equil()
+    for what in (_capi.LSX_J, _capi.LSX_I, _capi.LSX_N, _capi.LSX_GAMMA):
+        a = eng.get(what)
+        assert np.array_equal(a, a[:nuniq][src]), what
+    mask = (np.arange(ncol) % 3 != 1)
+    n0, J0 = eng.get(_capi.LSX_N), eng.get(_capi.LSX_J)
+    eng.set_active_columns(mask)
+    eng.formal_sol_gamma(); eng.stat_equil()
+    n1, J1 = eng.get(_capi.LSX_N), eng.get(_capi.LSX_J)
+    assert np.array_equal(n1[~mask], n0[~mask]) and np.array_equal(J1[~mask], J0[~mask])
+    assert not np.array_equal(n1[mask], n0[mask])
+    a = eng.get(_capi.LSX_N)
+    live = np.nonzero(mask)[0]
+    first = {int(s): int(i) for i, s in reversed(list(zip(live, src[live])))}        # an active copy of each original
+    assert all(np.array_equal(a[i], a[first[int(src[i])]]) for i in live)
+    eng.close()
