@@ -2191,7 +2191,7 @@ int lsx_time_formal_sol(lsx_ctx* c, int32_t warmup, int32_t reps, double* ms_tot
 
 // HIP-only introspection used by bench.py.  what: 0 = algorithmic bytes per column the sweep
 // kernel itself must move (B_alg without the C read / Gamma write of the epilogue), 1 = tiles per
-// column, 2 = LDS bytes per workgroup, 3 = wavelengths per tile, 4 = ms of the epilogue kernels in the
+// column, 2 = LDS bytes per workgroup (the largest class of the mapping in use), 3 = wavelengths per tile, 4 = ms of the epilogue kernels in the
 // last lsx_time_formal_sol, 5 = slab bytes per column (extra, non-algorithmic traffic of the design)
 double lsx_hip_info(const lsx_ctx* c, int32_t what)
 {
@@ -2199,7 +2199,13 @@ double lsx_hip_info(const lsx_ctx* c, int32_t what)
     switch (what) {
     case 0: return lsx_algorithmic_bytes_per_column(c) - 8.0 * c->Nspace * 2.0 * c->NL2tot;
     case 1: return (double)c->tiles.size();
-    case 2: return (double)c->lds_bytes;
+    case 2: {   // the largest workgroup of the sweep the next formal solution launches: the ray-serial instances carry the per-depth operand
+                // table of FIVE columns (lsx_plan.h, lsx_rs_lds_doubles), about twice the one-ray-per-lane layout of the same class
+        if (c->solver == LSX_SOLVER_PARABOLIC || !use_ray_serial(c)) return (double)c->lds_bytes;
+        size_t b = 0;
+        for (const auto& k : c->classes) b = std::max(b, k.rs ? (size_t)lsx_rs_lds_doubles(k.npt, c->Nspace) * sizeof(double) : k.lds_bytes);
+        return (double)b;
+    }
     case 3: return (double)c->L;
     case 4: return c->ms_finish;
     case 5: return 8.0 * c->Nspace * 4.0 * (double)c->tile_slots.size();
