@@ -69,6 +69,32 @@ __global__ void __launch_bounds__(256) k(double* out, int iters, double seed, un
                 asm volatile("v_cndmask_b32_e64 %0, %0, 0, %8\n v_cndmask_b32_e64 %1, %1, 0, %8\n v_cndmask_b32_e64 %2, %2, 0, %8\n v_cndmask_b32_e64 %3, %3, 0, %8\n"
                              "v_cndmask_b32_e64 %4, %4, 0, %8\n v_cndmask_b32_e64 %5, %5, 0, %8\n v_cndmask_b32_e64 %6, %6, 0, %8\n v_cndmask_b32_e64 %7, %7, 0, %8"
                              : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "s"(0x5555555555555555ull));
+            } else if constexpr (KIND == 13) {  // v_ldexp_f64 (the exponential's last step)
+                asm volatile("v_ldexp_f64 %0, %0, %8\n v_ldexp_f64 %1, %1, %8\n v_ldexp_f64 %2, %2, %8\n v_ldexp_f64 %3, %3, %8\n"
+                             "v_ldexp_f64 %4, %4, %8\n v_ldexp_f64 %5, %5, %8\n v_ldexp_f64 %6, %6, %8\n v_ldexp_f64 %7, %7, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(it & 1));
+            } else if constexpr (KIND == 14) {  // v_rndne_f64
+                asm volatile("v_rndne_f64 %0, %0\n v_rndne_f64 %1, %1\n v_rndne_f64 %2, %2\n v_rndne_f64 %3, %3\n"
+                             "v_rndne_f64 %4, %4\n v_rndne_f64 %5, %5\n v_rndne_f64 %6, %6\n v_rndne_f64 %7, %7"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if constexpr (KIND == 15) {  // v_cvt_i32_f64
+                asm volatile("v_cvt_i32_f64 %0, %8\n v_cvt_i32_f64 %1, %9\n v_cvt_i32_f64 %2, %10\n v_cvt_i32_f64 %3, %11\n"
+                             "v_cvt_i32_f64 %4, %8\n v_cvt_i32_f64 %5, %9\n v_cvt_i32_f64 %6, %10\n v_cvt_i32_f64 %7, %11"
+                             : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+            } else if constexpr (KIND == 16) {  // v_cmp_lt_f64 into an SGPR pair
+                unsigned long long s0, s1;
+                asm volatile("v_cmp_lt_f64 %0, %2, %3\n v_cmp_lt_f64 %1, %3, %4\n v_cmp_lt_f64 %0, %4, %5\n v_cmp_lt_f64 %1, %5, %2\n"
+                             "v_cmp_lt_f64 %0, %2, %4\n v_cmp_lt_f64 %1, %3, %5\n v_cmp_lt_f64 %0, %4, %2\n v_cmp_lt_f64 %1, %5, %3"
+                             : "=s"(s0), "=s"(s1) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+                i0 += (int)(s0 & s1 & 0);
+            } else if constexpr (KIND == 17) {  // v_min_f64
+                asm volatile("v_min_f64 %0, %0, %8\n v_min_f64 %1, %1, %8\n v_min_f64 %2, %2, %8\n v_min_f64 %3, %3, %8\n"
+                             "v_min_f64 %4, %4, %8\n v_min_f64 %5, %5, %8\n v_min_f64 %6, %6, %8\n v_min_f64 %7, %7, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));
+            } else if constexpr (KIND == 18) {  // v_accvgpr_write_b32 + v_accvgpr_read_b32 (the register-file spill moves)
+                asm volatile("v_accvgpr_write_b32 a0, %0\n v_accvgpr_read_b32 %1, a0\n v_accvgpr_write_b32 a1, %2\n v_accvgpr_read_b32 %3, a1\n"
+                             "v_accvgpr_write_b32 a2, %4\n v_accvgpr_read_b32 %5, a2\n v_accvgpr_write_b32 a3, %6\n v_accvgpr_read_b32 %7, a3"
+                             : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : : "a0", "a1", "a2", "a3");
             } else if constexpr (KIND == 11) {  // v_fma_f64 with one wave-uniform SGPR operand... same as 0 but literal 0.5
                 asm volatile("v_fma_f64 %0, %0, 0.5, %8\n v_fma_f64 %1, %1, 0.5, %8\n v_fma_f64 %2, %2, 0.5, %8\n v_fma_f64 %3, %3, 0.5, %8\n"
                              "v_fma_f64 %4, %4, 0.5, %8\n v_fma_f64 %5, %5, 0.5, %8\n v_fma_f64 %6, %6, 0.5, %8\n v_fma_f64 %7, %7, 0.5, %8"
@@ -116,13 +142,14 @@ int main()
     hipMalloc(&d_out, sizeof(double) * 256 * 256 * 8);
     hipMalloc(&d_clk, 16 * 256 * 4 * 8 * 4);
     const char* names[] = {"v_fma_f64", "v_mul_f64", "v_add_f64", "v_rcp_f64", "v_cndmask_b32", "v_add_u32", "v_mov_b32_dpp",
-                           "v_permlane32_swap", "v_mov_b64", "fma_f64+cndmask (per instr)", "s_mul_i32", "v_fma_f64 (inline const)", "v_cndmask_b32_e64 (sgpr mask)"};
+                           "v_permlane32_swap", "v_mov_b64", "fma_f64+cndmask (per instr)", "s_mul_i32", "v_fma_f64 (inline const)", "v_cndmask_b32_e64 (sgpr mask)",
+                           "v_ldexp_f64", "v_rndne_f64", "v_cvt_i32_f64", "v_cmp_lt_f64 (sgpr)", "v_min_f64", "v_accvgpr write+read"};
     printf("cycles (at a nominal 2.4 GHz) per wave64 instruction per SIMD; waves per SIMD = 1, 2, 4, 8\n");
-    for (int w : {1, 2, 4, 8}) {
-        double r[13], sc[13], gh[13], lo[13], hi[13];
+    for (int w : {1, 2, 4}) {
+        double r[19], sc[19], gh[19], lo[19], hi[19];
 #define RUN(i) r[i] = run<i>(w, d_out); sc[i] = g_shader_cyc; gh[i] = g_ghz; lo[i] = g_min; hi[i] = g_max;
-        RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12)
-        for (int i = 0; i < 13; ++i)
+        RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16) RUN(17) RUN(18)
+        for (int i = 0; i < 19; ++i)
             printf("W=%d %-32s wall@2.4GHz %.2f | per wave: shader cycles per own instr avg %.2f (min %.2f max %.2f) -> per SIMD %.2f | clock %.2f GHz\n", w, names[i], r[i],
                    sc[i], lo[i], hi[i], sc[i] / w, gh[i]);
     }
