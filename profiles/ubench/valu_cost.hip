@@ -95,6 +95,30 @@ __global__ void __launch_bounds__(256) k(double* out, int iters, double seed, un
                 asm volatile("v_accvgpr_write_b32 a0, %0\n v_accvgpr_read_b32 %1, a0\n v_accvgpr_write_b32 a1, %2\n v_accvgpr_read_b32 %3, a1\n"
                              "v_accvgpr_write_b32 a2, %4\n v_accvgpr_read_b32 %5, a2\n v_accvgpr_write_b32 a3, %6\n v_accvgpr_read_b32 %7, a3"
                              : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : : "a0", "a1", "a2", "a3");
+            } else if constexpr (KIND == 19) {  // a double's select as the compiler writes it: TWO vcc cndmasks in a row, then two fmas
+                asm volatile("v_cndmask_b32 %4, %4, %10, vcc\n v_cndmask_b32 %5, %5, %10, vcc\n v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n"
+                             "v_cndmask_b32 %6, %6, %10, vcc\n v_cndmask_b32 %7, %7, %10, vcc\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(m), "v"(c), "v"(it) : "vcc");
+            } else if constexpr (KIND == 20) {  // the same with the mask in an SGPR pair (VOP3 form)
+                asm volatile("v_cndmask_b32_e64 %4, %4, %10, %11\n v_cndmask_b32_e64 %5, %5, %10, %11\n v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n"
+                             "v_cndmask_b32_e64 %6, %6, %10, %11\n v_cndmask_b32_e64 %7, %7, %10, %11\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(m), "v"(c), "v"(it), "s"(0x5555555555555555ull));
+            } else if constexpr (KIND == 21) {  // six vcc cndmasks in a row (three doubles selected on one condition), then two fmas
+                asm volatile("v_cndmask_b32 %2, %2, %10, vcc\n v_cndmask_b32 %3, %3, %10, vcc\n v_cndmask_b32 %4, %4, %10, vcc\n v_cndmask_b32 %5, %5, %10, vcc\n"
+                             "v_cndmask_b32 %6, %6, %10, vcc\n v_cndmask_b32 %7, %7, %10, vcc\n v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9"
+                             : "+v"(a0), "+v"(a1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(m), "v"(c), "v"(it) : "vcc");
+            } else if constexpr (KIND == 22) {  // a compare into vcc followed by the two cndmasks that use it, then an fma (the compiler's select of a double)
+                asm volatile("v_cmp_lt_f64 vcc, %0, %1\n v_cndmask_b32 %4, %4, %10, vcc\n v_cndmask_b32 %5, %5, %10, vcc\n v_fma_f64 %2, %2, %8, %9\n"
+                             "v_cmp_lt_f64 vcc, %1, %0\n v_cndmask_b32 %6, %6, %10, vcc\n v_cndmask_b32 %7, %7, %10, vcc\n v_fma_f64 %3, %3, %8, %9"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(m), "v"(c), "v"(it) : "vcc");
+            } else if constexpr (KIND == 23) {  // FOUR vcc cndmasks in a row (two doubles on one condition: the linear rule's w2 series branch), then four fmas
+                asm volatile("v_cndmask_b32 %4, %4, %10, vcc\n v_cndmask_b32 %5, %5, %10, vcc\n v_cndmask_b32 %6, %6, %10, vcc\n v_cndmask_b32 %7, %7, %10, vcc\n"
+                             "v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(m), "v"(c), "v"(it) : "vcc");
+            } else if constexpr (KIND == 24) {  // six SGPR-mask cndmasks in a row, then two fmas
+                asm volatile("v_cndmask_b32_e64 %2, %2, %10, %11\n v_cndmask_b32_e64 %3, %3, %10, %11\n v_cndmask_b32_e64 %4, %4, %10, %11\n v_cndmask_b32_e64 %5, %5, %10, %11\n"
+                             "v_cndmask_b32_e64 %6, %6, %10, %11\n v_cndmask_b32_e64 %7, %7, %10, %11\n v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9"
+                             : "+v"(a0), "+v"(a1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(m), "v"(c), "v"(it), "s"(0x5555555555555555ull));
             } else if constexpr (KIND == 11) {  // v_fma_f64 with one wave-uniform SGPR operand... same as 0 but literal 0.5
                 asm volatile("v_fma_f64 %0, %0, 0.5, %8\n v_fma_f64 %1, %1, 0.5, %8\n v_fma_f64 %2, %2, 0.5, %8\n v_fma_f64 %3, %3, 0.5, %8\n"
                              "v_fma_f64 %4, %4, 0.5, %8\n v_fma_f64 %5, %5, 0.5, %8\n v_fma_f64 %6, %6, 0.5, %8\n v_fma_f64 %7, %7, 0.5, %8"
@@ -143,13 +167,14 @@ int main()
     hipMalloc(&d_clk, 16 * 256 * 4 * 8 * 4);
     const char* names[] = {"v_fma_f64", "v_mul_f64", "v_add_f64", "v_rcp_f64", "v_cndmask_b32", "v_add_u32", "v_mov_b32_dpp",
                            "v_permlane32_swap", "v_mov_b64", "fma_f64+cndmask (per instr)", "s_mul_i32", "v_fma_f64 (inline const)", "v_cndmask_b32_e64 (sgpr mask)",
-                           "v_ldexp_f64", "v_rndne_f64", "v_cvt_i32_f64", "v_cmp_lt_f64 (sgpr)", "v_min_f64", "v_accvgpr write+read"};
+                           "v_ldexp_f64", "v_rndne_f64", "v_cvt_i32_f64", "v_cmp_lt_f64 (sgpr)", "v_min_f64", "v_accvgpr write+read",
+                           "2 cndmask(vcc) + 2 fma", "2 cndmask(sgpr) + 2 fma", "6 cndmask(vcc) + 2 fma", "cmp->vcc, 2 cndmask(vcc), fma", "4 cndmask(vcc) + 4 fma", "6 cndmask(sgpr) + 2 fma"};
     printf("cycles (at a nominal 2.4 GHz) per wave64 instruction per SIMD; waves per SIMD = 1, 2, 4, 8\n");
     for (int w : {1, 2, 4}) {
-        double r[19], sc[19], gh[19], lo[19], hi[19];
+        double r[25], sc[25], gh[25], lo[25], hi[25];
 #define RUN(i) r[i] = run<i>(w, d_out); sc[i] = g_shader_cyc; gh[i] = g_ghz; lo[i] = g_min; hi[i] = g_max;
-        RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16) RUN(17) RUN(18)
-        for (int i = 0; i < 19; ++i)
+        RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16) RUN(17) RUN(18) RUN(19) RUN(20) RUN(21) RUN(22) RUN(23) RUN(24)
+        for (int i = 0; i < 25; ++i)
             printf("W=%d %-32s wall@2.4GHz %.2f | per wave: shader cycles per own instr avg %.2f (min %.2f max %.2f) -> per SIMD %.2f | clock %.2f GHz\n", w, names[i], r[i],
                    sc[i], lo[i], hi[i], sc[i] / w, gh[i]);
     }
