@@ -653,10 +653,14 @@ lsx_sweep_rs_kernel(const SweepParams p)
         // point m is finished in step m + 1: m < nA first visitor, m = nA (odd Nspace) the midpoint, then second visitor
         const int nA = Ns / 2;
         one(1, std::integral_constant<int, 0>{}, F1{});                              // point 0: the boundary value (depth 1 is already requested... and 2 is now)
-        run(2, nA + 1, std::integral_constant<int, 0>{});
-        if (Ns & 1) one(nA + 1, std::integral_constant<int, 1>{}, F0{});
-        run(nA + 1 + (Ns & 1), Ns - 1, std::integral_constant<int, 2>{});
-        one(Ns - 1, std::integral_constant<int, 2>{}, F2{});                         // finishes point Ns - 2; nothing left to request
+        if (Ns == 3) {
+            one(2, std::integral_constant<int, 1>{}, F2{});                          // three depths: the midpoint's step is the last one, nothing left to request
+        } else {
+            run(2, nA + 1, std::integral_constant<int, 0>{});
+            if (Ns & 1) one(nA + 1, std::integral_constant<int, 1>{}, F0{});
+            run(nA + 1 + (Ns & 1), Ns - 1, std::integral_constant<int, 2>{});
+            one(Ns - 1, std::integral_constant<int, 2>{}, F2{});                     // finishes point Ns - 2; nothing left to request
+        }
         // the end point: the linear rule with its own weights (no downwind neighbour)
         {
             const int mpt = Ns - 1;

@@ -78,3 +78,30 @@ def test_case_meets_the_oracle(hip_lib, oracle_lib, case, mode):
     else:
         assert not serial
     eh.close(); eo.close()
+
+
+@pytest.mark.parametrize('mode', ['lane', 'serial', 'parabolic', 'parabolic-serial'])
+@pytest.mark.parametrize('Ns', [3, 4, 5, 6])
+def test_shallow_columns_meet_the_oracle(hip_lib, oracle_lib, Ns, mode):
+    """the smallest atmospheres lsx_create admits (Nspace >= 3, formal_solver.py:120-139): the first point, the meeting point of the two
+    directions and the end point fall into neighbouring steps -- three depths: the midpoint's step is the last one; four: no midpoint --
+    on every mapping and both rules (the parabolic rule runs one depth behind the opacities: its last request must not leave the column)"""
+    prob, block = ic.build('two_atoms', 33, Ns, False)
+    eh = Engine(prob, 33, lib=hip_lib, sweep_policy='ray-serial' if mode.endswith('serial') else 'ray-per-lane')
+    eo = Engine(prob, 33, lib=oracle_lib)
+    for e in (eh, eo):
+        e.set_columns(0, block)
+        e.set_formal_solver('parabolic' if mode.startswith('parabolic') else 'linear')
+    for it in range(4):
+        dh, do = eh.formal_sol_gamma(), eo.formal_sol_gamma()
+        eI, eJ = relerr(eh.get(_capi.LSX_I), eo.get(_capi.LSX_I)), relerr(eh.get(_capi.LSX_J), eo.get(_capi.LSX_J))
+        off, diag = gamma_err(eh.get(_capi.LSX_GAMMA), eo.get(_capi.LSX_GAMMA), prob)
+        assert eI < 2e-10 and eJ < 2e-10 and off < 1e-10 and diag < 1e-11, (it, eI, eJ, off, diag)
+        assert abs(dh - do) <= 1e-7 * max(abs(do), 1e-3)
+        if it >= 1:
+            ph, po = eh.stat_equil(), eo.stat_equil()
+            assert abs(ph - po) <= 1e-6 * max(abs(po), 1e-3)
+    table, fused = classes_run(hip_lib, eh)
+    serial = {k for k, (_, rs) in table.items() if rs}
+    assert fused == 0 and bool(serial) == mode.endswith('serial')
+    eh.close(); eo.close()
