@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/lsx.h"
@@ -33,6 +34,15 @@ struct SweepClass : lsxd::PlanClass {   // a plan class + what the runtime keeps
     hipEvent_t done = nullptr;
 };
 
+struct FsGraphKey {            // what a captured formal solution's kernel arguments depend on beyond the context's fixed state
+    int jcur; const void* results; int clear_dp, solver, policy, policy_columns; const void* colmask;
+    bool operator==(const FsGraphKey& o) const
+    {
+        return jcur == o.jcur && results == o.results && clear_dp == o.clear_dp && solver == o.solver && policy == o.policy &&
+               policy_columns == o.policy_columns && colmask == o.colmask;
+    }
+};
+
 struct lsx_ctx : lsxd::LsxPlan {        // the plan (lsx_plan.h: dimensions, tables, tile schedule, strides, launch shapes) + device state
     int device = 0;
     hipStream_t stream = nullptr;
@@ -52,6 +62,8 @@ struct lsx_ctx : lsxd::LsxPlan {        // the plan (lsx_plan.h: dimensions, tab
     int *d_tile_slots = nullptr, *d_Nlevel = nullptr, *d_lev2_off = nullptr, *d_fin_ptr = nullptr, *d_fin_idx = nullptr, *d_atom_ptr = nullptr, *d_atom_slots = nullptr;
     bool dp_zeroed = false;          // the Gamma epilogue has zeroed dPcol / the singular flag for the next stat_equil
     bool opt_finish_big = false;     // LSX_FINISH_BIG=1: the many-column Gamma epilogue also for small batches (tests)
+    bool opt_graph = false;          // LSX_GRAPH=1: a formal solution's launches as a captured HIP graph (enqueue_fs; measurement)
+    std::vector<std::pair<FsGraphKey, hipGraphExec_t>> fs_graphs;
     bool opt_fused_epilogue = false; // LSX_FUSED_EPILOGUE=1: the fused launch also runs its fast tiles' Gamma epilogue (measured: slower, see enqueue_fs)
     int opt_abl_fast = 0;            // LSX_ABL_FUSED_FAST: timing ablations of the fused launch's fast-continuum work
     bool opt_no_fused_fast = false;  // LSX_NO_FUSED_FAST=1: small batches launch the fast-continuum kernels around the fused sweep (tests)

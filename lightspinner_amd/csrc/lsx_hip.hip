@@ -1138,6 +1138,7 @@ void lsx_destroy(lsx_ctx* c)
         if (k.d_fast_rest) (void)hipFree(k.d_fast_rest);
         if (k.stream) { (void)hipStreamSynchronize(k.stream); (void)hipStreamDestroy(k.stream); }
     }
+    for (auto& g : c->fs_graphs) if (g.second) (void)hipGraphExecDestroy(g.second);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (hipEvent_t e : {c->ev0, c->ev1, c->ev2})
         if (e) (void)hipEventDestroy(e);
@@ -1211,6 +1212,7 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
     c->opt_finish_big = getenv("LSX_FINISH_BIG") != nullptr;      // the many-column Gamma epilogue also for small batches
     c->opt_abl_fast = getenv("LSX_ABL_FUSED_FAST") ? atoi(getenv("LSX_ABL_FUSED_FAST")) & 6 : 0;
     c->opt_fused_epilogue = getenv("LSX_FUSED_EPILOGUE") != nullptr;
+    c->opt_graph = getenv("LSX_GRAPH") != nullptr;
     c->opt_no_fused_fast = getenv("LSX_NO_FUSED_FAST") != nullptr; // small batches: the fast-continuum kernels as launches of their own (tests)
     const int Ns = c->Nspace, Nspect = c->Nspect;
     double work_total = 0.0, work_seen = 0.0;
@@ -1564,6 +1566,24 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
     const bool parabolic = c->solver == LSX_SOLVER_PARABOLIC;
     const bool ray_serial = !parabolic && use_ray_serial(c);
     const bool ray_serial_par = parabolic && use_ray_serial(c);
+    const int clear_dp = (c->se_pending && !speculative) ? 0 : 1;
+    // LSX_GRAPH=1 (measurement): the launches of a call -- fork, the classes' chains on their streams, join, Gamma epilogue -- captured
+    // once per (J buffer parity, result buffers, epilogue flavour, rule, mapping, column mask) as a HIP graph and replayed with ONE host
+    // call: the host's enqueue time of a dozen launches on five streams is then not what staggers the classes' starts
+    hipGraphExec_t gexec = nullptr;
+    bool capturing = false;
+    const FsGraphKey gkey{c->jcur, (const void*)c->d_I, clear_dp, (int)c->solver, (int)c->sweep_policy, c->policy_columns, (const void*)c->d_colmask};
+    if (c->opt_graph && !timed) {
+        for (auto& g : c->fs_graphs) if (g.first == gkey) gexec = g.second;
+        if (!gexec) {
+            note(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+            capturing = lerr == hipSuccess;
+        }
+    }
+    if (gexec) {
+        if (!per_class_launches(c)) c->fused_launches++;
+        else for (auto& k : c->classes) k.launches++;
+    } else {
     if (!per_class_launches(c)) {
         p.ncell_lev = S.fused_ncell_lev; p.ncell_atom = S.fused_ncell_atom;
         c->fused_launches++;
@@ -1638,13 +1658,22 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
     // `FS; SE; FS; sync` (and `SE; formal_sol_gamma(&dJ)`): the statistical equilibrium's per-column maxima and its singular flag
     // have not been read back yet -- they live in the block this epilogue would clear.  Then the epilogue leaves them alone and
     // the next stat_equil clears them itself.  (A speculative call writes the second block: nothing pending there.)
-    f.clear_dp = (c->se_pending && !speculative) ? 0 : 1;
+    f.clear_dp = clear_dp;
     const long nthreads = (long)c->ncol * c->Nspace;
     if (c->ncol < 32 && !c->opt_finish_big)
         hipLaunchKernelGGL(k_gamma_finish_small, dim3((unsigned)nthreads), dim3(64), (size_t)c->NL2tot * sizeof(double), c->stream, f);
     else
         hipLaunchKernelGGL(k_gamma_finish, dim3((unsigned)((nthreads + S.finish_nt - 1) / S.finish_nt), (unsigned)c->Natoms), dim3(S.finish_nt), S.finish_lds, c->stream, f);
-    c->dp_zeroed = f.clear_dp != 0;
+    }   // (!gexec)
+    if (capturing) {
+        hipGraph_t g = nullptr;
+        note(hipStreamEndCapture(c->stream, &g));
+        if (lerr == hipSuccess) note(hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0));
+        if (g) (void)hipGraphDestroy(g);
+        if (lerr == hipSuccess) c->fs_graphs.emplace_back(gkey, gexec);
+    }
+    if (gexec) note(hipGraphLaunch(gexec, c->stream));
+    c->dp_zeroed = clear_dp != 0;
     note(hipGetLastError());
     if (timed) note(hipEventRecord(c->ev2, c->stream));
     c->jcur ^= 1;

@@ -278,3 +278,43 @@ def test_fused_launch_runs_the_fast_continuum_work_itself_with_the_same_bits(hip
         for a, b in zip(out[0][0], other[0]):
             assert np.array_equal(a, b)
         assert out[0][1] == other[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,ncol', [('falc_ca.npz', 1), ('falc_cah.npz', 40)])
+def test_formal_solution_replayed_as_a_captured_graph_gives_the_same_bits(hip_lib, monkeypatch, name, ncol):
+    """LSX_GRAPH=1 (a measurement switch): the launches of a formal solution -- fork, the classes' chains on their streams,
+    join, Gamma epilogue -- are captured once per (J buffer parity, result buffers, epilogue flavour, rule, mapping, mask) and replayed
+    as a HIP graph.  The same kernels with the same arguments: J, I, Gamma, populations and monitors bit for bit, through the
+    synchronous calls, the enqueue-only sequence FS; SE; FS; sync, a frozen column and a change of rule."""
+    prob, base, raw = fixtures.load_problem_npz(golden(name), phi_compact=False)
+    blk, prof = synth.perturbed_columns(prob, base, raw, ncol=ncol, seed=31, vlos_sigma=1.5e3)
+    out = []
+    for leg in ('eager', 'graph'):
+        if leg == 'graph':
+            monkeypatch.setenv('LSX_GRAPH', '1')
+        else:
+            monkeypatch.delenv('LSX_GRAPH', raising=False)
+        e = Engine(prob, ncol, lib=hip_lib)
+        synth.load_columns(e, blk, prof)
+        mon = []
+        for it in range(5):
+            mon.append(e.formal_sol_gamma())
+            if it >= 2:
+                mon.append(e.stat_equil())
+        e.formal_sol_gamma_async(); e.stat_equil_async(); e.formal_sol_gamma_async()
+        mon.append(e.sync())
+        if ncol > 1:
+            e.set_active_columns(np.arange(ncol) % 2 == 0)
+            mon.append(e.formal_sol_gamma()); mon.append(e.stat_equil())
+            e.set_active_columns(None)
+        e.set_formal_solver('parabolic')
+        mon.append(e.formal_sol_gamma())
+        e.set_formal_solver('linear')
+        mon.append(e.formal_sol_gamma())
+        out.append((mon, [e.get(w) for w in (_capi.LSX_J, _capi.LSX_I, _capi.LSX_N, _capi.LSX_GAMMA, _capi.LSX_DJ_COL, _capi.LSX_DPOPS_COL)]))
+        e.close()
+    (m0, a0), (m1, a1) = out
+    assert repr(m0) == repr(m1)
+    for x, y in zip(a0, a1):
+        assert np.array_equal(x, y)
