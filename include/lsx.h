@@ -397,8 +397,9 @@ int lsx_set_formal_solver(lsx_ctx* ctx, int32_t solver);
  * lane walks the five rays of one wavelength, five columns per wavefront).  They compute the same terms and associate the
  * angle / wavelength sums differently: results agree to rounding (1e-13), not bit for bit.  Which one pays depends on how many
  * columns there are, so LSX_SWEEP_AUTO decides by a column count: ray-serial from 160 columns on (if the context's shape
- * admits it: five rays, wavelength-independent scattering), else one ray per lane; the parabolic rule (below) likewise takes its
- * compile-time tile classes from 32 columns on and its generic instance below.
+ * admits it: five rays, wavelength-independent scattering), else one ray per lane; the parabolic rule (above) likewise takes its
+ * compile-time tile classes from 32 columns on and its generic instance below, and from 160 columns on the ray-serial instances it
+ * has for tiles of at most one line (the other classes stay on one ray per lane).
  * `decide_for_columns` is that count: 0 = the context's own columns (the default), > 0 = decide as for a context of that many
  * columns.  A driver that shards N columns over several contexts (ranks, GPUs, sub-batches) passes N to every one of them: every
  * column then gets the bits it gets when all N sit in one context, whatever the shard sizes (tests/test_sharding_invariance.py).
@@ -406,7 +407,8 @@ int lsx_set_formal_solver(lsx_ctx* ctx, int32_t solver);
  * admit the ray-serial kernel).  Takes effect from the next formal solution on.  The oracle accepts and ignores the call. */
 enum { LSX_SWEEP_AUTO = 0, LSX_SWEEP_RAY_PER_LANE = 1, LSX_SWEEP_RAY_SERIAL = 2 };
 int lsx_set_sweep_policy(lsx_ctx* ctx, int32_t policy, int32_t decide_for_columns);
-/* the mapping the next (linear-rule) formal solution will use: LSX_SWEEP_RAY_PER_LANE or LSX_SWEEP_RAY_SERIAL; the oracle: 0 */
+/* the mapping the policy selects for the next formal solution: LSX_SWEEP_RAY_PER_LANE or LSX_SWEEP_RAY_SERIAL (under either rule: the
+ * classes that have an instance of the rule on that mapping use it); the oracle: 0 */
 int32_t lsx_sweep_policy(const lsx_ctx* ctx);
 
 /* Measurement hooks (bench.py): time `reps` back-to-back FS calls with device events

@@ -259,7 +259,8 @@ class Engine:
         self.lib.check(self.lib.dll.lsx_set_sweep_policy(self._h, kind, int(decide_for_columns or 0)))
 
     def sweep_policy(self) -> str:
-        """the mapping the next linear-rule formal solution runs ('oracle' for the CPU restatement, which has one code path)"""
+        """the mapping the next formal solution runs -- under the parabolic rule: for the classes that have a ray-serial instance of it
+        ('oracle' for the CPU restatement, which has one code path)"""
         return {0: 'oracle', 1: 'ray-per-lane', 2: 'ray-serial'}[int(self.lib.dll.lsx_sweep_policy(self._h))]
 
     def set_active_columns(self, mask=None):
