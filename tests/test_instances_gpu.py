@@ -105,3 +105,23 @@ def test_shallow_columns_meet_the_oracle(hip_lib, oracle_lib, Ns, mode):
     serial = {k for k, (_, rs) in table.items() if rs}
     assert fused == 0 and bool(serial) == mode.endswith('serial')
     eh.close(); eo.close()
+
+
+@pytest.mark.parametrize('ncol', [3, 40])
+def test_atom_without_radiative_transitions(hip_lib, oracle_lib, ncol):
+    """three atoms, the middle one with collisions only: its Gamma is its C with the diagonal of rh_method.py:698-703 -- the Gamma epilogue
+    runs per (column, depth, atom) and that atom's slot list is empty (fewer than 32 columns: the small-batch epilogue)"""
+    from toy import spec_problem
+    atoms = [(3, [('l', 0, 1, 0.1, 0.5), ('c', 1, 2, 0.0, 0.3)]), (2, []), (3, [('l', 0, 2, 0.4, 0.9), ('c', 0, 2, 0.0, 0.2)])]
+    prob, block = spec_problem(atoms, seed=5, Nspace=30, Nrays=5, Nspect=200, ncol=ncol)
+    eh, eo = Engine(prob, ncol, lib=hip_lib), Engine(prob, ncol, lib=oracle_lib)
+    for e in (eh, eo):
+        e.set_columns(0, block)
+    for it in range(4):
+        dh, do = eh.formal_sol_gamma(), eo.formal_sol_gamma()
+        off, diag = gamma_err(eh.get(_capi.LSX_GAMMA), eo.get(_capi.LSX_GAMMA), prob)
+        assert abs(dh - do) <= 1e-9 * max(abs(do), 1e-3) and off < 1e-10 and diag < 1e-11
+        ph, po = eh.stat_equil(), eo.stat_equil()
+        assert abs(ph - po) <= 1e-6 * max(abs(po), 1e-3)
+    assert relerr(eh.get(_capi.LSX_N), eo.get(_capi.LSX_N)) < 1e-9
+    eh.close(); eo.close()
