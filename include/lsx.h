@@ -411,6 +411,26 @@ int lsx_set_sweep_policy(lsx_ctx* ctx, int32_t policy, int32_t decide_for_column
  * classes that have an instance of the rule on that mapping use it); the oracle: 0 */
 int32_t lsx_sweep_policy(const lsx_ctx* ctx);
 
+/* ---- explicit options (round 5) --------------------------------------------------------------------------------------------
+ * The HIP library's plan (tile schedule, linked continua, which classes have a ray-serial instance, ...) and a few runtime
+ * choices can be steered.  Until round 4 that was possible through LSX_* environment variables only, read inside lsx_create:
+ * a sharded job whose ranks differ in their environment would silently associate its sums differently per rank.  Now
+ *   - lsx_create_with_options takes an explicit list "key=value,key=value" (NULL or "" = lsx_create).  Keys that change the
+ *     association of a sum: linked=0|1 (continua of a line's atom outside the sweep), tiler=dp|natural, topo=0|1, fast_rows=0|1,
+ *     rs=0|1 (ray-serial instances at all), rs_min_columns=N (LSX_SWEEP_AUTO's threshold), rs_max_npt=0..2; launch shape and
+ *     measurement only (same bits, tested): order=plan|cost, occ_wg=N, phi_group=0|1, se_lds, serial, finish_big, fused_epilogue,
+ *     graph, fused_fast (each 0|1), trace_classes.  Unknown keys / malformed values: LSX_EINVAL.  The LSX_* environment variables
+ *     of rounds 1-4 remain as diagnostic DEFAULTS that an explicit entry overrides;
+ *   - lsx_effective_options writes what the context ended up with, plus the rule, the sweep mapping the policy selects and the
+ *     plan's class list, as one "key=value;..." string (LSX_EINVAL if `n` is too small: 1024 bytes are enough for any context);
+ *   - lsx_options_signature is a 64-bit hash of that string.  Contexts with equal signatures on equal problems give every column
+ *     the same bits; a multi-process driver exchanges the signatures once and refuses to start on a mismatch
+ *     (lightspinner_amd/parallel.py, check_same_options).
+ * The oracle accepts any well-formed list, ignores it and reports "backend=oracle-c". */
+int lsx_create_with_options(const lsx_problem* desc, int32_t ncol, int32_t device, void* stream, const char* options, lsx_ctx** out);
+int lsx_effective_options(const lsx_ctx* ctx, char* buf, size_t n);
+uint64_t lsx_options_signature(const lsx_ctx* ctx);
+
 /* Measurement hooks (bench.py): time `reps` back-to-back FS calls with device events
  * on the context's stream.  ms_total = whole FS call (all kernels), ms_sweep = the
  * dominant sweep kernel(s) alone, both averaged per call. */

@@ -45,6 +45,7 @@ struct FsGraphKey {            // what a captured formal solution's kernel argum
 
 struct lsx_ctx : lsxd::LsxPlan {        // the plan (lsx_plan.h: dimensions, tables, tile schedule, strides, launch shapes) + device state
     int device = 0;
+    lsxd::CtxOptions options;       // what lsx_create_with_options ended up with (environment defaults + explicit list)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int ncol = 0;
@@ -89,6 +90,8 @@ struct lsx_ctx : lsxd::LsxPlan {        // the plan (lsx_plan.h: dimensions, tab
     double* d_voigt_w = nullptr;
     double *d_muz = nullptr, *d_wmu = nullptr;
     double* d_nsr = nullptr;     // [col][Ncont][k] nStar_i / nStar_j of the continua
+    double* d_optab = nullptr;   // ray-serial sweep: per-depth operands per (column group, transition) + geometry (lsx_plan.h), made on first use
+    int* d_trans_row = nullptr;  // per transition: row of wphi / nsr
     double* d_debug = nullptr;   // 64 x 16 x 8 B, diagnostic builds of the sweep kernel write stamps here
     int jcur = 0; // d_J[jcur] holds the current J (Jdag of the next call)
     // set-up chain (lsx_setup.hip): atomic data tables and what lsx_set_atmosphere derives per column

@@ -164,6 +164,10 @@ struct SweepParams {
     int32_t phi_G;              // columns per group of the line-profile store (phi_elem below): 5 where the ray-serial sweep can run, else 1
     int32_t fused_fast;         // fused small-batch launch: the workgroup of a tile with fast continua runs the tile's pre-pass before and
     int32_t nF_max;             // its Gamma epilogue after the sweep itself (lsx_fast.h); nF_max: the pre-pass's LDS layout
+    // ray-serial sweep: the per-depth operands of every transition and the geometry, per group of five columns (lsx_plan.h,
+    // "a RING in LDS"): optab[group]{[t < Ntrans][r <= Nspace][c < 5][3], [r <= Nspace][c < 5][2]}, rebuilt per formal solution
+    const double* optab;
+    int64_t optab_group_stride; // doubles per group
 };
 
 // ---- the line-profile store phi_T --------------------------------------------------------------------------------------------

@@ -249,6 +249,60 @@ __global__ void k_build_nsr(const double* __restrict__ nStar, double* __restrict
     }
 }
 
+// The ray-serial sweep's operand table (lsx_plan.h, "a RING in LDS"): per group of five columns and transition the three per-depth
+// numbers a slot of that transition needs -- lines: cB (n_i - g n_j) (rh_method.py:279-280, 613), n_j Uc (:281, 614), wphi (:451);
+// continua: n_i, n_j, nStar_i / nStar_j (:453) -- and per group the geometry: half length of the interval above the depth, scattering
+// coefficient.  Row Nspace of every block is zero.  A group's missing columns (the last group of a batch) repeat its last one.
+// One block per (group, transition | geometry); rebuilt at the start of every formal solution that runs ray-serial classes (the
+// populations change with every statistical equilibrium): 50 kB per column for FALC Ca+H, written once and read by the sweeps.
+struct OptabParams {
+    int Ns, Ntrans, ncol, NLtot, Nlines, Ncont;
+    const DevTrans* trans;
+    const int* trans_row;
+    const double *n, *wphi, *nsr, *height, *sca;
+    double* optab;
+    size_t gstride;
+};
+__global__ void k_build_optab(const OptabParams p)
+{
+    const int g = blockIdx.x, t = blockIdx.y, Ns = p.Ns;
+    constexpr int NC = LSX_RS_COLS;
+    const int ncg = min(NC, p.ncol - g * NC);
+    double* const grp = p.optab + (size_t)g * p.gstride;
+    if (t < p.Ntrans) {
+        const DevTrans tr = p.trans[t];
+        const double Uc = tr.AB * (tr.gij * tr.cB);               // DevSlot.Uc (lsx_plan.cpp)
+        double* const blk = grp + (size_t)t * (Ns + 1) * (3 * NC);
+        for (int e = threadIdx.x; e < (Ns + 1) * NC; e += blockDim.x) {
+            const int r = e / NC, c = e - r * NC;
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+            if (r < Ns) {
+                const size_t col = (size_t)g * NC + (c < ncg ? c : ncg - 1);
+                const double ni = p.n[(col * p.NLtot + tr.li) * Ns + r], nj = p.n[(col * p.NLtot + tr.lj) * Ns + r];
+                if (tr.is_line) {
+                    v0 = tr.cB * (ni - tr.gij * nj);
+                    v1 = nj * Uc;
+                    v2 = p.wphi[(col * p.Nlines + p.trans_row[t]) * Ns + r];
+                } else {
+                    v0 = ni;
+                    v1 = nj;
+                    v2 = p.nsr[(col * p.Ncont + p.trans_row[t]) * Ns + r];
+                }
+            }
+            blk[(size_t)e * 3 + 0] = v0; blk[(size_t)e * 3 + 1] = v1; blk[(size_t)e * 3 + 2] = v2;
+        }
+    } else {
+        double* const blk = grp + (size_t)p.Ntrans * (Ns + 1) * (3 * NC);
+        for (int e = threadIdx.x; e < (Ns + 1) * NC; e += blockDim.x) {
+            const int r = e / NC, c = e - r * NC;
+            const size_t col = (size_t)g * NC + (c < ncg ? c : ncg - 1);
+            const double* z = p.height + col * Ns;
+            blk[(size_t)e * 2 + 0] = (r > 0 && r < Ns) ? 0.5 * fabs(z[r - 1] - z[r]) : 0.0;
+            blk[(size_t)e * 2 + 1] = r < Ns ? p.sca[col * Ns + r] : 0.0;
+        }
+    }
+}
+
 // [col][la][k] (reference layout)  <->  [col][tile][k][j<L] (tile-major streams); unused j are zero
 __global__ void k_tiles_pack(const double* __restrict__ in, double* __restrict__ out, const DevTile* __restrict__ tiles,
                              int ntile, int L, int Ns, int Nspect, bool unpack)
@@ -1124,7 +1178,7 @@ void lsx_destroy(lsx_ctx* c)
                     c->d_tiles, c->d_slots, c->d_tile_slots, c->d_fin_ptr, c->d_fin_idx, c->d_atom_ptr, c->d_atom_slots, c->d_Nlevel, c->d_lev2_off, c->d_height,
                     c->d_temperature, c->d_nStar, c->d_nTotal, c->d_n, c->d_C, c->d_Gamma, c->d_wphi, c->d_bgchi,
                     c->d_bgeta, c->d_sca, c->d_phi, c->d_E, c->d_corr, c->d_Psi3, c->d_J[0], c->d_J[1], c->d_I, c->d_Gpart, c->d_dJpart,
-                    c->d_res, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_fast_cols[0], c->d_fast_cols[1], c->d_fast_cols[2], c->d_fast_cols[3], c->d_fast_rest, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab, c->d_voigt_w, c->d_muz, c->d_wmu,
+                    c->d_res, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_fast_cols[0], c->d_fast_cols[1], c->d_fast_cols[2], c->d_fast_cols[3], c->d_fast_rest, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab, c->d_voigt_w, c->d_muz, c->d_wmu, c->d_optab, c->d_trans_row,
                     c->d_sa_atoms, c->d_sa_lines, c->d_sa_colls, c->d_sa_spl, c->d_sa_levE, c->d_sa_levg, c->d_sa_levnD, c->d_sa_levdZ,
                     c->d_vBroad, c->d_aDamp};
     for (void* p : ptrs)
@@ -1154,24 +1208,25 @@ void lsx_destroy(lsx_ctx* c)
 
 int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream, lsx_ctx** out)
 {
+    return lsx_create_with_options(d, ncol, device, stream, nullptr, out);
+}
+
+int lsx_create_with_options(const lsx_problem* d, int32_t ncol, int32_t device, void* stream, const char* options, lsx_ctx** out)
+{
     if (!d || !out || ncol < 1) return fail(LSX_EINVAL, "lsx_create: null argument or ncol < 1");
     if (ncol > 65535) return fail(LSX_EUNSUPPORTED, "lsx_create: at most 65535 columns per context (the column is a grid dimension); use several contexts");
     // ---- the plan (lsx_plan.cpp, host only): descriptor checks, transition tables, tile schedule, slot table, sweep classes,
     // strides, LDS sizes and launch shapes.  Nothing below can fail on the problem's shape any more.
-    PlanOptions opt;
-    {   // diagnostic switches; the environment is read here only
-        const char* e;
-        opt.no_linked = getenv("LSX_NO_LINKED") != nullptr;
-        opt.natural_tiles = (e = getenv("LSX_TILER")) && std::string(e) == "natural";
-        opt.no_topo = getenv("LSX_NO_TOPO") != nullptr;
-        opt.fast_rows = getenv("LSX_FAST_ROWS") != nullptr;
-        opt.order_by_cost = (e = getenv("LSX_ORDER")) && std::string(e) == "cost";
-        opt.occ_wg = (e = getenv("LSX_OCC_WG")) ? atoi(e) : 0;
-        opt.no_rs = getenv("LSX_NO_RS") != nullptr;
-        opt.no_phi_group = (e = getenv("LSX_PHI_GROUP")) && atoi(e) == 1;
-        if ((e = getenv("LSX_RS_MIN_COLUMNS"))) opt.rs_min_columns = atoi(e);
-        if ((e = getenv("LSX_RS_MAX_NPT"))) opt.rs_max_npt = atoi(e);
+    // Switches: the LSX_* environment variables are diagnostic DEFAULTS, read here only (lsx_plan.cpp, options_from_env); an explicit
+    // `options` list overrides them entry by entry; what the context ended up with is reported by lsx_effective_options.
+    CtxOptions copt;
+    options_from_env(&copt);
+    {
+        std::string oerr;
+        const int orc = options_apply(options, &copt, &oerr);
+        if (orc) return fail(orc, "lsx_create_with_options: %s", oerr.c_str());
     }
+    const PlanOptions& opt = copt.plan;
     LsxPlan plan;
     {
         std::string perr;
@@ -1201,19 +1256,20 @@ int lsx_create(const lsx_problem* d, int32_t ncol, int32_t device, void* stream,
         if (e != hipSuccess) { delete c; return fail(LSX_EDEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
         c->own_stream = true;
     }
-    c->opt_se_lds = getenv("LSX_SE_LDS") != nullptr;
-    c->opt_trace_classes = getenv("LSX_TRACE_CLASSES") != nullptr;
+    c->options = copt;
+    c->opt_se_lds = copt.run.se_lds;
+    c->opt_trace_classes = copt.run.trace_classes;
     if (c->opt_trace_classes) {
         const char* q = getenv("GPU_MAX_HW_QUEUES");
         fprintf(stderr, "lsx_create: GPU_MAX_HW_QUEUES=%s at this point (%zu tile classes, each on a stream of its own; the runtime read the "
                         "variable at the process's first HIP call)\n", q ? q : "(unset: the runtime's default of 4)", c->plan_classes.size());
     }
-    c->opt_serial = getenv("LSX_SERIAL") != nullptr;              // every class on the context's stream, one after the other
-    c->opt_finish_big = getenv("LSX_FINISH_BIG") != nullptr;      // the many-column Gamma epilogue also for small batches
-    c->opt_abl_fast = getenv("LSX_ABL_FUSED_FAST") ? atoi(getenv("LSX_ABL_FUSED_FAST")) & 6 : 0;
-    c->opt_fused_epilogue = getenv("LSX_FUSED_EPILOGUE") != nullptr;
-    c->opt_graph = getenv("LSX_GRAPH") != nullptr;
-    c->opt_no_fused_fast = getenv("LSX_NO_FUSED_FAST") != nullptr; // small batches: the fast-continuum kernels as launches of their own (tests)
+    c->opt_serial = copt.run.serial;                    // every class on the context's stream, one after the other
+    c->opt_finish_big = copt.run.finish_big;            // the many-column Gamma epilogue also for small batches
+    c->opt_abl_fast = copt.run.abl_fast;
+    c->opt_fused_epilogue = copt.run.fused_epilogue;
+    c->opt_graph = copt.run.graph;
+    c->opt_no_fused_fast = copt.run.no_fused_fast;      // small batches: the fast-continuum kernels as launches of their own (tests)
     const int Ns = c->Nspace, Nspect = c->Nspect;
     double work_total = 0.0, work_seen = 0.0;
     for (auto& k : c->classes) work_total += k.work;
@@ -1485,7 +1541,17 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
         c->spec_last_dJ = c->last_dJ;
     }
     c->spec_valid = speculative;
+    // the ray-serial classes read their per-depth operands from a table that is rebuilt per call (k_build_optab): made on first use
+    bool rs_any = false;
+    if (use_ray_serial(c) && per_class_launches(c))
+        for (auto& k : c->classes) rs_any = rs_any || (c->solver == LSX_SOLVER_PARABOLIC ? k.rsp : k.rs);
+    if (rs_any && !c->d_optab) {
+        int rc = dmalloc(&c->d_optab, (size_t)((c->ncol + LSX_RS_COLS - 1) / LSX_RS_COLS) * lsx_optab_group_doubles(c->Ntrans, c->Nspace));
+        if (!rc) rc = upload(&c->d_trans_row, c->trans_row, c->stream);
+        if (rc) return rc;
+    }
     SweepParams p{};
+    p.optab = c->d_optab; p.optab_group_stride = (int64_t)lsx_optab_group_doubles(c->Ntrans, c->Nspace);
     p.Nspace = c->Nspace; p.Nrays = c->Nrays; p.Nspect = c->Nspect; p.Natoms = c->Natoms; p.Ntrans = c->Ntrans;
     p.ncol = c->ncol; p.NLtot = c->NLtot; p.NL2tot = c->NL2tot; p.Nlines = c->Nlines;
     p.sca_per_lambda = c->sca_per_lambda; p.phi_compact = c->phi_compact;
@@ -1561,6 +1627,13 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
     hipError_t lerr = hipSuccess;
     auto note = [&](hipError_t e) { if (e != hipSuccess && lerr == hipSuccess) lerr = e; };
     if (timed) note(hipEventRecord(c->ev0, c->stream));
+    if (rs_any) {
+        OptabParams op{};
+        op.Ns = c->Nspace; op.Ntrans = c->Ntrans; op.ncol = c->ncol; op.NLtot = c->NLtot; op.Nlines = c->Nlines; op.Ncont = c->Ncont;
+        op.trans = c->d_trans; op.trans_row = c->d_trans_row; op.n = c->d_n; op.wphi = c->d_wphi; op.nsr = c->d_nsr; op.height = c->d_height;
+        op.sca = c->d_sca; op.optab = c->d_optab; op.gstride = lsx_optab_group_doubles(c->Ntrans, c->Nspace);
+        hipLaunchKernelGGL(k_build_optab, dim3((unsigned)((c->ncol + LSX_RS_COLS - 1) / LSX_RS_COLS), (unsigned)(c->Ntrans + 1)), dim3(128), 0, c->stream, op);
+    }
     // small batches: one fused launch (n_class_tiles == ntile, identity tile list is not needed); the parabolic rule (N4) has one
     // generic instance for every tile and takes the same route at any size
     const bool parabolic = c->solver == LSX_SOLVER_PARABOLIC;
@@ -2149,6 +2222,32 @@ int lsx_set_sweep_policy(lsx_ctx* c, int32_t policy, int32_t decide_for_columns)
 int32_t lsx_sweep_policy(const lsx_ctx* c)
 {
     return c && use_ray_serial(c) ? LSX_SWEEP_RAY_SERIAL : LSX_SWEEP_RAY_PER_LANE;
+}
+
+// the canonical description of everything that decides how this context associates its sums and launches its kernels
+static std::string effective_options(const lsx_ctx* c)
+{
+    std::string s = "backend=hip-gfx950;";
+    s += options_string(c->options);
+    s += c->solver == LSX_SOLVER_PARABOLIC ? ";solver=parabolic" : ";solver=linear";
+    s += use_ray_serial(c) ? ";mapping=ray-serial" : ";mapping=ray-per-lane";
+    if (c->solver == LSX_SOLVER_PARABOLIC) s += per_class_launches(c) ? ";parabolic=classes" : ";parabolic=generic";
+    s += ";classes=" + plan_class_string(*c);
+    return s;
+}
+
+int lsx_effective_options(const lsx_ctx* c, char* buf, size_t n)
+{
+    if (!c || !buf || n == 0) return fail(LSX_EINVAL, "lsx_effective_options: bad argument");
+    const std::string s = effective_options(c);
+    if (s.size() + 1 > n) return fail(LSX_EINVAL, "lsx_effective_options: %zu bytes needed", s.size() + 1);
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return LSX_OK;
+}
+
+uint64_t lsx_options_signature(const lsx_ctx* c)
+{
+    return c ? fnv1a64(effective_options(c)) : 0;
 }
 
 int lsx_set_formal_solver(lsx_ctx* c, int32_t solver)

@@ -11,7 +11,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <string>
 
 namespace lsxd {
 namespace {
@@ -184,6 +186,8 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
     P.Ncont = 0;
     for (int t = 0; t < P.Ntrans; ++t)
         if (!P.htrans[t].is_line) cont_index[t] = P.Ncont++;
+    P.trans_row.assign(P.Ntrans, 0);
+    for (int t = 0; t < P.Ntrans; ++t) P.trans_row[t] = P.htrans[t].is_line ? P.htrans[t].line_idx : cont_index[t];
     for (size_t ic = 0; ic + 1 < cuts.size(); ++ic) {
         const int la0 = cuts[ic];
         DevTile tl{};
@@ -372,7 +376,7 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
         if (npt >= 0) P.static_max = std::max(P.static_max, npt);
         PlanClass* k = nullptr;
         for (auto& q : P.plan_classes)
-            if (q.npt == npt && q.nl == nl && q.linked == lk && q.topo == topo) k = &q;
+            if (q.npt == npt && q.nl == nl && q.linked == lk && q.topo == topo && (opt.class_chunk <= 0 || (int)q.tiles.size() < opt.class_chunk)) k = &q;
         if (!k) { P.plan_classes.push_back(PlanClass()); k = &P.plan_classes.back(); k->npt = npt; k->nl = nl; k->linked = lk; k->topo = topo; }
         k->tiles.push_back((int)P.tiles.size());
         if (tl.nF > 0) {
@@ -441,8 +445,10 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
     // ---- ray-serial sweep: five columns per wavefront, addressed as one base + 32-bit byte offsets
     {
         const size_t big = std::max(std::max(P.til_col, P.phi_col), std::max(std::max(P.corr_col, P.pp_col), (size_t)std::max(P.NLtot, std::max(P.Nlines, P.Ncont)) * Ns));
+        // (round 5: the per-depth operands come through a ring in LDS, lsx_plan.h -- no limit on the depth count any more; the table
+        // that feeds it is addressed with 32-bit byte offsets inside a column group)
         P.rs_ok = !opt.no_rs && P.Nrays == LSX_RS_RAYS && !P.sca_per_lambda && (LSX_RS_COLS + 1) * big * 8 < 0xffffffffull &&
-                  (size_t)lsx_rs_lds_doubles(2, Ns) * sizeof(double) <= 64 * 1024;      // (the operand table of a two-slot tile fits)
+                  lsx_optab_group_doubles(P.Ntrans, Ns) * 8 < 0xffffffffull;
         P.rs_min_columns = opt.rs_min_columns;
         P.phi_group = (P.rs_ok && !opt.no_phi_group) ? LSX_RS_COLS : 1;
         for (auto& k : P.plan_classes) {
@@ -523,6 +529,130 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
         }
     }
     return LSX_OK;
+}
+
+} // namespace lsxd
+
+// ---- options (lsx_plan.h): environment defaults, explicit list, canonical string -----------------------------------
+namespace lsxd {
+
+void options_from_env(CtxOptions* o)
+{
+    const char* e;
+    PlanOptions& p = o->plan;
+    RunOptions& r = o->run;
+    p.no_linked = getenv("LSX_NO_LINKED") != nullptr;
+    p.natural_tiles = (e = getenv("LSX_TILER")) && std::string(e) == "natural";
+    p.no_topo = getenv("LSX_NO_TOPO") != nullptr;
+    p.fast_rows = getenv("LSX_FAST_ROWS") != nullptr;
+    p.order_by_cost = (e = getenv("LSX_ORDER")) && std::string(e) == "cost";
+    p.occ_wg = (e = getenv("LSX_OCC_WG")) ? atoi(e) : 0;
+    p.no_rs = getenv("LSX_NO_RS") != nullptr;
+    p.no_phi_group = (e = getenv("LSX_PHI_GROUP")) && atoi(e) == 1;
+    if ((e = getenv("LSX_RS_MIN_COLUMNS"))) p.rs_min_columns = atoi(e);
+    if ((e = getenv("LSX_RS_MAX_NPT"))) p.rs_max_npt = atoi(e);
+    if ((e = getenv("LSX_CLASS_CHUNK"))) p.class_chunk = atoi(e);
+    r.se_lds = getenv("LSX_SE_LDS") != nullptr;
+    r.trace_classes = getenv("LSX_TRACE_CLASSES") != nullptr;
+    r.serial = getenv("LSX_SERIAL") != nullptr;
+    r.finish_big = getenv("LSX_FINISH_BIG") != nullptr;
+    r.abl_fast = (e = getenv("LSX_ABL_FUSED_FAST")) ? atoi(e) & 6 : 0;
+    r.fused_epilogue = getenv("LSX_FUSED_EPILOGUE") != nullptr;
+    r.graph = getenv("LSX_GRAPH") != nullptr;
+    r.no_fused_fast = getenv("LSX_NO_FUSED_FAST") != nullptr;
+}
+
+int options_apply(const char* list, CtxOptions* o, std::string* err)
+{
+    if (!list) return LSX_OK;
+    PlanOptions& p = o->plan;
+    RunOptions& r = o->run;
+    std::string s(list);
+    size_t pos = 0;
+    while (pos < s.size()) {
+        size_t end = s.find_first_of(",;", pos);
+        if (end == std::string::npos) end = s.size();
+        std::string kv = s.substr(pos, end - pos);
+        pos = end + 1;
+        while (!kv.empty() && kv.front() == ' ') kv.erase(kv.begin());
+        while (!kv.empty() && kv.back() == ' ') kv.pop_back();
+        if (kv.empty()) continue;
+        const size_t eq = kv.find('=');
+        if (eq == std::string::npos || eq == 0 || eq + 1 >= kv.size()) { *err = "options: expected key=value, got '" + kv + "'"; return LSX_EINVAL; }
+        const std::string key = kv.substr(0, eq), val = kv.substr(eq + 1);
+        char* endp = nullptr;
+        const long iv = strtol(val.c_str(), &endp, 10);
+        const bool is_int = endp && *endp == 0;
+        auto flag = [&](bool* dst, bool invert) {
+            if (!is_int || (iv != 0 && iv != 1)) { *err = "options: " + key + " takes 0 or 1, got '" + val + "'"; return false; }
+            *dst = invert ? iv == 0 : iv == 1;
+            return true;
+        };
+        auto count = [&](int* dst, long lo, long hi) {
+            if (!is_int || iv < lo || iv > hi) { *err = "options: " + key + " out of range: '" + val + "'"; return false; }
+            *dst = (int)iv;
+            return true;
+        };
+        bool ok = true;
+        if (key == "linked") ok = flag(&p.no_linked, true);
+        else if (key == "topo") ok = flag(&p.no_topo, true);
+        else if (key == "fast_rows") ok = flag(&p.fast_rows, false);
+        else if (key == "rs") ok = flag(&p.no_rs, true);
+        else if (key == "phi_group") ok = flag(&p.no_phi_group, true);      // 1: grouped where the ray-serial sweep can run (default), 0: per column
+        else if (key == "rs_min_columns") ok = count(&p.rs_min_columns, 1, 1 << 30);
+        else if (key == "rs_max_npt") ok = count(&p.rs_max_npt, 0, 2);
+        else if (key == "occ_wg") ok = count(&p.occ_wg, 0, 64);
+        else if (key == "class_chunk") ok = count(&p.class_chunk, 0, 4096);
+        else if (key == "tiler") {
+            if (val == "natural") p.natural_tiles = true; else if (val == "dp") p.natural_tiles = false;
+            else { *err = "options: tiler takes dp or natural"; ok = false; }
+        } else if (key == "order") {
+            if (val == "cost") p.order_by_cost = true; else if (val == "plan") p.order_by_cost = false;
+            else { *err = "options: order takes plan or cost"; ok = false; }
+        }
+        else if (key == "se_lds") ok = flag(&r.se_lds, false);
+        else if (key == "serial") ok = flag(&r.serial, false);
+        else if (key == "finish_big") ok = flag(&r.finish_big, false);
+        else if (key == "fused_epilogue") ok = flag(&r.fused_epilogue, false);
+        else if (key == "graph") ok = flag(&r.graph, false);
+        else if (key == "fused_fast") ok = flag(&r.no_fused_fast, true);
+        else if (key == "trace_classes") ok = flag(&r.trace_classes, false);
+        else { *err = "options: unknown key '" + key + "'"; ok = false; }
+        if (!ok) return LSX_EINVAL;
+    }
+    return LSX_OK;
+}
+
+std::string options_string(const CtxOptions& o)
+{
+    const PlanOptions& p = o.plan;
+    const RunOptions& r = o.run;
+    char b[512];
+    snprintf(b, sizeof b,
+             "linked=%d;tiler=%s;topo=%d;fast_rows=%d;order=%s;occ_wg=%d;class_chunk=%d;rs=%d;phi_group=%d;rs_min_columns=%d;rs_max_npt=%d;"
+             "se_lds=%d;serial=%d;finish_big=%d;fused_epilogue=%d;graph=%d;fused_fast=%d;abl_fused_fast=%d",
+             !p.no_linked, p.natural_tiles ? "natural" : "dp", !p.no_topo, (int)p.fast_rows, p.order_by_cost ? "cost" : "plan", p.occ_wg, p.class_chunk,
+             !p.no_rs, !p.no_phi_group, p.rs_min_columns, p.rs_max_npt, (int)r.se_lds, (int)r.serial, (int)r.finish_big,
+             (int)r.fused_epilogue, (int)r.graph, !r.no_fused_fast, r.abl_fast);
+    return b;
+}
+
+std::string plan_class_string(const LsxPlan& P)
+{
+    std::string s;
+    char b[64];
+    for (const PlanClass& k : P.plan_classes) {
+        snprintf(b, sizeof b, "%s%d.%d.%d.%d:%zu%s", s.empty() ? "" : ",", k.npt, k.nl, (int)k.linked, k.topo, k.tiles.size(), k.rs ? "s" : "");
+        s += b;
+    }
+    return s;
+}
+
+uint64_t fnv1a64(const std::string& s)
+{
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (unsigned char c : s) { h ^= c; h *= 0x100000001b3ull; }
+    return h;
 }
 
 } // namespace lsxd

@@ -105,6 +105,9 @@ constexpr SweepLds lsx_sweep_lds(int npt, bool linked, int Ns, int ncell_lev, in
 // other in registers, LSX_RS_COLS columns per wavefront.  Instances exist for the classes below (at most two per-ray slots);
 // a context uses them when it has LSX_RS_RAYS rays, a wavelength-independent scattering coefficient, enough columns to fill
 // the machine with five-column wavefronts, and column blocks small enough for 32-bit offsets across a column group.
+#ifndef LSX_CLASS_CHUNK
+#define LSX_CLASS_CHUNK 0
+#endif
 #define LSX_RS_RAYS 5
 #define LSX_RS_COLS 5
 #define LSX_RS_MIN_COLUMNS 160         // default of PlanOptions::rs_min_columns
@@ -141,19 +144,32 @@ inline bool lsx_rsp_instance_exists(int npt, int nl, bool lk, int topo)
     default: return false;
     }
 }
-// LDS doubles of a ray-serial workgroup: exp table, [2 waves][2 npt + 1] rows of 64 (parked Gamma integrands, dJ), [2][64] J
-// exchange, the per-depth operand table of the group's columns [LSX_RS_COLS][Nspace + 1][3 npt + 2], the parked Gamma totals
-// doubles between two columns of the operand table: the five columns of a wavefront read the same row at once, so their
-// rows must not share LDS banks (a stride that is a multiple of 8 doubles would put columns 0 and 4 on the same banks)
-constexpr int lsx_rs_ucol_stride(int npt, int Ns) { return (Ns + 1) * (3 * npt + 2) + ((((Ns + 1) * (3 * npt + 2)) % 8) == 0 ? 1 : 0); }
+// ---- the ray-serial sweep's per-depth operands (round 5): a RING in LDS, fed from a table in HBM ---------------------------------
+// What a depth step needs of the lane's column beyond its streams -- per per-ray slot three numbers (lines: cB (n_i - g n_j), n_j Uc,
+// wphi; continua: n_i, n_j, nStar_i / nStar_j), the half length of the interval above the depth and the scattering coefficient -- is
+// wave-uniform per column.  Rounds 3-4 staged the WHOLE column of the five columns of a wavefront in LDS when the workgroup started
+// ([5][Nspace + 1][3 npt + 2]: 17-27 kB at 82 depths, growing with Nspace, and the reason contexts of more than ~160 depths fell back
+// to the one-ray-per-lane kernel).  Now `k_build_optab` (lsx_hip.hip) writes those numbers once per formal solution into a table
+//     optab[group of 5 columns][transition t < Ntrans | geometry][row r = 0 .. Nspace][c < 5][3 | 2]
+// (row Nspace: zeros -- the up-going sweep reads the interval behind its first depth there), 50 kB per column for FALC Ca+H, and
+// each WAVE keeps a ring of LSX_RS_RING rows [slot u][c][3] + [c][2] of the depths around its own: every depth step the first
+// 15 npt + 10 lanes fetch one element each of the row LSX_RS_RING - 1 steps ahead (one coalesced load per segment, landing a step
+// later) and write it over the row that was consumed two steps ago.  LDS per workgroup no longer depends on Nspace.
+#define LSX_RS_RING 8                   // rows per wave (a power of two)
+constexpr int lsx_rs_row_doubles(int npt) { return 3 * LSX_RS_COLS * npt + 2 * LSX_RS_COLS; }
+// doubles per column group of the table: Ntrans blocks of (Nspace + 1) rows of 15, then the geometry block of (Nspace + 1) rows of 10
+constexpr size_t lsx_optab_group_doubles(int Ntrans, int Ns) { return ((size_t)Ntrans * 3 * LSX_RS_COLS + 2 * LSX_RS_COLS) * (size_t)(Ns + 1); }
 // (the parabolic instances park 16 depths in every class: they need the LDS for the lane-private cells below)
 constexpr int lsx_rs_park(int npt, bool par = false) { return (npt >= 2 || par) ? 16 : 64; }      // depths a row of parked Gamma totals holds (two slots: 16, for two workgroups more per CU)
 // parabolic instances: rows of 64 lane-private cells per wave -- 1 / opacity, opacity and the line profiles of the rays at the point
 // that waits for its downwind neighbour
 constexpr int lsx_rs_par_rows(int npt) { return LSX_RS_RAYS * (2 + npt); }
+// LDS doubles of a ray-serial workgroup: exp table, [2 waves][2 npt + 1] rows of 64 (parked Gamma integrands, dJ), [2][64] J
+// exchange, the two waves' operand rings, the parked Gamma totals, the angle quadrature, the parabolic instances' cells
 constexpr int lsx_rs_lds_doubles(int npt, int Ns, bool par = false)
 {
-    return LSX_EXP_TAB + 2 * (2 * (npt > 0 ? npt : 1) + 1) * 64 + 2 * LSX_WAVE + LSX_RS_COLS * lsx_rs_ucol_stride(npt, Ns) +
+    (void)Ns;
+    return LSX_EXP_TAB + 2 * (2 * (npt > 0 ? npt : 1) + 1) * 64 + 2 * LSX_WAVE + 2 * LSX_RS_RING * lsx_rs_row_doubles(npt) +
            2 * LSX_RS_COLS * 2 * (npt > 0 ? npt : 1) * lsx_rs_park(npt, par) +  // + [2 waves][columns x values][entries] parked Gamma totals
            2 * LSX_RS_RAYS + 2 +                                            // + the angle quadrature (two-slot instances read it from here)
            (par ? 2 * lsx_rs_par_rows(npt) * LSX_WAVE : 0);
@@ -186,11 +202,37 @@ struct PlanOptions {           // diagnostic switches (lsx_create reads them fro
     bool fast_rows = false;    // LSX_FAST_ROWS: the row-mapped epilogue for every tile
     bool order_by_cost = false; // LSX_ORDER=cost
     int occ_wg = 0;            // LSX_OCC_WG: at most this many workgroups per CU (through the LDS request)
+    int class_chunk = LSX_CLASS_CHUNK;   // class_chunk / LSX_CLASS_CHUNK: a tile class is cut into launch groups of at most this many tiles, each
+                               // with its own stream and pre-pass -> sweep -> epilogue chain (0: one group per class); same kernels, same bits
     bool no_rs = false;        // LSX_NO_RS: every class through lsx_sweep.hip (one ray per lane)
     int rs_min_columns = LSX_RS_MIN_COLUMNS;   // LSX_RS_MIN_COLUMNS: contexts with fewer columns keep one ray per lane (too few wavefronts otherwise)
     bool no_phi_group = false; // LSX_PHI_GROUP=1: the plain per-column profile store also where the ray-serial sweep can run (measurements)
     int rs_max_npt = 2;        // LSX_RS_MAX_NPT: classes with more per-ray slots keep one ray per lane (diagnostic: 1 leaves the two-slot tiles to lsx_sweep.hip)
 };
+
+struct RunOptions {            // switches of the runtime around the plan (lsx_hip.hip); same life cycle as PlanOptions
+    bool se_lds = false;       // LSX_SE_LDS / se_lds: stat_equil with its system in LDS also for small atoms
+    bool serial = false;       // LSX_SERIAL / serial: every class on the context's stream, one after the other
+    bool finish_big = false;   // LSX_FINISH_BIG / finish_big: the many-column Gamma epilogue also for small batches
+    bool fused_epilogue = false; // LSX_FUSED_EPILOGUE / fused_epilogue
+    bool graph = false;        // LSX_GRAPH / graph: a formal solution's launches as a captured HIP graph
+    bool no_fused_fast = false; // LSX_NO_FUSED_FAST / fused_fast=0
+    int abl_fast = 0;          // LSX_ABL_FUSED_FAST (timing ablation)
+    bool trace_classes = false; // LSX_TRACE_CLASSES (prints; changes nothing)
+};
+struct CtxOptions { PlanOptions plan; RunOptions run; };
+
+// Every switch that decides how a context's sums are associated or its kernels launched, in one place (round 5):
+//   options_from_env    the LSX_* diagnostic variables as DEFAULTS (read once per lsx_create, here only);
+//   options_apply       an explicit "key=value,key=value" list (lsx_create_with_options) on top of them; unknown keys and
+//                       malformed values are errors;
+//   options_string      the canonical "key=value;..." form of the result -- what lsx_effective_options reports and what
+//                       lsx_options_signature hashes together with the plan's class list, the sweep mapping and the rule.
+void options_from_env(CtxOptions* o);
+int options_apply(const char* list, CtxOptions* o, std::string* err);
+std::string options_string(const CtxOptions& o);
+std::string plan_class_string(const struct LsxPlan& P);
+uint64_t fnv1a64(const std::string& s);
 
 // launch shapes of the kernels around the sweep, fixed when the plan is made so that no enqueue path can fail on them
 struct LaunchShapes {
@@ -219,6 +261,7 @@ struct LsxPlan {
     std::vector<PlanClass> plan_classes;         // in launch order
     std::vector<int> fast_tiles, fast_cols[4], fast_rest;
     std::vector<int> cont_li, cont_lj;
+    std::vector<int> trans_row;                  // per transition: its row of wphi (lines: the line index) / of nsr (continua: the continuum index)
     int nF_max = 0, Ncont = 0, static_max = -1, nL_linked_max = 0;
     bool fast_generic = false, any_cont = false;
     size_t lds_bytes = 0;                        // largest sweep class

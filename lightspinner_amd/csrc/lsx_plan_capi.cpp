@@ -183,6 +183,23 @@ int lsx_plan_probe(const lsx_problem* d, uint32_t option_bits, int64_t* summary,
     return LSX_OK;
 }
 
+// What lsx_effective_options / lsx_options_signature of the product report for a context of this problem, as far as the host side
+// decides it: the options (environment defaults + explicit list, lsx_plan.cpp) and the plan's class list.  -> the FNV-1a hash of
+// the string (0 and a message in `buf` if the list or the problem is refused).  tests/test_distributed_gloo.py: a rank whose
+// environment differs is refused by parallel.check_same_options.
+extern "C" uint64_t lsx_plan_signature(const lsx_problem* d, const char* options, char* buf, int32_t buflen)
+{
+    CtxOptions o;
+    options_from_env(&o);
+    std::string e;
+    LsxPlan P;
+    int rc = options_apply(options, &o, &e);
+    if (rc == LSX_OK) rc = plan_build(d, o.plan, &P, &e);
+    const std::string s = rc ? e : "backend=host-plan;" + options_string(o) + ";classes=" + plan_class_string(P);
+    if (buf && buflen > 0) { strncpy(buf, s.c_str(), (size_t)buflen - 1); buf[buflen - 1] = 0; }
+    return rc ? 0 : fnv1a64(s);
+}
+
 // The compiled template instances, from the lists the kernels are instantiated from (lsx_plan.h): which = 0 the one-ray-per-lane
 // sweep (LSX_SWEEP_INSTANCES), 1 the ray-serial sweep = the parabolic rule's compile-time classes (LSX_RS_INSTANCES).  -> count;
 // codes[i] = lsx_class_code(per-ray slots, lines, linked, two-line relation).  tests/test_instance_ledger.py: every instance that

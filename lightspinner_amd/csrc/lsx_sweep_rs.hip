@@ -89,14 +89,22 @@ lsx_sweep_rs_kernel(const SweepParams p)
     // correction slots) and these instances read NO correction streams: two loads per line, wavelength and depth less, and the
     // pre-pass writes none.  (The unfactored instance <2,2,true,0> applies them ray by ray, like the one-ray-per-lane kernels.)
     constexpr bool CORR = LK && !FACT;
+    // a second depth of stream prefetch (a third operand set) where the register file has room for it: at most one per-ray slot
+#if defined(LSX_RS_PF2)
+    constexpr bool PF2 = !PAR && NPT <= LSX_RS_PF2;
+#else
+    constexpr bool PF2 = false;
+#endif
     const int lane = threadIdx.x & (LSX_WAVE - 1);
     const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0: down (toFrom False), 1: up (True)
     lds_f64* const red = etab + LSX_EXP_TAB + (size_t)dir * (NV + 1) * RROW;   // this wave's reduction rows (+ one for dJ)
-    // per-depth operands of the group's columns, staged once per workgroup: utab[c][k][TR] = per slot (lines: cB (n_i - g n_j),
-    // n_j Uc, wphi; continua: n_i, n_j, nStar_i / nStar_j), then the half length of the interval above depth k and the
-    // scattering coefficient (row Nspace of a column: zeros -- the up sweep reads the interval behind depth k from row k + 1)
-    constexpr int TR = 3 * NPT + 2;
-    lds_f64* const utab = etab + LSX_EXP_TAB + 2 * (NV + 1) * RROW + 2 * LSX_WAVE;
+    // per-depth operands of the group's columns: a ring of RING rows per wave (lsx_plan.h, "a RING in LDS"), row of step v =
+    // [slot u][column c][3] (lines: cB (n_i - g n_j), n_j Uc, wphi; continua: n_i, n_j, nStar_i / nStar_j) then [c][2] (the half
+    // length of the interval above the depth, the scattering coefficient), fed one row per step from the table k_build_optab made
+    constexpr int RING = LSX_RS_RING, RL = lsx_rs_row_doubles(NPT);
+    static_assert((RING & (RING - 1)) == 0 && RING >= 4 && RL <= LSX_WAVE, "operand ring");
+    lds_f64* const utab = etab + LSX_EXP_TAB + 2 * (NV + 1) * RROW + 2 * LSX_WAVE;      // [2 waves][RING][RL]
+    lds_f64* const ring_end = utab + 2 * RING * RL;
 
     // XCD-aware block -> (column group, tile): every XCD gets a contiguous range (speed only)
     int vb;
@@ -125,39 +133,38 @@ lsx_sweep_rs_kernel(const SweepParams p)
     const bool act = valid && live_col;
 
     etab[threadIdx.x] = p.exp2_tab[threadIdx.x];
+    const int kS = dir ? Ns - 1 : 0;
+    const int dk = dir ? -1 : 1;
+    // ---- the operand ring.  Step v of this wave (depth kS + dk v) is row tabrow(v) of the table: v for the down-going sweep,
+    // Nspace - 1 - v for the up-going one -- whose "step -1" is the table's zero row Nspace: the interval behind its first depth.
+    // Lane e < RL owns element e of every row: it fetches that element of the row RING - 1 steps ahead and, a step later, writes it
+    // over the row that was consumed two steps ago (the steps read rows v - 1 and v only).
+    lds_f64* const ring = utab + (size_t)dir * RING * RL;
+    const int re = lane < RL ? lane : RL - 1;
+    const double* __restrict__ otab = p.optab + (size_t)grp * p.optab_group_stride;
+    unsigned o_ob, o_os;                                 // byte offset of the lane's element in row 0 of its block, bytes per row
     {
-        const int Nsp = p.Nspace;
-        const int ucs = lsx_rs_ucol_stride(NPT, Nsp);
-        for (int e = threadIdx.x; e < NC * (Nsp + 1); e += 2 * LSX_WAVE) {
-            const int c = e / (Nsp + 1), k = e - c * (Nsp + 1);
-            const int colc = col0 + (c < ncg ? c : ncg - 1);
-            lds_f64* row = utab + (size_t)c * ucs + (size_t)k * TR;
-            if (k == Nsp) {
-#pragma unroll
-                for (int t = 0; t < TR; ++t) row[t] = 0.0;
-                continue;
-            }
-            const double* ncolp = p.n + (size_t)colc * p.NLtot * Nsp;
-#pragma unroll
-            for (int u = 0; u < NPT; ++u) {
-                const double ni = ncolp[(size_t)slots[u].li * Nsp + k], nj = ncolp[(size_t)slots[u].lj * Nsp + k];
-                if (u < NL) {
-                    row[3 * u + 0] = slots[u].cB * (ni - slots[u].g * nj);          // :279-280, :613
-                    row[3 * u + 1] = nj * slots[u].Uc;                               // eta = n_j Uji = (n_j Uc) phi, :281, :614
-                    row[3 * u + 2] = p.wphi[(size_t)colc * p.Nlines * Nsp + slots[u].wphi_off + k];
-                } else {
-                    row[3 * u + 0] = ni;
-                    row[3 * u + 1] = nj;
-                    row[3 * u + 2] = p.nsr[(size_t)colc * p.Ncont * Nsp + slots[u].base + k];   // g_ij = this x E, :453
-                }
-            }
-            const double* zc = p.height + (size_t)colc * Nsp;
-            row[3 * NPT + 0] = k > 0 ? 0.5 * fabs(zc[k - 1] - zc[k]) : 0.0;
-            row[3 * NPT + 1] = p.sca[(size_t)colc * Nsp + k];
-        }
+        const bool geo = re >= 3 * NC * NPT;
+        const int u = geo ? 0 : re / (3 * NC), w = geo ? re - 3 * NC * NPT : re - u * (3 * NC);
+        const int trans = (NPT > 0 && !geo) ? slots[u < NPT ? u : 0].trans : p.Ntrans;
+        o_os = geo ? 2u * NC * 8u : 3u * NC * 8u;
+        o_ob = (unsigned)((size_t)trans * (Ns + 1) * (3 * NC) * 8u) + (unsigned)w * 8u;
     }
+    auto tabrow = [&](int v) __attribute__((always_inline)) { return dir ? Ns - 1 - min(v, Ns - 1) : max(min(v, Ns - 1), 0); };
+    auto ring_row = [&](int v) __attribute__((always_inline)) { return ring + ((v + 1) & (RING - 1)) * RL; };
+    for (int v = -1; v <= RING - 3; ++v) {
+        const double x = at(otab, o_ob + (unsigned)tabrow(v) * o_os);
+        if (lane < RL) ring_row(v)[lane] = x;
+    }
+    double ring_pend = at(otab, o_ob + (unsigned)tabrow(RING - 2) * o_os);       // row RING - 2: written at step 0
+    // one row per step: the element fetched a step ago goes over row s - 2, the element of row s + RING - 1 is requested
+    auto ring_step = [&](const int s) __attribute__((always_inline)) {
+        if (lane < RL) ring_row(s + RING - 2)[lane] = ring_pend;
+        ring_pend = at(otab, o_ob + (unsigned)tabrow(s + RING - 1) * o_os);
+    };
     __syncthreads();
-    const lds_f64* const ucol = utab + (size_t)cc * lsx_rs_ucol_stride(NPT, p.Nspace);       // this lane's column
+    const int lc3 = cc * 3, lcg = 3 * NC * NPT + cc * 2;   // the lane's column inside a row: slot values at lc3 + 15 u + t, geometry at lcg + {0, 1}
+    constexpr int TU = 3 * NC;                             // doubles between two slots of a row
 
     // ---- per-lane bases: every stream of a column is addressed as (wave-uniform base of column col0) + 32-bit byte offset
     const size_t til_col = (size_t)ntile * Ns * LW;
@@ -183,16 +190,18 @@ lsx_sweep_rs_kernel(const SweepParams p)
     double* __restrict__ ppsum = LK ? p.Psi3_T + ((size_t)dir * p.ncol + col0) * p.pp_col_stride + tilep->pp_off : nullptr;
     const unsigned o_pp = LK ? (unsigned)((size_t)cc * p.pp_col_stride * 8u) + (unsigned)j * 8u : 0u;
     const size_t plane = (size_t)Ns * LW;
-    const int kS = dir ? Ns - 1 : 0;
-    const int dk = dir ? -1 : 1;
     const bool compact = p.phi_compact != 0;
     const double wav = p.wavelength[la];
     const double u_la = p.u_la[la];
     // angle quadrature: wave-uniform
     // two-slot instances: the ten quadrature constants live in LDS behind the parked totals and are read where they are used
     // (broadcast reads with immediate offsets): twenty vector registers less in the instances that sit at the 256-register limit
+    #ifdef LSX_RS_PF2_QLDS
+    constexpr bool QLDS = NPT >= 2 || (PAR && LSX_RSP_WPE >= 2) || (PF2 && NPT >= 1);
+#else
     constexpr bool QLDS = NPT >= 2 || (PAR && LSX_RSP_WPE >= 2);
-    lds_f64* const qtab = utab + (size_t)NC * lsx_rs_ucol_stride(NPT, p.Nspace) + (size_t)2 * NC * NV * lsx_rs_park(NPT, PAR);
+#endif
+    lds_f64* const qtab = ring_end + (size_t)2 * NC * NV * lsx_rs_park(NPT, PAR);
     if (QLDS && threadIdx.x < 2 * NR) qtab[threadIdx.x] = threadIdx.x < NR ? LSX_CONST(double, p.zmu)[threadIdx.x] : LSX_CONST(double, p.wmuh)[threadIdx.x - NR];
     double zmu_r[NR], wmuh_r[NR];
 #pragma unroll
@@ -279,16 +288,16 @@ lsx_sweep_rs_kernel(const SweepParams p)
 #endif
     };
     // total opacity of ray m from one depth's operands (rh_method.py:613, 279-285)
-    auto chi_of = [&](const Ops& o, int kk, int m) __attribute__((always_inline)) {
-        const lds_f64* tk = ucol + kk * TR;
+    auto chi_of = [&](const Ops& o, int v, int m) __attribute__((always_inline)) {          // v: step index of the depth
+        const lds_f64* tk = ring_row(v) + lc3;
         double c = o.bc;
 #pragma unroll
         for (int u = 0; u < NPT; ++u) {
-            if (u < NL) c = fma(tk[3 * u + 0], o.ph[u][m], c);
+            if (u < NL) c = fma(tk[TU * u + 0], o.ph[u][m], c);
             else {
                 const bool a = (pact >> u) & 1u;
-                const double Vji = a ? (tk[3 * u + 2] * o.E) * alv[u] : 0.0;
-                c += tk[3 * u + 0] * alv[u] - tk[3 * u + 1] * Vji;
+                const double Vji = a ? (tk[TU * u + 2] * o.E) * alv[u] : 0.0;
+                c += tk[TU * u + 0] * alv[u] - tk[TU * u + 1] * Vji;
             }
         }
         return c;
@@ -298,17 +307,17 @@ lsx_sweep_rs_kernel(const SweepParams p)
     double Iu[NR], chi_prev[NR], S_prev[NR], dtau_prev[NR];
 #pragma unroll
     for (int m = 0; m < NR; ++m) { Iu[m] = 0.0; chi_prev[m] = 1.0; S_prev[m] = 0.0; dtau_prev[m] = 1.0; }
-    Ops opA, opB;
+    Ops opA, opB, opC;
     load_ops(kS, opA);
     load_ops(kS + dk, opB);
     if (dir) {
         const Ops &cur = opA, &nxt = opB;
         const auto* tcol = p.temperature + (size_t)col * Ns;
         const double B0 = planck(tcol[Ns - 2], wav), B1 = planck(tcol[Ns - 1], wav);
-        const double hz = ucol[(kS + dk + 1) * TR + 3 * NPT];          // 0.5 |z[Ns - 2] - z[Ns - 1]|: the interval behind depth kS + dk
+        const double hz = ring_row(0)[lcg];                          // 0.5 |z[Ns - 2] - z[Ns - 1]|: the interval behind depth kS + dk
 #pragma unroll
         for (int m = 0; m < NR; ++m) {
-            const double dtau_uw = zmu(m) * (chi_of(cur, kS, m) + chi_of(nxt, kS + dk, m)) * hz;
+            const double dtau_uw = zmu(m) * (chi_of(cur, 0, m) + chi_of(nxt, 1, m)) * hz;
             Iu[m] = B1 - (B0 - B1) / dtau_uw;
         }
     }
@@ -320,7 +329,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
     const int o_c = lane / NV, o_q = lane - o_c * NV;
     const bool own = lane < NC * NV;
     constexpr int PE = lsx_rs_park(NPT, PAR);
-    lds_f64* const park = utab + (size_t)NC * lsx_rs_ucol_stride(NPT, p.Nspace) + (size_t)dir * NC * NV * PE;
+    lds_f64* const park = ring_end + (size_t)dir * NC * NV * PE;
     double* __restrict__ gbase = p.Gpart + (((size_t)col0 * p.nslot_total + slot0) * 4 + (size_t)dir) * Ns;      // + (c nslot 4 + q 2) Ns + k
     auto flush = [&](int sprev) __attribute__((always_inline)) {         // the totals of step sprev (depth kS + dk sprev)
         if constexpr (NPT >= 1) {
@@ -375,15 +384,15 @@ lsx_sweep_rs_kernel(const SweepParams p)
     auto set_chi = [&](int m, double v) __attribute__((always_inline)) { if constexpr (CELLS) cell[(NR + m) * LSX_WAVE] = v; else chi_r[m] = v; };
     auto set_ph = [&](int u, int m, double v) __attribute__((always_inline)) { if constexpr (CELLS) cell[(2 * NR + u * NR + m) * LSX_WAVE] = v; else ph_r[u][m] = v; };
     {   // point 0's own values (the boundary condition above has read the same operands)
-        const lds_f64* tk = ucol + kS * TR;
-        const double etaB = opA.be + tk[3 * NPT + 1] * opA.jd;
+        const lds_f64* tk = ring_row(0) + lc3;
+        const double etaB = opA.be + ring_row(0)[lcg + 1] * opA.jd;
 #pragma unroll
         for (int m = 0; m < NR; ++m) {
             double chiTot = opA.bc, etaTot = etaB;
 #pragma unroll
             for (int u = 0; u < NL; ++u) {
-                chiTot = fma(tk[3 * u + 0], opA.ph[u][m], chiTot);
-                etaTot = fma(tk[3 * u + 1], opA.ph[u][m], etaTot);
+                chiTot = fma(tk[TU * u + 0], opA.ph[u][m], chiTot);
+                etaTot = fma(tk[TU * u + 1], opA.ph[u][m], etaTot);
                 set_ph(u, m, opA.ph[u][m]);
             }
             set_chi(m, chiTot);
@@ -402,10 +411,10 @@ lsx_sweep_rs_kernel(const SweepParams p)
         constexpr bool LASTPT = decltype(last_c)::value;
         const int km = kS + dk * mpt;
         const unsigned kt = o_til + (unsigned)(km * LW) * 8u;
-        const lds_f64* tm = ucol + km * TR;
+        const lds_f64* tm = ring_row(mpt) + lc3;
         double X[NS], njUc[NS], w3k[NS];
 #pragma unroll
-        for (int u = 0; u < NPT; ++u) { X[u] = tm[3 * u + 0]; njUc[u] = tm[3 * u + 1]; w3k[u] = tm[3 * u + 2]; }
+        for (int u = 0; u < NPT; ++u) { X[u] = tm[TU * u + 0]; njUc[u] = tm[TU * u + 1]; w3k[u] = tm[TU * u + 2]; }
         double Jacc = 0.0, Pacc = 0.0, PP[NLK], G1[NS], G2[NS];
 #pragma unroll
         for (int u = 0; u < NLK; ++u) PP[u] = 0.0;
@@ -579,13 +588,14 @@ lsx_sweep_rs_kernel(const SweepParams p)
         double jhalf = 0.0;
         if constexpr (PH == 2) jhalf = at(Jnew, o_til + (unsigned)((k - dk) * LW) * 8u);
         if constexpr (!FIRSTPT && NPT >= 1) flush(mpt - 1);
-        const lds_f64* tk = ucol + k * TR;
-        const double hdz = (ucol + TR * dir)[k * TR + 3 * NPT];            // the interval between points m and m + 1: row k (down) / k + 1 (up)
-        const double etaB = cur.be + tk[3 * NPT + 1] * cur.jd, chiB = cur.bc, jd_k = cur.jd;
+        const lds_f64* tk = ring_row(s) + lc3;
+        const double hdz = ring_row(s - dir)[lcg];                         // the interval between points m and m + 1: row k (down) / k + 1 (up)
+        const double etaB = cur.be + ring_row(s)[lcg + 1] * cur.jd, chiB = cur.bc, jd_k = cur.jd;
         double Xk[NS], njk[NS];
 #pragma unroll
-        for (int u = 0; u < NPT; ++u) { Xk[u] = tk[3 * u + 0]; njk[u] = tk[3 * u + 1]; }
+        for (int u = 0; u < NPT; ++u) { Xk[u] = tk[TU * u + 0]; njk[u] = tk[TU * u + 1]; }
         if constexpr (!NOREQ) load_ops(k + dk, nxt);
+        ring_step(s);
         double ev[NR], s2[NR];
         if constexpr (!FIRSTPT) exps(ev, s2);
         point(mpt, phase_c, std::false_type{}, jhalf, [&](const int m, double& I, double& Psi, const double (&)[NS]) __attribute__((always_inline)) {
@@ -652,6 +662,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
         };
         // point m is finished in step m + 1: m < nA first visitor, m = nA (odd Nspace) the midpoint, then second visitor
         const int nA = Ns / 2;
+        ring_step(0);                                                                // (there is no step 0 here: the ring moves on by its row)
         one(1, std::integral_constant<int, 0>{}, F1{});                              // point 0: the boundary value (depth 1 is already requested... and 2 is now)
         if (Ns == 3) {
             one(2, std::integral_constant<int, 1>{}, F2{});                          // three depths: the midpoint's step is the last one, nothing left to request
@@ -702,25 +713,25 @@ lsx_sweep_rs_kernel(const SweepParams p)
         }
 
         // ---- ray-independent part (rh_method.py:601-632): continuum slots, emissivity without the lines
-        const lds_f64* tk = ucol + k * TR;                                 // this depth's row of the lane's column
-        const double hdz = (ucol + TR * dir)[k * TR + 3 * NPT];            // the interval behind this ray: row k (down) / k + 1 (up)
-        double etaB = cur.be + tk[3 * NPT + 1] * cur.jd;
+        const lds_f64* tk = ring_row(s) + lc3;                             // this depth's row, the lane's column
+        const double hdz = ring_row(s - dir)[lcg];                         // the interval behind this ray: row k (down) / k + 1 (up)
+        double etaB = cur.be + ring_row(s)[lcg + 1] * cur.jd;
         double chiB = cur.bc;
         double X[NS], Vjc[NS], Ujc[NS], chic[NS], njUc[NS], njc[NS], w3k[NS];   // lines: X = cB (n_i - g n_j), n_j Uc, wphi; continua: Vji, Uji, chi, n_j
 #pragma unroll
         for (int u = 0; u < NPT; ++u) {
-            w3k[u] = tk[3 * u + 2];
+            w3k[u] = tk[TU * u + 2];
             if (u < NL) {
-                X[u] = tk[3 * u + 0];
-                njUc[u] = tk[3 * u + 1];
+                X[u] = tk[TU * u + 0];
+                njUc[u] = tk[TU * u + 1];
                 Vjc[u] = Ujc[u] = chic[u] = njc[u] = 0.0;
             } else {
                 const bool a = (pact >> u) & 1u;
                 X[u] = njUc[u] = 0.0;
-                njc[u] = tk[3 * u + 1];
+                njc[u] = tk[TU * u + 1];
                 Vjc[u] = a ? (w3k[u] * cur.E) * alv[u] : 0.0;             // g_ij alpha, :284-285, :453
                 Ujc[u] = u_la * Vjc[u];                                   // :286
-                chic[u] = tk[3 * u + 0] * alv[u] - njc[u] * Vjc[u];
+                chic[u] = tk[TU * u + 0] * alv[u] - njc[u] * Vjc[u];
                 chiB += chic[u];
                 etaB = fma(njc[u], Ujc[u], etaB);
             }
@@ -729,7 +740,15 @@ lsx_sweep_rs_kernel(const SweepParams p)
         // the next depth's operands are requested HERE, after the ray-independent part has consumed this depth's background,
         // populations and geometry: their registers are free again, so the two operand sets overlap only in the profiles
         // (the first point's neighbour was loaded for the boundary condition)
-        if constexpr (!LAST && !FIRST) load_ops(k + dk, nxt);
+        if constexpr (PF2) {
+            // two depths of prefetch: the request goes two steps ahead into the buffer the PREVIOUS step consumed (three operand sets
+            // rotate, nothing is copied); the last-but-one step repeats the end point's request (a valid address, never used), so
+            // every step of a phase issues the same loads and the compiler's vmcnt counts stay exact
+            if constexpr (!LAST) load_ops(s + 2 < Ns ? k + 2 * dk : kS + dk * (Ns - 1), nxt);
+        } else {
+            if constexpr (!LAST && !FIRST) load_ops(k + dk, nxt);
+        }
+        ring_step(s);       // the operand ring moves on by one row (one more load per step, the same in every step)
 
         // ---- the five rays of this wavelength, in three straight-line passes so that the five independent chains interleave
         // (a branch per ray -- the skipped exponential, the skipped series of w2 -- would cut the instruction stream into
@@ -1003,12 +1022,21 @@ lsx_sweep_rs_kernel(const SweepParams p)
         constexpr bool SWAP = NPT <= 1 || (!LK && TOPO != 0);      // (two lines with a known relation, no linked continua: 2 spilled registers)
 #endif
         auto one = [&](int s, auto ph) __attribute__((always_inline)) {
-            if constexpr (SWAP) { if (s & 1) step(s, ph, opB, opA); else step(s, ph, opA, opB); }
+            if constexpr (PF2) {
+                const int r = s % 3;                 // step s reads set s mod 3 and requests depth s + 2 into set (s + 2) mod 3
+                if (r == 0) step(s, ph, opA, opC); else if (r == 1) step(s, ph, opB, opA); else step(s, ph, opC, opB);
+            }
+            else if constexpr (SWAP) { if (s & 1) step(s, ph, opB, opA); else step(s, ph, opA, opB); }
             else { step(s, ph, opA, opB); opA = opB; }
         };
         auto run = [&](int s0, int s1, auto ph) __attribute__((always_inline)) {           // steps [s0, s1) of one phase
             int s = s0;
-            if constexpr (SWAP) {
+            if constexpr (PF2) {
+                while (s < s1 && s % 3 != 0) { one(s, ph); ++s; }
+                __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): no load is pending on any path into the loop
+                for (; s + 2 < s1; s += 3) { step(s, ph, opA, opC); step(s + 1, ph, opB, opA); step(s + 2, ph, opC, opB); }
+                for (; s < s1; ++s) one(s, ph);
+            } else if constexpr (SWAP) {
                 if (s < s1 && (s & 1)) { step(s, ph, opB, opA); ++s; }
                 __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): no load is pending on any path into the loop
                 for (; s + 1 < s1; s += 2) { step(s, ph, opA, opB); step(s + 1, ph, opB, opA); }
@@ -1024,8 +1052,9 @@ lsx_sweep_rs_kernel(const SweepParams p)
         unsigned long long tk0, tr0, tk1, tr1;
         asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk0), "=s"(tr0)::"memory");
 #endif
-        step(0, std::integral_constant<int, 4>{}, opA, opB);          // the ray's first point (depth 1 is already requested: its load is skipped there)
-        if constexpr (!SWAP) opA = opB;
+        if constexpr (PF2) step(0, std::integral_constant<int, 4>{}, opA, opC);     // ... and requests depth 2 into the third set
+        else step(0, std::integral_constant<int, 4>{}, opA, opB);     // the ray's first point (depth 1 is already requested: its load is skipped there)
+        if constexpr (!SWAP && !PF2) opA = opB;
         run(1, nA, std::integral_constant<int, 0>{});
         if (Ns & 1) one(nA, std::integral_constant<int, 1>{});
         run(nA + (Ns & 1), Ns - 1, std::integral_constant<int, 2>{});

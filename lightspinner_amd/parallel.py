@@ -24,6 +24,33 @@ def env_rank_world():
     return int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
 
 
+class OptionsMismatch(RuntimeError):
+    """ranks of one job hold engines that would associate their sums differently (different options, rule, sweep mapping or plan)"""
+
+
+def check_same_options(eng, group=None):
+    """Start-up check of a sharded job ("per-column results must be bitwise equal to the 1-GPU run"): every rank's engine
+    must have been made with the same options, rule, sweep mapping and plan -- `Engine.options_signature()` (include/lsx.h,
+    lsx_options_signature) is exchanged once and a mismatch is refused ON EVERY RANK, naming the ranks that differ from rank 0 and this
+    rank's own effective options.  (An environment variable such as LSX_NO_LINKED set on one rank only used to change that rank's bits
+    silently.)  `eng`: a problem.Engine, or anything with options_signature() / effective_options().  No-op in a single process."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2:
+        return
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sig = int(eng.options_signature()) & 0xffffffffffffffff
+    dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
+    mine = torch.tensor([sig >> 32, sig & 0xffffffff], dtype=torch.int64, device=dev)
+    every = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(every, mine, group=group)
+    sigs = [(int(t[0]) << 32) | int(t[1]) for t in every]
+    bad = [r for r in range(world) if sigs[r] != sigs[0]]
+    if bad:
+        raise OptionsMismatch('rank %d: the engines of this job were not made alike -- ranks %s differ from rank 0 in their options '
+                              'signature (%s); this rank: %s' % (rank, bad, ', '.join('%016x' % x for x in sigs), eng.effective_options()))
+
+
 class MaxReducer:
     """all-reduce(MAX) of the convergence monitors (dJ, dPops) over the ranks -- the one exchange of the sharded MALI
     loop.  NaN must win like in the single-process max (numpy max semantics, rh_method.py:706): MAX collectives do not
@@ -46,6 +73,12 @@ class MaxReducer:
         self._dev_scratch = None
         self._pending = None            # engine_begin / engine_end: the result of an exchange that had nothing to overlap with
         self._host4 = None
+        self._checked = set()           # engines whose options signature has been compared across the ranks (once each)
+
+    def _check(self, eng):
+        if self.active and id(eng) not in self._checked and hasattr(eng, 'options_signature'):
+            check_same_options(eng, self.group)
+            self._checked.add(id(eng))
 
     def __call__(self, dJ: float, dPops: float):
         if not self.active:
@@ -62,6 +95,7 @@ class MaxReducer:
     def engine(self, eng):
         """-> (dJ, dPops) over all columns of all ranks for the calls enqueued on `eng` (problem.Engine).
         Raises LsxSingularError on every rank if any rank met a singular system."""
+        self._check(eng)
         torch = self.torch
         on_device = eng.lib.backend.startswith('hip')
         if on_device and self.buf.is_cuda:
@@ -99,6 +133,7 @@ class MaxReducer:
     # iterate_mali_engine): begin enqueues reduction, all-reduce and read-back behind the iteration's kernels, the caller then
     # enqueues the next formal solution, end waits for the read-back only
     def engine_begin(self, eng):
+        self._check(eng)
         torch = self.torch
         on_device = eng.lib.backend.startswith('hip')
         if on_device and self.buf.is_cuda and self.stream is not None:
@@ -143,13 +178,17 @@ class AllDone:
     """logical AND over ranks of "every column of my shard has converged" (the per-column driver's stop test,
     drivers.iterate_mali_columns(all_done=...))"""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, engine=None):
+        """engine: this rank's problem.Engine -- its options signature is compared across the ranks before the first exchange
+        (check_same_options)"""
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
         self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         dev = 'cuda' if self.active and dist.get_backend(group) == 'nccl' else 'cpu'
         self.buf = torch.zeros(1, dtype=torch.int32, device=dev)
+        if self.active and engine is not None:
+            check_same_options(engine, group)
 
     def __call__(self, done: bool) -> bool:
         if not self.active:

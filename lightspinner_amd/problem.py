@@ -175,17 +175,24 @@ class Engine:
     """One lsx_ctx.  `lib=None` binds the HIP backend (and raises if it is not built)."""
 
     def __init__(self, problem: Problem, ncol: int, device: int = 0, stream: Optional[int] = None, lib=None,
-                 policy_columns: Optional[int] = None, sweep_policy: str = 'auto'):
+                 policy_columns: Optional[int] = None, sweep_policy: str = 'auto', options=None):
         """policy_columns: the column count of the WHOLE problem this engine holds a shard of (None: its own `ncol`).  The HIP
         library picks its sweep kernel by a column count; a driver that splits N columns over several engines passes N to all
-        of them, so that every column gets the bits it gets when all N sit in one engine (include/lsx.h, lsx_set_sweep_policy)."""
+        of them, so that every column gets the bits it gets when all N sit in one engine (include/lsx.h, lsx_set_sweep_policy).
+        options: explicit plan / runtime switches, "key=value,..." or a dict (include/lsx.h, lsx_create_with_options); what the
+        engine ended up with: effective_options() / options_signature()."""
         self.lib = lib if lib is not None else _capi.load_hip_library()
         self.problem = problem
         self.ncol = int(ncol)
         self._h = C.c_void_p()
         cprob, self._keep = problem.to_c()
-        self.lib.check(self.lib.dll.lsx_create(C.byref(cprob), self.ncol, int(device),
-                                               C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        if isinstance(options, dict):
+            options = ','.join('%s=%s' % (k, int(v) if isinstance(v, bool) else v) for k, v in options.items())
+        if getattr(self.lib, 'old_abi', False) and not options:
+            self.lib.check(self.lib.dll.lsx_create(C.byref(cprob), self.ncol, int(device), C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        else:
+            self.lib.check(self.lib.dll.lsx_create_with_options(C.byref(cprob), self.ncol, int(device), C.c_void_p(stream) if stream else None,
+                                                                options.encode() if options else None, C.byref(self._h)))
         if policy_columns is not None or sweep_policy != 'auto':
             self.set_sweep_policy(sweep_policy, policy_columns)
 
@@ -257,6 +264,17 @@ class Engine:
         kind = {'auto': _capi.LSX_SWEEP_AUTO, 'ray-per-lane': _capi.LSX_SWEEP_RAY_PER_LANE,
                 'ray-serial': _capi.LSX_SWEEP_RAY_SERIAL}[policy]
         self.lib.check(self.lib.dll.lsx_set_sweep_policy(self._h, kind, int(decide_for_columns or 0)))
+
+    def effective_options(self) -> str:
+        """everything that decides how this engine associates its sums and launches its kernels: the options it was created with
+        (environment defaults + explicit list), the rule, the sweep mapping the policy selects, the plan's class list"""
+        buf = C.create_string_buffer(4096)
+        self.lib.check(self.lib.dll.lsx_effective_options(self._h, buf, 4096))
+        return buf.value.decode()
+
+    def options_signature(self) -> int:
+        """64-bit hash of effective_options(): engines with equal signatures on equal problems give every column the same bits"""
+        return int(self.lib.dll.lsx_options_signature(self._h))
 
     def sweep_policy(self) -> str:
         """the mapping the next formal solution runs -- under the parabolic rule: for the classes that have a ray-serial instance of it

@@ -97,8 +97,14 @@ def run_response_function(prob: Problem, base: ColumnBlock, fixture: dict, ks, l
     e0.set_columns(0, base.slice(0, 1))
     it0 = drivers.iterate_mali_columns(e0, log=log)
     I_base, n_base = e0.get(_capi.LSX_I)[0], e0.get(_capi.LSX_N)[0]
-    e0.close()
     jobs = [(int(k), tag) for k in ks for tag in ('p', 'm')]
+    if world > 1:
+        # start-up check of the sharded job: every rank's engines must be made alike (options, rule, plan, and the mapping the
+        # whole problem's column count selects) -- on the base engine, which every rank has, even one with an empty shard
+        from .parallel import check_same_options
+        e0.set_sweep_policy('auto', len(jobs))
+        check_same_options(e0)
+    e0.close()
     first, count = shard_columns(len(jobs), rank, world)
     cols = [apply_delta(prob, base, deltas_of(fixture, k, tag), k, start_n=n_base) for k, tag in jobs[first:first + count]]
     if cols:

@@ -1355,6 +1355,42 @@ int32_t lsx_sweep_policy(const lsx_ctx* c)
     return 0;
 }
 
+/* include/lsx.h, explicit options: the oracle has ONE code path, so a well-formed list is accepted and ignored */
+int lsx_create_with_options(const lsx_problem* d, int32_t ncol, int32_t device, void* stream, const char* options, lsx_ctx** out)
+{
+    if (options) {
+        const char* p = options;
+        while (*p) {                                   /* key=value(,|;)... : every entry needs a '=' with text on both sides */
+            const char* e = p;
+            while (*e && *e != ',' && *e != ';') ++e;
+            const char* q = p;
+            while (q < e && *q != '=') ++q;
+            int blank = 1;
+            for (const char* t = p; t < e; ++t) if (*t != ' ') blank = 0;
+            if (!blank && (q == p || q >= e - 1)) return fail(LSX_EINVAL, "lsx_create_with_options: expected key=value");
+            p = *e ? e + 1 : e;
+        }
+    }
+    return lsx_create(d, ncol, device, stream, out);
+}
+
+int lsx_effective_options(const lsx_ctx* c, char* buf, size_t n)
+{
+    static const char kWhat[] = "backend=oracle-c";
+    if (!c || !buf || n < sizeof kWhat) return fail(LSX_EINVAL, "lsx_effective_options: bad argument");
+    memcpy(buf, kWhat, sizeof kWhat);
+    return LSX_OK;
+}
+
+uint64_t lsx_options_signature(const lsx_ctx* c)
+{
+    static const char kWhat[] = "backend=oracle-c";
+    uint64_t h = 0xcbf29ce484222325ull;                /* FNV-1a, as the HIP library hashes its own string */
+    if (!c) return 0;
+    for (const char* p = kWhat; *p; ++p) { h ^= (unsigned char)*p; h *= 0x100000001b3ull; }
+    return h;
+}
+
 int lsx_set_active_columns(lsx_ctx* c, const uint8_t* active)
 {
     if (!c) return fail(LSX_EINVAL, "null ctx");

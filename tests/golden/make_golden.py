@@ -12,7 +12,7 @@ under /root/reference is touched:
     arrays (numpy<1.25 semantics; only used for list membership in setup).
 (np.bool, used at rh_method.py:124, exists again in numpy 2.x.)
 
-Usage:  python tests/golden/make_golden.py [units] [falc_ca] [falc_cah] [falc_ca_vlos] [rf] [rf_inputs] [setup] [all]
+Usage:  python tests/golden/make_golden.py [units] [falc_ca] [falc_cah] [falc_ca_vlos] [falc_c] [falc_fe] [falc_mg] [rf] [rf_inputs] [setup] [all]
 """
 import os
 import sys
@@ -42,7 +42,7 @@ atomic_model.avoid_recursion_eq = _compat_eq
 
 import formal_solver  # noqa: E402
 from fal import Falc82  # noqa: E402
-from rh_atoms import CaII_atom, H_6_atom  # noqa: E402
+from rh_atoms import CaII_atom, H_6_atom, C_atom, Fe_simple_atom, MgII_atom  # noqa: E402
 from atomic_set import RadiativeSet  # noqa: E402
 from rh_method import Context  # noqa: E402
 from background import Background  # noqa: E402
@@ -50,8 +50,9 @@ from atomic_model import AtomicLine  # noqa: E402
 
 
 # ----------------------------------------------------------------------------
-def build_ctx(active, vlos=None, temp_pert=None, start_pops=None, nrays=5):
-    """Reproduces the setup of test.py:8-18 / response_fn.py:23-37."""
+def build_ctx(active, vlos=None, temp_pert=None, start_pops=None, nrays=5, models=None):
+    """Reproduces the setup of test.py:8-18 / response_fn.py:23-37.  models: the RadiativeSet's atomic models (default: test.py's
+    CaII + H); hydrogen must be among them (its ground-level populations enter the van der Waals damping, rh_method.py:223)."""
     ac = Falc82()
     ac.quadrature(nrays)
     if temp_pert is not None:
@@ -60,7 +61,7 @@ def build_ctx(active, vlos=None, temp_pert=None, start_pops=None, nrays=5):
     if vlos is not None:
         ac.vlos[:] = vlos  # m/s (constructor already converted to SI)
     atmos = ac.convert_scales()
-    aSet = RadiativeSet([CaII_atom(), H_6_atom()])
+    aSet = RadiativeSet(models if models is not None else [CaII_atom(), H_6_atom()])
     aSet.set_active(*active)
     spect = aSet.compute_wavelength_grid()
     eqPops = aSet.compute_eq_pops(atmos)
@@ -295,6 +296,24 @@ def gen_falc_ca_vlos():
     save('falc_ca_vlos.npz', d)
 
 
+def gen_falc_multilevel(which):
+    """FALC with one of the reference's larger model atoms active (rh_atoms.py:194 C_atom: 15 levels, 16 lines, 14 bound-free
+    continua onto C II; :355 Fe_simple_atom: 15 levels, 15 lines, 14 continua; :50 MgII_atom: 11 levels, 15 lines, 10 continua):
+    up to 14 transitions overlap at a wavelength, every continuum shares its atom with the lines it overlaps
+    (rh_method.py:606-627, 654-681: the atom.eta / atom.chi / atom.U cross terms between lines and continua of one atom).
+    Inputs + J, I, Gamma, dJ after formal solutions 1-4 and n, dPops after the first statistical equilibrium."""
+    ctor, name = {'c': (C_atom, 'C'), 'fe': (Fe_simple_atom, 'Fe'), 'mg': (MgII_atom, 'MG')}[which]
+    ctx = build_ctx([name], models=[H_6_atom(), ctor()])
+    d = dump_inputs(ctx)
+    run_mali(ctx, d, snap_iters=(1, 2, 3, 4), stop_after=4, log='falc_' + which)
+    for k in ('fs2_J', 'fs3_J'):          # keep the file small: J after calls 1 and 4 (fs1_J is the J-dagger of call 2, and so on)
+        del d[k]
+    for k in list(d.keys()):              # the rates' snapshots pin I at every depth: keep them for call 1 only
+        if k.startswith('fs2_R'):
+            del d[k]
+    save('falc_%s.npz' % which, d)
+
+
 def gen_rf(ks=(20, 48, 70)):
     """response_fn.py:23-67 for a handful of depth indices: delta-encoded inputs
     (only the depth-k entries differ) + converged emergent I."""
@@ -499,9 +518,10 @@ def gen_setup():
 if __name__ == '__main__':
     what = sys.argv[1:] or ['all']
     if 'all' in what:
-        what = ['units', 'falc_ca', 'falc_cah', 'falc_ca_vlos', 'rf']
+        what = ['units', 'falc_ca', 'falc_cah', 'falc_ca_vlos', 'falc_c', 'falc_fe', 'falc_mg', 'rf']
     for w in what:
         t0 = time.time()
         {'units': gen_units, 'falc_ca': gen_falc_ca, 'falc_cah': gen_falc_cah,
-         'falc_ca_vlos': gen_falc_ca_vlos, 'rf': gen_rf, 'rf_inputs': gen_rf_inputs, 'setup': gen_setup}[w]()
+         'falc_ca_vlos': gen_falc_ca_vlos, 'rf': gen_rf, 'falc_c': lambda: gen_falc_multilevel('c'),
+         'falc_fe': lambda: gen_falc_multilevel('fe'), 'falc_mg': lambda: gen_falc_multilevel('mg'), 'rf_inputs': gen_rf_inputs, 'setup': gen_setup}[w]()
         print('%s done in %.1fs' % (w, time.time() - t0), flush=True)

@@ -34,6 +34,17 @@ class HostOnly(_capi.LsxLibrary):
         d.lsx_continuum_alpha.argtypes = [C.POINTER(_capi.LsxContinuumModel), C.c_int32, _dp, _dp]
         d.lsx_plan_probe.argtypes = [C.POINTER(_capi.LsxProblem), C.c_uint32, C.POINTER(C.c_int64), ip, C.c_int32, C.c_char_p, C.c_int32]
 
+    def signature(self, prob, options=None):
+        """-> (hash, string): what the product's lsx_options_signature / lsx_effective_options report as far as the host side decides
+        it (options from the environment + the explicit list, the plan's class list)"""
+        p, keep = prob.to_c()
+        f = self.dll.lsx_plan_signature
+        f.restype = C.c_uint64
+        f.argtypes = [C.POINTER(_capi.LsxProblem), C.c_char_p, C.c_char_p, C.c_int32]
+        buf = C.create_string_buffer(4096)
+        h = f(C.byref(p), options.encode() if options else None, buf, 4096)
+        return int(h), buf.value.decode()
+
     def probe(self, prob, bits=0):
         """-> (rc, message, summary[16], tiles[ntile][8])"""
         p, keep = prob.to_c()

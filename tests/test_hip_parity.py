@@ -58,9 +58,15 @@ def test_piecewise_linear_1d_units(hip_lib, oracle_lib):
         assert np.all(np.abs(Psi - Po) * chi <= 1e-11 * np.abs(Po) * chi + 1e-12)
 
 
-@pytest.mark.parametrize('name,compact,tol', [('falc_ca.npz', True, 1e-12), ('falc_ca.npz', False, 1e-12),
-                                              ('falc_cah.npz', True, 3e-11), ('falc_cah.npz', False, 3e-11)])
-def test_single_calls_match_reference_and_oracle(hip_lib, oracle_lib, name, compact, tol):
+# falc_c / falc_fe / falc_mg (round 5): FALC with the reference's 15-level carbon and iron atoms and its 11-level MgII atom active
+# (rh_atoms.py:194, :355, :50), generated from the reference like the others (make_golden.py, gen_falc_multilevel) -- up to 14
+# transitions of one atom at a wavelength, continua linked to one, two and three lines.  ntol: populations after the first
+# statistical equilibrium against the REFERENCE's (a 15-level system: the oracle itself is at 1.1e-8 there, test_oracle_golden.py).
+@pytest.mark.parametrize('name,compact,tol,ntol', [('falc_ca.npz', True, 1e-12, 2e-9), ('falc_ca.npz', False, 1e-12, 2e-9),
+                                                   ('falc_cah.npz', True, 3e-11, 2e-9), ('falc_cah.npz', False, 3e-11, 2e-9),
+                                                   ('falc_c.npz', True, 3e-11, 1e-7), ('falc_fe.npz', True, 3e-11, 1e-7),
+                                                   ('falc_mg.npz', True, 3e-11, 1e-7), ('falc_mg.npz', False, 3e-11, 1e-7)])
+def test_single_calls_match_reference_and_oracle(hip_lib, oracle_lib, name, compact, tol, ntol):
     prob, block, d = fixtures.load_problem_npz(golden(name), phi_compact=compact)
     eng = Engine(prob, 1, lib=hip_lib)
     ora = Engine(prob, 1, lib=oracle_lib)
@@ -74,24 +80,26 @@ def test_single_calls_match_reference_and_oracle(hip_lib, oracle_lib, name, comp
         J, I, G = eng.get(_capi.LSX_J)[0], eng.get(_capi.LSX_I)[0], eng.get(_capi.LSX_GAMMA)[0]
         Jo, Io, Go = ora.get(_capi.LSX_J)[0], ora.get(_capi.LSX_I)[0], ora.get(_capi.LSX_GAMMA)[0]
         # after the first statistical-equilibrium solve the two sides' populations differ by the LU's rounding times its
-        # conditioning -- measured 1.2e-10 on n, 1.2e-11 on J and I: asserted at ten times that
-        assert relerr(J, Jo) < (tol if tight else 2e-10)
-        assert relerr(I, Io) < (tol if tight else 2e-10)
+        # conditioning -- measured 1.2e-10 on n, 1.2e-11 on J and I (CaII, Ca+H): asserted at ten times that; the 15-level atoms:
+        # 1e-8 on n (ntol), 3e-9 on J
+        loose = 2e-10 if ntol < 1e-8 else ntol
+        assert relerr(J, Jo, floor=1e-300) < (tol if tight else loose)
+        assert relerr(I, Io) < (tol if tight else loose)
         off, diag = gamma_err(G, Go, prob)
-        assert off < (10 * tol if tight else 1e-8) and diag < (tol if tight else 1e-9), (it, off, diag)
+        assert off < (10 * tol if tight else 50 * loose) and diag < (tol if tight else 5 * loose), (it, off, diag)
         tag = 'fs%d' % it
         if tag + '_I' in d:   # golden vectors of the reference itself
-            assert relerr(I, d[tag + '_I']) < (tol if tight else 2e-10)
+            assert relerr(I, d[tag + '_I']) < (tol if tight else loose)
             if tag + '_J' in d:
-                assert relerr(J, d[tag + '_J']) < (tol if tight else 2e-10)
+                assert relerr(J, d[tag + '_J'], floor=1e-300) < (tol if tight else loose)
             off, diag = gamma_err(G, fixtures.gamma_from_raw(d, tag, prob), prob)
-            assert off < (10 * tol if tight else 1e-8) and diag < (tol if tight else 1e-9)
+            assert off < (10 * tol if tight else 50 * loose) and diag < (tol if tight else 5 * loose)
         if it > 3:
             dP, dPo = eng.stat_equil(), ora.stat_equil()
             assert dP == pytest.approx(dPo, rel=1e-7)
-            assert relerr(eng.get(_capi.LSX_N)[0], ora.get(_capi.LSX_N)[0]) < 2e-9
+            assert relerr(eng.get(_capi.LSX_N)[0], ora.get(_capi.LSX_N)[0]) < ntol
             if 'se%d_dPops' % it in d:
-                assert relerr(eng.get(_capi.LSX_N)[0], fixtures.pops_from_raw(d, 'se%d' % it, prob)) < 2e-9
+                assert relerr(eng.get(_capi.LSX_N)[0], fixtures.pops_from_raw(d, 'se%d' % it, prob)) < ntol
     eng.close()
 
 

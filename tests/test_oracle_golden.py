@@ -93,6 +93,35 @@ def test_first_calls_match_reference(oracle_lib, name, compact, tol):
     eng.close()
 
 
+# The reference's larger model atoms (rh_atoms.py:194 C_atom, :355 Fe_simple_atom, :50 MgII_atom; tests/golden/make_golden.py,
+# gen_falc_multilevel): 11-15 levels, 15-16 lines and 10-14 bound-free continua of ONE atom, up to 14 transitions at a wavelength,
+# every continuum sharing its atom with the lines it overlaps -- the atom.eta / atom.chi / atom.U cross terms between lines and
+# continua of rh_method.py:606-627, 654-681 that CaII (+ H) never reaches.  Measured oracle-vs-reference: I 3.4e-12 (C; the w2
+# cancellation next to the Taylor switch, as for Ca+H), J 7e-13, Gamma off-diagonal 6e-14; populations after the first statistical
+# equilibrium 1.1e-8 (Fe: a 15-level system, LU rounding x conditioning; dPops itself to 5e-10).  C's J holds zeros at its
+# shortest wavelengths, so dJ = 1.0 on every call (rh_method.py:705-706) -- reproduced.
+@pytest.mark.parametrize('name,compact', [('falc_c.npz', True), ('falc_fe.npz', True), ('falc_mg.npz', True), ('falc_mg.npz', False)])
+def test_multilevel_reference_atoms_match_reference(oracle_lib, name, compact):
+    prob, block, d = fixtures.load_problem_npz(golden(name), phi_compact=compact)
+    assert prob.Natoms == 1 and prob.Nlevel[0] >= 11 and prob.Ntrans >= 25
+    eng = Engine(prob, 1, lib=oracle_lib)
+    eng.set_columns(0, block)
+    tol = 1e-11
+    for it in range(1, 5):
+        dJ = eng.formal_sol_gamma()
+        tag = 'fs%d' % it
+        assert dJ == pytest.approx(float(d[tag + '_dJ']), rel=1e-9)
+        assert relerr(eng.get(_capi.LSX_I)[0], d[tag + '_I']) < tol
+        if tag + '_J' in d:
+            assert relerr(eng.get(_capi.LSX_J)[0], d[tag + '_J'], floor=1e-300) < tol
+        off, diag = gamma_err(eng.get(_capi.LSX_GAMMA)[0], fixtures.gamma_from_raw(d, tag, prob), prob)
+        assert off < 1e-12 and diag < 1e-12, (it, off, diag)
+    dP = eng.stat_equil()
+    assert dP == pytest.approx(float(d['se4_dPops']), rel=1e-8)
+    assert relerr(eng.get(_capi.LSX_N)[0], fixtures.pops_from_raw(d, 'se4', prob)) < 1e-7
+    eng.close()
+
+
 def test_rates_quirk_accumulate_across_calls(oracle_lib):
     """rh_method.py:691-692: Rij/Rji are never zeroed and Rji uses Vij.  Not part of the ABI (nothing reads
     them in the reference); the oracle keeps them because the golden files hold them and they test I at every depth."""

@@ -40,13 +40,15 @@ def class_table(lib, eng):
     return table, fused
 
 
-def _run_pair(hip_lib, oracle_lib, name, ncol, seed, tol, expect_classes):
+def _run_pair(hip_lib, oracle_lib, name, ncol, seed, tol, expect_classes, ntol=1e-8, **engine_kw):
+    """engine_kw: what the HIP engine is made with (sweep_policy=, options=: include/lsx.h, lsx_set_sweep_policy /
+    lsx_create_with_options) -- explicit arguments, not the process environment"""
     prob, base, raw = fixtures.load_problem_npz(golden(name), phi_compact=False)
     blk, (aD, vB, vlos) = synth.perturbed_columns(prob, base, raw, ncol=ncol, seed=seed, vlos_sigma=2.0e3)
     assert vlos is not None and np.any(vlos[1] != 0.0)
     engs = []
     for lib in (hip_lib, oracle_lib):
-        e = Engine(prob, ncol, lib=lib)
+        e = Engine(prob, ncol, lib=lib, **(engine_kw if lib is hip_lib else {}))
         e.set_columns(0, blk)
         e.set_line_profiles(0, aD, vB, vlos)
         engs.append(e)
@@ -68,9 +70,9 @@ def _run_pair(hip_lib, oracle_lib, name, ncol, seed, tol, expect_classes):
         if it > 3:
             dP, dPo = hip.stat_equil(), ora.stat_equil()
             assert dP == pytest.approx(dPo, rel=1e-6)
-    assert relerr(hip.get(_capi.LSX_N), ora.get(_capi.LSX_N)) < 1e-8
-    assert relerr(hip.get(_capi.LSX_J), ora.get(_capi.LSX_J)) < 1e-8
-    assert relerr(hip.get(_capi.LSX_I), ora.get(_capi.LSX_I)) < 1e-8
+    assert relerr(hip.get(_capi.LSX_N), ora.get(_capi.LSX_N)) < ntol
+    assert relerr(hip.get(_capi.LSX_J), ora.get(_capi.LSX_J), floor=1e-300) < ntol
+    assert relerr(hip.get(_capi.LSX_I), ora.get(_capi.LSX_I)) < ntol
     # ---- the production instantiations are what ran
     table, fused = class_table(hip_lib, hip)
     assert fused == 0, 'the fused small-batch kernel must not be what this test measures'
@@ -89,9 +91,8 @@ def _run_pair(hip_lib, oracle_lib, name, ncol, seed, tol, expect_classes):
 def test_c3_caii_columns_per_class_path(hip_lib, oracle_lib, monkeypatch, ray_serial):
     """C3: CaII, 64 columns (12 full column groups + one of 4), ray-dependent device-built profiles; tile classes 0, 1 (one
     line), 2 (H & K overlap)"""
-    monkeypatch.setenv('LSX_RS_MIN_COLUMNS', '1' if ray_serial else '1000000')
-    monkeypatch.setenv('LSX_RS_MAX_NPT', '2')          # every ray-serial instance, also the two-slot ones the default leaves to lsx_sweep.hip
-    table = _run_pair(hip_lib, oracle_lib, 'falc_ca.npz', 64, 1234, 1e-12, [(0, 0, 0, 0), (1, 1, 0, 0), (2, 2, 0, 1)])      # H & K share their lower level: relation 1
+    table = _run_pair(hip_lib, oracle_lib, 'falc_ca.npz', 64, 1234, 1e-12, [(0, 0, 0, 0), (1, 1, 0, 0), (2, 2, 0, 1)],      # H & K share their lower level: relation 1
+                      sweep_policy='ray-serial' if ray_serial else 'ray-per-lane', options='rs_max_npt=2')
     assert sum(t for t, _ in table.values()) == 25          # DESIGN 4.1: 25 tiles for FALC CaII
     assert all(v == ray_serial for v in class_table.ray_serial.values()), class_table.ray_serial
 
@@ -100,9 +101,8 @@ def test_c3_caii_columns_per_class_path(hip_lib, oracle_lib, monkeypatch, ray_se
 def test_c4_cah_columns_linked_continua(hip_lib, oracle_lib, monkeypatch, ray_serial):
     """C4: Ca+H, 41 columns.  Every hydrogen line tile carries linked continua: classes (1 line) and (2 lines), each with and
     without linked continua, plus the continuum-only tiles"""
-    monkeypatch.setenv('LSX_RS_MIN_COLUMNS', '1' if ray_serial else '1000000')
-    monkeypatch.setenv('LSX_RS_MAX_NPT', '2')
-    table = _run_pair(hip_lib, oracle_lib, 'falc_cah.npz', 41, 4321, 3e-11, [(0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 0), (2, 2, 0, 1), (2, 2, 1, 1)])
+    table = _run_pair(hip_lib, oracle_lib, 'falc_cah.npz', 41, 4321, 3e-11, [(0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 0), (2, 2, 0, 1), (2, 2, 1, 1)],
+                      sweep_policy='ray-serial' if ray_serial else 'ray-per-lane', options='rs_max_npt=2')
     assert -1 not in [k[0] for k in table]                  # no tile falls back to the generic instance
     assert max(k[0] for k in table) == 2                    # no continuum goes through the sweep
     assert all(v == ray_serial for v in class_table.ray_serial.values()), class_table.ray_serial
@@ -111,10 +111,41 @@ def test_c4_cah_columns_linked_continua(hip_lib, oracle_lib, monkeypatch, ray_se
 def test_c4_cah_columns_three_and_four_slot_instances(hip_lib, oracle_lib, monkeypatch):
     """the same columns with the linking switched off: hydrogen's continua become per-ray slots again, and
     lsx_sweep_kernel<3, {1,2}, 5, false> and <4, {1,2}, 5, false> meet the oracle"""
-    monkeypatch.setenv('LSX_NO_LINKED', '1')
     table = _run_pair(hip_lib, oracle_lib, 'falc_cah.npz', 40, 4321, 3e-11,
-                      [(1, 1, 0, 0), (2, 1, 0, 0), (2, 2, 0, 1), (3, 1, 0, 0), (3, 2, 0, 0), (4, 1, 0, 0), (4, 2, 0, 0)])
+                      [(1, 1, 0, 0), (2, 1, 0, 0), (2, 2, 0, 1), (3, 1, 0, 0), (3, 2, 0, 0), (4, 1, 0, 0), (4, 2, 0, 0)], options='linked=0')
     assert -1 not in [k[0] for k in table]
+
+
+# The reference's own larger atoms through the production launch path (round 5; fixtures generated from the reference:
+# tests/golden/make_golden.py, gen_falc_multilevel; the single-column calls meet the reference's golden vectors in
+# tests/test_hip_parity.py).  Classes as the product's planner files them (tests/test_instance_ledger.py walks the same plans on
+# the CPU): carbon -- 119 tiles, continua linked to one line; iron -- 78 tiles; MgII -- continua linked to one, two and THREE lines
+# (class (3, 3, linked)) and tiles the generic instance takes; with the linking switched off the continua of a line's atom become
+# per-ray slots: (2, 1) for carbon, (4, 1) for MgII -- per-ray-continuum instances planned by a REFERENCE problem.
+MULTILEVEL = {
+    'falc_c.npz': ([(0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 0), (2, 2, 0, 0), (2, 2, 0, 1)], [(2, 1, 0, 0), (-1, 0, 0, 0)]),
+    'falc_fe.npz': ([(0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 0), (2, 2, 0, 0), (2, 2, 0, 1)], [(2, 2, 0, 0), (2, 2, 0, 1)]),
+    'falc_mg.npz': ([(0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 0), (2, 2, 0, 0), (2, 2, 1, 0), (2, 2, 1, 1), (3, 3, 1, 0), (-1, 0, 1, 0)],
+                    [(4, 1, 0, 0), (-1, 0, 0, 0)]),
+}
+
+
+@pytest.mark.parametrize('mode', ['ray-per-lane', 'ray-serial', 'unlinked'])
+@pytest.mark.parametrize('name', sorted(MULTILEVEL))
+def test_multilevel_reference_atoms_per_class_path(hip_lib, oracle_lib, name, mode):
+    linked, unlinked = MULTILEVEL[name]
+    if mode == 'unlinked':
+        table = _run_pair(hip_lib, oracle_lib, name, 33, 2468, 3e-11, unlinked, ntol=1e-7, options='linked=0')
+    else:
+        table = _run_pair(hip_lib, oracle_lib, name, 36, 2468, 3e-11, linked, ntol=1e-7, sweep_policy=mode)
+        # the classes with at most two per-ray slots run the mapping that was asked for, the others one ray per lane -- and so does a
+        # class with linked continua if one of its tiles needs the row-mapped epilogue (more than six continua of an atom at a
+        # wavelength, as carbon's and magnesium's have: the ray-serial instances leave the linked corrections to the column-mapped one)
+        for key, serial in class_table.ray_serial.items():
+            want = mode == 'ray-serial' and 0 <= key[0] <= 2
+            assert serial == want or (want and key[2] == 1 and not serial), (key, serial)
+        if mode == 'ray-serial':
+            assert any(class_table.ray_serial.values())
 
 
 def test_single_column_reaches_the_fused_kernel(hip_lib):
@@ -139,9 +170,7 @@ def test_small_batch_gamma_epilogue_gives_the_bits_of_the_many_column_one(hip_li
     blk, (aD, vB, vlos) = synth.perturbed_columns(prob, base, raw, ncol=ncol, seed=11, vlos_sigma=1.0e3)
     out = []
     for big in (False, True):
-        if big:
-            monkeypatch.setenv('LSX_FINISH_BIG', '1')
-        e = Engine(prob, ncol, lib=hip_lib)
+        e = Engine(prob, ncol, lib=hip_lib, options='finish_big=%d' % big)
         e.set_columns(0, blk)
         e.set_line_profiles(0, aD, vB, vlos)
         mon = []
@@ -196,15 +225,11 @@ def test_full_size_batches_by_size_independent_properties(hip_lib, oracle_lib, m
     nsmall = 37 if ray_serial else nuniq
     ssrc = src[:nsmall]
     pick = lambda idx: (type(blk).concatenate([blk.slice(int(q), int(q) + 1) for q in idx]), tuple(p[idx] for p in prof))
-    if ray_serial:
-        monkeypatch.setenv('LSX_RS_MIN_COLUMNS', '1')
-        if mode == 'mixed':
-            monkeypatch.setenv('LSX_RS_MAX_NPT', '1')
-    else:
-        monkeypatch.setenv('LSX_NO_RS', '1')
-    small = Engine(prob, nsmall, lib=hip_lib)
-    monkeypatch.delenv('LSX_RS_MIN_COLUMNS', raising=False)
-    big = Engine(prob, ncol, lib=hip_lib)
+    # explicit arguments, not the environment: the small batch is made for the BIG problem's column count (policy_columns: the
+    # kernel choice belongs to the problem), `mixed` leaves the two-slot tiles to one ray per lane, `ray-per-lane` pins that mapping
+    kw = dict(options='rs_max_npt=1' if mode == 'mixed' else None, sweep_policy='auto' if ray_serial else 'ray-per-lane')
+    small = Engine(prob, nsmall, lib=hip_lib, policy_columns=ncol, **kw)
+    big = Engine(prob, ncol, lib=hip_lib, **kw)
     synth.load_columns(small, *pick(ssrc))
     synth.load_columns(big, *pick(src))
     ora = Engine(prob, nuniq, lib=oracle_lib)
@@ -257,13 +282,8 @@ def test_fused_launch_runs_the_fast_continuum_work_itself_with_the_same_bits(hip
     blk, (aD, vB, vlos) = synth.perturbed_columns(prob, base, raw, ncol=ncol, seed=21, vlos_sigma=1.5e3)
     out = []
     for leg in ('default', 'separate', 'epilogue-inside'):      # default: the pre-pass inside the fused launch, the epilogue a launch of its own
-        monkeypatch.delenv('LSX_NO_FUSED_FAST', raising=False)
-        monkeypatch.delenv('LSX_FUSED_EPILOGUE', raising=False)
-        if leg == 'separate':
-            monkeypatch.setenv('LSX_NO_FUSED_FAST', '1')
-        if leg == 'epilogue-inside':
-            monkeypatch.setenv('LSX_FUSED_EPILOGUE', '1')       # (measured slower: the epilogue then extends the longest workgroups)
-        e = Engine(prob, ncol, lib=hip_lib)
+        # (epilogue-inside was measured slower: the epilogue then extends the longest workgroups)
+        e = Engine(prob, ncol, lib=hip_lib, options={'default': None, 'separate': 'fused_fast=0', 'epilogue-inside': 'fused_epilogue=1'}[leg])
         e.set_columns(0, blk)
         e.set_line_profiles(0, aD, vB, vlos)
         mon = []
@@ -291,11 +311,7 @@ def test_formal_solution_replayed_as_a_captured_graph_gives_the_same_bits(hip_li
     blk, prof = synth.perturbed_columns(prob, base, raw, ncol=ncol, seed=31, vlos_sigma=1.5e3)
     out = []
     for leg in ('eager', 'graph'):
-        if leg == 'graph':
-            monkeypatch.setenv('LSX_GRAPH', '1')
-        else:
-            monkeypatch.delenv('LSX_GRAPH', raising=False)
-        e = Engine(prob, ncol, lib=hip_lib)
+        e = Engine(prob, ncol, lib=hip_lib, options='graph=%d' % (leg == 'graph'))
         synth.load_columns(e, blk, prof)
         mon = []
         for it in range(5):

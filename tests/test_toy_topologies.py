@@ -132,11 +132,10 @@ def test_toy_parity_on_the_ray_serial_kernel(hip_lib, oracle_lib, monkeypatch, k
     minimal depth counts, compact profiles, every tile shape the toy atoms produce with at most two per-ray slots; then the same
     batch with every third column frozen (lsx_set_active_columns): frozen columns keep their J, I, Gamma and populations, the
     others do not notice"""
-    monkeypatch.setenv('LSX_RS_MIN_COLUMNS', '1')
     kw = dict(kw)
     ncol = kw['ncol']
     prob, block = toy_problem(**kw)
-    eh, eo = Engine(prob, ncol, lib=hip_lib), Engine(prob, ncol, lib=oracle_lib)
+    eh, eo = Engine(prob, ncol, lib=hip_lib, sweep_policy='ray-serial'), Engine(prob, ncol, lib=oracle_lib)
     for e in (eh, eo):
         e.set_columns(0, block)
     tol = 2e-10 if kw.get('multiplet') else 1e-11
