@@ -136,10 +136,21 @@ def run_c5(args, rank, local_rank, world):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the scaling record proves itself (round 5): what every rank saw -- its own time for the K steps, the world size and backend of
+    # the process group it was in, the sweep mapping its engine ran and its options signature -- gathered onto rank 0's line
+    scaling_record = None
     if world > 1:
+        dt_own = dt
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        mine = dict(rank=rank, ms_per_step=dt_own / args.steps * 1e3, world_seen=dist.get_world_size(), backend=dist.get_backend(),
+                    sweep_policy=eng.sweep_policy(), columns=ncol, options_signature='%016x' % eng.options_signature(),
+                    device=torch.cuda.get_device_name(dev) if dev.type == 'cuda' else str(dev))
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        scaling_record = dict(world_seen=dist.get_world_size(), backend=dist.get_backend(), per_rank=every,
+                              ms_per_step_max_over_ranks=dt / args.steps * 1e3)
     ref = dict(np.load(os.path.join(gold, 'rf_ca.npz')))
     err = 0.0
     for k in [int(k) for k in ref['ks']]:
@@ -525,7 +536,10 @@ def main():
                                   Nrays=prob.Nrays, profiles='compact (vlos=0)' if compact else 'ray dependent (vlos!=0)',
                                   columns='populations, rates and profiles derived by the library from each column\'s perturbed atmosphere' if t_chain is not None else 'input-level perturbations (BASELINE C3 / C4)',
                                   parallelism=parallelism_text(world, rehearsal), sweep_policy=eng.sweep_policy(),
-                                  runtime_env=dict(GPU_MAX_HW_QUEUES=os.environ.get('GPU_MAX_HW_QUEUES'))),
+                                  runtime_env=dict(GPU_MAX_HW_QUEUES=os.environ.get('GPU_MAX_HW_QUEUES'),
+                                                   LSX_env={k: v for k, v in os.environ.items() if k.startswith('LSX_')},
+                                                   effective_options=eng.effective_options(),
+                                                   options_signature='%016x' % eng.options_signature())),
                       step_ms=dict(stats_ms(per_step), note='host clock on rank 0 between the monitor read-backs of consecutive steps; loop: ' +
                                    ('look-ahead (the next formal solution is enqueued before a read-back is waited for)' if eng.prefers_lookahead()
                                     else 'plain (formal solution, stat_equil, read-back; lsx_prefers_lookahead = 0 for this context)')),
@@ -536,6 +550,8 @@ def main():
                       setup=dict(generate_s=t_gen, upload_s=t_up, upload_GB=upload_bytes / 1e9, device_chain_s=t_chain,
                                  line_profiles='built on the device (lsx_set_line_profiles)' if prof is not None else 'ray independent (vlos = 0): the fixture\'s profiles',
                                  note='PCIe-inclusive upload (and the device-side profile build) is outside the timed region (inputs resident in HBM)'))
+        if scaling_record is not None:
+            result['scaling_record'] = scaling_record
         if rehearsal:
             result.update(rehearsal)
     eng.close()

@@ -168,6 +168,8 @@ struct SweepParams {
     // "a RING in LDS"): optab[group]{[t < Ntrans][r <= Nspace][c < 5][3], [r <= Nspace][c < 5][2]}, rebuilt per formal solution
     const double* optab;
     int64_t optab_group_stride; // doubles per group
+    const int32_t* trans_row;   // per transition: its row of wphi (lines) / its continuum index (continua)
+    int32_t fold, fold_nF;      // the launched class runs its FOLDED instance (lsx_plan.h); the most fast continua a tile of it has
 };
 
 // ---- the line-profile store phi_T --------------------------------------------------------------------------------------------

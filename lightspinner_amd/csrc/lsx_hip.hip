@@ -259,6 +259,7 @@ struct OptabParams {
     int Ns, Ntrans, ncol, NLtot, Nlines, Ncont;
     const DevTrans* trans;
     const int* trans_row;
+    const int *cont_li, *cont_lj;
     const double *n, *wphi, *nsr, *height, *sca;
     double* optab;
     size_t gstride;
@@ -266,17 +267,18 @@ struct OptabParams {
 __global__ void k_build_optab(const OptabParams p)
 {
     const int g = blockIdx.x, t = blockIdx.y, Ns = p.Ns;
-    constexpr int NC = LSX_RS_COLS;
+    constexpr int NC = LSX_RS_COLS, PAD = LSX_RS_RING;
+    const int NR = lsx_optab_rows(Ns);                           // rows per block: depth r is row r + PAD, zero rows around
     const int ncg = min(NC, p.ncol - g * NC);
     double* const grp = p.optab + (size_t)g * p.gstride;
     if (t < p.Ntrans) {
         const DevTrans tr = p.trans[t];
         const double Uc = tr.AB * (tr.gij * tr.cB);               // DevSlot.Uc (lsx_plan.cpp)
-        double* const blk = grp + (size_t)t * (Ns + 1) * (3 * NC);
-        for (int e = threadIdx.x; e < (Ns + 1) * NC; e += blockDim.x) {
-            const int r = e / NC, c = e - r * NC;
+        double* const blk = grp + (size_t)t * NR * (3 * NC);
+        for (int e = threadIdx.x; e < NR * NC; e += blockDim.x) {
+            const int r = e / NC - PAD, c = e - (e / NC) * NC;
             double v0 = 0.0, v1 = 0.0, v2 = 0.0;
-            if (r < Ns) {
+            if (r >= 0 && r < Ns) {
                 const size_t col = (size_t)g * NC + (c < ncg ? c : ncg - 1);
                 const double ni = p.n[(col * p.NLtot + tr.li) * Ns + r], nj = p.n[(col * p.NLtot + tr.lj) * Ns + r];
                 if (tr.is_line) {
@@ -291,14 +293,31 @@ __global__ void k_build_optab(const OptabParams p)
             }
             blk[(size_t)e * 3 + 0] = v0; blk[(size_t)e * 3 + 1] = v1; blk[(size_t)e * 3 + 2] = v2;
         }
-    } else {
-        double* const blk = grp + (size_t)p.Ntrans * (Ns + 1) * (3 * NC);
-        for (int e = threadIdx.x; e < (Ns + 1) * NC; e += blockDim.x) {
-            const int r = e / NC, c = e - r * NC;
+    } else if (t < p.Ntrans + 2) {
+        const int up = t - p.Ntrans;                              // 0: the down-going sweep's geometry, 1: the up-going one's
+        double* const blk = grp + ((size_t)p.Ntrans * (3 * NC) + (size_t)up * (2 * NC)) * NR;
+        for (int e = threadIdx.x; e < NR * NC; e += blockDim.x) {
+            const int r = e / NC - PAD, c = e - (e / NC) * NC;
             const size_t col = (size_t)g * NC + (c < ncg ? c : ncg - 1);
             const double* z = p.height + col * Ns;
-            blk[(size_t)e * 2 + 0] = (r > 0 && r < Ns) ? 0.5 * fabs(z[r - 1] - z[r]) : 0.0;
-            blk[(size_t)e * 2 + 1] = r < Ns ? p.sca[col * Ns + r] : 0.0;
+            double hz = 0.0;
+            if (r >= 0 && r < Ns) hz = up ? (r + 1 < Ns ? 0.5 * fabs(z[r] - z[r + 1]) : 0.0) : (r > 0 ? 0.5 * fabs(z[r - 1] - z[r]) : 0.0);
+            blk[(size_t)e * 2 + 0] = hz;
+            blk[(size_t)e * 2 + 1] = (r >= 0 && r < Ns) ? p.sca[col * Ns + r] : 0.0;
+        }
+    } else {
+        const int q = t - p.Ntrans - 2;                           // continuum q: n_i, n_j nStar_i / nStar_j (the folded instances' operands)
+        double* const blk = grp + ((size_t)p.Ntrans * (3 * NC) + 2 * (2 * NC) + (size_t)q * (2 * NC)) * NR;
+        const int li = p.cont_li[q], lj = p.cont_lj[q];
+        for (int e = threadIdx.x; e < NR * NC; e += blockDim.x) {
+            const int r = e / NC - PAD, c = e - (e / NC) * NC;
+            double v0 = 0.0, v1 = 0.0;
+            if (r >= 0 && r < Ns) {
+                const size_t col = (size_t)g * NC + (c < ncg ? c : ncg - 1);
+                v0 = p.n[(col * p.NLtot + li) * Ns + r];
+                v1 = p.n[(col * p.NLtot + lj) * Ns + r] * p.nsr[(col * p.Ncont + q) * Ns + r];
+            }
+            blk[(size_t)e * 2 + 0] = v0; blk[(size_t)e * 2 + 1] = v1;
         }
     }
 }
@@ -1546,12 +1565,12 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
     if (use_ray_serial(c) && per_class_launches(c))
         for (auto& k : c->classes) rs_any = rs_any || (c->solver == LSX_SOLVER_PARABOLIC ? k.rsp : k.rs);
     if (rs_any && !c->d_optab) {
-        int rc = dmalloc(&c->d_optab, (size_t)((c->ncol + LSX_RS_COLS - 1) / LSX_RS_COLS) * lsx_optab_group_doubles(c->Ntrans, c->Nspace));
+        int rc = dmalloc(&c->d_optab, (size_t)((c->ncol + LSX_RS_COLS - 1) / LSX_RS_COLS) * lsx_optab_group_doubles(c->Ntrans, c->Nspace, c->Ncont));
         if (!rc) rc = upload(&c->d_trans_row, c->trans_row, c->stream);
         if (rc) return rc;
     }
     SweepParams p{};
-    p.optab = c->d_optab; p.optab_group_stride = (int64_t)lsx_optab_group_doubles(c->Ntrans, c->Nspace);
+    p.optab = c->d_optab; p.optab_group_stride = (int64_t)lsx_optab_group_doubles(c->Ntrans, c->Nspace, c->Ncont); p.trans_row = c->d_trans_row;
     p.Nspace = c->Nspace; p.Nrays = c->Nrays; p.Nspect = c->Nspect; p.Natoms = c->Natoms; p.Ntrans = c->Ntrans;
     p.ncol = c->ncol; p.NLtot = c->NLtot; p.NL2tot = c->NL2tot; p.Nlines = c->Nlines;
     p.sca_per_lambda = c->sca_per_lambda; p.phi_compact = c->phi_compact;
@@ -1630,9 +1649,13 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
     if (rs_any) {
         OptabParams op{};
         op.Ns = c->Nspace; op.Ntrans = c->Ntrans; op.ncol = c->ncol; op.NLtot = c->NLtot; op.Nlines = c->Nlines; op.Ncont = c->Ncont;
-        op.trans = c->d_trans; op.trans_row = c->d_trans_row; op.n = c->d_n; op.wphi = c->d_wphi; op.nsr = c->d_nsr; op.height = c->d_height;
-        op.sca = c->d_sca; op.optab = c->d_optab; op.gstride = lsx_optab_group_doubles(c->Ntrans, c->Nspace);
-        hipLaunchKernelGGL(k_build_optab, dim3((unsigned)((c->ncol + LSX_RS_COLS - 1) / LSX_RS_COLS), (unsigned)(c->Ntrans + 1)), dim3(128), 0, c->stream, op);
+        op.trans = c->d_trans; op.trans_row = c->d_trans_row; op.cont_li = c->d_cont_li; op.cont_lj = c->d_cont_lj;
+        op.n = c->d_n; op.wphi = c->d_wphi; op.nsr = c->d_nsr; op.height = c->d_height;
+        op.sca = c->d_sca; op.optab = c->d_optab; op.gstride = lsx_optab_group_doubles(c->Ntrans, c->Nspace, c->Ncont);
+        bool fold_any = false;
+        for (auto& k : c->classes) fold_any = fold_any || (k.fold && c->solver != LSX_SOLVER_PARABOLIC);
+        hipLaunchKernelGGL(k_build_optab, dim3((unsigned)((c->ncol + LSX_RS_COLS - 1) / LSX_RS_COLS), (unsigned)(c->Ntrans + 2 + (fold_any ? c->Ncont : 0))),
+                           dim3(128), 0, c->stream, op);
     }
     // small batches: one fused launch (n_class_tiles == ntile, identity tile list is not needed); the parabolic rule (N4) has one
     // generic instance for every tile and takes the same route at any size
@@ -1693,7 +1716,10 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
             // that every tile of the class takes that epilogue)
             const bool rs_here = (k.rs && ray_serial) || (k.rsp && ray_serial_par);
             const bool epi = k.lk_epi && rs_here;
-            if (!k.fast_tiles.empty()) launch_prepass(st, k.d_fast_tiles, k.fast_tiles.size(), epi);
+            // folded instances (lsx_plan.h): the sweep forms the fast continua's opacity and emissivity itself -- no pre-pass
+            const bool fold = k.fold && k.rs && ray_serial;
+            p.fold = fold ? 1 : 0; p.fold_nF = k.fold_nF;
+            if (!k.fast_tiles.empty() && !fold) launch_prepass(st, k.d_fast_tiles, k.fast_tiles.size(), epi);
             const long nblocks = (long)k.tiles.size() * c->ncol;
             p.class_tiles = k.d_tiles;
             p.n_class_tiles = (int)k.tiles.size();

@@ -448,7 +448,7 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
         // (round 5: the per-depth operands come through a ring in LDS, lsx_plan.h -- no limit on the depth count any more; the table
         // that feeds it is addressed with 32-bit byte offsets inside a column group)
         P.rs_ok = !opt.no_rs && P.Nrays == LSX_RS_RAYS && !P.sca_per_lambda && (LSX_RS_COLS + 1) * big * 8 < 0xffffffffull &&
-                  lsx_optab_group_doubles(P.Ntrans, Ns) * 8 < 0xffffffffull;
+                  lsx_optab_group_doubles(P.Ntrans, Ns, P.Ncont) * 8 < 0xffffffffull;
         P.rs_min_columns = opt.rs_min_columns;
         P.phi_group = (P.rs_ok && !opt.no_phi_group) ? LSX_RS_COLS : 1;
         for (auto& k : P.plan_classes) {
@@ -460,6 +460,17 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
             if (k.rs && k.lk_epi)
                 for (int t : k.tiles)
                     if (P.tiles[t].fast_simple != 2) k.rs = false;
+            // folded fast continua (lsx_plan.h): every tile's row fits two elements per lane, and the class needs no correction
+            // streams from the pre-pass (the unfactored linked instance reads them)
+            // (not the two-line instances with a known relation and no linked continua: they sit at the register limit -- folded they
+            // spill; their classes keep the pre-pass)
+            k.fold = k.rs && !opt.no_fold && k.has_fast && (!k.linked || k.lk_epi) && !(k.npt == 2 && !k.linked && k.topo != 0);
+            k.fold_nF = 0;
+            for (int t : k.tiles) {
+                k.fold_nF = std::max(k.fold_nF, (int)P.tiles[t].nF);
+                if (lsx_rs_row_doubles(k.npt, P.tiles[t].nF) > LSX_RS_FOLD_ROW_MAX || P.tiles[t].nF > 12) k.fold = false;
+            }
+            if (k.fold && (size_t)lsx_rs_lds_doubles(k.npt, Ns, false, k.fold_nF) * sizeof(double) > 64 * 1024) k.fold = false;
             k.rsp = k.rs && lsx_rsp_instance_exists(k.npt, k.nl, k.linked, k.topo) &&
                     (size_t)lsx_rs_lds_doubles(k.npt, Ns, true) * sizeof(double) <= 64 * 1024;
         }
@@ -548,6 +559,7 @@ void options_from_env(CtxOptions* o)
     p.order_by_cost = (e = getenv("LSX_ORDER")) && std::string(e) == "cost";
     p.occ_wg = (e = getenv("LSX_OCC_WG")) ? atoi(e) : 0;
     p.no_rs = getenv("LSX_NO_RS") != nullptr;
+    p.no_fold = getenv("LSX_NO_FOLD") != nullptr;
     p.no_phi_group = (e = getenv("LSX_PHI_GROUP")) && atoi(e) == 1;
     if ((e = getenv("LSX_RS_MIN_COLUMNS"))) p.rs_min_columns = atoi(e);
     if ((e = getenv("LSX_RS_MAX_NPT"))) p.rs_max_npt = atoi(e);
@@ -598,6 +610,7 @@ int options_apply(const char* list, CtxOptions* o, std::string* err)
         else if (key == "topo") ok = flag(&p.no_topo, true);
         else if (key == "fast_rows") ok = flag(&p.fast_rows, false);
         else if (key == "rs") ok = flag(&p.no_rs, true);
+        else if (key == "fold") ok = flag(&p.no_fold, true);
         else if (key == "phi_group") ok = flag(&p.no_phi_group, true);      // 1: grouped where the ray-serial sweep can run (default), 0: per column
         else if (key == "rs_min_columns") ok = count(&p.rs_min_columns, 1, 1 << 30);
         else if (key == "rs_max_npt") ok = count(&p.rs_max_npt, 0, 2);
@@ -629,10 +642,10 @@ std::string options_string(const CtxOptions& o)
     const RunOptions& r = o.run;
     char b[512];
     snprintf(b, sizeof b,
-             "linked=%d;tiler=%s;topo=%d;fast_rows=%d;order=%s;occ_wg=%d;class_chunk=%d;rs=%d;phi_group=%d;rs_min_columns=%d;rs_max_npt=%d;"
+             "linked=%d;tiler=%s;topo=%d;fast_rows=%d;order=%s;occ_wg=%d;class_chunk=%d;rs=%d;fold=%d;phi_group=%d;rs_min_columns=%d;rs_max_npt=%d;"
              "se_lds=%d;serial=%d;finish_big=%d;fused_epilogue=%d;graph=%d;fused_fast=%d;abl_fused_fast=%d",
              !p.no_linked, p.natural_tiles ? "natural" : "dp", !p.no_topo, (int)p.fast_rows, p.order_by_cost ? "cost" : "plan", p.occ_wg, p.class_chunk,
-             !p.no_rs, !p.no_phi_group, p.rs_min_columns, p.rs_max_npt, (int)r.se_lds, (int)r.serial, (int)r.finish_big,
+             !p.no_rs, !p.no_fold, !p.no_phi_group, p.rs_min_columns, p.rs_max_npt, (int)r.se_lds, (int)r.serial, (int)r.finish_big,
              (int)r.fused_epilogue, (int)r.graph, !r.no_fused_fast, r.abl_fast);
     return b;
 }
@@ -642,7 +655,7 @@ std::string plan_class_string(const LsxPlan& P)
     std::string s;
     char b[64];
     for (const PlanClass& k : P.plan_classes) {
-        snprintf(b, sizeof b, "%s%d.%d.%d.%d:%zu%s", s.empty() ? "" : ",", k.npt, k.nl, (int)k.linked, k.topo, k.tiles.size(), k.rs ? "s" : "");
+        snprintf(b, sizeof b, "%s%d.%d.%d.%d:%zu%s", s.empty() ? "" : ",", k.npt, k.nl, (int)k.linked, k.topo, k.tiles.size(), k.rs ? (k.fold ? "sf" : "s") : "");
         s += b;
     }
     return s;

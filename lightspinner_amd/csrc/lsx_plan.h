@@ -150,15 +150,36 @@ inline bool lsx_rsp_instance_exists(int npt, int nl, bool lk, int topo)
 // wave-uniform per column.  Rounds 3-4 staged the WHOLE column of the five columns of a wavefront in LDS when the workgroup started
 // ([5][Nspace + 1][3 npt + 2]: 17-27 kB at 82 depths, growing with Nspace, and the reason contexts of more than ~160 depths fell back
 // to the one-ray-per-lane kernel).  Now `k_build_optab` (lsx_hip.hip) writes those numbers once per formal solution into a table
-//     optab[group of 5 columns][transition t < Ntrans | geometry][row r = 0 .. Nspace][c < 5][3 | 2]
-// (row Nspace: zeros -- the up-going sweep reads the interval behind its first depth there), 50 kB per column for FALC Ca+H, and
+//     optab[group of 5 columns][transition t < Ntrans | geometry (down, up) | continuum (folded instances)][row][c < 5][3 | 2]
+// (50 kB per column for FALC Ca+H), and
 // each WAVE keeps a ring of LSX_RS_RING rows [slot u][c][3] + [c][2] of the depths around its own: every depth step the first
 // 15 npt + 10 lanes fetch one element each of the row LSX_RS_RING - 1 steps ahead (one coalesced load per segment, landing a step
 // later) and write it over the row that was consumed two steps ago.  LDS per workgroup no longer depends on Nspace.
+// FOLDED fast continua (round 5): a class whose tiles have fast continua can run instances that form the continua's opacity and
+// emissivity themselves (what k_fast_prepass added to the background, rh_method.py:284-286, 453-455, 613-614) -- per continuum q and
+// depth the table holds a third kind of block, [c][2] = n_i, n_j nStar_i / nStar_j, the row of a tile with nF fast continua is
+// 15 npt + 10 + 10 nF doubles (two elements per lane: at most 128), and per (wavelength, depth) the lane needs two fused
+// multiply-adds per continuum: chi += sum_q alpha_q n_i,q - E sum_q alpha_q (n_j nsr)_q, eta += (2hc/lambda^3) E sum_q alpha_q (n_j nsr)_q,
+// E = exp(-hc / k lambda T) the tile's Boltzmann stream.  No pre-pass launch, no effective-background streams for those classes.
 #define LSX_RS_RING 8                   // rows per wave (a power of two)
-constexpr int lsx_rs_row_doubles(int npt) { return 3 * LSX_RS_COLS * npt + 2 * LSX_RS_COLS; }
-// doubles per column group of the table: Ntrans blocks of (Nspace + 1) rows of 15, then the geometry block of (Nspace + 1) rows of 10
-constexpr size_t lsx_optab_group_doubles(int Ntrans, int Ns) { return ((size_t)Ntrans * 3 * LSX_RS_COLS + 2 * LSX_RS_COLS) * (size_t)(Ns + 1); }
+#define LSX_RS_FOLD_ROW_MAX 128         // doubles of a folded row: two elements per lane
+constexpr int lsx_rs_row_doubles(int npt, int nF = 0) { return 3 * LSX_RS_COLS * npt + 2 * LSX_RS_COLS + 2 * LSX_RS_COLS * nF; }
+// the folded instances take the fast continua four at a time in straight-line code (the LDS reads of a chunk in flight together; a
+// continuum the tile does not have: zero cross-section against a zeroed pad of the row), so the rings' rows and the cross-section
+// table are laid out for the class's largest tile rounded up to a multiple of four
+constexpr int lsx_rs_fold_pad(int nF) { return (nF + 3) & ~3; }
+constexpr int lsx_rs_row_pitch(int npt, int nF = 0) { return (lsx_rs_row_doubles(npt, lsx_rs_fold_pad(nF)) + 1) & ~1; }
+// doubles per column group of the table: Ntrans blocks of (Nspace + 1) rows of 15, the geometry block of (Nspace + 1) rows of 10,
+// Ncont blocks of (Nspace + 1) rows of 10 (the folded fast continua's operands)
+// Every block has LSX_RS_RING zero rows in front of depth 0 and behind depth Nspace - 1 (depth r is row r + LSX_RS_RING): the ring runs
+// ahead of the sweep and past its end without clamping its row index -- a lane's table offset just moves by one row per step.
+// Two geometry blocks: [half length of the interval ABOVE the depth, sigma] for the down-going sweep, [... BELOW the depth, sigma]
+// for the up-going one -- "the interval behind this ray" sits in the depth's own row for both.
+constexpr int lsx_optab_rows(int Ns) { return Ns + 2 * LSX_RS_RING; }
+constexpr size_t lsx_optab_group_doubles(int Ntrans, int Ns, int Ncont)
+{
+    return ((size_t)Ntrans * 3 * LSX_RS_COLS + 2 * 2 * LSX_RS_COLS + (size_t)Ncont * 2 * LSX_RS_COLS) * (size_t)lsx_optab_rows(Ns);
+}
 // (the parabolic instances park 16 depths in every class: they need the LDS for the lane-private cells below)
 constexpr int lsx_rs_park(int npt, bool par = false) { return (npt >= 2 || par) ? 16 : 64; }      // depths a row of parked Gamma totals holds (two slots: 16, for two workgroups more per CU)
 // parabolic instances: rows of 64 lane-private cells per wave -- 1 / opacity, opacity and the line profiles of the rays at the point
@@ -166,10 +187,13 @@ constexpr int lsx_rs_park(int npt, bool par = false) { return (npt >= 2 || par) 
 constexpr int lsx_rs_par_rows(int npt) { return LSX_RS_RAYS * (2 + npt); }
 // LDS doubles of a ray-serial workgroup: exp table, [2 waves][2 npt + 1] rows of 64 (parked Gamma integrands, dJ), [2][64] J
 // exchange, the two waves' operand rings, the parked Gamma totals, the angle quadrature, the parabolic instances' cells
-constexpr int lsx_rs_lds_doubles(int npt, int Ns, bool par = false)
+// (fold_nF >= 0: a folded instance whose tiles have at most that many fast continua -- the rings' row pitch and the [q][64] table of
+// the continua's cross-sections per lane)
+constexpr int lsx_rs_lds_doubles(int npt, int Ns, bool par = false, int fold_nF = -1)
 {
     (void)Ns;
-    return LSX_EXP_TAB + 2 * (2 * (npt > 0 ? npt : 1) + 1) * 64 + 2 * LSX_WAVE + 2 * LSX_RS_RING * lsx_rs_row_doubles(npt) +
+    return LSX_EXP_TAB + 2 * (2 * (npt > 0 ? npt : 1) + 1) * 64 + 2 * LSX_WAVE +
+           2 * LSX_RS_RING * (fold_nF >= 0 ? lsx_rs_row_pitch(npt, fold_nF) : lsx_rs_row_doubles(npt)) + (fold_nF > 0 ? lsx_rs_fold_pad(fold_nF) * LSX_WAVE : 0) +
            2 * LSX_RS_COLS * 2 * (npt > 0 ? npt : 1) * lsx_rs_park(npt, par) +  // + [2 waves][columns x values][entries] parked Gamma totals
            2 * LSX_RS_RAYS + 2 +                                            // + the angle quadrature (two-slot instances read it from here)
            (par ? 2 * lsx_rs_par_rows(npt) * LSX_WAVE : 0);
@@ -192,6 +216,8 @@ struct PlanClass {             // tiles that run the same kernel instantiation
     bool rs = false;           // the class has a ray-serial instance (lsx_sweep_rs.hip); lsx_create decides by the column count
     bool rsp = false;          // ... and a ray-serial instance of the parabolic rule (N4; LSX_RSP_INSTANCES)
     bool lk_epi = false;       // ... whose linked corrections the fast-continuum epilogue applies (lsx_fast.h), not the sweep
+    bool fold = false;         // the ray-serial instance forms the fast continua's opacity / emissivity itself: no pre-pass for this class
+    int fold_nF = 0;           // ... the most fast continua a tile of the class has
     int code() const { return npt >= 0 ? lsx_class_code(npt, nl, linked, topo) : (linked ? -3 : -1); }
 };
 
@@ -207,6 +233,7 @@ struct PlanOptions {           // diagnostic switches (lsx_create reads them fro
     bool no_rs = false;        // LSX_NO_RS: every class through lsx_sweep.hip (one ray per lane)
     int rs_min_columns = LSX_RS_MIN_COLUMNS;   // LSX_RS_MIN_COLUMNS: contexts with fewer columns keep one ray per lane (too few wavefronts otherwise)
     bool no_phi_group = false; // LSX_PHI_GROUP=1: the plain per-column profile store also where the ray-serial sweep can run (measurements)
+    bool no_fold = false;      // fold=0 / LSX_NO_FOLD: the ray-serial classes keep the pre-pass and the effective-background streams (round 4)
     int rs_max_npt = 2;        // LSX_RS_MAX_NPT: classes with more per-ray slots keep one ray per lane (diagnostic: 1 leaves the two-slot tiles to lsx_sweep.hip)
 };
 

@@ -71,8 +71,8 @@ constexpr int RROW = 64;               // doubles per row of the reduction buffe
 #ifndef LSX_RSP_WPE
 #define LSX_RSP_WPE 1
 #endif
-template <int NPT, int NL, bool LK, int TOPO, bool PAR>
-__global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(PAR ? LSX_RSP_WPE : LSX_RS_WPE(NPT, LK))))
+template <int NPT, int NL, bool LK, int TOPO, bool PAR, bool FOLD>
+__global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(PAR ? LSX_RSP_WPE : (NPT == 0 ? 3 : LSX_RS_WPE(NPT, LK)))))
 lsx_sweep_rs_kernel(const SweepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
@@ -101,10 +101,16 @@ lsx_sweep_rs_kernel(const SweepParams p)
     // per-depth operands of the group's columns: a ring of RING rows per wave (lsx_plan.h, "a RING in LDS"), row of step v =
     // [slot u][column c][3] (lines: cB (n_i - g n_j), n_j Uc, wphi; continua: n_i, n_j, nStar_i / nStar_j) then [c][2] (the half
     // length of the interval above the depth, the scattering coefficient), fed one row per step from the table k_build_optab made
-    constexpr int RING = LSX_RS_RING, RL = lsx_rs_row_doubles(NPT);
-    static_assert((RING & (RING - 1)) == 0 && RING >= 4 && RL <= LSX_WAVE, "operand ring");
-    lds_f64* const utab = etab + LSX_EXP_TAB + 2 * (NV + 1) * RROW + 2 * LSX_WAVE;      // [2 waves][RING][RL]
-    lds_f64* const ring_end = utab + 2 * RING * RL;
+    // FOLD (lsx_plan.h, "FOLDED fast continua"): the row also carries [fast continuum q][c][2] = n_i, n_j nStar_i / nStar_j, and the
+    // step forms the fast continua's opacity and emissivity itself -- two elements per lane and row, the pitch from the class's
+    // largest tile (p.fold_nF)
+    constexpr int RING = LSX_RS_RING, RL0 = lsx_rs_row_doubles(NPT);
+    static_assert((RING & (RING - 1)) == 0 && RING >= 4 && RL0 <= LSX_WAVE, "operand ring");
+    static_assert(!(FOLD && PAR), "the parabolic instances keep the pre-pass");
+    const int RLP = FOLD ? lsx_rs_row_pitch(NPT, p.fold_nF) : RL0;                        // doubles between two rows of a ring
+    lds_f64* const utab = etab + LSX_EXP_TAB + 2 * (NV + 1) * RROW + 2 * LSX_WAVE;      // [2 waves][RING][RLP]
+    lds_f64* const atab = utab + 2 * RING * RLP;                                        // FOLD: [q < fold_nF][64] the continua's cross-sections per lane
+    lds_f64* const ring_end = atab + (FOLD ? lsx_rs_fold_pad(p.fold_nF) * LSX_WAVE : 0);
 
     // XCD-aware block -> (column group, tile): every XCD gets a contiguous range (speed only)
     int vb;
@@ -135,43 +141,125 @@ lsx_sweep_rs_kernel(const SweepParams p)
     etab[threadIdx.x] = p.exp2_tab[threadIdx.x];
     const int kS = dir ? Ns - 1 : 0;
     const int dk = dir ? -1 : 1;
-    // ---- the operand ring.  Step v of this wave (depth kS + dk v) is row tabrow(v) of the table: v for the down-going sweep,
-    // Nspace - 1 - v for the up-going one -- whose "step -1" is the table's zero row Nspace: the interval behind its first depth.
+    // ---- the operand ring.  Step v of this wave (depth kS + dk v) is row RING + kS + dk v of the table's blocks (RING zero rows
+    // in front of depth 0 and behind depth Nspace - 1: the ring runs ahead of the sweep and past its end without clamping).
     // Lane e < RL owns element e of every row: it fetches that element of the row RING - 1 steps ahead and, a step later, writes it
-    // over the row that was consumed two steps ago (the steps read rows v - 1 and v only).
-    lds_f64* const ring = utab + (size_t)dir * RING * RL;
-    const int re = lane < RL ? lane : RL - 1;
+    // over the row that was consumed two steps ago (the steps read rows v - 1 and v only); its table offset moves by one row per step.
+    lds_f64* const ring = utab + (size_t)dir * RING * RLP;
+    const int RL = FOLD ? lsx_rs_row_doubles(NPT, nF) : RL0;        // this tile's row
+    if constexpr (FOLD) {       // the rows' pad behind the tile's own continua is read (against zero cross-sections): keep it finite
+        for (int e = lane; e < RING * RLP; e += LSX_WAVE) ring[e] = 0.0;
+    }
     const double* __restrict__ otab = p.optab + (size_t)grp * p.optab_group_stride;
-    unsigned o_ob, o_os;                                 // byte offset of the lane's element in row 0 of its block, bytes per row
-    {
-        const bool geo = re >= 3 * NC * NPT;
-        const int u = geo ? 0 : re / (3 * NC), w = geo ? re - 3 * NC * NPT : re - u * (3 * NC);
-        const int trans = (NPT > 0 && !geo) ? slots[u < NPT ? u : 0].trans : p.Ntrans;
-        o_os = geo ? 2u * NC * 8u : 3u * NC * 8u;
-        o_ob = (unsigned)((size_t)trans * (Ns + 1) * (3 * NC) * 8u) + (unsigned)w * 8u;
+    const int NRT = lsx_optab_rows(Ns);
+    // byte offset of element e of the row of step 0 inside the group's table, and bytes per step (signed: the up sweep walks backwards)
+    auto elem = [&](const int e0, unsigned& ob, int& os) __attribute__((always_inline)) {
+        const int e = e0 < RL ? e0 : RL - 1;
+        size_t blk;                                       // the block's first double
+        int w, rowd;                                      // element inside the block's row, doubles per row
+        if (e < 3 * NC * NPT) {
+            const int u = e / (3 * NC);
+            w = e - u * (3 * NC); rowd = 3 * NC;
+            blk = (size_t)slots[NPT > 0 ? (u < NPT ? u : 0) : 0].trans * NRT * (3 * NC);
+        } else if (e < RL0) {
+            w = e - 3 * NC * NPT; rowd = 2 * NC;
+            blk = ((size_t)p.Ntrans * (3 * NC) + (size_t)dir * (2 * NC)) * NRT;
+        } else {
+            const int q = (e - RL0) / (2 * NC);
+            w = e - RL0 - q * (2 * NC); rowd = 2 * NC;
+            blk = ((size_t)p.Ntrans * (3 * NC) + 2 * (2 * NC) + (size_t)LSX_CONST(int32_t, p.trans_row)[slots[NPT + q].trans] * (2 * NC)) * NRT;
+        }
+        ob = (unsigned)((blk + (size_t)(RING + kS) * rowd + w) * 8u);
+        os = dk * rowd * 8;
+    };
+    unsigned o_e0, o_e1 = 0;                              // running offsets: the element of the row that is requested next
+    int o_s0, o_s1 = 0;
+    elem(lane, o_e0, o_s0);
+    if constexpr (FOLD) elem(LSX_WAVE + lane, o_e1, o_s1);
+    auto ring_row = [&](int v) __attribute__((always_inline)) { return ring + ((v + 1) & (RING - 1)) * RLP; };
+    o_e0 -= (unsigned)o_s0; o_e1 -= (unsigned)o_s1;       // row -1 first
+    {   // rows -1 .. RING - 3: all requests first, then the writes (one memory round trip, not RING - 1 of them one after the other)
+        double x0[RING - 1], x1[RING - 1];
+#pragma unroll
+        for (int i = 0; i < RING - 1; ++i) {
+            x0[i] = at(otab, o_e0);
+            x1[i] = FOLD ? at(otab, o_e1) : 0.0;
+            o_e0 += (unsigned)o_s0; o_e1 += (unsigned)o_s1;
+        }
+#pragma unroll
+        for (int i = 0; i < RING - 1; ++i) {
+            if (lane < RL) ring_row(i - 1)[lane] = x0[i];
+            if constexpr (FOLD) {
+                if (LSX_WAVE + lane < RL) ring_row(i - 1)[LSX_WAVE + lane] = x1[i];
+            }
+        }
     }
-    auto tabrow = [&](int v) __attribute__((always_inline)) { return dir ? Ns - 1 - min(v, Ns - 1) : max(min(v, Ns - 1), 0); };
-    auto ring_row = [&](int v) __attribute__((always_inline)) { return ring + ((v + 1) & (RING - 1)) * RL; };
-    for (int v = -1; v <= RING - 3; ++v) {
-        const double x = at(otab, o_ob + (unsigned)tabrow(v) * o_os);
-        if (lane < RL) ring_row(v)[lane] = x;
-    }
-    double ring_pend = at(otab, o_ob + (unsigned)tabrow(RING - 2) * o_os);       // row RING - 2: written at step 0
+    double ring_pend0 = at(otab, o_e0), ring_pend1 = 0.0;                        // row RING - 2: written at step 0
+    if constexpr (FOLD) ring_pend1 = at(otab, o_e1);
     // one row per step: the element fetched a step ago goes over row s - 2, the element of row s + RING - 1 is requested
     auto ring_step = [&](const int s) __attribute__((always_inline)) {
-        if (lane < RL) ring_row(s + RING - 2)[lane] = ring_pend;
-        ring_pend = at(otab, o_ob + (unsigned)tabrow(s + RING - 1) * o_os);
+        lds_f64* const w = ring_row(s - 2);
+        if (lane < RL) w[lane] = ring_pend0;
+        o_e0 += (unsigned)o_s0;
+        ring_pend0 = at(otab, o_e0);
+        if constexpr (FOLD) {
+            if (LSX_WAVE + lane < RL) w[LSX_WAVE + lane] = ring_pend1;
+            o_e1 += (unsigned)o_s1;
+            ring_pend1 = at(otab, o_e1);
+        }
     };
+    if constexpr (FOLD) {
+        // the fast continua's cross-sections for this lane's wavelength (0 where the continuum is not active there, and for the
+        // continua the tile does not have up to the next multiple of four): [q][lane]
+        for (int e = nF * LSX_WAVE + threadIdx.x; e < lsx_rs_fold_pad(nF) * LSX_WAVE; e += 2 * LSX_WAVE) atab[e] = 0.0;
+        for (int e = threadIdx.x; e < nF * LSX_WAVE; e += 2 * LSX_WAVE) {
+            const int q = e >> 6, l = e & (LSX_WAVE - 1);
+            // (a lane without a wavelength of its own shadows the tile's last one and stores the same bits to the same address: it needs
+            // that wavelength's cross-sections, not zeros)
+            const int jl = l - (l / LW) * LW;
+            const int laq = la0 + (jl < nla ? jl : nla - 1), lt = laq - slots[NPT + q].Nblue;
+            const bool a = lt >= 0 && lt < slots[NPT + q].Nlam && p.active[(size_t)slots[NPT + q].trans * Nspect + laq] != 0;
+            atab[e] = a ? p.alpha[slots[NPT + q].wl_off + lt] : 0.0;
+        }
+    }
     __syncthreads();
     const int lc3 = cc * 3, lcg = 3 * NC * NPT + cc * 2;   // the lane's column inside a row: slot values at lc3 + 15 u + t, geometry at lcg + {0, 1}
+    const int lcf = RL0 + cc * 2;                          // ... the fast continua's pairs at lcf + 10 q + {0, 1}
     constexpr int TU = 3 * NC;                             // doubles between two slots of a row
+    // what the tile's fast continua add to opacity and emissivity at the depth of step v (rh_method.py:284-286, 453-455, 613-614):
+    // chi += sum_q alpha_q n_i,q - E sum_q alpha_q (n_j nsr)_q,  eta += u_la E sum_q alpha_q (n_j nsr)_q
+    auto fast_fold = [&](const int v, const double E, const double ula, double& chi, double& eta) __attribute__((always_inline)) {
+        if constexpr (FOLD) {
+            // four continua at a time, straight-line: the chunk's eight LDS reads are in flight together (a loop over nF waited
+            // for each continuum's reads in turn: measured, the fold then cost what the pre-pass had cost)
+            const lds_f64* fr = ring_row(v) + lcf;
+            const lds_f64* al = atab + lane;
+            double SA = 0.0, SB = 0.0;
+            // (two at a time where registers are short: the two-slot instances, and the continuum tiles' instance at three waves per SIMD)
+            constexpr int CH = NPT <= 1 ? 4 : 2;
+            auto chunk = [&](const int q0) __attribute__((always_inline)) {
+                double a[CH], x[CH], y[CH];
+#pragma unroll
+                for (int i = 0; i < CH; ++i) { a[i] = al[(q0 + i) * LSX_WAVE]; x[i] = fr[2 * NC * (q0 + i) + 0]; y[i] = fr[2 * NC * (q0 + i) + 1]; }
+#pragma unroll
+                for (int i = 0; i < CH; ++i) { SA = fma(a[i], x[i], SA); SB = fma(a[i], y[i], SB); }
+            };
+            chunk(0);
+            if constexpr (CH == 2) { if (nF > 2) chunk(2); }
+            if (nF > 4) { chunk(4); if constexpr (CH == 2) { if (nF > 6) chunk(6); } }
+            if (nF > 8) { chunk(8); if constexpr (CH == 2) { if (nF > 10) chunk(10); } }
+            const double EB = E * SB;
+            chi += SA - EB;
+            eta = fma(ula, EB, eta);
+        }
+    };
 
     // ---- per-lane bases: every stream of a column is addressed as (wave-uniform base of column col0) + 32-bit byte offset
     const size_t til_col = (size_t)ntile * Ns * LW;
     const size_t tb0 = ((size_t)col0 * ntile + tile_id) * Ns * LW;
     const unsigned o_til = (unsigned)((size_t)cc * til_col * 8u) + (unsigned)j * 8u;           // + k * LW * 8
-    const double* __restrict__ bgchi = (nF > 0 ? p.bgxchi_T : p.bgchi_T) + tb0;
-    const double* __restrict__ bgeta = (nF > 0 ? p.bgxeta_T : p.bgeta_T) + tb0;
+    const double* __restrict__ bgchi = ((nF > 0 && !FOLD) ? p.bgxchi_T : p.bgchi_T) + tb0;      // (FOLD: the plain background; see fast_fold)
+    const double* __restrict__ bgeta = ((nF > 0 && !FOLD) ? p.bgxeta_T : p.bgeta_T) + tb0;
     const double* __restrict__ Jdag = p.Jdag_T + tb0;
     double* __restrict__ Jnew = p.Jnew_T + tb0;
     double* __restrict__ psibar = p.Psi2_T + ((size_t)dir * p.ncol * ntile) * Ns * LW + tb0;
@@ -199,7 +287,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
     #ifdef LSX_RS_PF2_QLDS
     constexpr bool QLDS = NPT >= 2 || (PAR && LSX_RSP_WPE >= 2) || (PF2 && NPT >= 1);
 #else
-    constexpr bool QLDS = NPT >= 2 || (PAR && LSX_RSP_WPE >= 2);
+    constexpr bool QLDS = NPT >= 2 || (PAR && LSX_RSP_WPE >= 2) || (FOLD && NPT == 0);      // (the folded continuum instance: three waves per SIMD)
 #endif
     lds_f64* const qtab = ring_end + (size_t)2 * NC * NV * lsx_rs_park(NPT, PAR);
     if (QLDS && threadIdx.x < 2 * NR) qtab[threadIdx.x] = threadIdx.x < NR ? LSX_CONST(double, p.zmu)[threadIdx.x] : LSX_CONST(double, p.wmuh)[threadIdx.x - NR];
@@ -267,7 +355,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
         o.bc = at(bgchi, kt);
         o.be = at(bgeta, kt);
         o.E = 0.0;
-        if constexpr (HASC) o.E = at(Eb, kt);
+        if constexpr (HASC || FOLD) o.E = at(Eb, kt);
 #pragma unroll
         for (int u = 0; u < NL; ++u)
 #pragma unroll
@@ -291,6 +379,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
     auto chi_of = [&](const Ops& o, int v, int m) __attribute__((always_inline)) {          // v: step index of the depth
         const lds_f64* tk = ring_row(v) + lc3;
         double c = o.bc;
+        if constexpr (FOLD) { double e_ = 0.0; fast_fold(v, o.E, u_la, c, e_); }
 #pragma unroll
         for (int u = 0; u < NPT; ++u) {
             if (u < NL) c = fma(tk[TU * u + 0], o.ph[u][m], c);
@@ -314,7 +403,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
         const Ops &cur = opA, &nxt = opB;
         const auto* tcol = p.temperature + (size_t)col * Ns;
         const double B0 = planck(tcol[Ns - 2], wav), B1 = planck(tcol[Ns - 1], wav);
-        const double hz = ring_row(0)[lcg];                          // 0.5 |z[Ns - 2] - z[Ns - 1]|: the interval behind depth kS + dk
+        const double hz = ring_row(1)[lcg];                          // 0.5 |z[Ns - 2] - z[Ns - 1]|: the interval behind depth kS + dk (the up sweep's geometry: below the depth)
 #pragma unroll
         for (int m = 0; m < NR; ++m) {
             const double dtau_uw = zmu(m) * (chi_of(cur, 0, m) + chi_of(nxt, 1, m)) * hz;
@@ -589,7 +678,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
         if constexpr (PH == 2) jhalf = at(Jnew, o_til + (unsigned)((k - dk) * LW) * 8u);
         if constexpr (!FIRSTPT && NPT >= 1) flush(mpt - 1);
         const lds_f64* tk = ring_row(s) + lc3;
-        const double hdz = ring_row(s - dir)[lcg];                         // the interval between points m and m + 1: row k (down) / k + 1 (up)
+        const double hdz = ring_row(s)[lcg];                         // the interval between points m and m + 1: row k (down) / k + 1 (up)
         const double etaB = cur.be + ring_row(s)[lcg + 1] * cur.jd, chiB = cur.bc, jd_k = cur.jd;
         double Xk[NS], njk[NS];
 #pragma unroll
@@ -714,9 +803,10 @@ lsx_sweep_rs_kernel(const SweepParams p)
 
         // ---- ray-independent part (rh_method.py:601-632): continuum slots, emissivity without the lines
         const lds_f64* tk = ring_row(s) + lc3;                             // this depth's row, the lane's column
-        const double hdz = ring_row(s - dir)[lcg];                         // the interval behind this ray: row k (down) / k + 1 (up)
+        const double hdz = ring_row(s)[lcg];                         // the interval behind this ray: row k (down) / k + 1 (up)
         double etaB = cur.be + ring_row(s)[lcg + 1] * cur.jd;
         double chiB = cur.bc;
+        fast_fold(s, cur.E, u_la, chiB, etaB);
         double X[NS], Vjc[NS], Ujc[NS], chic[NS], njUc[NS], njc[NS], w3k[NS];   // lines: X = cB (n_i - g n_j), n_j Uc, wphi; continua: Vji, Uji, chi, n_j
 #pragma unroll
         for (int u = 0; u < NPT; ++u) {
@@ -1089,11 +1179,11 @@ lsx_sweep_rs_kernel(const SweepParams p)
 #undef zmu
 #undef wmuh
 
-template <int NPT, int NL, bool LK, int TOPO, bool PAR>
+template <int NPT, int NL, bool LK, int TOPO, bool PAR, bool FOLD>
 static hipError_t launch_rs(const SweepParams& p, int ngroups, hipStream_t st)
 {
     const dim3 g((unsigned)(ngroups * p.n_class_tiles)), b(2 * LSX_WAVE);
-    hipLaunchKernelGGL((lsx_sweep_rs_kernel<NPT, NL, LK, TOPO, PAR>), g, b, lsx_rs_lds_doubles(NPT, p.Nspace, PAR) * sizeof(double), st, p);
+    hipLaunchKernelGGL((lsx_sweep_rs_kernel<NPT, NL, LK, TOPO, PAR, FOLD>), g, b, lsx_rs_lds_doubles(NPT, p.Nspace, PAR, FOLD ? p.fold_nF : -1) * sizeof(double), st, p);
     return hipGetLastError();
 }
 
@@ -1105,7 +1195,8 @@ extern "C" hipError_t lsx_launch_sweep_rs(const SweepParams* p, int code, hipStr
     if (p->Nrays != LSX_RS_RAYS || p->sca_per_lambda || p->L != LW) return hipErrorNotSupported;
     const int ngroups = (p->ncol + NC - 1) / NC;
     switch (code) {
-#define LSX_X(NPT, NL, LK, TOPO) case lsx_class_code(NPT, NL, LK, TOPO): return launch_rs<NPT, NL, LK, TOPO, false>(*p, ngroups, st);
+#define LSX_X(NPT, NL, LK, TOPO) case lsx_class_code(NPT, NL, LK, TOPO): \
+        return p->fold ? launch_rs<NPT, NL, LK, TOPO, false, true>(*p, ngroups, st) : launch_rs<NPT, NL, LK, TOPO, false, false>(*p, ngroups, st);
         LSX_RS_INSTANCES(LSX_X)
 #undef LSX_X
     default: return hipErrorNotSupported;
@@ -1117,7 +1208,7 @@ extern "C" hipError_t lsx_launch_sweep_rs_par(const SweepParams* p, int code, hi
     if (p->Nrays != LSX_RS_RAYS || p->sca_per_lambda || p->L != LW) return hipErrorNotSupported;
     const int ngroups = (p->ncol + NC - 1) / NC;
     switch (code) {
-#define LSX_X(NPT, NL, LK, TOPO) case lsx_class_code(NPT, NL, LK, TOPO): return launch_rs<NPT, NL, LK, TOPO, true>(*p, ngroups, st);
+#define LSX_X(NPT, NL, LK, TOPO) case lsx_class_code(NPT, NL, LK, TOPO): return launch_rs<NPT, NL, LK, TOPO, true, false>(*p, ngroups, st);
         LSX_RSP_INSTANCES(LSX_X)
 #undef LSX_X
     default: return hipErrorNotSupported;

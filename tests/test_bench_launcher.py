@@ -89,3 +89,12 @@ def test_two_rank_rehearsal_on_one_gpu(which):
     else:
         assert r['steps'] == 5 and r['config']['columns_total'] == 400 and math.isfinite(r['last_dJ'])
         assert r['config']['sweep_policy'] == 'ray-serial'        # decided for the 400 columns of the job, not for a rank's 200
+        # the scaling record proves itself: what every rank saw (round 5) -- both ranks, the world size they were in, their backend,
+        # their own time, the mapping they ran and one options signature for the whole job
+        sr = r['scaling_record']
+        assert sr['world_seen'] == 2 and sr['backend'] == 'gloo' and [q['rank'] for q in sr['per_rank']] == [0, 1]
+        for q in sr['per_rank']:
+            assert q['world_seen'] == 2 and q['columns'] == 200 and q['sweep_policy'] == 'ray-serial' and math.isfinite(q['ms_per_step'])
+        assert len({q['options_signature'] for q in sr['per_rank']}) == 1
+        assert max(q['ms_per_step'] for q in sr['per_rank']) == pytest.approx(r['ms_per_step'], rel=1e-9)
+        assert 'mapping=ray-serial' in r['config']['runtime_env']['effective_options']

@@ -14,6 +14,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import envelope
 from conftest import relerr, gamma_err
 import instance_cases as ic
 from lightspinner_amd import _capi
@@ -48,16 +49,17 @@ def test_case_meets_the_oracle(hip_lib, oracle_lib, case, mode):
     for e in (eh, eo):
         e.set_columns(0, block)
         e.set_formal_solver('parabolic' if mode.startswith('parabolic') else 'linear')
-    # (crowd: measured 2.17e-10 on the emergent intensity of one ray -- the same value on both kernels -- with J at 1.4e-13 and
-    # Gamma at 5e-15: the signature of an interval just above the 5e-4 switch of w2, where w1 = (1 - e) - dtau e cancels to
-    # dtau^2 / 2 and a 1-ulp difference between the two libraries' exp() is up to 1e-9 of that ray's contribution)
-    tol = 5e-10 if name == 'crowd' else 2e-10
+    # (crowd: 2.17e-10 on the emergent intensity of one ray -- the same value on both kernels -- with J at 1.4e-13 and Gamma at 5e-15:
+    # the signature of an interval just above the 5e-4 switch of w2, where w1 = (1 - e) - dtau e cancels to dtau^2 / 2.  Round 4 set
+    # 5e-10 / 2e-10 from such measurements; now every entry has to lie inside 1e-11 + 3 x what a one-ulp change of the oracle's OWN
+    # exp() does to that entry: tests/envelope.py)
     for it in range(6):
         dh, do = eh.formal_sol_gamma(), eo.formal_sol_gamma()
         if it == 0:
-            eI, eJ = relerr(eh.get(_capi.LSX_I), eo.get(_capi.LSX_I)), relerr(eh.get(_capi.LSX_J), eo.get(_capi.LSX_J))
+            envelope.first_call_inside(oracle_lib, prob, block, eh.get(_capi.LSX_I), eh.get(_capi.LSX_J),
+                                       solver='parabolic' if mode.startswith('parabolic') else 'linear')
             off, diag = gamma_err(eh.get(_capi.LSX_GAMMA), eo.get(_capi.LSX_GAMMA), prob)
-            assert eI < tol and eJ < tol and off < 1e-10 and diag < 1e-11, (eI, eJ, off, diag)
+            assert off < 1e-10 and diag < 1e-11, (off, diag)
         assert abs(dh - do) <= 1e-7 * max(abs(do), 1e-3)
         if it >= 2:
             ph, po = eh.stat_equil(), eo.stat_equil()
@@ -92,11 +94,22 @@ def test_shallow_columns_meet_the_oracle(hip_lib, oracle_lib, Ns, mode):
     for e in (eh, eo):
         e.set_columns(0, block)
         e.set_formal_solver('parabolic' if mode.startswith('parabolic') else 'linear')
+    solver = 'parabolic' if mode.startswith('parabolic') else 'linear'
+
+    def make():
+        e = Engine(prob, 33, lib=oracle_lib)
+        e.set_columns(0, block)
+        e.set_formal_solver(solver)
+        return e
+    runs = envelope.oracle_runs(oracle_lib, make, 4, se_from=1, what=(_capi.LSX_I, _capi.LSX_J))     # the oracle as it is and with exp() a ulp up / down
     for it in range(4):
         dh, do = eh.formal_sol_gamma(), eo.formal_sol_gamma()
-        eI, eJ = relerr(eh.get(_capi.LSX_I), eo.get(_capi.LSX_I)), relerr(eh.get(_capi.LSX_J), eo.get(_capi.LSX_J))
+        # inside the one-ulp-exp envelope entry by entry (tests/envelope.py; round 4: 2e-10 throughout, from a measurement); after the
+        # first statistical equilibrium the two sides' populations differ by the LU's rounding x conditioning: 2e-10 as the floor then
+        for w in (_capi.LSX_I, _capi.LSX_J):
+            envelope.inside(eh.get(w), runs, it, w, 1e-11 if it < 2 else 2e-10)
         off, diag = gamma_err(eh.get(_capi.LSX_GAMMA), eo.get(_capi.LSX_GAMMA), prob)
-        assert eI < 2e-10 and eJ < 2e-10 and off < 1e-10 and diag < 1e-11, (it, eI, eJ, off, diag)
+        assert off < 1e-10 and diag < 1e-11, (it, off, diag)
         assert abs(dh - do) <= 1e-7 * max(abs(do), 1e-3)
         if it >= 1:
             ph, po = eh.stat_equil(), eo.stat_equil()

@@ -122,9 +122,10 @@ def test_pinned_mappings_and_the_counts_that_decide(hip_lib):
     for q in (1, 2, 3):
         assert np.array_equal(res['as-1000'][q], res['serial'][q])
         assert np.array_equal(res['own'][q], res['lane-as-1000'][q])
-    # the two mappings agree to rounding, not bit for bit (include/lsx.h; five iterations, two of them with stat_equil: 1e-11)
+    # the two mappings agree to rounding, not bit for bit (include/lsx.h): five iterations, two of them with stat_equil -- measured
+    # 1.04e-11 in round 4.  Asserted at three times that (round 4 asserted 1e-9 beside a comment that said 1e-11).
     d = np.max(np.abs(res['own'][1] - res['serial'][1]) / np.abs(res['serial'][1]))
-    assert 0.0 < d < 1e-9
+    assert 0.0 < d < 3.2e-11, d
     # the parabolic rule takes its compile-time tile classes from 32 columns on: the same knob
     out = []
     for kw in ({}, dict(policy_columns=12)):
