@@ -136,21 +136,16 @@ def run_c5(args, rank, local_rank, world):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    # the scaling record proves itself (round 5): what every rank saw -- its own time for the K steps, the world size and backend of
-    # the process group it was in, the sweep mapping its engine ran and its options signature -- gathered onto rank 0's line
     scaling_record = None
     if world > 1:
         dt_own = dt
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        mine = dict(rank=rank, ms_per_step=dt_own / args.steps * 1e3, world_seen=dist.get_world_size(), backend=dist.get_backend(),
-                    sweep_policy=eng.sweep_policy(), columns=ncol, options_signature='%016x' % eng.options_signature(),
-                    device=torch.cuda.get_device_name(dev) if dev.type == 'cuda' else str(dev))
         every = [None] * world
-        dist.all_gather_object(every, mine)
-        scaling_record = dict(world_seen=dist.get_world_size(), backend=dist.get_backend(), per_rank=every,
-                              ms_per_step_max_over_ranks=dt / args.steps * 1e3)
+        dist.all_gather_object(every, dict(rank=rank, seconds=dt_own, world_seen=dist.get_world_size(), backend=dist.get_backend(),
+                                           shard=[int(x) for x in out['shard']]))
+        scaling_record = dict(world_seen=dist.get_world_size(), backend=dist.get_backend(), per_rank=every, seconds_max_over_ranks=dt)
     ref = dict(np.load(os.path.join(gold, 'rf_ca.npz')))
     err = 0.0
     for k in [int(k) for k in ref['ks']]:
@@ -178,6 +173,8 @@ def run_c5(args, rank, local_rank, world):
                                reference_depths_checked=[int(k) for k in ref['ks']],
                                note='the reference runs these 165 MALI solves one after the other in pure Python (~2 h here)'),
         roofline=None, cpu_baseline=None)
+    if scaling_record is not None:
+        result['scaling_record'] = scaling_record
     if rehearsal:
         result.update(rehearsal)
     emit(result)
@@ -265,10 +262,12 @@ def roofline_block(eng, lib, prob, ncol, workload, kernel_reps):
     bsweep = info(0)                               # the part of it the sweep kernel itself moves
     ach = bsweep * ncol / (ms_sweep * 1e-3) / 1e9
     fig, src, stale = profile_figures(workload)
-    traffic = valu = None
+    traffic = valu = traffic_all = None
     if fig and not stale:
         if fig.get('hbm_bytes_per_call_per_column') is not None:
             traffic = fig['hbm_bytes_per_call_per_column'] * ncol
+        if fig.get('hbm_bytes_per_call_per_column_all_kernels') is not None:      # every kernel of the call, not the sweep classes only
+            traffic_all = fig['hbm_bytes_per_call_per_column_all_kernels'] * ncol
         if fig.get('valu_insts_per_call_per_column') is not None:
             rate = fig['valu_insts_per_call_per_column'] * ncol / (ms_sweep * 1e-3)
             valu = dict(achieved=rate, peak=VALU_PEAK, unit='wave64 VALU instructions/s', frac=rate / VALU_PEAK,
@@ -304,6 +303,11 @@ def roofline_block(eng, lib, prob, ncol, workload, kernel_reps):
                            '15-18 %: memory queueing latency against one depth of prefetch; a third wave per SIMD fits neither the register file nor, '
                            'beside the per-depth operand table, the LDS',
                 fs_call=dict(ms=ms_total, ms_sweep_kernel=ms_sweep, ms_epilogue_kernels=info(4), alg_bytes=balg * ncol,
+                             traffic=traffic_all, traffic_over_alg=(traffic_all / (balg * ncol)) if traffic_all else None,
+                             traffic_note='HBM bytes of EVERY kernel of a formal solution (sweeps, fast-continuum kernels, operand-table build, '
+                                          'Gamma epilogue) from the same counter passes as roofline.traffic (profiles/summarize.py: '
+                                          'fs_call_hbm_bytes_per_call); null when those figures are stale',
+
                              achieved_GBps=balg * ncol / (ms_total * 1e-3) / 1e9,
                              frac=balg * ncol / (ms_total * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                              frac_of_measured_peak=balg * ncol / (ms_total * 1e-3) / 1e9 / HBM_MEASURED_GBPS),
@@ -492,10 +496,21 @@ def main():
         torch.cuda.synchronize()
 
     dt, per_step, dJ, dP = timed_steps(eng, reducer, args.steps, args.warmup, barrier)
+    # the scaling record proves itself (round 5): what every rank saw -- its own time for the K steps, the world size and backend of
+    # the process group it was in, the sweep mapping its engine ran and its options signature -- gathered onto rank 0's line
+    scaling_record = None
     if world > 1:
+        dt_own = dt
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        mine = dict(rank=rank, ms_per_step=dt_own / args.steps * 1e3, world_seen=dist.get_world_size(), backend=dist.get_backend(),
+                    sweep_policy=eng.sweep_policy(), columns=ncol, options_signature='%016x' % eng.options_signature(),
+                    device=torch.cuda.get_device_name(dev) if dev.type == 'cuda' else str(dev))
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        scaling_record = dict(world_seen=dist.get_world_size(), backend=dist.get_backend(), per_rank=every,
+                              ms_per_step_max_over_ranks=dt / args.steps * 1e3)
 
     units = prob.work_units_per_column() * ncol * world * args.steps
     result = None

@@ -2353,11 +2353,12 @@ double lsx_hip_info(const lsx_ctx* c, int32_t what)
     switch (what) {
     case 0: return lsx_algorithmic_bytes_per_column(c) - 8.0 * c->Nspace * 2.0 * c->NL2tot;
     case 1: return (double)c->tiles.size();
-    case 2: {   // the largest workgroup of the sweep the next formal solution launches: the ray-serial instances carry the per-depth operand
-                // table of FIVE columns (lsx_plan.h, lsx_rs_lds_doubles), about twice the one-ray-per-lane layout of the same class
+    case 2: {   // the largest workgroup of the sweep the next formal solution launches (the ray-serial instances: operand rings of eight
+                // rows per wave, lsx_plan.h -- independent of Nspace since round 5; folded classes: wider rows and the cross-section table)
         if (c->solver == LSX_SOLVER_PARABOLIC || !use_ray_serial(c)) return (double)c->lds_bytes;
         size_t b = 0;
-        for (const auto& k : c->classes) b = std::max(b, k.rs ? (size_t)lsx_rs_lds_doubles(k.npt, c->Nspace) * sizeof(double) : k.lds_bytes);
+        for (const auto& k : c->classes)
+            b = std::max(b, k.rs ? (size_t)lsx_rs_lds_doubles(k.npt, c->Nspace, false, k.fold ? k.fold_nF : -1) * sizeof(double) : k.lds_bytes);
         return (double)b;
     }
     case 3: return (double)c->L;
@@ -2382,6 +2383,28 @@ int32_t lsx_hip_class_info(const lsx_ctx* c, int32_t idx, int64_t* out)
         out[6] = ((c->solver == LSX_SOLVER_PARABOLIC ? k.rsp : k.rs) && use_ray_serial(c)) ? 1 : 0;
     }
     return (int32_t)c->classes.size();
+}
+
+// diagnostic (tests/test_lds_hygiene.py): fill the LDS of every CU with signalling garbage.  LDS keeps its contents from one kernel
+// to the next, and on an idle machine they are mostly zeros -- a kernel that reads LDS it has not written then looks correct.  After
+// this call such a read returns NaN (round 5: a folded ray-serial tile without fast continua read four rows of cross-sections nobody
+// had written; the failure showed up once in a dozen runs).  `rounds` launches of 4 x (CUs) workgroups of 64 kB.
+__global__ void k_poison_lds(double* sink)
+{
+    extern __shared__ double sm[];
+    const double bad = __builtin_nan("");
+    for (int e = threadIdx.x; e < 8192; e += blockDim.x) sm[e] = bad;
+    __syncthreads();
+    if (sink && sm[(threadIdx.x * 37) & 8191] == 1.0) *sink = 1.0;      // (keeps the stores)
+}
+extern "C" int lsx_hip_poison_lds(int32_t device, int32_t rounds)
+{
+    if (hipSetDevice(device) != hipSuccess) return LSX_EDEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return LSX_EDEVICE;
+    for (int r = 0; r < std::max(1, (int)rounds); ++r)
+        hipLaunchKernelGGL(k_poison_lds, dim3((unsigned)(4 * prop.multiProcessorCount)), dim3(256), 65536, 0, (double*)nullptr);
+    return hipDeviceSynchronize() == hipSuccess ? LSX_OK : LSX_EDEVICE;
 }
 
 // diagnostic: stream `gib` GiB once in the sweep's access shape (see k_calib_read); returns the bytes read

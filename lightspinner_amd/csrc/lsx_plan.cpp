@@ -464,7 +464,7 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
             // streams from the pre-pass (the unfactored linked instance reads them)
             // (not the two-line instances with a known relation and no linked continua: they sit at the register limit -- folded they
             // spill; their classes keep the pre-pass)
-            k.fold = k.rs && !opt.no_fold && k.has_fast && (!k.linked || k.lk_epi) && !(k.npt == 2 && !k.linked && k.topo != 0);
+            k.fold = k.rs && !opt.no_fold && k.has_fast && (!k.linked || k.lk_epi) && lsx_rs_fold_instance_exists(k.npt, k.linked, k.topo);
             k.fold_nF = 0;
             for (int t : k.tiles) {
                 k.fold_nF = std::max(k.fold_nF, (int)P.tiles[t].nF);

@@ -167,6 +167,7 @@ constexpr int lsx_rs_row_doubles(int npt, int nF = 0) { return 3 * LSX_RS_COLS *
 // the folded instances take the fast continua four at a time in straight-line code (the LDS reads of a chunk in flight together; a
 // continuum the tile does not have: zero cross-section against a zeroed pad of the row), so the rings' rows and the cross-section
 // table are laid out for the class's largest tile rounded up to a multiple of four
+constexpr bool lsx_rs_fold_instance_exists(int npt, bool lk, int topo) { return !(npt == 2 && !lk && topo != 0); }
 constexpr int lsx_rs_fold_pad(int nF) { return (nF + 3) & ~3; }
 constexpr int lsx_rs_row_pitch(int npt, int nF = 0) { return (lsx_rs_row_doubles(npt, lsx_rs_fold_pad(nF)) + 1) & ~1; }
 // doubles per column group of the table: Ntrans blocks of (Nspace + 1) rows of 15, the geometry block of (Nspace + 1) rows of 10,

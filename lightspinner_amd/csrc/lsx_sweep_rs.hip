@@ -211,7 +211,8 @@ lsx_sweep_rs_kernel(const SweepParams p)
     if constexpr (FOLD) {
         // the fast continua's cross-sections for this lane's wavelength (0 where the continuum is not active there, and for the
         // continua the tile does not have up to the next multiple of four): [q][lane]
-        for (int e = nF * LSX_WAVE + threadIdx.x; e < lsx_rs_fold_pad(nF) * LSX_WAVE; e += 2 * LSX_WAVE) atab[e] = 0.0;
+        // (a tile without fast continua in a folded class still runs the first chunk: four zero rows)
+        for (int e = nF * LSX_WAVE + threadIdx.x; e < max(lsx_rs_fold_pad(nF), 4) * LSX_WAVE; e += 2 * LSX_WAVE) atab[e] = 0.0;
         for (int e = threadIdx.x; e < nF * LSX_WAVE; e += 2 * LSX_WAVE) {
             const int q = e >> 6, l = e & (LSX_WAVE - 1);
             // (a lane without a wavelength of its own shadows the tile's last one and stores the same bits to the same address: it needs
@@ -244,10 +245,14 @@ lsx_sweep_rs_kernel(const SweepParams p)
 #pragma unroll
                 for (int i = 0; i < CH; ++i) { SA = fma(a[i], x[i], SA); SB = fma(a[i], y[i], SB); }
             };
+#ifdef LSX_ABL_FOLD_NOCHUNK
+            SA = al[0]; SB = fr[0];                    // ablation build (wrong results): no sums over the continua
+#else
             chunk(0);
             if constexpr (CH == 2) { if (nF > 2) chunk(2); }
             if (nF > 4) { chunk(4); if constexpr (CH == 2) { if (nF > 6) chunk(6); } }
             if (nF > 8) { chunk(8); if constexpr (CH == 2) { if (nF > 10) chunk(10); } }
+#endif
             const double EB = E * SB;
             chi += SA - EB;
             eta = fma(ula, EB, eta);
@@ -355,7 +360,12 @@ lsx_sweep_rs_kernel(const SweepParams p)
         o.bc = at(bgchi, kt);
         o.be = at(bgeta, kt);
         o.E = 0.0;
+#ifdef LSX_ABL_FOLD_NOE
+        if constexpr (HASC) o.E = at(Eb, kt);          // ablation build (wrong results): the folded instances do not read the Boltzmann stream
+        else if constexpr (FOLD) o.E = 0.5;
+#else
         if constexpr (HASC || FOLD) o.E = at(Eb, kt);
+#endif
 #pragma unroll
         for (int u = 0; u < NL; ++u)
 #pragma unroll
@@ -1187,6 +1197,21 @@ static hipError_t launch_rs(const SweepParams& p, int ngroups, hipStream_t st)
     return hipGetLastError();
 }
 
+// the folded or the plain instance of a class.  The two-line instances with a known relation and no linked continua sit at the
+// register limit (folded they would spill): the plan never folds their classes (lsx_plan.cpp), and no folded instance of them exists.
+#ifndef LSX_RS_PARABOLIC_TU
+template <int NPT, int NL, bool LK, int TOPO>
+static hipError_t launch_rs_pick(const SweepParams& p, int ngroups, hipStream_t st)
+{
+    constexpr bool kFoldable = lsx_rs_fold_instance_exists(NPT, LK, TOPO);
+    if (p.fold) {
+        if constexpr (kFoldable) return launch_rs<NPT, NL, LK, TOPO, false, true>(p, ngroups, st);
+        else return hipErrorNotSupported;
+    }
+    return launch_rs<NPT, NL, LK, TOPO, false, false>(p, ngroups, st);
+}
+#endif
+
 // the ray-serial instance of a class (code = lsx_class_code of the class), NC columns per wavefront.  This file is compiled twice
 // (Makefile): as it is for the reference's piecewise-linear rule, and with LSX_RS_PARABOLIC_TU for the parabolic instances (N4).
 #ifndef LSX_RS_PARABOLIC_TU
@@ -1195,8 +1220,7 @@ extern "C" hipError_t lsx_launch_sweep_rs(const SweepParams* p, int code, hipStr
     if (p->Nrays != LSX_RS_RAYS || p->sca_per_lambda || p->L != LW) return hipErrorNotSupported;
     const int ngroups = (p->ncol + NC - 1) / NC;
     switch (code) {
-#define LSX_X(NPT, NL, LK, TOPO) case lsx_class_code(NPT, NL, LK, TOPO): \
-        return p->fold ? launch_rs<NPT, NL, LK, TOPO, false, true>(*p, ngroups, st) : launch_rs<NPT, NL, LK, TOPO, false, false>(*p, ngroups, st);
+#define LSX_X(NPT, NL, LK, TOPO) case lsx_class_code(NPT, NL, LK, TOPO): return launch_rs_pick<NPT, NL, LK, TOPO>(*p, ngroups, st);
         LSX_RS_INSTANCES(LSX_X)
 #undef LSX_X
     default: return hipErrorNotSupported;

@@ -49,6 +49,31 @@ def main():
             for r in csv.DictReader(open(f)):
                 if 'lsx_sweep_' in r['Kernel_Name']:
                     ctr[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+    # ---- whole-call HBM traffic (round 5): every kernel of a formal solution -- the sweeps, the fast-continuum kernels around them,
+    # the operand-table build, the Gamma epilogue -- summed over a pass and divided by the number of calls in it (= launches of
+    # k_gamma_finish).  SURVEY 8d: re-reads caused by kernel splitting do not count as algorithmic bytes, so they have to be visible.
+    FS_KERNELS = ('lsx_sweep_', 'k_fast_', 'k_gamma_finish', 'k_build_optab')
+    allk = collections.defaultdict(lambda: collections.defaultdict(float))
+    ncalls = collections.Counter()
+    for d in sorted(glob.glob(tag + '_pmc*')):
+        for f in glob.glob(os.path.join(d, '*counter_collection.csv')):
+            for r in csv.DictReader(open(f)):
+                if r['Counter_Name'] not in ('FETCH_SIZE', 'WRITE_SIZE'):
+                    continue
+                nm = short(r['Kernel_Name'])
+                if any(x in r['Kernel_Name'] for x in FS_KERNELS):
+                    allk[r['Counter_Name']][nm] += float(r['Counter_Value'])
+                    if 'k_gamma_finish' in r['Kernel_Name']:
+                        ncalls[r['Counter_Name']] += 1
+    if allk.get('FETCH_SIZE') and allk.get('WRITE_SIZE') and ncalls['FETCH_SIZE'] and ncalls['WRITE_SIZE']:
+        per_kernel = {}
+        for nm in sorted(set(allk['FETCH_SIZE']) | set(allk['WRITE_SIZE'])):
+            per_kernel[nm] = (2.0 * allk['FETCH_SIZE'].get(nm, 0.0) / ncalls['FETCH_SIZE'] + allk['WRITE_SIZE'].get(nm, 0.0) / ncalls['WRITE_SIZE']) * 1024.0
+        out['fs_call_hbm_bytes_per_call_by_kernel'] = {k: round(v) for k, v in per_kernel.items()}
+        out['fs_call_hbm_bytes_per_call'] = sum(per_kernel.values())
+        out['fs_calls_counted'] = dict(ncalls)
+        if ncol:
+            out['fs_call_hbm_bytes_per_call_per_column'] = out['fs_call_hbm_bytes_per_call'] / ncol
     if ctr:
         pc = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in ctr.items()}
         out['sweep_counters_per_launch'] = {k: {c: round(v, 1) for c, v in d.items()} for k, d in sorted(pc.items())}
@@ -107,6 +132,8 @@ def main():
         # (round 2 quoted SQ_ACTIVE_INST_VALU * 4 / (SIMDs x GRBM cycles) as "VALU busy"; its sibling ratio for all instructions
         # exceeds 1, so it is not a utilisation and is no longer published; the pipe estimate per class stays in
         # sweep_binding_resource, the clock the chip actually holds is measured in the kernel: profiles/stamps.py)
+        if 'fs_call_hbm_bytes_per_call_per_column' in out:
+            fig['hbm_bytes_per_call_per_column_all_kernels'] = out['fs_call_hbm_bytes_per_call_per_column']
         if fig:
             out['figures'] = fig
     cal = glob.glob(tag + '_calib/*counter_collection.csv')
