@@ -734,7 +734,8 @@ __global__ void __launch_bounds__(NT) k_fast_gamma(const FastParams f)
 template <int NLC, int NPC>   // NLC: lines of the tile that linked continua feed (0: the tile has no linked continuum)
 // four waves per SIMD asked for where no linked continuum is carried: <0,6> then fits 128 VGPRs without scratch (140 before);
 // the time did not change (profiles/r04/ab_epilogue_waves_per_simd.txt): the kernel runs beside the sweeps, whose waves hold the registers
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLC == 0 ? 4 : 3))) k_fast_gamma_cols(const FastParams f)
+// (the instances for tile widths other than twelve wavelengths, NPC = 0: one wave less -- they spilled 12 - 100 bytes per lane)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NLC == 0 ? 4 : 3) - (NPC == 0 ? 1 : 0)))) k_fast_gamma_cols(const FastParams f)
 {
     extern __shared__ double sm[];
     fast_gamma_cols_rows<NLC, NPC, 4>(f, f.fast_tiles[blockIdx.y], (long)blockIdx.x * 4 * LSX_FGC_ROWS, (long)f.ncol * f.Nspace, sm);   // lsx_fast.h

@@ -1482,8 +1482,12 @@ __device__ __forceinline__ void sweep_tile_par(const SweepParams& p, const int v
 #define LSX_WPE4 (LSX_WAVES_PER_EU - 1)
 #endif
 #define LSX_WPE(NPT) ((NPT) == 0 ? LSX_WPE0 : ((NPT) == 1 ? LSX_WPE1 : ((NPT) == 2 ? LSX_WPE2 : ((NPT) == 3 ? LSX_WPE3 : ((NPT) == 4 ? LSX_WPE4 : LSX_WAVES_PER_EU)))))
+// ... and one wave per SIMD less where the class's budget spilled (round 5: no instance the planner can dispatch uses scratch --
+// tests/test_no_scratch.py parses the compiler's resource report): two and three slots with linked continua (their correction
+// streams), one slot with linked continua at a run-time ray count, four slots
+#define LSX_WPE_OF(NPT, NR, LK) (LSX_WPE(NPT) - ((((NPT) >= 2 && (LK)) || ((NPT) == 1 && (LK) && (NR) == 0) || (NPT) == 4) ? 1 : 0))
 template <int NPT, int NL, int NR, bool SCAL, bool LK, int TOPO = 0>
-__global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(LSX_WPE(NPT))))
+__global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(LSX_WPE_OF(NPT, NR, LK))))
 lsx_sweep_kernel(const SweepParams p)
 {
     // XCD-aware block -> (column, tile): workgroups are dealt round-robin over the 8 XCDs (b and
