@@ -1739,7 +1739,9 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
                 if (!k.tdone) note(hipEventCreate(&k.tdone));
                 if (k.tdone) note(hipEventRecord(k.tdone, st));
             }
+#ifndef LSX_ABL_NO_FAST_GAMMA       // (ablation build, wrong results: what a call costs without the fast-continuum epilogue -- profiles/r05)
             if (!k.fast_tiles.empty()) launch_fast_gamma(st, k.fast_cols, k.d_fast_cols, k.d_fast_rest, k.fast_rest.size(), epi);
+#endif
             if (fork) {
                 note(hipEventRecord(k.done, st));
                 note(hipStreamWaitEvent(c->stream, k.done, 0));
