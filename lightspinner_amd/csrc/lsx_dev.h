@@ -170,6 +170,7 @@ struct SweepParams {
     int64_t optab_group_stride; // doubles per group
     const int32_t* trans_row;   // per transition: its row of wphi (lines) / its continuum index (continua)
     int32_t fold, fold_nF;      // the launched class runs its FOLDED instance (lsx_plan.h); the most fast continua a tile of it has
+    int32_t epi, pad_epi;       // ... its EPI instance: the second visitor of a depth forms the fast continua's Gamma integrands itself
 };
 
 // ---- the line-profile store phi_T --------------------------------------------------------------------------------------------

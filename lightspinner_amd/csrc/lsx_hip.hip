@@ -306,18 +306,19 @@ __global__ void k_build_optab(const OptabParams p)
             blk[(size_t)e * 2 + 1] = (r >= 0 && r < Ns) ? p.sca[col * Ns + r] : 0.0;
         }
     } else {
-        const int q = t - p.Ntrans - 2;                           // continuum q: n_i, n_j nStar_i / nStar_j (the folded instances' operands)
-        double* const blk = grp + ((size_t)p.Ntrans * (3 * NC) + 2 * (2 * NC) + (size_t)q * (2 * NC)) * NR;
+        const int q = t - p.Ntrans - 2;                           // continuum q: n_i, n_j nStar_i / nStar_j, nStar_i / nStar_j (the folded instances' operands)
+        double* const blk = grp + ((size_t)p.Ntrans * (3 * NC) + 2 * (2 * NC) + (size_t)q * (3 * NC)) * NR;
         const int li = p.cont_li[q], lj = p.cont_lj[q];
         for (int e = threadIdx.x; e < NR * NC; e += blockDim.x) {
             const int r = e / NC - PAD, c = e - (e / NC) * NC;
-            double v0 = 0.0, v1 = 0.0;
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0;
             if (r >= 0 && r < Ns) {
                 const size_t col = (size_t)g * NC + (c < ncg ? c : ncg - 1);
+                v2 = p.nsr[(col * p.Ncont + q) * Ns + r];
                 v0 = p.n[(col * p.NLtot + li) * Ns + r];
-                v1 = p.n[(col * p.NLtot + lj) * Ns + r] * p.nsr[(col * p.Ncont + q) * Ns + r];
+                v1 = p.n[(col * p.NLtot + lj) * Ns + r] * v2;
             }
-            blk[(size_t)e * 2 + 0] = v0; blk[(size_t)e * 2 + 1] = v1;
+            blk[(size_t)e * 3 + 0] = v0; blk[(size_t)e * 3 + 1] = v1; blk[(size_t)e * 3 + 2] = v2;
         }
     }
 }
@@ -1719,7 +1720,8 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
             const bool epi = k.lk_epi && rs_here;
             // folded instances (lsx_plan.h): the sweep forms the fast continua's opacity and emissivity itself -- no pre-pass
             const bool fold = k.fold && k.rs && ray_serial;
-            p.fold = fold ? 1 : 0; p.fold_nF = k.fold_nF;
+            const bool epi_in_sweep = fold && k.epi;          // ... and their Gamma integrands: no epilogue launch
+            p.fold = fold ? 1 : 0; p.fold_nF = k.fold_nF; p.epi = epi_in_sweep ? 1 : 0;
             if (!k.fast_tiles.empty() && !fold) launch_prepass(st, k.d_fast_tiles, k.fast_tiles.size(), epi);
             const long nblocks = (long)k.tiles.size() * c->ncol;
             p.class_tiles = k.d_tiles;
@@ -1740,7 +1742,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
                 if (k.tdone) note(hipEventRecord(k.tdone, st));
             }
 #ifndef LSX_ABL_NO_FAST_GAMMA       // (ablation build, wrong results: what a call costs without the fast-continuum epilogue -- profiles/r05)
-            if (!k.fast_tiles.empty()) launch_fast_gamma(st, k.fast_cols, k.d_fast_cols, k.d_fast_rest, k.fast_rest.size(), epi);
+            if (!k.fast_tiles.empty() && !epi_in_sweep) launch_fast_gamma(st, k.fast_cols, k.d_fast_cols, k.d_fast_rest, k.fast_rest.size(), epi);
 #endif
             if (fork) {
                 note(hipEventRecord(k.done, st));
@@ -2361,7 +2363,7 @@ double lsx_hip_info(const lsx_ctx* c, int32_t what)
         if (c->solver == LSX_SOLVER_PARABOLIC || !use_ray_serial(c)) return (double)c->lds_bytes;
         size_t b = 0;
         for (const auto& k : c->classes)
-            b = std::max(b, k.rs ? (size_t)lsx_rs_lds_doubles(k.npt, c->Nspace, false, k.fold ? k.fold_nF : -1) * sizeof(double) : k.lds_bytes);
+            b = std::max(b, k.rs ? (size_t)lsx_rs_lds_doubles(k.npt, c->Nspace, false, k.fold ? k.fold_nF : -1, k.epi, k.linked ? k.nl : 0) * sizeof(double) : k.lds_bytes);
         return (double)b;
     }
     case 3: return (double)c->L;

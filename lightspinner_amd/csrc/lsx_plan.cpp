@@ -471,6 +471,13 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
                 if (lsx_rs_row_doubles(k.npt, P.tiles[t].nF) > LSX_RS_FOLD_ROW_MAX || P.tiles[t].nF > 12) k.fold = false;
             }
             if (k.fold && (size_t)lsx_rs_lds_doubles(k.npt, Ns, false, k.fold_nF) * sizeof(double) > 64 * 1024) k.fold = false;
+            // ... and the fast continua's Gamma integrands (EPI, lsx_plan.h): every tile of the class is one the column-mapped epilogue
+            // takes (simple bound-free sets, at most two linked lines), its class needs no correction streams (checked above), and the
+            // workgroup's LDS leaves room for four per CU
+            k.epi = k.fold && !opt.no_epi;
+            for (int t : k.tiles)
+                if (P.tiles[t].nF > 0 && P.tiles[t].fast_simple != 2) k.epi = false;
+            if (k.epi && (size_t)lsx_rs_lds_doubles(k.npt, Ns, false, k.fold_nF, true, k.linked ? k.nl : 0) * sizeof(double) > 40 * 1024) k.epi = false;
             k.rsp = k.rs && lsx_rsp_instance_exists(k.npt, k.nl, k.linked, k.topo) &&
                     (size_t)lsx_rs_lds_doubles(k.npt, Ns, true) * sizeof(double) <= 64 * 1024;
         }
@@ -560,6 +567,7 @@ void options_from_env(CtxOptions* o)
     p.occ_wg = (e = getenv("LSX_OCC_WG")) ? atoi(e) : 0;
     p.no_rs = getenv("LSX_NO_RS") != nullptr;
     p.no_fold = getenv("LSX_NO_FOLD") != nullptr;
+    p.no_epi = getenv("LSX_EPI") == nullptr;
     p.no_phi_group = (e = getenv("LSX_PHI_GROUP")) && atoi(e) == 1;
     if ((e = getenv("LSX_RS_MIN_COLUMNS"))) p.rs_min_columns = atoi(e);
     if ((e = getenv("LSX_RS_MAX_NPT"))) p.rs_max_npt = atoi(e);
@@ -611,6 +619,7 @@ int options_apply(const char* list, CtxOptions* o, std::string* err)
         else if (key == "fast_rows") ok = flag(&p.fast_rows, false);
         else if (key == "rs") ok = flag(&p.no_rs, true);
         else if (key == "fold") ok = flag(&p.no_fold, true);
+        else if (key == "epi") ok = flag(&p.no_epi, true);
         else if (key == "phi_group") ok = flag(&p.no_phi_group, true);      // 1: grouped where the ray-serial sweep can run (default), 0: per column
         else if (key == "rs_min_columns") ok = count(&p.rs_min_columns, 1, 1 << 30);
         else if (key == "rs_max_npt") ok = count(&p.rs_max_npt, 0, 2);
@@ -642,10 +651,10 @@ std::string options_string(const CtxOptions& o)
     const RunOptions& r = o.run;
     char b[512];
     snprintf(b, sizeof b,
-             "linked=%d;tiler=%s;topo=%d;fast_rows=%d;order=%s;occ_wg=%d;class_chunk=%d;rs=%d;fold=%d;phi_group=%d;rs_min_columns=%d;rs_max_npt=%d;"
+             "linked=%d;tiler=%s;topo=%d;fast_rows=%d;order=%s;occ_wg=%d;class_chunk=%d;rs=%d;fold=%d;epi=%d;phi_group=%d;rs_min_columns=%d;rs_max_npt=%d;"
              "se_lds=%d;serial=%d;finish_big=%d;fused_epilogue=%d;graph=%d;fused_fast=%d;abl_fused_fast=%d",
              !p.no_linked, p.natural_tiles ? "natural" : "dp", !p.no_topo, (int)p.fast_rows, p.order_by_cost ? "cost" : "plan", p.occ_wg, p.class_chunk,
-             !p.no_rs, !p.no_fold, !p.no_phi_group, p.rs_min_columns, p.rs_max_npt, (int)r.se_lds, (int)r.serial, (int)r.finish_big,
+             !p.no_rs, !p.no_fold, !p.no_epi, !p.no_phi_group, p.rs_min_columns, p.rs_max_npt, (int)r.se_lds, (int)r.serial, (int)r.finish_big,
              (int)r.fused_epilogue, (int)r.graph, !r.no_fused_fast, r.abl_fast);
     return b;
 }
@@ -655,7 +664,7 @@ std::string plan_class_string(const LsxPlan& P)
     std::string s;
     char b[64];
     for (const PlanClass& k : P.plan_classes) {
-        snprintf(b, sizeof b, "%s%d.%d.%d.%d:%zu%s", s.empty() ? "" : ",", k.npt, k.nl, (int)k.linked, k.topo, k.tiles.size(), k.rs ? (k.fold ? "sf" : "s") : "");
+        snprintf(b, sizeof b, "%s%d.%d.%d.%d:%zu%s", s.empty() ? "" : ",", k.npt, k.nl, (int)k.linked, k.topo, k.tiles.size(), k.rs ? (k.fold ? (k.epi ? "sfe" : "sf") : "s") : "");
         s += b;
     }
     return s;

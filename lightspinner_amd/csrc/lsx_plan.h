@@ -157,17 +157,26 @@ inline bool lsx_rsp_instance_exists(int npt, int nl, bool lk, int topo)
 // later) and write it over the row that was consumed two steps ago.  LDS per workgroup no longer depends on Nspace.
 // FOLDED fast continua (round 5): a class whose tiles have fast continua can run instances that form the continua's opacity and
 // emissivity themselves (what k_fast_prepass added to the background, rh_method.py:284-286, 453-455, 613-614) -- per continuum q and
-// depth the table holds a third kind of block, [c][2] = n_i, n_j nStar_i / nStar_j, the row of a tile with nF fast continua is
-// 15 npt + 10 + 10 nF doubles (two elements per lane: at most 128), and per (wavelength, depth) the lane needs two fused
+// depth the table holds a third kind of block, [c][3] = n_i, n_j nStar_i / nStar_j, nStar_i / nStar_j, the row of a tile with nF fast
+// continua is 15 npt + 10 + 15 nF doubles (two elements per lane: at most 128), and per (wavelength, depth) the lane needs two fused
 // multiply-adds per continuum: chi += sum_q alpha_q n_i,q - E sum_q alpha_q (n_j nsr)_q, eta += (2hc/lambda^3) E sum_q alpha_q (n_j nsr)_q,
 // E = exp(-hc / k lambda T) the tile's Boltzmann stream.  No pre-pass launch, no effective-background streams for those classes.
+// ... and their GAMMA INTEGRANDS (EPI instances; what k_fast_gamma_cols did, rh_method.py:652, 677-681 for a ray-independent
+// transition): the wave that visits a depth SECOND has the total mean intensity there; it also fetches the first visitor's half of
+// Psibar (and of sum_mu w Psi* phi per linked line), forms every fast continuum's two rate integrands and the linked lines'
+// corrections for its wavelength, reduces them over the tile's wavelengths (twelve values per round through LDS rows, like the
+// per-ray integrands) and stores the slabs -- one entry per rate, both directions in it, as the epilogue kernel did: k_gamma_finish does
+// not change.  No k_fast_gamma_cols launch for those classes, and the second visitor stores neither Psibar nor the Psi* phi sums.
 #define LSX_RS_RING 8                   // rows per wave (a power of two)
+#define LSX_RS_RING_EPI 4               // ... of the EPI instances (their reduction rows need the LDS)
+#define LSX_RS_EPI_ROUND 12             // values per reduction round: 64 lanes / 5 columns
 #define LSX_RS_FOLD_ROW_MAX 128         // doubles of a folded row: two elements per lane
-constexpr int lsx_rs_row_doubles(int npt, int nF = 0) { return 3 * LSX_RS_COLS * npt + 2 * LSX_RS_COLS + 2 * LSX_RS_COLS * nF; }
+constexpr int lsx_rs_row_doubles(int npt, int nF = 0) { return 3 * LSX_RS_COLS * npt + 2 * LSX_RS_COLS + 3 * LSX_RS_COLS * nF; }
 // the folded instances take the fast continua four at a time in straight-line code (the LDS reads of a chunk in flight together; a
 // continuum the tile does not have: zero cross-section against a zeroed pad of the row), so the rings' rows and the cross-section
 // table are laid out for the class's largest tile rounded up to a multiple of four
-constexpr bool lsx_rs_fold_instance_exists(int npt, bool lk, int topo) { return !(npt == 2 && !lk && topo != 0); }
+// (nor of the unfactored two-line instance with linked continua: it reads the pre-pass's correction streams)
+constexpr bool lsx_rs_fold_instance_exists(int npt, bool lk, int topo) { return !(npt == 2 && !lk && topo != 0) && !(npt == 2 && lk && topo == 0); }
 constexpr int lsx_rs_fold_pad(int nF) { return (nF + 3) & ~3; }
 constexpr int lsx_rs_row_pitch(int npt, int nF = 0) { return (lsx_rs_row_doubles(npt, lsx_rs_fold_pad(nF)) + 1) & ~1; }
 // doubles per column group of the table: Ntrans blocks of (Nspace + 1) rows of 15, the geometry block of (Nspace + 1) rows of 10,
@@ -179,7 +188,7 @@ constexpr int lsx_rs_row_pitch(int npt, int nF = 0) { return (lsx_rs_row_doubles
 constexpr int lsx_optab_rows(int Ns) { return Ns + 2 * LSX_RS_RING; }
 constexpr size_t lsx_optab_group_doubles(int Ntrans, int Ns, int Ncont)
 {
-    return ((size_t)Ntrans * 3 * LSX_RS_COLS + 2 * 2 * LSX_RS_COLS + (size_t)Ncont * 2 * LSX_RS_COLS) * (size_t)lsx_optab_rows(Ns);
+    return ((size_t)Ntrans * 3 * LSX_RS_COLS + 2 * 2 * LSX_RS_COLS + (size_t)Ncont * 3 * LSX_RS_COLS) * (size_t)lsx_optab_rows(Ns);
 }
 // (the parabolic instances park 16 depths in every class: they need the LDS for the lane-private cells below)
 constexpr int lsx_rs_park(int npt, bool par = false) { return (npt >= 2 || par) ? 16 : 64; }      // depths a row of parked Gamma totals holds (two slots: 16, for two workgroups more per CU)
@@ -190,12 +199,16 @@ constexpr int lsx_rs_par_rows(int npt) { return LSX_RS_RAYS * (2 + npt); }
 // exchange, the two waves' operand rings, the parked Gamma totals, the angle quadrature, the parabolic instances' cells
 // (fold_nF >= 0: a folded instance whose tiles have at most that many fast continua -- the rings' row pitch and the [q][64] table of
 // the continua's cross-sections per lane)
-constexpr int lsx_rs_lds_doubles(int npt, int Ns, bool par = false, int fold_nF = -1)
+// (epi: the EPI instance of the class -- shorter rings and parked rows, [2 waves][12] reduction rows for the fast values, a second [q][64]
+// table (the continua's wavelength weights), the midpoint's exchange of Psibar and the Psi* phi sums)
+constexpr int lsx_rs_lds_doubles(int npt, int Ns, bool par = false, int fold_nF = -1, bool epi = false, int nlk = 0)
 {
     (void)Ns;
     return LSX_EXP_TAB + 2 * (2 * (npt > 0 ? npt : 1) + 1) * 64 + 2 * LSX_WAVE +
-           2 * LSX_RS_RING * (fold_nF >= 0 ? lsx_rs_row_pitch(npt, fold_nF) : lsx_rs_row_doubles(npt)) + (fold_nF > 0 ? lsx_rs_fold_pad(fold_nF) * LSX_WAVE : 0) +
-           2 * LSX_RS_COLS * 2 * (npt > 0 ? npt : 1) * lsx_rs_park(npt, par) +  // + [2 waves][columns x values][entries] parked Gamma totals
+           2 * (epi ? LSX_RS_RING_EPI : LSX_RS_RING) * (fold_nF >= 0 ? lsx_rs_row_pitch(npt, fold_nF) : lsx_rs_row_doubles(npt)) +
+           (fold_nF > 0 ? (epi ? 2 : 1) * lsx_rs_fold_pad(fold_nF) * LSX_WAVE : 0) +
+           (epi ? 2 * LSX_RS_EPI_ROUND * LSX_WAVE + 2 * (1 + nlk) * LSX_WAVE + 2 * LSX_WAVE : 0) +
+           2 * LSX_RS_COLS * 2 * (npt > 0 ? npt : 1) * lsx_rs_park(npt, par || epi) +  // + [2 waves][columns x values][entries] parked Gamma totals
            2 * LSX_RS_RAYS + 2 +                                            // + the angle quadrature (two-slot instances read it from here)
            (par ? 2 * lsx_rs_par_rows(npt) * LSX_WAVE : 0);
 }
@@ -219,6 +232,7 @@ struct PlanClass {             // tiles that run the same kernel instantiation
     bool lk_epi = false;       // ... whose linked corrections the fast-continuum epilogue applies (lsx_fast.h), not the sweep
     bool fold = false;         // the ray-serial instance forms the fast continua's opacity / emissivity itself: no pre-pass for this class
     int fold_nF = 0;           // ... the most fast continua a tile of the class has
+    bool epi = false;          // ... and the Gamma integrands of its fast continua (the EPI instance): no epilogue launch for this class either
     int code() const { return npt >= 0 ? lsx_class_code(npt, nl, linked, topo) : (linked ? -3 : -1); }
 };
 
@@ -234,6 +248,9 @@ struct PlanOptions {           // diagnostic switches (lsx_create reads them fro
     bool no_rs = false;        // LSX_NO_RS: every class through lsx_sweep.hip (one ray per lane)
     int rs_min_columns = LSX_RS_MIN_COLUMNS;   // LSX_RS_MIN_COLUMNS: contexts with fewer columns keep one ray per lane (too few wavefronts otherwise)
     bool no_phi_group = false; // LSX_PHI_GROUP=1: the plain per-column profile store also where the ray-serial sweep can run (measurements)
+    bool no_epi = true;        // epi=1 / LSX_EPI=1 switches the EPI instances on (the second visitor of a depth forms the fast continua's Gamma
+                               // integrands itself).  OFF by default: built, parity-green on every GPU test, and measured 2 % SLOWER than the
+                               // epilogue kernel it replaces (profiles/r05/ab_epilogue_in_sweep.txt; DESIGN.md 4.2 says what it would take)
     bool no_fold = false;      // fold=0 / LSX_NO_FOLD: the ray-serial classes keep the pre-pass and the effective-background streams (round 4)
     int rs_max_npt = 2;        // LSX_RS_MAX_NPT: classes with more per-ray slots keep one ray per lane (diagnostic: 1 leaves the two-slot tiles to lsx_sweep.hip)
 };

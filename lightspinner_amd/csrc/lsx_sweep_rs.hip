@@ -71,7 +71,7 @@ constexpr int RROW = 64;               // doubles per row of the reduction buffe
 #ifndef LSX_RSP_WPE
 #define LSX_RSP_WPE 1
 #endif
-template <int NPT, int NL, bool LK, int TOPO, bool PAR, bool FOLD>
+template <int NPT, int NL, bool LK, int TOPO, bool PAR, bool FOLD, bool EPI>
 __global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_eu(PAR ? LSX_RSP_WPE : (NPT == 0 ? 3 : LSX_RS_WPE(NPT, LK)))))
 lsx_sweep_rs_kernel(const SweepParams p)
 {
@@ -104,13 +104,20 @@ lsx_sweep_rs_kernel(const SweepParams p)
     // FOLD (lsx_plan.h, "FOLDED fast continua"): the row also carries [fast continuum q][c][2] = n_i, n_j nStar_i / nStar_j, and the
     // step forms the fast continua's opacity and emissivity itself -- two elements per lane and row, the pitch from the class's
     // largest tile (p.fold_nF)
-    constexpr int RING = LSX_RS_RING, RL0 = lsx_rs_row_doubles(NPT);
-    static_assert((RING & (RING - 1)) == 0 && RING >= 4 && RL0 <= LSX_WAVE, "operand ring");
-    static_assert(!(FOLD && PAR), "the parabolic instances keep the pre-pass");
+    // EPI (lsx_plan.h): the wave that visits a depth second also forms the Gamma integrands of the tile's fast continua and the linked
+    // lines' corrections (what k_fast_gamma_cols did) -- see epi_fast below
+    constexpr int RING = EPI ? LSX_RS_RING_EPI : LSX_RS_RING, RL0 = lsx_rs_row_doubles(NPT);
+    static_assert((RING & (RING - 1)) == 0 && RING >= 4 && RING <= LSX_RS_RING && RL0 <= LSX_WAVE, "operand ring");
+    static_assert(!(FOLD && PAR) && (FOLD || !EPI), "the parabolic instances keep the pre-pass; EPI instances are folded ones");
     const int RLP = FOLD ? lsx_rs_row_pitch(NPT, p.fold_nF) : RL0;                        // doubles between two rows of a ring
+    const int NFP = FOLD ? lsx_rs_fold_pad(p.fold_nF) : 0;
     lds_f64* const utab = etab + LSX_EXP_TAB + 2 * (NV + 1) * RROW + 2 * LSX_WAVE;      // [2 waves][RING][RLP]
-    lds_f64* const atab = utab + 2 * RING * RLP;                                        // FOLD: [q < fold_nF][64] the continua's cross-sections per lane
-    lds_f64* const ring_end = atab + (FOLD ? lsx_rs_fold_pad(p.fold_nF) * LSX_WAVE : 0);
+    lds_f64* const atab = utab + 2 * RING * RLP;                                        // FOLD: [q < NFP][64] the continua's cross-sections per lane
+    lds_f64* const wtab = atab + NFP * LSX_WAVE;                                        // EPI: [q < NFP][64] their wavelength weights (0 in lanes without a wavelength)
+    lds_f64* const fred = wtab + (EPI ? NFP * LSX_WAVE : 0);                            // EPI: [2 waves][LSX_RS_EPI_ROUND][64] reduction rows of the fast values
+    lds_f64* const xw2 = fred + (EPI ? 2 * LSX_RS_EPI_ROUND * LSX_WAVE : 0);            // EPI: [2 waves][1 + lines][64] the midpoint's exchange of Psibar, Psi* phi
+    lds_f64* const qinf = xw2 + (EPI ? 2 * (1 + (LK ? NL : 0)) * LSX_WAVE : 0);         // EPI: [64] per fast continuum: its linking bits, first-of-its-atom flag (as integers), then 64 spare
+    lds_f64* const ring_end = qinf + (EPI ? 2 * LSX_WAVE : 0);
 
     // XCD-aware block -> (column group, tile): every XCD gets a contiguous range (speed only)
     int vb;
@@ -165,11 +172,11 @@ lsx_sweep_rs_kernel(const SweepParams p)
             w = e - 3 * NC * NPT; rowd = 2 * NC;
             blk = ((size_t)p.Ntrans * (3 * NC) + (size_t)dir * (2 * NC)) * NRT;
         } else {
-            const int q = (e - RL0) / (2 * NC);
-            w = e - RL0 - q * (2 * NC); rowd = 2 * NC;
-            blk = ((size_t)p.Ntrans * (3 * NC) + 2 * (2 * NC) + (size_t)LSX_CONST(int32_t, p.trans_row)[slots[NPT + q].trans] * (2 * NC)) * NRT;
+            const int q = (e - RL0) / (3 * NC);
+            w = e - RL0 - q * (3 * NC); rowd = 3 * NC;
+            blk = ((size_t)p.Ntrans * (3 * NC) + 2 * (2 * NC) + (size_t)LSX_CONST(int32_t, p.trans_row)[slots[NPT + q].trans] * (3 * NC)) * NRT;
         }
-        ob = (unsigned)((blk + (size_t)(RING + kS) * rowd + w) * 8u);
+        ob = (unsigned)((blk + (size_t)(LSX_RS_RING + kS) * rowd + w) * 8u);       // (the table's pad: LSX_RS_RING rows, whatever this instance's ring)
         os = dk * rowd * 8;
     };
     unsigned o_e0, o_e1 = 0;                              // running offsets: the element of the row that is requested next
@@ -221,11 +228,21 @@ lsx_sweep_rs_kernel(const SweepParams p)
             const int laq = la0 + (jl < nla ? jl : nla - 1), lt = laq - slots[NPT + q].Nblue;
             const bool a = lt >= 0 && lt < slots[NPT + q].Nlam && p.active[(size_t)slots[NPT + q].trans * Nspect + laq] != 0;
             atab[e] = a ? p.alpha[slots[NPT + q].wl_off + lt] : 0.0;
+            if constexpr (EPI) wtab[e] = (a && jl < nla) ? p.wl[slots[NPT + q].wl_off + lt] : 0.0;      // (the wavelength sums take real wavelengths only)
+        }
+        if constexpr (EPI) {
+            for (int e = nF * LSX_WAVE + threadIdx.x; e < max(lsx_rs_fold_pad(nF), 4) * LSX_WAVE; e += 2 * LSX_WAVE) wtab[e] = 0.0;
+            // per fast continuum: its linking bits (DevSlot.lkbits) and whether it is the first of its atom's run
+            for (int q = threadIdx.x; q < LSX_WAVE; q += 2 * LSX_WAVE) {
+                unsigned bits = 0;
+                if (q < nF) bits = (slots[NPT + q].lkbits & 0x00ffffffu) | ((q == 0 || slots[NPT + q].atom != slots[NPT + q - 1].atom) ? 0x80000000u : 0u);
+                ((__attribute__((address_space(3))) unsigned*)qinf)[q] = bits;
+            }
         }
     }
     __syncthreads();
     const int lc3 = cc * 3, lcg = 3 * NC * NPT + cc * 2;   // the lane's column inside a row: slot values at lc3 + 15 u + t, geometry at lcg + {0, 1}
-    const int lcf = RL0 + cc * 2;                          // ... the fast continua's pairs at lcf + 10 q + {0, 1}
+    const int lcf = RL0 + cc * 3;                          // ... the fast continua's triples (n_i, n_j nsr, nsr) at lcf + 15 q + {0, 1, 2}
     constexpr int TU = 3 * NC;                             // doubles between two slots of a row
     // what the tile's fast continua add to opacity and emissivity at the depth of step v (rh_method.py:284-286, 453-455, 613-614):
     // chi += sum_q alpha_q n_i,q - E sum_q alpha_q (n_j nsr)_q,  eta += u_la E sum_q alpha_q (n_j nsr)_q
@@ -241,7 +258,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
             auto chunk = [&](const int q0) __attribute__((always_inline)) {
                 double a[CH], x[CH], y[CH];
 #pragma unroll
-                for (int i = 0; i < CH; ++i) { a[i] = al[(q0 + i) * LSX_WAVE]; x[i] = fr[2 * NC * (q0 + i) + 0]; y[i] = fr[2 * NC * (q0 + i) + 1]; }
+                for (int i = 0; i < CH; ++i) { a[i] = al[(q0 + i) * LSX_WAVE]; x[i] = fr[3 * NC * (q0 + i) + 0]; y[i] = fr[3 * NC * (q0 + i) + 1]; }
 #pragma unroll
                 for (int i = 0; i < CH; ++i) { SA = fma(a[i], x[i], SA); SB = fma(a[i], y[i], SB); }
             };
@@ -281,6 +298,9 @@ lsx_sweep_rs_kernel(const SweepParams p)
     const double* __restrict__ corr = CORR ? p.corr_T + (size_t)col0 * p.corr_col_stride + tilep->corr_off : nullptr;
     const unsigned o_corr = CORR ? (unsigned)((size_t)cc * p.corr_col_stride * 8u) + (unsigned)j * 8u : 0u;
     double* __restrict__ ppsum = LK ? p.Psi3_T + ((size_t)dir * p.ncol + col0) * p.pp_col_stride + tilep->pp_off : nullptr;
+    // EPI: the partner wave's halves of the same sums (what it stored as the first visitor of the depths this wave visits second)
+    const double* __restrict__ psibar_o = p.Psi2_T + ((size_t)(1 - dir) * p.ncol * ntile) * Ns * LW + tb0;
+    const double* __restrict__ ppsum_o = LK ? p.Psi3_T + ((size_t)(1 - dir) * p.ncol + col0) * p.pp_col_stride + tilep->pp_off : nullptr;
     const unsigned o_pp = LK ? (unsigned)((size_t)cc * p.pp_col_stride * 8u) + (unsigned)j * 8u : 0u;
     const size_t plane = (size_t)Ns * LW;
     const bool compact = p.phi_compact != 0;
@@ -294,7 +314,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
 #else
     constexpr bool QLDS = NPT >= 2 || (PAR && LSX_RSP_WPE >= 2) || (FOLD && NPT == 0);      // (the folded continuum instance: three waves per SIMD)
 #endif
-    lds_f64* const qtab = ring_end + (size_t)2 * NC * NV * lsx_rs_park(NPT, PAR);
+    lds_f64* const qtab = ring_end + (size_t)2 * NC * NV * lsx_rs_park(NPT, PAR || EPI);
     if (QLDS && threadIdx.x < 2 * NR) qtab[threadIdx.x] = threadIdx.x < NR ? LSX_CONST(double, p.zmu)[threadIdx.x] : LSX_CONST(double, p.wmuh)[threadIdx.x - NR];
     double zmu_r[NR], wmuh_r[NR];
 #pragma unroll
@@ -427,7 +447,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
     // park[c NV + q][PE]; every PE steps (and at the end) each row leaves as ONE coalesced store of PE consecutive depths.
     const int o_c = lane / NV, o_q = lane - o_c * NV;
     const bool own = lane < NC * NV;
-    constexpr int PE = lsx_rs_park(NPT, PAR);
+    constexpr int PE = lsx_rs_park(NPT, PAR || EPI);
     lds_f64* const park = ring_end + (size_t)dir * NC * NV * PE;
     double* __restrict__ gbase = p.Gpart + (((size_t)col0 * p.nslot_total + slot0) * 4 + (size_t)dir) * Ns;      // + (c nslot 4 + q 2) Ns + k
     auto flush = [&](int sprev) __attribute__((always_inline)) {         // the totals of step sprev (depth kS + dk sprev)
@@ -454,6 +474,143 @@ lsx_sweep_rs_kernel(const SweepParams p)
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
+            }
+        }
+    };
+
+    // ---- EPI: the Gamma integrands of the tile's fast continua at the depth of step s, by the wave that visits it second ---------
+    // (rh_method.py:652, 677-681 for transitions whose coefficients do not depend on the ray; the arithmetic of lsx_fast.h,
+    // fast_gamma_cols_rows, per wavelength -- here one wavelength per lane).  Jv: the depth's mean intensity (both directions), Ptot:
+    // Psibar (both directions, x 4 pi), PPt[u]: sum_mu w Psi* phi of line u (likewise); X, njUc, w3k: this depth's line operands
+    // (chi_line = X phi, eta_line = njUc phi, wphi).  Per continuum two values (rates j -> i and i -> j), per linked line two more (what
+    // the linked continua add to the line's own rates: the correction slots), reduced over the tile's wavelengths LSX_RS_EPI_ROUND
+    // values at a time through this wave's rows `fred` -- lane (c, v) of the first 60 sums the twelve wavelengths of column c for value
+    // v -- and stored straight into the slabs (one entry per rate and depth, both directions in it, as k_fast_gamma_cols wrote them).
+    constexpr int ER = LSX_RS_EPI_ROUND;
+    double sW = 0.0;
+    if constexpr (EPI) {
+#pragma unroll
+        for (int m = 0; m < NR; ++m) sW += 2.0 * wmuh(m) * (4.0 * kPi);          // both directions
+    }
+    auto epi_fast = [&](const int s, const int k, const double Jv, const double Ptot, const double (&PPt)[NLK], const double E,
+                        const double (&Xl)[NS], const double (&nUl)[NS], const double (&wpl)[NS]) __attribute__((always_inline)) {
+        if constexpr (EPI) {
+            if (nF > 0) {
+                constexpr int NLL = LK ? NL : 0;
+                const double sI = Jv * (4.0 * kPi), sPsi = Ptot;
+                const lds_f64* fr = ring_row(s) + lcf;
+                const lds_f64* al = atab + lane;
+                const lds_f64* wq = wtab + lane;
+                const auto* qi = (const __attribute__((address_space(3))) unsigned*)qinf;
+                lds_f64* const rows = fred + (size_t)dir * ER * LSX_WAVE;
+                double tchi[NLK], teta[NLK], tU[NLK], xa[NLK], xb[NLK];
+#pragma unroll
+                for (int u = 0; u < NLK; ++u) {
+                    tchi[u] = teta[u] = tU[u] = xa[u] = xb[u] = 0.0;
+                    if (u < NLL) { tchi[u] = Xl[u] * PPt[u]; teta[u] = nUl[u] * PPt[u]; tU[u] = Uc[u] * PPt[u]; }
+                }
+                // one round of the wavelength reduction: rows [0, vr) hold values v0 .. v0 + vr - 1 (value 2 q + e: rate e of fast
+                // continuum q; then 2 u + e: correction e of linked line u)
+                const int oc = lane / ER, ov = lane - oc * ER;
+                const bool ocol = oc < ncg && (p.colmask ? LSX_CONST(uint8_t, p.colmask)[col0 + (oc < ncg ? oc : 0)] != 0 : true);
+                auto flush_round = [&](const int v0, const int vr) __attribute__((always_inline)) {
+#ifdef LSX_ABL_EPI_NOFLUSH
+                    return;                 // ablation build (wrong results): the fast values are formed and written to the rows, not reduced or stored
+#endif
+                    typedef double lds_pair __attribute__((ext_vector_type(2)));
+                    __builtin_amdgcn_wave_barrier();
+                    const auto* src = (const __attribute__((address_space(3))) lds_pair*)(rows + ov * LSX_WAVE + (oc < NC ? oc : 0) * LW);
+                    lds_pair v2 = src[0];
+                    double acc = v2.x + v2.y;
+#pragma unroll
+                    for (int e = 1; e < LW / 2; ++e) { v2 = src[e]; acc += v2.x + v2.y; }
+                    if (ocol && ov < vr) {
+                        const int gv = v0 + ov;
+                        const int slot = slot0 + NPT + (gv >> 1);          // fast continua first, then the correction slots: consecutive in the slot table
+                        p.Gpart[(((size_t)(col0 + oc) * p.nslot_total + slot) * 4 + (size_t)(gv & 1) * 2) * Ns + k] = acc;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                };
+                int v0 = 0, vr = 0;
+#ifdef LSX_ABL_EPI_NOMATH
+                // ablation build (wrong results): the rounds of the reduction and their stores without the arithmetic in front of them
+                for (int q = 0; q < nF; ++q) {
+                    rows[vr * LSX_WAVE + lane] = sI; rows[(vr + 1) * LSX_WAVE + lane] = sPsi;
+                    vr += 2;
+                    if (vr == ER) { flush_round(v0, ER); v0 += ER; vr = 0; }
+                }
+                if (vr > 0) flush_round(v0, vr);
+                return;
+#endif
+                for (int q0 = 0; q0 < nF;) {                               // one atom's run of continua at a time
+                    int q1 = q0 + 1;
+                    while (q1 < nF && !(qi[q1] & 0x80000000u)) ++q1;
+                    const unsigned lk0 = qi[q0];
+                    double Usum = 0.0, Esum = 0.0, Csum = 0.0, XCi[NLK];
+#pragma unroll
+                    for (int u = 0; u < NLK; ++u) XCi[u] = 0.0;
+                    for (int q = q0; q < q1; ++q) {                        // rh_method.py:284-286, 453-455, 613-614; atom.chi / atom.U / atom.eta of :616-627
+                        const double alf = al[q * LSX_WAVE], ni = fr[3 * NC * q + 0], br = fr[3 * NC * q + 1], nr = fr[3 * NC * q + 2];
+                        const double g = nr * E, ng = br * E, hq = ni - ng;
+                        Usum = fma(g, alf, Usum);
+                        Esum = fma(ng, alf, Esum);
+                        if constexpr (LK) {
+                            Csum = fma(hq, alf, Csum);                     // = -atom.chi[j]
+                            const unsigned lkq = qi[q];
+#pragma unroll
+                            for (int u = 0; u < NLL; ++u)
+                                if (lkq & (2u << (8 * u))) XCi[u] = fma(hq, alf, XCi[u]);      // chi of the continua on line u's lower level
+                        }
+                    }
+                    const double U_j = u_la * Usum, etaA = u_la * Esum;
+                    double le = 0.0;
+                    if constexpr (LK) {
+#pragma unroll
+                        for (int u = 0; u < NLL; ++u)
+                            if (lk0 & (1u << (8 * u))) {                    // line u belongs to this atom
+                                le += teta[u];
+                                const double tt = (wlam[u] * (1.0 / (4.0 * kPi))) * PPt[u];
+                                xa[u] = fma(tt, etaA, xa[u]);
+                                xb[u] = fma(tt, XCi[u], xb[u]);
+                            }
+                    }
+                    const double sIe = (sI - etaA * sPsi) - le;
+                    const double T = fma(u_la, sW, sIe), UP = U_j * sPsi;
+                    for (int q = q0; q < q1; ++q) {
+                        const double alf = al[q * LSX_WAVE], wl_ = wq[q * LSX_WAVE];
+                        const double ni = fr[3 * NC * q + 0], br = fr[3 * NC * q + 1], nr = fr[3 * NC * q + 2];
+                        const double g = nr * E, hq = ni - br * E;
+                        const double wa = alf * wl_;
+                        double a1 = wa * fma(-hq, UP, g * T), a2 = wa * sIe;
+                        if constexpr (LK) {
+                            const unsigned lkq = qi[q];
+                            double lchi = 0.0, lU = 0.0;
+#pragma unroll
+                            for (int u = 0; u < NLL; ++u) {
+                                if (lkq & (2u << (8 * u))) lchi += tchi[u];
+                                if (lkq & (4u << (8 * u))) { lchi -= tchi[u]; lU += tU[u]; }
+                            }
+                            a1 = fma(-wl_, lchi * U_j, a1);                 // the lines on the continuum's lower level: chi_a[i] Psi U_a[j]
+                            a2 = fma(wl_, Csum * lU, a2);                   // -chi_a[j] (Psi U_a[i]), U_a[i] from the lines that end there
+                        }
+                        rows[vr * LSX_WAVE + lane] = a1;
+                        rows[(vr + 1) * LSX_WAVE + lane] = a2;
+                        vr += 2;
+                        if (vr == ER) { flush_round(v0, ER); v0 += ER; vr = 0; }
+                    }
+                    q0 = q1;
+                }
+                if constexpr (LK) {
+                    // the correction slots of the tile's lines: -wphi [Uc dB + Vc dA] and -wphi cB dA (lsx_fast.h)
+#pragma unroll
+                    for (int u = 0; u < NLL; ++u) {
+                        rows[vr * LSX_WAVE + lane] = -wpl[u] * fma(Uc[u], xb[u], Vc[u] * xa[u]);
+                        rows[(vr + 1) * LSX_WAVE + lane] = -wpl[u] * (cB[u] * xa[u]);
+                        vr += 2;
+                        if (vr == ER) { flush_round(v0, ER); v0 += ER; vr = 0; }
+                    }
+                }
+                if (vr > 0) flush_round(v0, vr);
             }
         }
     };
@@ -806,6 +963,17 @@ lsx_sweep_rs_kernel(const SweepParams p)
         }
         double jhalf = 0.0;
         if constexpr (SECOND) jhalf = at(Jnew, kt);
+        // EPI: the partner's halves of Psibar and the Psi* phi sums at this depth (requested with J's half, used at the end of the step)
+        double phalf = 0.0, pph[NLK];
+#pragma unroll
+        for (int u = 0; u < NLK; ++u) pph[u] = 0.0;
+        if constexpr (EPI && SECOND) {
+            phalf = at(psibar_o, kt);
+            if constexpr (LK) {
+#pragma unroll
+                for (int u = 0; u < NL; ++u) pph[u] = at(ppsum_o, (unsigned)(u * plane) * 8u + o_pp + (unsigned)(k * LW) * 8u);
+            }
+        }
         // the Gamma totals of the previous depth (their values were parked at the end of the previous step)
         if constexpr (!FIRST && NPT >= 1) {
             flush(s - 1);
@@ -1071,9 +1239,10 @@ lsx_sweep_rs_kernel(const SweepParams p)
         // address, so the store needs no lane mask (no branch around it: the compiler counts it when it places its waits -- loads and
         // stores retire in issue order, a wait for the next depth's operands waits for every store before them); the
         // Psibar of a frozen column is read by nobody (the fast-continuum kernels skip frozen columns)
-        if (LK || nF > 0) at(psibar, kt) = Pacc;      // (a tile with linked continua has fast continua: no test at all in those instances)
+        // (EPI: only the FIRST visitor of a depth stores them -- for the second visitor, which finishes the fast continua's rates itself)
+        if constexpr (!EPI || PH == 0) { if (LK || nF > 0) at(psibar, kt) = Pacc; }      // (a tile with linked continua has fast continua: no test at all in those instances)
 #endif
-        if constexpr (LK) {       // (no lane mask either: shadow lanes repeat their lane's store, a frozen column's sums are read by nobody)
+        if constexpr (LK && (!EPI || PH == 0)) {       // (no lane mask either: shadow lanes repeat their lane's store, a frozen column's sums are read by nobody)
 #pragma unroll
             for (int u = 0; u < NL; ++u) at(ppsum, (unsigned)(u * plane) * 8u + o_pp + (unsigned)(k * LW) * 8u) = PP[u];
         }
@@ -1095,14 +1264,35 @@ lsx_sweep_rs_kernel(const SweepParams p)
         } else if constexpr (PH == 1) {                                   // odd Nspace: both waves are at the same depth
             lds_f64* const xwg = etab + LSX_EXP_TAB + 2 * (NV + 1) * RROW;
             xwg[dir * LSX_WAVE + lane] = Jacc;
+            if constexpr (EPI) {                                          // ... and the down-going wave finishes the fast continua's rates there
+                xw2[(dir * (1 + (LK ? NL : 0))) * LSX_WAVE + lane] = Pacc;
+                if constexpr (LK) {
+#pragma unroll
+                    for (int u = 0; u < NL; ++u) xw2[(dir * (1 + NL) + 1 + u) * LSX_WAVE + lane] = PP[u];
+                }
+            }
             __syncthreads();
             if (dir == 0 && valid) {
                 const double Jv = Jacc + xwg[LSX_WAVE + lane];
                 at(Jnew, kt) = live_col ? Jv : cur.jd;
                 if (live_col) dJ = nanmax(dJ, fabs(1.0 - cur.jd * rcp(Jv)));    // :705
             }
+            if constexpr (EPI) {
+                if (dir == 0) {
+                    double PPt[NLK];
+#pragma unroll
+                    for (int u = 0; u < NLK; ++u) PPt[u] = (LK && u < NL) ? PP[u] + xw2[((1 + NL) + 1 + u) * LSX_WAVE + lane] : 0.0;
+                    epi_fast(s, k, Jacc + xwg[LSX_WAVE + lane], Pacc + xw2[(1 + (LK ? NL : 0)) * LSX_WAVE + lane], PPt, cur.E, X, njUc, w3k);
+                }
+            }
         } else {
             const double Jv = jhalf + Jacc;
+            if constexpr (EPI) {
+                double PPt[NLK];
+#pragma unroll
+                for (int u = 0; u < NLK; ++u) PPt[u] = pph[u] + ((LK && u < NL) ? PP[u] : 0.0);
+                epi_fast(s, k, Jv, phalf + Pacc, PPt, cur.E, X, njUc, w3k);
+            }
 #ifdef LSX_ABL_NOSTORE
             if (valid && Jv == 1.2345) at(Jnew, kt) = Jv;
 #else
@@ -1189,11 +1379,12 @@ lsx_sweep_rs_kernel(const SweepParams p)
 #undef zmu
 #undef wmuh
 
-template <int NPT, int NL, bool LK, int TOPO, bool PAR, bool FOLD>
+template <int NPT, int NL, bool LK, int TOPO, bool PAR, bool FOLD, bool EPI>
 static hipError_t launch_rs(const SweepParams& p, int ngroups, hipStream_t st)
 {
     const dim3 g((unsigned)(ngroups * p.n_class_tiles)), b(2 * LSX_WAVE);
-    hipLaunchKernelGGL((lsx_sweep_rs_kernel<NPT, NL, LK, TOPO, PAR, FOLD>), g, b, lsx_rs_lds_doubles(NPT, p.Nspace, PAR, FOLD ? p.fold_nF : -1) * sizeof(double), st, p);
+    hipLaunchKernelGGL((lsx_sweep_rs_kernel<NPT, NL, LK, TOPO, PAR, FOLD, EPI>), g, b,
+                       lsx_rs_lds_doubles(NPT, p.Nspace, PAR, FOLD ? p.fold_nF : -1, EPI, LK ? NL : 0) * sizeof(double), st, p);
     return hipGetLastError();
 }
 
@@ -1205,10 +1396,12 @@ static hipError_t launch_rs_pick(const SweepParams& p, int ngroups, hipStream_t 
 {
     constexpr bool kFoldable = lsx_rs_fold_instance_exists(NPT, LK, TOPO);
     if (p.fold) {
-        if constexpr (kFoldable) return launch_rs<NPT, NL, LK, TOPO, false, true>(p, ngroups, st);
-        else return hipErrorNotSupported;
+        if constexpr (kFoldable) {
+            if (p.epi) return launch_rs<NPT, NL, LK, TOPO, false, true, true>(p, ngroups, st);
+            return launch_rs<NPT, NL, LK, TOPO, false, true, false>(p, ngroups, st);
+        } else return hipErrorNotSupported;
     }
-    return launch_rs<NPT, NL, LK, TOPO, false, false>(p, ngroups, st);
+    return launch_rs<NPT, NL, LK, TOPO, false, false, false>(p, ngroups, st);
 }
 #endif
 
@@ -1232,7 +1425,7 @@ extern "C" hipError_t lsx_launch_sweep_rs_par(const SweepParams* p, int code, hi
     if (p->Nrays != LSX_RS_RAYS || p->sca_per_lambda || p->L != LW) return hipErrorNotSupported;
     const int ngroups = (p->ncol + NC - 1) / NC;
     switch (code) {
-#define LSX_X(NPT, NL, LK, TOPO) case lsx_class_code(NPT, NL, LK, TOPO): return launch_rs<NPT, NL, LK, TOPO, true, false>(*p, ngroups, st);
+#define LSX_X(NPT, NL, LK, TOPO) case lsx_class_code(NPT, NL, LK, TOPO): return launch_rs<NPT, NL, LK, TOPO, true, false, false>(*p, ngroups, st);
         LSX_RSP_INSTANCES(LSX_X)
 #undef LSX_X
     default: return hipErrorNotSupported;
