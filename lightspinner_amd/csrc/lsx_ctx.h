@@ -92,6 +92,7 @@ struct lsx_ctx : lsxd::LsxPlan {        // the plan (lsx_plan.h: dimensions, tab
     double* d_nsr = nullptr;     // [col][Ncont][k] nStar_i / nStar_j of the continua
     double* d_optab = nullptr;   // ray-serial sweep: per-depth operands per (column group, transition) + geometry (lsx_plan.h), made on first use
     int* d_trans_row = nullptr;  // per transition: row of wphi / nsr
+    bool optab_fresh = false;    // d_optab was built from the current n, wphi, nStar ratios, heights and sigma
     double* d_debug = nullptr;   // 64 x 16 x 8 B, diagnostic builds of the sweep kernel write stamps here
     int jcur = 0; // d_J[jcur] holds the current J (Jdag of the next call)
     // set-up chain (lsx_setup.hip): atomic data tables and what lsx_set_atmosphere derives per column

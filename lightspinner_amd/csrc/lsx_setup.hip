@@ -352,6 +352,7 @@ int lsx_set_atomic_data(lsx_ctx* c, const lsx_atomic_data* d)
 
 int lsx_set_atmosphere(lsx_ctx* c, int32_t col0, int32_t ncol, const lsx_atmosphere* s)
 {
+    if (c) c->optab_fresh = false;
     if (!c || !s || col0 < 0 || ncol < 1 || col0 + ncol > c->ncol) return fail(LSX_EINVAL, "lsx_set_atmosphere: bad range");
     if (!c->have_atomic_data) return fail(LSX_EINVAL, "lsx_set_atmosphere: lsx_set_atomic_data has not been called");
     if (!s->temperature || !s->ne || !s->vturb || !s->nHGround || !s->nTotal) return fail(LSX_EINVAL, "lsx_set_atmosphere: null array pointer");
