@@ -2,7 +2,7 @@
 """One variant of the HIP library, timed and checked on one box:
     python tests/ab_run.py ab_so/x.so [c3|c4] [ncol]
 prints ONE line: sweep / formal-solution / MALI-step times (HIP events in the library, host clock for the step) and the
-parity of the variant against the oracle on 40 columns of the same ensemble (first call and after 6 iterations).
+parity of the variant against the oracle on 40 columns of the same ensemble, on the mapping the timed context ran (first call and after 6 iterations).
 Used by profiles/ab.sh to compare prebuilt variants interleaved on the same GPU."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -51,7 +51,7 @@ eng.close()
 import oracle
 ora = oracle.load()
 nchk = 40
-e1, e2 = Engine(prob, nchk, lib=lib), Engine(prob, nchk, lib=ora)
+e1, e2 = Engine(prob, nchk, lib=lib, policy_columns=ncol), Engine(prob, nchk, lib=ora)      # (the mapping the timed context ran: decided for its column count)
 for e in (e1, e2):
     e.set_formal_solver(solver)
     load(e, blk, prof, nchk)

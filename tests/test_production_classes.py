@@ -3,7 +3,7 @@ instantiation per tile class on forked streams (lsx_hip.hip: enqueue_fs), not th
 single-column tests reach.  C4 (Ca+H): hydrogen's bound-free continua overlap its lines; they are "linked" continua
 (handled outside the sweep with the line's sum_mu w Psi* phi, lsx_hip.hip: roles_of), so the classes that run are the
 line-only ones with and without linked continua -- all of them meet the oracle here; the classes with three and four
-per-ray slots (round 1's `lsx_sweep_kernel<3|4, ...>`) run with the linking switched off (LSX_NO_LINKED).
+per-ray slots (round 1's `lsx_sweep_kernel<3|4, ...>`) run with the linking switched off (options='linked=0').
 
 Inputs: synth.perturbed_columns(..., vlos_sigma=2e3) -- FALC-perturbed columns with a smooth line-of-sight
 velocity (2 km/s), so the line profiles are ray dependent and are built by each library's own lsx_set_line_profiles
@@ -85,10 +85,10 @@ def _run_pair(hip_lib, oracle_lib, name, ncol, seed, tol, expect_classes, ntol=1
 
 
 # Both sweep kernels are production paths: one ray per lane (lsx_sweep.hip; what contexts with few columns run) and the
-# ray-serial kernel (lsx_sweep_rs.hip: five columns per wavefront; contexts with LSX_RS_MIN_COLUMNS = 160 columns or more).
-# The threshold is lowered / raised through the environment so that both meet the oracle on the same columns.
+# ray-serial kernel (lsx_sweep_rs.hip: five columns per wavefront; contexts of 160 columns or more).
+# The mapping is pinned with Engine(sweep_policy=...) so that both meet the oracle on the same columns.
 @pytest.mark.parametrize('ray_serial', [False, True], ids=['ray-per-lane', 'ray-serial'])
-def test_c3_caii_columns_per_class_path(hip_lib, oracle_lib, monkeypatch, ray_serial):
+def test_c3_caii_columns_per_class_path(hip_lib, oracle_lib, ray_serial):
     """C3: CaII, 64 columns (12 full column groups + one of 4), ray-dependent device-built profiles; tile classes 0, 1 (one
     line), 2 (H & K overlap)"""
     table = _run_pair(hip_lib, oracle_lib, 'falc_ca.npz', 64, 1234, 1e-12, [(0, 0, 0, 0), (1, 1, 0, 0), (2, 2, 0, 1)],      # H & K share their lower level: relation 1
@@ -98,7 +98,7 @@ def test_c3_caii_columns_per_class_path(hip_lib, oracle_lib, monkeypatch, ray_se
 
 
 @pytest.mark.parametrize('ray_serial', [False, True], ids=['ray-per-lane', 'ray-serial'])
-def test_c4_cah_columns_linked_continua(hip_lib, oracle_lib, monkeypatch, ray_serial):
+def test_c4_cah_columns_linked_continua(hip_lib, oracle_lib, ray_serial):
     """C4: Ca+H, 41 columns.  Every hydrogen line tile carries linked continua: classes (1 line) and (2 lines), each with and
     without linked continua, plus the continuum-only tiles"""
     table = _run_pair(hip_lib, oracle_lib, 'falc_cah.npz', 41, 4321, 3e-11, [(0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 0), (2, 2, 0, 1), (2, 2, 1, 1)],
@@ -108,7 +108,7 @@ def test_c4_cah_columns_linked_continua(hip_lib, oracle_lib, monkeypatch, ray_se
     assert all(v == ray_serial for v in class_table.ray_serial.values()), class_table.ray_serial
 
 
-def test_c4_cah_columns_three_and_four_slot_instances(hip_lib, oracle_lib, monkeypatch):
+def test_c4_cah_columns_three_and_four_slot_instances(hip_lib, oracle_lib):
     """the same columns with the linking switched off: hydrogen's continua become per-ray slots again, and
     lsx_sweep_kernel<3, {1,2}, 5, false> and <4, {1,2}, 5, false> meet the oracle"""
     table = _run_pair(hip_lib, oracle_lib, 'falc_cah.npz', 40, 4321, 3e-11,
@@ -160,7 +160,7 @@ def test_single_column_reaches_the_fused_kernel(hip_lib):
 
 
 @pytest.mark.parametrize('name,ncol', [('falc_ca.npz', 1), ('falc_cah.npz', 3)])
-def test_small_batch_gamma_epilogue_gives_the_bits_of_the_many_column_one(hip_lib, monkeypatch, name, ncol):
+def test_small_batch_gamma_epilogue_gives_the_bits_of_the_many_column_one(hip_lib, name, ncol):
     """fewer than 32 columns: the Gamma epilogue runs one wavefront per (column, depth) with one entry per lane
     (k_gamma_finish_small); it sums every entry in the order the many-column kernel does, so Gamma, the monitors and the
     populations after five iterations are the same bits.  A second stat_equil on the same Gamma (the epilogue has zeroed the
@@ -206,15 +206,15 @@ def test_profiles_must_be_set_before_a_formal_solution(hip_lib):
 
 @pytest.mark.parametrize('mode', ['default', 'mixed', 'ray-per-lane'])
 @pytest.mark.parametrize('name,ncol,nuniq', [('falc_ca.npz', 1000, 8), ('falc_cah.npz', 1250, 10)])
-def test_full_size_batches_by_size_independent_properties(hip_lib, oracle_lib, monkeypatch, name, ncol, nuniq, mode):
+def test_full_size_batches_by_size_independent_properties(hip_lib, oracle_lib, name, ncol, nuniq, mode):
     """BASELINE sizes (C3: 1000 CaII columns, C4: one GPU's 1250 Ca+H columns), where the oracle would take minutes:
     columns are independent 1-D problems, so a batch built from `nuniq` distinct columns repeated in a scrambled order must
     give every copy the bits its original gets in a small batch -- whatever its position, its neighbours, its place inside
     a five-column wavefront or the size of the grid; the small batch itself is checked against the oracle.
     default (what a context of this size runs: the ray-serial kernel for every class, all of which have at most two per-ray
-    slots here) and mixed (LSX_RS_MAX_NPT=1: ray-serial for tiles with at most one per-ray slot, one ray per lane for the
+    slots here) and mixed (options='rs_max_npt=1': ray-serial for tiles with at most one per-ray slot, one ray per lane for the
     two-line tiles, side by side in one call): the small batch is 37 columns (seven column groups and one of two) forced
-    onto the same kernels; ray-per-lane (LSX_NO_RS): the small batch takes the fused launch, the big one the per-class
+    onto the same kernels; ray-per-lane (sweep_policy='ray-per-lane'): the small batch takes the fused launch, the big one the per-class
     launches.  Also: a frozen column keeps its state bit for bit while its neighbours
     iterate (lsx_set_active_columns)."""
     ray_serial = mode != 'ray-per-lane'
@@ -273,7 +273,7 @@ def test_full_size_batches_by_size_independent_properties(hip_lib, oracle_lib, m
 
 
 @pytest.mark.parametrize('name,ncol', [('falc_ca.npz', 1), ('falc_cah.npz', 3), ('falc_cah.npz', 31)])
-def test_fused_launch_runs_the_fast_continuum_work_itself_with_the_same_bits(hip_lib, monkeypatch, name, ncol):
+def test_fused_launch_runs_the_fast_continuum_work_itself_with_the_same_bits(hip_lib, name, ncol):
     """fewer than 32 columns: the workgroup of a tile with fast continua runs the tile's pre-pass itself, before its own sweep, inside
     the ONE fused launch (lsx_sweep.hip, lsx_fast.h) instead of a launch in front of it (LSX_NO_FUSED_FAST=1 restores that; with
     LSX_FUSED_EPILOGUE=1 the Gamma epilogue runs inside as well): the same device functions, the same bits -- J, I, Gamma, populations
@@ -302,7 +302,7 @@ def test_fused_launch_runs_the_fast_continuum_work_itself_with_the_same_bits(hip
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('name,ncol', [('falc_ca.npz', 1), ('falc_cah.npz', 40)])
-def test_formal_solution_replayed_as_a_captured_graph_gives_the_same_bits(hip_lib, monkeypatch, name, ncol):
+def test_formal_solution_replayed_as_a_captured_graph_gives_the_same_bits(hip_lib, name, ncol):
     """LSX_GRAPH=1 (a measurement switch): the launches of a formal solution -- fork, the classes' chains on their streams,
     join, Gamma epilogue -- are captured once per (J buffer parity, result buffers, epilogue flavour, rule, mapping, mask) and replayed
     as a HIP graph.  The same kernels with the same arguments: J, I, Gamma, populations and monitors bit for bit, through the

@@ -128,7 +128,7 @@ RS_CASES = [
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('kw', RS_CASES, ids=lambda k: '-'.join('%s%s' % (a[:3], b) for a, b in k.items()))
-def test_toy_parity_on_the_ray_serial_kernel(hip_lib, oracle_lib, monkeypatch, kw):
+def test_toy_parity_on_the_ray_serial_kernel(hip_lib, oracle_lib, kw):
     """the ray-serial sweep (production: contexts of >= 160 columns) forced onto small toy batches: ragged column groups (>= 32 columns: the per-class launch path), odd and
     minimal depth counts, compact profiles, every tile shape the toy atoms produce with at most two per-ray slots; then the same
     batch with every third column frozen (lsx_set_active_columns): frozen columns keep their J, I, Gamma and populations, the
