@@ -116,7 +116,7 @@ constexpr SweepLds lsx_sweep_lds(int npt, bool linked, int Ns, int ncell_lev, in
     X(1, 1, true, 0) X(2, 2, true, 0)                                                                            \
     X(2, 2, false, 1) X(2, 2, false, 2) X(2, 2, true, 1) X(2, 2, true, 2)
 // ... and for the parabolic rule (N4): line-only classes whose Gamma integrands factor (one line; two lines that share one level)
-#define LSX_RSP_INSTANCES(X) X(0, 0, false, 0) X(1, 1, false, 0) X(1, 1, true, 0)
+#define LSX_RSP_INSTANCES(X) X(0, 0, false, 0) X(1, 1, false, 0) X(1, 1, true, 0) X(2, 2, false, 1) X(2, 2, false, 2)
 #ifndef LSX_RS_WPE1
 #define LSX_RS_WPE1 2
 #endif

@@ -86,4 +86,4 @@ EXPECT = {
 }
 # the classes that have a ray-serial instance of the parabolic rule (lsx_plan.h, LSX_RSP_INSTANCES; the CPU ledger checks the two lists
 # against each other): mode 'parabolic-serial' of tests/test_instances_gpu.py expects exactly these on the ray-serial kernel
-PARABOLIC_SERIAL = [(0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 0)]
+PARABOLIC_SERIAL = [(0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 0), (2, 2, 0, 1), (2, 2, 0, 2)]      # (round 5: the two-line classes with a known relation)

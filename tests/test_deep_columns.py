@@ -50,5 +50,5 @@ def test_deep_columns_run_the_ray_serial_kernel_and_meet_the_oracle(hip_lib, ora
     if solver == 'linear':
         assert serial == {k for k in table if 0 <= k[0] <= 2}
     else:
-        assert serial == {k for k in table if k in ((0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 0))} and serial
+        assert serial == {k for k in table if k in ((0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 0), (2, 2, 0, 1), (2, 2, 0, 2))} and serial
     hip.close(); ora.close()
