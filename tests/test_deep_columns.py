@@ -52,3 +52,41 @@ def test_deep_columns_run_the_ray_serial_kernel_and_meet_the_oracle(hip_lib, ora
     else:
         assert serial == {k for k in table if k in ((0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 0), (2, 2, 0, 1), (2, 2, 0, 2))} and serial
     hip.close(); ora.close()
+
+
+def test_switching_mapping_and_rule_on_one_context_gives_each_configuration_its_own_bits(hip_lib):
+    """One context, 36 FALC Ca+H columns: the sweep policy and the rule are switched between formal solutions -- ray-serial (folded
+    instances, operand table), one ray per lane, the parabolic rule on both mappings, back again.  Every call gives exactly the bits a
+    fresh context pinned to that configuration gives from the same populations: nothing of one mapping's state (the operand table and
+    its freshness, the effective-background streams of the pre-pass, the per-direction sums) leaks into the next."""
+    prob, base, raw = fixtures.load_problem_npz(golden('falc_cah.npz'), phi_compact=False)
+    blk, prof = synth.perturbed_columns(prob, base, raw, ncol=36, seed=808, vlos_sigma=2.0e3)
+    seq = [('linear', 'ray-serial'), ('linear', 'ray-per-lane'), ('parabolic', 'ray-serial'), ('linear', 'ray-serial'),
+           ('parabolic', 'ray-per-lane'), ('linear', 'ray-per-lane'), ('linear', 'ray-serial')]
+    one = Engine(prob, 36, lib=hip_lib)
+    synth.load_columns(one, blk, prof)
+    got = []
+    for i, (rule, policy) in enumerate(seq):
+        one.set_formal_solver(rule)
+        one.set_sweep_policy(policy)
+        one.formal_sol_gamma()
+        if i % 2 == 1:
+            one.stat_equil()                  # the populations move: the operand table has to follow
+        got.append({w: one.get(w) for w in (_capi.LSX_J, _capi.LSX_I, _capi.LSX_GAMMA, _capi.LSX_N)})
+    # replay: a fresh context per step, started from the state the one context had before that step
+    n_before, J_before = blk.n.copy(), None
+    for i, (rule, policy) in enumerate(seq):
+        e = Engine(prob, 36, lib=hip_lib, sweep_policy=policy)
+        synth.load_columns(e, blk, prof)
+        e.set(_capi.LSX_N, n_before)
+        if J_before is not None:
+            e.set(_capi.LSX_J, J_before)
+        e.set_formal_solver(rule)
+        e.formal_sol_gamma()
+        if i % 2 == 1:
+            e.stat_equil()
+        for w in (_capi.LSX_J, _capi.LSX_I, _capi.LSX_GAMMA, _capi.LSX_N):
+            assert np.array_equal(e.get(w), got[i][w]), (i, rule, policy, w)
+        n_before, J_before = got[i][_capi.LSX_N], got[i][_capi.LSX_J]
+        e.close()
+    one.close()
