@@ -281,7 +281,8 @@ def roofline_block(eng, lib, prob, ncol, workload, kernel_reps):
                                'column; divided by the LIVE duration)' % (src, fig.get('csrc_hash')))
     return dict(bound='hbm', bound_means='the roofline the metric is DEFINED on (BASELINE.json north_star: fraction of the HBM roofline); what the '
                                          'kernel actually waits for is in `limited_by` / `binding`',
-                binding='latency at two waves per SIMD (neither HBM nor vector issue is saturated)',
+                binding='vector issue and memory-request latency at two waves per SIMD (neither HBM bytes nor the vector pipe is saturated: VALU busy 0.5-0.56 '
+                        'in the line classes, waves wait 24-37 % of their cycles; profiles/r05_pmc_summary.json)',
                 kernel='the sweep of one formal solution: lsx_sweep_rs_kernel<slots,lines,linked,topo> (ray-serial, five columns per '
                                     'wavefront: every tile class with at most two per-ray slots in contexts of >= 160 columns) and '
                                     'lsx_sweep_kernel<slots,lines,rays,sca,linked,topo> (one ray per lane: the other classes and smaller contexts), '
@@ -300,8 +301,11 @@ def roofline_block(eng, lib, prob, ncol, workload, kernel_reps):
                            'one-ray-per-lane kernel it replaced sat on vector issue at the clock the chip holds under fp64 load (1.6-1.8 GHz) '
                            '(profiles/r03_bound_evidence.md: in-kernel clock, stamps, occupancy sweep, ablations, class schedule). Round 4 '
                            '(profiles/r04_bound_evidence.md): without its J / Psibar stores it is 7-10 % faster, with a fifth of the profile bytes '
-                           '15-18 %: memory queueing latency against one depth of prefetch; a third wave per SIMD fits neither the register file nor, '
-                           'beside the per-depth operand table, the LDS',
+                           '15-18 %: memory queueing latency against one depth of prefetch; a third wave per SIMD does not fit the register file. '
+                           'Round 5 (profiles/r05_bound_evidence.md): a SECOND depth of prefetch was built and changes nothing (the kernel does not '
+                           'wait for HBM at one depth), while ONE more stream per step (the Boltzmann factor of the folded fast continua) costs 8 % -- '
+                           'what is scarce is vector issue and memory REQUESTS per wave at two waves per SIMD, not bytes; the per-depth operands now '
+                           'come through a ring in LDS (no depth limit) and the fast continua\'s opacity is formed in the lane (no pre-pass)',
                 fs_call=dict(ms=ms_total, ms_sweep_kernel=ms_sweep, ms_epilogue_kernels=info(4), alg_bytes=balg * ncol,
                              traffic=traffic_all, traffic_over_alg=(traffic_all / (balg * ncol)) if traffic_all else None,
                              traffic_note='HBM bytes of EVERY kernel of a formal solution (sweeps, fast-continuum kernels, operand-table build, '
