@@ -421,7 +421,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', default='c3', choices=['c2', 'c3', 'c4', 'c5'])
+    ap.add_argument('--workload', default='c3', choices=['c2', 'c3', 'c4', 'c5', 'all'])
     ap.add_argument('--columns', type=int, default=None, help='columns per GPU (default 1000 / 1 / 1250)')
     ap.add_argument('--compact-phi', action='store_true', help='vlos == 0: ray independent profiles (P = 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -448,8 +448,8 @@ def main():
                          'with --nproc-per-node equal to --gpus' % (args.gpus, world))
     if args.workload == 'c5':
         return run_c5(args, rank, local_rank, world)
-    fixture = os.path.join(ROOT, 'tests', 'golden', 'falc_cah.npz' if args.workload == 'c4' else 'falc_ca.npz')
-    ncol = args.columns or {'c2': 1, 'c3': 1000, 'c4': 1250}[args.workload]
+    fixture = os.path.join(ROOT, 'tests', 'golden', {'c4': 'falc_cah.npz', 'all': 'falc_all.npz'}.get(args.workload, 'falc_ca.npz'))
+    ncol = args.columns or {'c2': 1, 'c3': 1000, 'c4': 1250, 'all': 250}[args.workload]
     compact = args.compact_phi or args.workload == 'c2'
 
     # ---- host-side input generation, before any GPU initialisation -------------------
@@ -550,7 +550,10 @@ def main():
                       higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
                       config=dict(workload={'c2': 'C2: single FALC 82-depth CaII column, 5 rays',
                                             'c3': 'C3: %d FALC-perturbed CaII columns per GPU, 82 depth x 287 wavelengths x 5 rays x 2 directions' % ncol,
-                                            'c4': 'C4 share: %d FALC-perturbed Ca+H columns per GPU, 82 depth x 777 wavelengths x 5 rays x 2' % ncol}[args.workload],
+                                            'c4': 'C4 share: %d FALC-perturbed Ca+H columns per GPU, 82 depth x 777 wavelengths x 5 rays x 2' % ncol,
+                                            'all': 'all five of the reference\'s model atoms active (H, C, MgII, CaII, Fe: 53 levels, 109 transitions): %d '
+                                                   'FALC-perturbed columns per GPU, 82 depth x 3966 wavelengths x 5 rays x 2 (not a BASELINE configuration: '
+                                                   'the largest problem the reference\'s own model atoms make)' % ncol}[args.workload],
                                   columns_per_gpu=ncol, columns_total=ncol * world, Nspace=prob.Nspace, Nspect=prob.Nspect,
                                   Nrays=prob.Nrays, profiles='compact (vlos=0)' if compact else 'ray dependent (vlos!=0)',
                                   columns='populations, rates and profiles derived by the library from each column\'s perturbed atmosphere' if t_chain is not None else 'input-level perturbations (BASELINE C3 / C4)',

@@ -28,7 +28,7 @@
 
 #define LSX_WAVE 64
 #define LSX_MAX_ATOMS 8
-#define LSX_MAX_FAST 32   // fast continua per tile (activity bit mask in one VGPR)
+#define LSX_MAX_FAST 64   // fast continua per tile (all five of the reference's model atoms active: 44 bound-free continua overlap at 91 nm)
 #define LSX_MAX_PER_RAY 32
 
 struct DevTrans {           // one radiative transition, column independent (host + Gamma epilogue)

@@ -12,7 +12,7 @@ under /root/reference is touched:
     arrays (numpy<1.25 semantics; only used for list membership in setup).
 (np.bool, used at rh_method.py:124, exists again in numpy 2.x.)
 
-Usage:  python tests/golden/make_golden.py [units] [falc_ca] [falc_cah] [falc_ca_vlos] [falc_c] [falc_fe] [falc_mg] [rf] [rf_inputs] [setup] [all]
+Usage:  python tests/golden/make_golden.py [units] [falc_ca] [falc_cah] [falc_ca_vlos] [falc_c] [falc_fe] [falc_mg] [falc_all] [rf] [rf_inputs] [setup] [all]
 """
 import os
 import sys
@@ -314,6 +314,22 @@ def gen_falc_multilevel(which):
     save('falc_%s.npz' % which, d)
 
 
+def gen_falc_all():
+    """FALC with ALL FIVE of the reference's model atoms in the set and active at once (rh_atoms.py:4 H_6, :50 MgII, :152 CaII,
+    :194 C, :355 Fe_simple): 53 levels, 109 transitions, up to 44 bound-free continua of five atoms overlap at a wavelength, five Gamma matrices and five
+    statistical equilibria per iteration (rh_method.py:586-590 the loop over the active atoms at a wavelength, :710 over the atoms
+    of a statistical equilibrium).  Inputs + I, Gamma, dJ after formal solutions 1 and 4, J after 4, n and dPops after the first
+    statistical equilibrium."""
+    ctx = build_ctx(['H', 'Ca', 'MG', 'C', 'Fe'], models=[H_6_atom(), CaII_atom(), MgII_atom(), C_atom(), Fe_simple_atom()])
+    d = dump_inputs(ctx)
+    run_mali(ctx, d, snap_iters=(1, 4), stop_after=4, log='falc_all')
+    del d['fs1_J']
+    for k in list(d.keys()):
+        if k.startswith('fs1_R'):
+            del d[k]
+    save('falc_all.npz', d)
+
+
 def gen_rf(ks=(20, 48, 70)):
     """response_fn.py:23-67 for a handful of depth indices: delta-encoded inputs
     (only the depth-k entries differ) + converged emergent I."""
@@ -518,10 +534,10 @@ def gen_setup():
 if __name__ == '__main__':
     what = sys.argv[1:] or ['all']
     if 'all' in what:
-        what = ['units', 'falc_ca', 'falc_cah', 'falc_ca_vlos', 'falc_c', 'falc_fe', 'falc_mg', 'rf']
+        what = ['units', 'falc_ca', 'falc_cah', 'falc_ca_vlos', 'falc_c', 'falc_fe', 'falc_mg', 'falc_all', 'rf']
     for w in what:
         t0 = time.time()
         {'units': gen_units, 'falc_ca': gen_falc_ca, 'falc_cah': gen_falc_cah,
          'falc_ca_vlos': gen_falc_ca_vlos, 'rf': gen_rf, 'falc_c': lambda: gen_falc_multilevel('c'),
-         'falc_fe': lambda: gen_falc_multilevel('fe'), 'falc_mg': lambda: gen_falc_multilevel('mg'), 'rf_inputs': gen_rf_inputs, 'setup': gen_setup}[w]()
+         'falc_fe': lambda: gen_falc_multilevel('fe'), 'falc_mg': lambda: gen_falc_multilevel('mg'), 'falc_all': gen_falc_all, 'rf_inputs': gen_rf_inputs, 'setup': gen_setup}[w]()
         print('%s done in %.1fs' % (w, time.time() - t0), flush=True)

@@ -62,10 +62,12 @@ def test_piecewise_linear_1d_units(hip_lib, oracle_lib):
 # (rh_atoms.py:194, :355, :50), generated from the reference like the others (make_golden.py, gen_falc_multilevel) -- up to 14
 # transitions of one atom at a wavelength, continua linked to one, two and three lines.  ntol: populations after the first
 # statistical equilibrium against the REFERENCE's (a 15-level system: the oracle itself is at 1.1e-8 there, test_oracle_golden.py).
+# falc_all: all five model atoms active at once (gen_falc_all) -- 53 levels, 109 transitions, 44 fast continua in one tile.
 @pytest.mark.parametrize('name,compact,tol,ntol', [('falc_ca.npz', True, 1e-12, 2e-9), ('falc_ca.npz', False, 1e-12, 2e-9),
                                                    ('falc_cah.npz', True, 3e-11, 2e-9), ('falc_cah.npz', False, 3e-11, 2e-9),
                                                    ('falc_c.npz', True, 3e-11, 1e-7), ('falc_fe.npz', True, 3e-11, 1e-7),
-                                                   ('falc_mg.npz', True, 3e-11, 1e-7), ('falc_mg.npz', False, 3e-11, 1e-7)])
+                                                   ('falc_mg.npz', True, 3e-11, 1e-7), ('falc_mg.npz', False, 3e-11, 1e-7),
+                                                   ('falc_all.npz', True, 3e-11, 1e-7)])
 def test_single_calls_match_reference_and_oracle(hip_lib, oracle_lib, name, compact, tol, ntol):
     prob, block, d = fixtures.load_problem_npz(golden(name), phi_compact=compact)
     eng = Engine(prob, 1, lib=hip_lib)

@@ -63,13 +63,14 @@ def test_every_compiled_instance_is_planned_by_a_gpu_parity_test(host):
     # ... and the reference's larger atoms (round 5: carbon, iron, MgII -- tests/test_production_classes.py,
     # test_multilevel_reference_atoms_per_class_path): linked to one, two and three lines; with the linking off their continua become
     # per-ray slots -- per-ray-continuum instances planned by a REFERENCE problem
-    for fx in ('falc_ca.npz', 'falc_cah.npz', 'falc_c.npz', 'falc_fe.npz', 'falc_mg.npz'):
+    for fx in ('falc_ca.npz', 'falc_cah.npz', 'falc_c.npz', 'falc_fe.npz', 'falc_mg.npz', 'falc_all.npz'):
         prob, base, raw = fixtures.load_problem_npz(golden(fx), phi_compact=False)
         by_case[fx] = (_planned(host, prob), _rs_classes(host, prob), _rs_classes(host, prob, 2))
-        if fx in ('falc_c.npz', 'falc_fe.npz', 'falc_mg.npz'):
+        if fx in ('falc_c.npz', 'falc_fe.npz', 'falc_mg.npz', 'falc_all.npz'):
             by_case[fx + ':unlinked'] = (_planned(host, prob, 1), set(), set())
     assert (2, 1, 0, 0) in by_case['falc_c.npz:unlinked'][0] and (4, 1, 0, 0) in by_case['falc_mg.npz:unlinked'][0]
     assert (3, 3, 1, 0) in by_case['falc_mg.npz'][0]
+    assert (2, 2, 0, 2) in by_case['falc_all.npz'][0] and (3, 1, 0, 0) in by_case['falc_all.npz:unlinked'][0]      # all five atoms active
     lane_hit = set().union(*(g for g, _, _ in by_case.values()))
     serial_hit = set().union(*(r for _, r, _ in by_case.values()))
     # the ray-serial instances of the parabolic rule (tests/test_instances_gpu.py, mode 'parabolic-serial'): a subset of the ray-serial list

@@ -122,6 +122,33 @@ def test_multilevel_reference_atoms_match_reference(oracle_lib, name, compact):
     eng.close()
 
 
+# All five of the reference's model atoms in the set and active at once (round 5, tests/golden/make_golden.py gen_falc_all): 53
+# levels, 109 transitions, 3966 wavelengths, up to 44 bound-free continua of five atoms at one wavelength (91 nm), five Gamma matrices
+# and five statistical equilibria per iteration (rh_method.py:586-590, 710).  Measured oracle-vs-reference: I 8.4e-12 (the w2
+# cancellation next to the Taylor switch), J 2.6e-12, Gamma 1e-13 off the diagonal; after the first statistical equilibrium dPops =
+# 277.97 (the LTE start is far off for C and Fe) to 2e-10 and the populations to 1.4e-8.
+def test_all_five_reference_atoms_active_match_reference(oracle_lib):
+    prob, block, d = fixtures.load_problem_npz(golden('falc_all.npz'))
+    assert prob.Natoms == 5 and sum(prob.Nlevel) == 53 and prob.Ntrans == 109 and prob.Nspect == 3966
+    eng = Engine(prob, 1, lib=oracle_lib)
+    eng.set_columns(0, block)
+    for it in range(1, 5):
+        dJ = eng.formal_sol_gamma()
+        tag = 'fs%d' % it
+        if tag + '_I' not in d:
+            continue
+        assert dJ == pytest.approx(float(d[tag + '_dJ']), rel=1e-9)
+        assert relerr(eng.get(_capi.LSX_I)[0], d[tag + '_I']) < 2e-11
+        if tag + '_J' in d:
+            assert relerr(eng.get(_capi.LSX_J)[0], d[tag + '_J'], floor=1e-300) < 1e-11
+        off, diag = gamma_err(eng.get(_capi.LSX_GAMMA)[0], fixtures.gamma_from_raw(d, tag, prob), prob)
+        assert off < 1e-12 and diag < 1e-12, (it, off, diag)
+    dP = eng.stat_equil()
+    assert dP == pytest.approx(float(d['se4_dPops']), rel=1e-8)
+    assert relerr(eng.get(_capi.LSX_N)[0], fixtures.pops_from_raw(d, 'se4', prob)) < 1e-7
+    eng.close()
+
+
 def test_rates_quirk_accumulate_across_calls(oracle_lib):
     """rh_method.py:691-692: Rij/Rji are never zeroed and Rji uses Vij.  Not part of the ABI (nothing reads
     them in the reference); the oracle keeps them because the golden files hold them and they test I at every depth."""

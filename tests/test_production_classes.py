@@ -40,7 +40,7 @@ def class_table(lib, eng):
     return table, fused
 
 
-def _run_pair(hip_lib, oracle_lib, name, ncol, seed, tol, expect_classes, ntol=1e-8, **engine_kw):
+def _run_pair(hip_lib, oracle_lib, name, ncol, seed, tol, expect_classes, ntol=1e-8, iters=8, **engine_kw):
     """engine_kw: what the HIP engine is made with (sweep_policy=, options=: include/lsx.h, lsx_set_sweep_policy /
     lsx_create_with_options) -- explicit arguments, not the process environment"""
     prob, base, raw = fixtures.load_problem_npz(golden(name), phi_compact=False)
@@ -63,8 +63,8 @@ def _run_pair(hip_lib, oracle_lib, name, ncol, seed, tol, expect_classes, ntol=1
     assert off < 10 * tol and diag < tol, (off, diag)
     # per-column monitors agree column by column
     assert np.allclose(hip.get(_capi.LSX_DJ_COL), ora.get(_capi.LSX_DJ_COL), rtol=1e-9)
-    # ---- 8 MALI iterations (test.py:20-29: the first three update J only)
-    for it in range(2, 9):
+    # ---- `iters` (8) MALI iterations (test.py:20-29: the first three update J only)
+    for it in range(2, iters + 1):
         dJ, dJo = hip.formal_sol_gamma(), ora.formal_sol_gamma()
         assert dJ == pytest.approx(dJo, rel=1e-6)
         if it > 3:
@@ -77,8 +77,8 @@ def _run_pair(hip_lib, oracle_lib, name, ncol, seed, tol, expect_classes, ntol=1
     table, fused = class_table(hip_lib, hip)
     assert fused == 0, 'the fused small-batch kernel must not be what this test measures'
     for key in expect_classes:
-        assert key in table and table[key][1] == 8, (key, table)
-    assert all(launches == 8 for _, launches in table.values())
+        assert key in table and table[key][1] == iters, (key, table)
+    assert all(launches == iters for _, launches in table.values())
     for e in engs:
         e.close()
     return table
@@ -127,6 +127,9 @@ MULTILEVEL = {
     'falc_fe.npz': ([(0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 0), (2, 2, 0, 0), (2, 2, 0, 1)], [(2, 2, 0, 0), (2, 2, 0, 1)]),
     'falc_mg.npz': ([(0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 0), (2, 2, 0, 0), (2, 2, 1, 0), (2, 2, 1, 1), (3, 3, 1, 0), (-1, 0, 1, 0)],
                     [(4, 1, 0, 0), (-1, 0, 0, 0)]),
+    # all five model atoms active (gen_falc_all): 334 tiles; two lines of DIFFERENT atoms in a tile (relation 2) planned by a reference problem
+    'falc_all.npz': ([(0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 0), (2, 2, 0, 0), (2, 2, 0, 1), (2, 2, 0, 2), (2, 2, 1, 0), (2, 2, 1, 1), (3, 3, 1, 0), (-1, 0, 1, 0)],
+                     [(2, 1, 0, 0), (3, 1, 0, 0), (4, 1, 0, 0), (-1, 0, 0, 0)]),
 }
 
 
@@ -134,10 +137,15 @@ MULTILEVEL = {
 @pytest.mark.parametrize('name', sorted(MULTILEVEL))
 def test_multilevel_reference_atoms_per_class_path(hip_lib, oracle_lib, name, mode):
     linked, unlinked = MULTILEVEL[name]
+    # All five atoms from the LTE start: the eighth iteration of these columns is ill-conditioned -- J passes through zero at one
+    # wavelength of column 24 (dJ = 121) and the ORACLE'S OWN runs with exp() moved by +-1 ulp spread by 2.3e-5 in dJ and 1.8e-5 in J
+    # there (HIP: 5.2e-5; profiles/r05/diag_all_atoms_columns.txt, profiles/diag_all_atoms.py).  Seven iterations are compared: four
+    # statistical equilibria of five atoms each.
+    iters = 7 if name == 'falc_all.npz' else 8
     if mode == 'unlinked':
-        table = _run_pair(hip_lib, oracle_lib, name, 33, 2468, 3e-11, unlinked, ntol=1e-7, options='linked=0')
+        table = _run_pair(hip_lib, oracle_lib, name, 33, 2468, 3e-11, unlinked, ntol=1e-7, iters=iters, options='linked=0')
     else:
-        table = _run_pair(hip_lib, oracle_lib, name, 36, 2468, 3e-11, linked, ntol=1e-7, sweep_policy=mode)
+        table = _run_pair(hip_lib, oracle_lib, name, 36, 2468, 3e-11, linked, ntol=1e-7, iters=iters, sweep_policy=mode)
         # the classes with at most two per-ray slots run the mapping that was asked for, the others one ray per lane -- and so does a
         # class with linked continua if one of its tiles needs the row-mapped epilogue (more than six continua of an atom at a
         # wavelength, as carbon's and magnesium's have: the ray-serial instances leave the linked corrections to the column-mapped one)
