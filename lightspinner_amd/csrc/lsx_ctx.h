@@ -56,7 +56,7 @@ struct lsx_ctx : lsxd::LsxPlan {        // the plan (lsx_plan.h: dimensions, tab
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     // device: column independent
     double *d_wavelength = nullptr, *d_zmu = nullptr, *d_wmuh = nullptr, *d_wl = nullptr, *d_alpha = nullptr,
-           *d_u_la = nullptr;
+           *d_u_la = nullptr, *d_fgtab = nullptr;
     uint8_t* d_active = nullptr;
     DevTrans* d_trans = nullptr;
     DevTile* d_tiles = nullptr;

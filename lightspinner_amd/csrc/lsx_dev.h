@@ -129,6 +129,7 @@ struct SweepParams {
     const double* wl;           // per (transition, lt): wlambda(lt)/hc (lines) | wlambda(lt)/lambda/h (continua)
     const double* alpha;        // per (transition, lt) (continua; 0 for lines)
     const double* u_la;         // [Nspect] 2hc/lambda^3                        rh_method.py:286
+    const double* fgtab;        // the column-mapped fast-continuum epilogue's per-tile tables (lsx_fast.h)
     const uint8_t* active;      // [Ntrans][Nspect]
     const DevTile* tiles;
     const DevSlot* slots;       // per (tile, slot) parameters

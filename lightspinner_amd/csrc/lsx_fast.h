@@ -47,6 +47,7 @@ struct FastParams {
     // it ray by ray from the pre-pass's correction streams, or -- epi_corr, the ray-serial instances -- the column-mapped epilogue
     // applies it from the sums it has anyway (fast_gamma_cols_rows) and the pre-pass writes no correction streams
     int epi_corr, Nlines;
+    const double* fgtab;        // [tile][LSX_FGC_TAB(L)] the column-mapped epilogue's per-tile tables, ready made (lsx_create)
     const double* wphi;         // [col][Nlines][k]
 };
 
@@ -186,22 +187,16 @@ static __device__ __forceinline__ void fast_gamma_cols_rows(const FastParams& f,
     double* sU = sA + (size_t)2 * LSX_FGC_MAXF * L;            // [j] 2hc/lambda^3
     double* sLW = sU + L;                                      // [u < 2][j] the linked lines' wavelength weights (0 outside the line)
     double* sS = sLW + 2 * L + (size_t)wv * NST * R * L;      // this wave's streams: [J | Psibar | E | PsiPhi_u][row][j]
-    for (int e = tid; e < tl.nF * L; e += NT) {
-        const int q = e / L, jj = e - q * L, lq = tl.la0 + min(jj, tl.nla - 1), lt = lq - fs[q].Nblue;
-        const bool a = jj < tl.nla && lt >= 0 && lt < fs[q].Nlam && f.active[(size_t)fs[q].trans * f.Nspect + lq] != 0;
-        sA[e * 2 + 0] = a ? f.alpha[fs[q].wl_off + lt] : 0.0;
-        sA[e * 2 + 1] = a ? f.wl[fs[q].wl_off + lt] : 0.0;
-    }
-    for (int e = tid; e < L; e += NT) sU[e] = f.u_la[tl.la0 + min(e, tl.nla - 1)];
-    if constexpr (LINKS) {
-        for (int e = tid; e < 2 * L; e += NT) {
-            const int u = e / L, jj = e - u * L, lq = tl.la0 + min(jj, tl.nla - 1);
-            double w = 0.0;
-            if (u < min(tl.nL, NLC)) {
-                const int lt = lq - ls[u].Nblue;
-                if (jj < tl.nla && lt >= 0 && lt < ls[u].Nlam && f.active[(size_t)ls[u].trans * f.Nspect + lq] != 0) w = f.wl[ls[u].wl_off + lt];
-            }
-            sLW[e] = w;
+    // The tile's tables -- cross-section and wavelength weight of every fast continuum (0 where it is not active), 2hc/lambda^3, the
+    // linked lines' wavelength weights -- come ready made from lsx_create (f.fgtab, an image of this LDS area per tile): ONE coalesced
+    // copy.  (Round 5.  Gathered here from the slot table, the activity table and the atoms' arrays they were a chain of four
+    // dependent small loads at the head of every workgroup: profiles/r05/ablation_epilogue_kernel.txt.)
+    {
+        const double* tab = f.fgtab + (size_t)t * LSX_FGC_TAB(L);
+        const int nA = tl.nF * L, nB = 3 * L / 2;             // double2 pieces: [q][j]{alpha, wlambda} | u and the two lines' weights
+        for (int e = tid; e < nA + nB; e += NT) {
+            const int o = e < nA ? 2 * e : 2 * LSX_FGC_MAXF * L + 2 * (e - nA);
+            *reinterpret_cast<double2*>(sm + o) = *reinterpret_cast<const double2*>(tab + o);
         }
     }
     __syncthreads();

@@ -1202,7 +1202,7 @@ void lsx_destroy(lsx_ctx* c)
                     c->d_tiles, c->d_slots, c->d_tile_slots, c->d_fin_ptr, c->d_fin_idx, c->d_atom_ptr, c->d_atom_slots, c->d_Nlevel, c->d_lev2_off, c->d_height,
                     c->d_temperature, c->d_nStar, c->d_nTotal, c->d_n, c->d_C, c->d_Gamma, c->d_wphi, c->d_bgchi,
                     c->d_bgeta, c->d_sca, c->d_phi, c->d_E, c->d_corr, c->d_Psi3, c->d_J[0], c->d_J[1], c->d_I, c->d_Gpart, c->d_dJpart,
-                    c->d_res, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_fast_cols[0], c->d_fast_cols[1], c->d_fast_cols[2], c->d_fast_cols[3], c->d_fast_rest, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab, c->d_voigt_w, c->d_muz, c->d_wmu, c->d_optab, c->d_trans_row,
+                    c->d_res, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_fast_cols[0], c->d_fast_cols[1], c->d_fast_cols[2], c->d_fast_cols[3], c->d_fast_rest, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab, c->d_voigt_w, c->d_muz, c->d_wmu, c->d_optab, c->d_trans_row, c->d_fgtab,
                     c->d_sa_atoms, c->d_sa_lines, c->d_sa_colls, c->d_sa_spl, c->d_sa_levE, c->d_sa_levg, c->d_sa_levnD, c->d_sa_levdZ,
                     c->d_vBroad, c->d_aDamp};
     for (void* p : ptrs)
@@ -1353,6 +1353,39 @@ int lsx_create_with_options(const lsx_problem* d, int32_t ncol, int32_t device, 
         TRY(upload(&c->d_atom_slots, aslots, c->stream));
     }
     TRY(upload(&c->d_slots, c->slots, c->stream));
+    {   // the column-mapped fast-continuum epilogue's tables, one image of its LDS area per tile it takes (lsx_fast.h, fast_gamma_cols_rows):
+        // plain copies of alpha / wl / u_la entries, zero where a continuum or line is not active at the wavelength
+        const int L = c->L;
+        std::vector<double> tab(c->tiles.size() * (size_t)LSX_FGC_TAB(L), 0.0);
+        for (size_t t = 0; t < c->tiles.size(); ++t) {
+            const DevTile& tl = c->tiles[t];
+            if (tl.nF == 0 || tl.fast_simple != 2) continue;
+            double* T = tab.data() + t * (size_t)LSX_FGC_TAB(L);
+            const DevSlot* fs = c->slots.data() + tl.slot0 + tl.nP;
+            const DevSlot* ls = c->slots.data() + tl.slot0;
+            auto on = [&](const DevSlot& sl, int jj, int* lt) {
+                const int lq = tl.la0 + std::min(jj, tl.nla - 1);
+                *lt = lq - sl.Nblue;
+                return jj < tl.nla && *lt >= 0 && *lt < sl.Nlam && c->active[(size_t)sl.trans * c->Nspect + lq] != 0;
+            };
+            for (int q = 0; q < tl.nF; ++q)
+                for (int jj = 0; jj < L; ++jj) {
+                    int lt;
+                    const bool a = on(fs[q], jj, &lt);
+                    T[(q * L + jj) * 2 + 0] = a ? c->alpha[fs[q].wl_off + lt] : 0.0;
+                    T[(q * L + jj) * 2 + 1] = a ? c->wl[fs[q].wl_off + lt] : 0.0;
+                }
+            double* U = T + 2 * LSX_FGC_MAXF * L;
+            for (int jj = 0; jj < L; ++jj) U[jj] = c->u_la[tl.la0 + std::min(jj, tl.nla - 1)];
+            const int nlc = tl.nK > 0 ? std::min(tl.nL, 2) : 0;
+            for (int u = 0; u < nlc; ++u)
+                for (int jj = 0; jj < L; ++jj) {
+                    int lt;
+                    if (on(ls[u], jj, &lt)) U[L + u * L + jj] = c->wl[ls[u].wl_off + lt];
+                }
+        }
+        TRY(upload(&c->d_fgtab, tab, c->stream));
+    }
     TRY(upload(&c->d_Nlevel, c->Nlevel, c->stream));
     TRY(upload(&c->d_lev2_off, c->lev2_off, c->stream));
     // the fork / join events order kernels of THIS device only: a device-scope release when they are recorded, not the default
@@ -1601,7 +1634,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
     p.nslot_total = (int)c->tile_slots.size(); p.ntile_total = (int)c->tiles.size();
     p.L = c->L;
     p.wavelength = c->d_wavelength; p.zmu = c->d_zmu; p.wmuh = c->d_wmuh; p.wl = c->d_wl; p.alpha = c->d_alpha;
-    p.u_la = c->d_u_la; p.active = c->d_active; p.tiles = c->d_tiles; p.slots = c->d_slots;
+    p.u_la = c->d_u_la; p.fgtab = c->d_fgtab; p.active = c->d_active; p.tiles = c->d_tiles; p.slots = c->d_slots;
     p.phi_G = c->phi_group;
     p.phi_col_stride = (int64_t)c->phi_col; p.corr_col_stride = (int64_t)c->corr_col; p.pp_col_stride = (int64_t)c->pp_col;
     p.height = c->d_height; p.temperature = c->d_temperature; p.n = c->d_n; p.wphi = c->d_wphi;
@@ -1620,7 +1653,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
         ff.bgchi_T = c->d_bgchi; ff.bgeta_T = c->d_bgeta;
         ff.bgxchi_T = c->d_bgxchi; ff.bgxeta_T = c->d_bgxeta; ff.J_T = c->d_J[c->jcur ^ 1]; ff.Psi2_T = c->d_Psi2;
         ff.Gpart = c->d_Gpart; ff.colmask = c->d_colmask;
-        ff.epi_corr = 0; ff.Nlines = c->Nlines; ff.wphi = c->d_wphi;
+        ff.epi_corr = 0; ff.Nlines = c->Nlines; ff.wphi = c->d_wphi; ff.fgtab = c->d_fgtab;
     }
     // launch shapes (rows per pass, staged depths, LDS bytes): fixed and checked when the plan was made (lsx_plan.cpp)
     const LaunchShapes& S = c->shapes;

@@ -20,6 +20,7 @@
 #define LSX_MAX_TILE_LINES 4  // lines of one tile that linked continua may couple to (k_fast_prepass / k_fast_gamma)
 #define LSX_FAST_NQ 6         // k_fast_gamma_cols: fast continua per atom
 #define LSX_FGC_ROWS 32       // k_fast_gamma_cols: (column, depth) rows per wave
+#define LSX_FGC_TAB(L) (2 * LSX_FGC_MAXF * (L) + 3 * (L))   // doubles of a tile's table for k_fast_gamma_cols: [q][j]{alpha, w} | [j] u | [2][j] line weights
 #define LSX_FGC_MAXF 12       // k_fast_gamma_cols: fast continua per tile (sizes its operand table)
 
 // ---- the compiled instances of lsx_sweep_kernel<NPT, NL, NR, SCAL, LK, TOPO> (per-ray slots, lines among them, linked

@@ -1536,6 +1536,7 @@ static __device__ __forceinline__ FastParams fast_params_of(const SweepParams& p
     f.bgxchi_T = const_cast<double*>(p.bgxchi_T); f.bgxeta_T = const_cast<double*>(p.bgxeta_T); f.corr_T = const_cast<double*>(p.corr_T);
     f.corr_col_stride = p.corr_col_stride; f.pp_col_stride = p.pp_col_stride; f.J_T = p.Jnew_T; f.Psi2_T = p.Psi2_T; f.Psi3_T = p.Psi3_T;
     f.Gpart = p.Gpart; f.colmask = p.colmask;
+    f.fgtab = p.fgtab;
     f.epi_corr = 0; f.Nlines = p.Nlines; f.wphi = p.wphi;       // (one ray per lane: the sweep applies the linked corrections itself)
     return f;
 }
