@@ -289,6 +289,11 @@ def roofline_block(eng, lib, prob, ncol, workload, kernel_reps):
                                     'one instance per tile class, launched side by side; duration = span',
                 achieved=ach, peak=HBM_PEAK_GBPS, unit='GB/s', frac=ach / HBM_PEAK_GBPS, frac_of_measured_peak=ach / HBM_MEASURED_GBPS,
                 measured_peak=HBM_MEASURED_GBPS, traffic=traffic,
+                # the same duration against the bytes the sweeps REALLY move past the L2 (counter figure, over-fetch and the second
+                # direction's re-reads included): how close the kernel is to the memory system in real, not algorithmic, bytes
+                traffic_GBps=(traffic / (ms_sweep * 1e-3) / 1e9) if traffic else None,
+                traffic_frac_of_peak=(traffic / (ms_sweep * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                traffic_frac_of_measured_peak=(traffic / (ms_sweep * 1e-3) / 1e9 / HBM_MEASURED_GBPS) if traffic else None,
                 traffic_stale=bool(stale) if fig else None,
                 traffic_source=('%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a builder run at source hash %s, (2*FETCH_SIZE + '
                                 'WRITE_SIZE)*1024 per call per column x columns; not measured in this run%s'
