@@ -76,6 +76,10 @@ __global__ void __launch_bounds__(2 * LSX_WAVE) __attribute__((amdgpu_waves_per_
 lsx_sweep_rs_kernel(const SweepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+#ifdef LSX_CLOCK
+    unsigned long long tk_in;                                        // (diagnostic build: the shader clock at the wave's first instruction)
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk_in)::"memory");
+#endif
     lds_f64* const etab = (lds_f64*)lds_raw;                         // [64][2] exp table
     constexpr int NS = NPT > 0 ? NPT : 1;
     constexpr int NV = 2 * NS;                                       // Gamma integrands per lane and depth
@@ -241,6 +245,9 @@ lsx_sweep_rs_kernel(const SweepParams p)
         }
     }
     __syncthreads();
+#ifdef LSX_CLOCK
+    unsigned long long tk_s1; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk_s1)::"memory");
+#endif
     const int lc3 = cc * 3, lcg = 3 * NC * NPT + cc * 2;   // the lane's column inside a row: slot values at lc3 + 15 u + t, geometry at lcg + {0, 1}
     const int lcf = RL0 + cc * 3;                          // ... the fast continua's triples (n_i, n_j nsr, nsr) at lcf + 15 q + {0, 1, 2}
     constexpr int TU = 3 * NC;                             // doubles between two slots of a row
@@ -330,6 +337,9 @@ lsx_sweep_rs_kernel(const SweepParams p)
 #define wmuh(m) wmuh_of(m)
 
     if constexpr (QLDS) __syncthreads();
+#ifdef LSX_CLOCK
+    unsigned long long tk_s2; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk_s2)::"memory");
+#endif
     // ---- per-slot lane constants
     unsigned pact = 0;
 #pragma unroll
@@ -363,6 +373,9 @@ lsx_sweep_rs_kernel(const SweepParams p)
         if constexpr (NPT == 1 && !PAR) asm volatile("" : "+v"(cB[u]), "+v"(Vc[u]), "+v"(Uc[u]));
     }
 
+#ifdef LSX_CLOCK
+    unsigned long long tk_s3; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk_s3)::"memory");
+#endif
     // ---- one depth's operands ------------------------------------------------------------------------------------------
     struct Ops {
         double bc, be, jd, E;
@@ -440,6 +453,9 @@ lsx_sweep_rs_kernel(const SweepParams p)
             Iu[m] = B1 - (B0 - B1) / dtau_uw;
         }
     }
+#ifdef LSX_CLOCK
+    unsigned long long tk_s4; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk_s4)::"memory");
+#endif
     double dJ = 0.0;
 
     // Gamma integrands of the previous depth wait in this wave's reduction rows [value][lane]; lane (c, q) of the first
@@ -1358,7 +1374,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
         if (lane == 0 && dir == 0 && p.debug && col0 % 100 == 5) {      // the column groups that start at column 5, 105, ...
             unsigned long long* D = (unsigned long long*)p.debug + (size_t)(((col0 / 100) * ntile + tile_id) & 1023) * 16;
             for (int i = 0; i < 8; ++i) D[i] = 0;
-            D[7] = tk1 - tk0; D[1] = tr0;
+            D[7] = tk1 - tk0; D[1] = tr0; D[0] = tk0 - tk_in; D[2] = tk_s1 - tk_in; D[3] = tk_s2 - tk_in; D[4] = tk_s3 - tk_in; D[5] = tk_s4 - tk_in;        // (D[0]: entry -> first depth step, shader ticks: profiles/stamps.py)
             D[8] = tile_id; D[9] = NPT; D[10] = nF; D[11] = col0; D[12] = NL; D[13] = LK; D[14] = TOPO;
             D[15] = tr1 - tr0;
         }
