@@ -28,7 +28,7 @@ struct SweepClass : lsxd::PlanClass {   // a plan class + what the runtime keeps
     long launches = 0;         // how often this class's kernel has been launched (introspection for the tests)
     hipEvent_t tdone = nullptr; // timed runs: end of this class's launch
     int* d_fast_tiles = nullptr;
-    int *d_fast_cols[4] = {nullptr, nullptr, nullptr, nullptr}, *d_fast_rest = nullptr;
+    int *d_fast_cols[LSX_FGC_LISTS] = {}, *d_fast_rest = nullptr;
     int* d_tiles = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
@@ -84,7 +84,7 @@ struct lsx_ctx : lsxd::LsxPlan {        // the plan (lsx_plan.h: dimensions, tab
     uint8_t* d_colmask = nullptr; // per-column activity, nullptr = all active
     double *d_bgxchi = nullptr, *d_bgxeta = nullptr, *d_Psi2 = nullptr; // fast-continuum side arrays
     int* d_fast_tiles = nullptr;
-    int *d_fast_cols[4] = {nullptr, nullptr, nullptr, nullptr}, *d_fast_rest = nullptr;
+    int *d_fast_cols[LSX_FGC_LISTS] = {}, *d_fast_rest = nullptr;
     int *d_cont_li = nullptr, *d_cont_lj = nullptr;
     double* d_exp2_tab = nullptr;
     double* d_voigt_w = nullptr;

@@ -173,18 +173,26 @@ static __device__ __forceinline__ void fast_prepass_tile(const FastParams& f, co
 // three rounds, unrolled, with unconditional loads: all of a wave's loads are in flight together instead of round after round
 // As a device function: the NW waves of a block take the (column, depth) rows [row_begin + wave R, ... + R) below `nrows`
 // (k_fast_gamma_cols: consecutive chunks of all columns' rows; the fused small-batch sweep: the rows of the workgroup's own column).
-template <int NLC, int NPC, int NW>   // NLC: lines of the tile that linked continua feed (0: the tile has no linked continuum)
+// BIG (round 5): the instances for tiles in which an atom has MORE than LSX_FAST_NQ fast continua, or the tile more than LSX_FGC_MAXF
+// (carbon's and iron's fourteen and MgII's ten bound-free continua onto one level: with all five model atoms of the reference active
+// 192 of 328 tiles with fast continua).  An atom's sums over its continua at a wavelength -- atom.U[j], atom.eta, atom.chi[j] and the
+// linked lines' shares -- are formed FIRST, for the lane's six wavelengths, in a pass over the atom's continua in chunks of LSX_FAST_NQ;
+// a second pass takes the continua chunk by chunk through the arithmetic of the plain instance with the sums read instead of formed.
+// Same terms, same order of the sums over the continua and over the wavelengths.  Such tiles went through the row-mapped k_fast_gamma.
+template <int NLC, int NPC, int NW, bool BIG = false>   // NLC: lines of the tile that linked continua feed (0: the tile has no linked continuum)
 static __device__ __forceinline__ void fast_gamma_cols_rows(const FastParams& f, const int t, const long row_begin, const long nrows, double* sm)
 {
     constexpr bool LINKS = NLC > 0;
     constexpr int NL1 = NLC > 0 ? NLC : 1, NST = 3 + NLC, R = LSX_FGC_ROWS, NT = NW * 64;
+    constexpr int MAXF = BIG ? LSX_FGC_MAXF_BIG : LSX_FGC_MAXF;      // continua the LDS table area holds
+    static_assert(!BIG || NPC == 6, "big-set instances: twelve wavelengths per tile");
     const DevTile tl = f.tiles[t];
     __syncthreads();                                          // (a block that comes back for more rows: the previous call's readers are done)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, Ns = f.Nspace, L = NPC > 0 ? 2 * NPC : f.L, NP = NPC > 0 ? NPC : L / 2;
     const DevSlot* fs = f.slots + tl.slot0 + tl.nP;
     const DevSlot* ls = f.slots + tl.slot0;
     double* sA = sm;                                          // [q][j]{alpha, wlambda}, 0 where the continuum is inactive
-    double* sU = sA + (size_t)2 * LSX_FGC_MAXF * L;            // [j] 2hc/lambda^3
+    double* sU = sA + (size_t)2 * MAXF * L;                    // [j] 2hc/lambda^3
     double* sLW = sU + L;                                      // [u < 2][j] the linked lines' wavelength weights (0 outside the line)
     double* sS = sLW + 2 * L + (size_t)wv * NST * R * L;      // this wave's streams: [J | Psibar | E | PsiPhi_u][row][j]
     // The tile's tables -- cross-section and wavelength weight of every fast continuum (0 where it is not active), 2hc/lambda^3, the
@@ -194,9 +202,9 @@ static __device__ __forceinline__ void fast_gamma_cols_rows(const FastParams& f,
     {
         const double* tab = f.fgtab + (size_t)t * LSX_FGC_TAB(L);
         const int nA = tl.nF * L, nB = 3 * L / 2;             // double2 pieces: [q][j]{alpha, wlambda} | u and the two lines' weights
-        for (int e = tid; e < nA + nB; e += NT) {
-            const int o = e < nA ? 2 * e : 2 * LSX_FGC_MAXF * L + 2 * (e - nA);
-            *reinterpret_cast<double2*>(sm + o) = *reinterpret_cast<const double2*>(tab + o);
+        for (int e = tid; e < nA + nB; e += NT) {       // (the image in memory is laid out for LSX_FGC_MAXF_BIG continua, the LDS area for MAXF)
+            const int os = e < nA ? 2 * e : 2 * LSX_FGC_MAXF_BIG * L + 2 * (e - nA), od = e < nA ? 2 * e : 2 * MAXF * L + 2 * (e - nA);
+            *reinterpret_cast<double2*>(sm + od) = *reinterpret_cast<const double2*>(tab + os);
         }
     }
     __syncthreads();
@@ -285,7 +293,149 @@ static __device__ __forceinline__ void fast_gamma_cols_rows(const FastParams& f,
         const int atom = fs[q0].atom;
         int q1 = q0;
         while (q1 < tl.nF && fs[q1].atom == atom) ++q1;
-        const int nq = q1 - q0;                               // <= LSX_FAST_NQ (lsx_create)
+        const int nq = q1 - q0;                               // <= LSX_FAST_NQ (lsx_create) -- unless BIG
+        if constexpr (BIG) {
+            if (nq > LSX_FAST_NQ) {
+                constexpr int NQ = LSX_FAST_NQ, NPL = NPC / 2, NWL = NPC;      // pairs and wavelengths of a lane: pairs h, h + 2, h + 4
+                const unsigned lk0 = fs[q0].lkbits;
+                auto operands = [&](int c0, int nqc, double (&ni)[NQ], double (&nj)[NQ], double (&nr)[NQ]) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        ni[q] = nj[q] = nr[q] = 0.0;
+                        if (q < nqc) {
+                            ni[q] = nc[(size_t)fs[c0 + q].li * Ns];
+                            nj[q] = nc[(size_t)fs[c0 + q].lj * Ns];
+                            nr[q] = nsrc[(size_t)fs[c0 + q].base];
+                        }
+                    }
+                };
+                // ---- the atom's sums at the lane's wavelengths: U_a[j] / u, eta_a / u, -chi_a[j], chi of the continua on line u's lower level
+                double Us[NWL], Es[NWL], Cs[NWL], XC[NL1][NWL];
+#pragma unroll
+                for (int wi = 0; wi < NWL; ++wi) {
+                    Us[wi] = Es[wi] = Cs[wi] = 0.0;
+#pragma unroll
+                    for (int u = 0; u < NL1; ++u) XC[u][wi] = 0.0;
+                }
+                for (int c0 = q0; c0 < q1; c0 += NQ) {
+                    const int nqc = min(NQ, q1 - c0);
+                    double ni[NQ], nj[NQ], nr[NQ];
+                    operands(c0, nqc, ni, nj, nr);
+#pragma unroll
+                    for (int i = 0; i < NPL; ++i) {
+                        const int p = h + 2 * i;
+                        const double2 E2 = *reinterpret_cast<const double2*>(srow + (size_t)2 * R * L + 2 * p);
+#pragma unroll
+                        for (int w = 0; w < 2; ++w) {
+                            const int jw = 2 * p + w, wi = 2 * i + w;
+                            const double E = w ? E2.y : E2.x;
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) {
+                                if (q < nqc) {
+                                    const double alf = sA[(size_t)((c0 + q) * L + jw) * 2];
+                                    const double g = nr[q] * E, ng = nj[q] * g;
+                                    Us[wi] = fma(g, alf, Us[wi]);
+                                    Es[wi] = fma(ng, alf, Es[wi]);
+                                    if constexpr (LINKS) {
+                                        const double hq = ni[q] - ng;
+                                        Cs[wi] = fma(hq, alf, Cs[wi]);
+                                        const unsigned lkq = fs[c0 + q].lkbits;             // (wave-uniform)
+#pragma unroll
+                                        for (int u = 0; u < NL1; ++u)
+                                            if (lkq & (2u << (8 * u))) XC[u][wi] = fma(hq, alf, XC[u][wi]);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                // ---- the continua, chunk by chunk; the linked lines' corrections with the first chunk
+                for (int c0 = q0; c0 < q1; c0 += NQ) {
+                    const int nqc = min(NQ, q1 - c0);
+                    double ni[NQ], nj[NQ], nr[NQ], a1[NQ], a2[NQ];
+                    operands(c0, nqc, ni, nj, nr);
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) a1[q] = a2[q] = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NPL; ++i) {
+                        const int p = h + 2 * i;
+                        const double2 J2 = *reinterpret_cast<const double2*>(srow + 2 * p), P2 = *reinterpret_cast<const double2*>(srow + (size_t)R * L + 2 * p),
+                                      E2 = *reinterpret_cast<const double2*>(srow + (size_t)2 * R * L + 2 * p), U2 = *reinterpret_cast<const double2*>(sU + 2 * p);
+                        double2 L2[NL1];
+#pragma unroll
+                        for (int u = 0; u < NL1; ++u) L2[u] = LINKS ? *reinterpret_cast<const double2*>(srow + (size_t)(3 + u) * R * L + 2 * p) : zero2;
+#pragma unroll
+                        for (int w = 0; w < 2; ++w) {
+                            const int jw = 2 * p + w, wi = 2 * i + w;
+                            const double sI = (w ? J2.y : J2.x) * (4.0 * M_PI), sPsi = w ? P2.y : P2.x, E = w ? E2.y : E2.x, ula = w ? U2.y : U2.x;
+                            double tchi[NL1], teta[NL1], tU[NL1];
+#pragma unroll
+                            for (int u = 0; u < NL1; ++u) {
+                                const double sPP = w ? L2[u].y : L2[u].x;
+                                tchi[u] = Lx[u] * sPP;
+                                teta[u] = Ly[u] * sPP;
+                                tU[u] = LU[u] * sPP;
+                            }
+                            double le = 0.0;
+                            if constexpr (LINKS) {
+#pragma unroll
+                                for (int u = 0; u < NL1; ++u)
+                                    if (lk0 & (1u << (8 * u))) le += teta[u];
+                            }
+                            const double U_j = ula * Us[wi], etaA = ula * Es[wi];
+                            if constexpr (LINKS) {
+                                if (f.epi_corr && c0 == q0) {
+#pragma unroll
+                                    for (int u = 0; u < NL1; ++u)
+                                        if (lk0 & (1u << (8 * u))) {
+                                            const double tt = sLW[u * L + jw] * (w ? L2[u].y : L2[u].x);
+                                            dA[u] = fma(tt, etaA, dA[u]);
+                                            dB[u] = fma(tt, XC[u][wi], dB[u]);
+                                        }
+                                }
+                            }
+                            const double sIe = (sI - etaA * sPsi) - le;
+                            const double T = fma(ula, sW, sIe), UP = U_j * sPsi;
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) {
+                                if (q < nqc) {
+                                    const double2 A = *reinterpret_cast<const double2*>(sA + (size_t)((c0 + q) * L + jw) * 2);
+                                    const double g = nr[q] * E, hq = ni[q] - nj[q] * g;
+                                    const double wa = A.x * A.y;
+                                    const double tt = fma(-hq, UP, g * T);
+                                    a1[q] = fma(wa, tt, a1[q]);
+                                    a2[q] = fma(wa, sIe, a2[q]);
+                                    if constexpr (LINKS) {
+                                        const unsigned lk = fs[c0 + q].lkbits;
+                                        double lc = 0.0, lU = 0.0;
+#pragma unroll
+                                        for (int u = 0; u < NL1; ++u) {
+                                            if (lk & (2u << (8 * u))) lc += tchi[u];
+                                            if (lk & (4u << (8 * u))) { lc -= tchi[u]; lU += tU[u]; }
+                                        }
+                                        a1[q] = fma(-A.y, lc * U_j, a1[q]);
+                                        a2[q] = fma(A.y, Cs[wi] * lU, a2[q]);
+                                    }
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        if (q < nqc) {
+                            const double s1 = a1[q] + dpp_f64<0xB1, 0xf>(a1[q]), s2 = a2[q] + dpp_f64<0xB1, 0xf>(a2[q]);
+                            if (h == 0) {
+                                double* gp = f.Gpart + (((size_t)col * f.nslot_total + tl.slot0 + tl.nP + c0 + q) * 4) * (size_t)Ns + k;
+                                gp[0] = s1;
+                                gp[2 * (size_t)Ns] = s2;
+                            }
+                        }
+                    }
+                }
+                q0 = q1;
+                continue;
+            }
+        }
         double ni[LSX_FAST_NQ], nj[LSX_FAST_NQ], nr[LSX_FAST_NQ], a1[LSX_FAST_NQ], a2[LSX_FAST_NQ];
 #pragma unroll
         for (int q = 0; q < LSX_FAST_NQ; ++q) {

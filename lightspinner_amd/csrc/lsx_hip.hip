@@ -742,6 +742,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NLC =
     fast_gamma_cols_rows<NLC, NPC, 4>(f, f.fast_tiles[blockIdx.y], (long)blockIdx.x * 4 * LSX_FGC_ROWS, (long)f.ncol * f.Nspace, sm);   // lsx_fast.h
 }
 
+// the big-set instances (lsx_fast.h): workgroups of two waves
+template <int NLC>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(NLC == 0 ? 2 : 1))) k_fast_gamma_cols_big(const FastParams f)
+{
+    extern __shared__ double sm[];
+    fast_gamma_cols_rows<NLC, 6, 2, true>(f, f.fast_tiles[blockIdx.y], (long)blockIdx.x * 2 * LSX_FGC_ROWS, (long)f.ncol * f.Nspace, sm);
+}
+
 // singular system at (column, depth) = gid, atom: the flag keeps the FIRST one in (column, depth, atom) order --
 // one order-independent 64-bit atomicMax of (2^48 - key), 0 = none -- for lsx_last_error (cf. LinAlgError, rh_method.py:739)
 #define LSX_SING_BASE (1ull << 48)
@@ -1202,17 +1210,18 @@ void lsx_destroy(lsx_ctx* c)
                     c->d_tiles, c->d_slots, c->d_tile_slots, c->d_fin_ptr, c->d_fin_idx, c->d_atom_ptr, c->d_atom_slots, c->d_Nlevel, c->d_lev2_off, c->d_height,
                     c->d_temperature, c->d_nStar, c->d_nTotal, c->d_n, c->d_C, c->d_Gamma, c->d_wphi, c->d_bgchi,
                     c->d_bgeta, c->d_sca, c->d_phi, c->d_E, c->d_corr, c->d_Psi3, c->d_J[0], c->d_J[1], c->d_I, c->d_Gpart, c->d_dJpart,
-                    c->d_res, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_fast_cols[0], c->d_fast_cols[1], c->d_fast_cols[2], c->d_fast_cols[3], c->d_fast_rest, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab, c->d_voigt_w, c->d_muz, c->d_wmu, c->d_optab, c->d_trans_row, c->d_fgtab,
+                    c->d_res, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_fast_rest, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab, c->d_voigt_w, c->d_muz, c->d_wmu, c->d_optab, c->d_trans_row, c->d_fgtab,
                     c->d_sa_atoms, c->d_sa_lines, c->d_sa_colls, c->d_sa_spl, c->d_sa_levE, c->d_sa_levg, c->d_sa_levnD, c->d_sa_levdZ,
                     c->d_vBroad, c->d_aDamp};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    for (int v = 0; v < LSX_FGC_LISTS; ++v) if (c->d_fast_cols[v]) (void)hipFree(c->d_fast_cols[v]);
     for (auto& k : c->classes) {
         if (k.d_tiles) (void)hipFree(k.d_tiles);
         if (k.done) (void)hipEventDestroy(k.done);
         if (k.tdone) (void)hipEventDestroy(k.tdone);
         if (k.d_fast_tiles) (void)hipFree(k.d_fast_tiles);
-        for (int v = 0; v < 4; ++v) if (k.d_fast_cols[v]) (void)hipFree(k.d_fast_cols[v]);
+        for (int v = 0; v < LSX_FGC_LISTS; ++v) if (k.d_fast_cols[v]) (void)hipFree(k.d_fast_cols[v]);
         if (k.d_fast_rest) (void)hipFree(k.d_fast_rest);
         if (k.stream) { (void)hipStreamSynchronize(k.stream); (void)hipStreamDestroy(k.stream); }
     }
@@ -1359,7 +1368,7 @@ int lsx_create_with_options(const lsx_problem* d, int32_t ncol, int32_t device, 
         std::vector<double> tab(c->tiles.size() * (size_t)LSX_FGC_TAB(L), 0.0);
         for (size_t t = 0; t < c->tiles.size(); ++t) {
             const DevTile& tl = c->tiles[t];
-            if (tl.nF == 0 || tl.fast_simple != 2) continue;
+            if (tl.nF == 0 || tl.fast_simple < 2) continue;
             double* T = tab.data() + t * (size_t)LSX_FGC_TAB(L);
             const DevSlot* fs = c->slots.data() + tl.slot0 + tl.nP;
             const DevSlot* ls = c->slots.data() + tl.slot0;
@@ -1375,7 +1384,7 @@ int lsx_create_with_options(const lsx_problem* d, int32_t ncol, int32_t device, 
                     T[(q * L + jj) * 2 + 0] = a ? c->alpha[fs[q].wl_off + lt] : 0.0;
                     T[(q * L + jj) * 2 + 1] = a ? c->wl[fs[q].wl_off + lt] : 0.0;
                 }
-            double* U = T + 2 * LSX_FGC_MAXF * L;
+            double* U = T + 2 * LSX_FGC_MAXF_BIG * L;
             for (int jj = 0; jj < L; ++jj) U[jj] = c->u_la[tl.la0 + std::min(jj, tl.nla - 1)];
             const int nlc = tl.nK > 0 ? std::min(tl.nL, 2) : 0;
             for (int u = 0; u < nlc; ++u)
@@ -1395,7 +1404,7 @@ int lsx_create_with_options(const lsx_problem* d, int32_t ncol, int32_t device, 
     for (auto& k : c->classes) {
         TRY(upload(&k.d_tiles, k.tiles, c->stream));
         if (!k.fast_tiles.empty()) TRY(upload(&k.d_fast_tiles, k.fast_tiles, c->stream));
-        for (int v = 0; v < 4; ++v) if (!k.fast_cols[v].empty()) TRY(upload(&k.d_fast_cols[v], k.fast_cols[v], c->stream));
+        for (int v = 0; v < LSX_FGC_LISTS; ++v) if (!k.fast_cols[v].empty()) TRY(upload(&k.d_fast_cols[v], k.fast_cols[v], c->stream));
         if (!k.fast_rest.empty()) TRY(upload(&k.d_fast_rest, k.fast_rest, c->stream));
         int prio_lo = 0, prio_hi = 0;       // numerically lower = higher priority
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
@@ -1460,7 +1469,7 @@ int lsx_create_with_options(const lsx_problem* d, int32_t ncol, int32_t device, 
     }
     if (!c->fast_tiles.empty()) {
         TRY(upload(&c->d_fast_tiles, c->fast_tiles, c->stream));
-        for (int v = 0; v < 4; ++v) if (!c->fast_cols[v].empty()) TRY(upload(&c->d_fast_cols[v], c->fast_cols[v], c->stream));
+        for (int v = 0; v < LSX_FGC_LISTS; ++v) if (!c->fast_cols[v].empty()) TRY(upload(&c->d_fast_cols[v], c->fast_cols[v], c->stream));
         if (!c->fast_rest.empty()) TRY(upload(&c->d_fast_rest, c->fast_rest, c->stream));
         TRY(dmalloc(&c->d_bgxchi, nc * c->til_col));
         TRY(dmalloc(&c->d_bgxeta, nc * c->til_col));
@@ -1687,6 +1696,13 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
         FastParams fq = ff;
         fq.epi_corr = epi ? 1 : 0;
         fq.fast_tiles = d_list; fq.n_fast_tiles = (int)n;
+        if (v >= 4) {       // big sets: two waves per workgroup
+            dim3 gridb((unsigned)(((size_t)c->ncol * c->Nspace + 2 * LSX_FGC_ROWS - 1) / (2 * LSX_FGC_ROWS)), (unsigned)n);
+#define LSX_FC(NLCV) if (fgc_lines(v) == NLCV) hipLaunchKernelGGL((k_fast_gamma_cols_big<NLCV>), gridb, dim3(128), S.cols_lds[v], st, fq);
+            LSX_FC(0) LSX_FC(1) LSX_FC(2)
+#undef LSX_FC
+            return;
+        }
         dim3 grid((unsigned)(((size_t)c->ncol * c->Nspace + 4 * LSX_FGC_ROWS - 1) / (4 * LSX_FGC_ROWS)), (unsigned)n);
 #define LSX_FC(NLCV) if (kLkLines[v] == NLCV) { if (c->L == 12) hipLaunchKernelGGL((k_fast_gamma_cols<NLCV, 6>), grid, dim3(256), S.cols_lds[v], st, fq); \
                                                 else hipLaunchKernelGGL((k_fast_gamma_cols<NLCV, 0>), grid, dim3(256), S.cols_lds[v], st, fq); }
@@ -1694,8 +1710,8 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
 #undef LSX_FC
     };
     auto launch_fast_gamma = [&](hipStream_t st, const std::vector<int>* cols, int* const* d_cols, const int* d_rest, size_t nrest, bool epi = false) {
-        for (int v = 0; v < 3; ++v)
-            if (!cols[v].empty()) launch_fast_cols(st, d_cols[v], cols[v].size(), v, epi);
+        for (int v = 0; v < LSX_FGC_LISTS; ++v)
+            if (v != 3 && !cols[v].empty()) launch_fast_cols(st, d_cols[v], cols[v].size(), v, epi);
         if (nrest) launch_fast_rows(st, d_rest, nrest);
     };
     // From here on nothing returns before the class streams have been joined back and jcur / fs_pending advanced: a launch

@@ -349,9 +349,14 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
             const int lkn = tl.nK > 0 ? (int)lines.size() : 0;       // lines the linked continua feed
             const size_t lds_cols = ((size_t)2 * LSX_FGC_MAXF * P.L + (size_t)3 * P.L + (size_t)4 * (3 + lkn) * LSX_FGC_ROWS * P.L) * sizeof(double);
             const bool cols = simple && group_max <= LSX_FAST_NQ && (int)fast.size() <= LSX_FGC_MAXF && P.L % 2 == 0 && lkn <= 2 && lds_cols <= 64 * 1024 && !opt.fast_rows;
-            tl.fast_simple = simple ? (cols ? 2 : 1) : 0;
+            // 3: a simple set with MORE continua per atom (or per tile) than that -- carbon's and iron's fourteen, MgII's ten bound-free
+            // continua onto one level -- takes the big-set instances of the same kernel (lsx_fast.h: the atom's sums first, then its
+            // continua in chunks of LSX_FAST_NQ; twelve wavelengths per tile only)
+            const bool big = simple && !cols && P.L == 12 && (int)fast.size() <= LSX_FGC_MAXF_BIG && lkn <= 2 && !opt.fast_rows &&
+                             fgc_lds_bytes(P.L, LSX_FGC_MAXF_BIG, 2, lkn) <= 64 * 1024;
+            tl.fast_simple = simple ? (cols ? 2 : (big ? 3 : 1)) : 0;
             if (!simple) P.fast_generic = true;
-            (tl.fast_simple == 2 ? P.fast_cols[lkclass(tl)] : P.fast_rest).push_back((int)P.tiles.size());
+            (tl.fast_simple >= 2 ? P.fast_cols[fgc_list(tl)] : P.fast_rest).push_back((int)P.tiles.size());
         }
         // a compile-time slot count needs the per-depth operand table in LDS; very deep columns fall back to the
         // generic instance (runtime slot loops, operands through the scalar cache)
@@ -382,7 +387,7 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
         if (tl.nF > 0) {
             k->has_fast = true;
             k->fast_tiles.push_back((int)P.tiles.size());
-            (tl.fast_simple == 2 ? k->fast_cols[lkclass(tl)] : k->fast_rest).push_back((int)P.tiles.size());
+            (tl.fast_simple >= 2 ? k->fast_cols[fgc_list(tl)] : k->fast_rest).push_back((int)P.tiles.size());
         }
         k->ncell_lev = std::max(k->ncell_lev, (int)lev_ids.size());
         k->ncell_atom = std::max(k->ncell_atom, (int)atom_ids.size());
@@ -459,7 +464,7 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
             k.lk_epi = k.linked && k.npt >= 1 && k.nl == k.npt && (k.npt == 1 || k.topo != 0);
             if (k.rs && k.lk_epi)
                 for (int t : k.tiles)
-                    if (P.tiles[t].fast_simple != 2) k.rs = false;
+                    if (P.tiles[t].fast_simple < 2) k.rs = false;
             // folded fast continua (lsx_plan.h): every tile's row fits two elements per lane, and the class needs no correction
             // streams from the pre-pass (the unfactored linked instance reads them)
             // (not the two-line instances with a known relation and no linked continua: they sit at the register limit -- folded they
@@ -506,8 +511,9 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
         S.rows_seg = seg_for(S.rows_nt / S.rows_lp, per_depth, fixed_for(S.rows_nt), 40 * 1024);
         S.rows_lds = (per_depth * S.rows_seg + fixed_for(S.rows_nt)) * sizeof(double);
         if (!P.fast_rest.empty() && S.rows_lds > 64 * 1024) return perr(err, LSX_EUNSUPPORTED, "lsx_create: the fast-continuum epilogue needs %zu B of LDS", S.rows_lds);
-        for (int v = 0; v < 3; ++v) {
-            S.cols_lds[v] = ((size_t)2 * LSX_FGC_MAXF * P.L + (size_t)3 * P.L + (size_t)4 * (3 + kLkLines[v]) * LSX_FGC_ROWS * P.L) * sizeof(double);
+        for (int v = 0; v < LSX_FGC_LISTS; ++v) {
+            if (v == 3) continue;
+            S.cols_lds[v] = v < 3 ? fgc_lds_bytes(P.L, LSX_FGC_MAXF, 4, fgc_lines(v)) : fgc_lds_bytes(P.L, LSX_FGC_MAXF_BIG, 2, fgc_lines(v));
             if (!P.fast_cols[v].empty() && S.cols_lds[v] > 64 * 1024) return perr(err, LSX_EUNSUPPORTED, "lsx_create: the fast-continuum epilogue (column mapped) needs %zu B of LDS", S.cols_lds[v]);
         }
     }
@@ -537,11 +543,12 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
         // fast tile has the column-mapped epilogue with at most two linked lines, twelve wavelengths per tile, and a column's operands
         // fit the pre-pass's LDS in one piece; its two waves then need the larger of the three LDS layouts
         if (!P.fast_tiles.empty()) {
-            bool ok = P.Nrays == 5 && !P.sca_per_lambda && P.L == 12 && P.fast_rest.empty() && P.fast_cols[3].empty() && S.prepass_seg >= Ns;
+            bool ok = P.Nrays == 5 && !P.sca_per_lambda && P.L == 12 && P.fast_rest.empty() && S.prepass_seg >= Ns;
+            for (int v = 3; v < LSX_FGC_LISTS; ++v) ok = ok && P.fast_cols[v].empty();       // (big sets: launches of their own at any size)
             size_t need = std::max(S.fused_lds, S.prepass_lds);
             for (int v = 0; v < 3; ++v)
                 if (!P.fast_cols[v].empty())
-                    need = std::max(need, ((size_t)2 * LSX_FGC_MAXF * P.L + (size_t)3 * P.L + (size_t)2 * (3 + kLkLines[v]) * LSX_FGC_ROWS * P.L) * sizeof(double));
+                    need = std::max(need, fgc_lds_bytes(P.L, LSX_FGC_MAXF, 2, kLkLines[v]));
             S.fused_fast = ok && need <= 64 * 1024;
             S.fused_fast_lds = need;
         }

@@ -20,7 +20,9 @@
 #define LSX_MAX_TILE_LINES 4  // lines of one tile that linked continua may couple to (k_fast_prepass / k_fast_gamma)
 #define LSX_FAST_NQ 6         // k_fast_gamma_cols: fast continua per atom
 #define LSX_FGC_ROWS 32       // k_fast_gamma_cols: (column, depth) rows per wave
-#define LSX_FGC_TAB(L) (2 * LSX_FGC_MAXF * (L) + 3 * (L))   // doubles of a tile's table for k_fast_gamma_cols: [q][j]{alpha, w} | [j] u | [2][j] line weights
+#define LSX_FGC_MAXF_BIG 48   // ... of the instances for atoms with MORE than LSX_FAST_NQ continua at a wavelength (k_fast_gamma_cols_big: carbon, iron, MgII)
+#define LSX_FGC_LISTS 7       // tile lists of the column-mapped epilogue: [0..2] 0 / 1 / 2 lines fed by linked continua, [3] unused, [4..6] the same, big sets
+#define LSX_FGC_TAB(L) (2 * LSX_FGC_MAXF_BIG * (L) + 3 * (L))   // doubles of a tile's ready-made table (lsx_create): [q][j]{alpha, w} | [j] u | [2][j] line weights
 #define LSX_FGC_MAXF 12       // k_fast_gamma_cols: fast continua per tile (sizes its operand table)
 
 // ---- the compiled instances of lsx_sweep_kernel<NPT, NL, NR, SCAL, LK, TOPO> (per-ray slots, lines among them, linked
@@ -224,7 +226,7 @@ struct PlanClass {             // tiles that run the same kernel instantiation
     bool has_fast = false;     // some tile of the class has fast continua: the class reads the pre-pass output
     std::vector<int> tiles;
     std::vector<int> fast_tiles;                  // the class's tiles that have fast continua ...
-    std::vector<int> fast_cols[4], fast_rest;     // ... split by the kernel that builds their Gamma slabs
+    std::vector<int> fast_cols[LSX_FGC_LISTS], fast_rest;     // ... split by the kernel that builds their Gamma slabs
     int ncell_lev = 1, ncell_atom = 1;
     size_t lds_bytes = 0;
     double work = 0.0;         // estimated share of the call (launch order; stream priority tiers under LSX_PRIO)
@@ -284,7 +286,7 @@ uint64_t fnv1a64(const std::string& s);
 struct LaunchShapes {
     int prepass_seg = 0; size_t prepass_lds = 0;                  // k_fast_prepass: depths staged at a time, LDS bytes
     int rows_lp = 16, rows_nt = 256, rows_seg = 0; size_t rows_lds = 0;   // k_fast_gamma
-    size_t cols_lds[3] = {0, 0, 0};                              // k_fast_gamma_cols<0, 1, 2>
+    size_t cols_lds[LSX_FGC_LISTS] = {0, 0, 0, 0, 0, 0, 0};      // k_fast_gamma_cols<0, 1, 2>, [4..6]: k_fast_gamma_cols_big<0, 1, 2>
     int finish_nt = 128; size_t finish_lds = 0;                   // k_gamma_finish
     size_t fused_lds = 0; int fused_ncell_lev = 1, fused_ncell_atom = 1;   // fused small-batch / parabolic launch
     bool fused_fast = false; size_t fused_fast_lds = 0;          // the fused launch runs pre-pass and Gamma epilogue of its fast tiles itself
@@ -305,7 +307,7 @@ struct LsxPlan {
     std::vector<uint8_t> tile_slot_fast;         // per slot: fast continuum (its slabs use the first direction entry only)
     std::vector<DevSlot> slots;
     std::vector<PlanClass> plan_classes;         // in launch order
-    std::vector<int> fast_tiles, fast_cols[4], fast_rest;
+    std::vector<int> fast_tiles, fast_cols[LSX_FGC_LISTS], fast_rest;
     std::vector<int> cont_li, cont_lj;
     std::vector<int> trans_row;                  // per transition: its row of wphi (lines: the line index) / of nsr (continua: the continuum index)
     int nF_max = 0, Ncont = 0, static_max = -1, nL_linked_max = 0;
@@ -329,5 +331,10 @@ inline int lkclass(const DevTile& tl)
     const int n = tl.nK > 0 ? (tl.nL < LSX_MAX_TILE_LINES ? tl.nL : LSX_MAX_TILE_LINES) : 0;
     return n == 0 ? 0 : (n == 1 ? 1 : (n == 2 ? 2 : 3));
 }
+// ... and the list of the column-mapped epilogue it is filed in (DevTile.fast_simple: 2 the plain instances, 3 the big-set ones)
+inline int fgc_list(const DevTile& tl) { return lkclass(tl) + (tl.fast_simple == 3 ? 4 : 0); }
+inline int fgc_lines(int v) { return kLkLines[v & 3]; }
+// LDS of a workgroup of NW waves of the column-mapped epilogue: tables for MAXF continua, NW x (3 + lines) streams of LSX_FGC_ROWS rows
+inline size_t fgc_lds_bytes(int L, int maxf, int nw, int lines) { return ((size_t)2 * maxf * L + (size_t)3 * L + (size_t)nw * (3 + lines) * LSX_FGC_ROWS * L) * sizeof(double); }
 
 } // namespace lsxd

@@ -116,10 +116,10 @@ void verify(const LsxPlan& P, Checker& ck)
         const bool in_fast = std::find(P.fast_tiles.begin(), P.fast_tiles.end(), (int)ti) != P.fast_tiles.end();
         if (in_fast != (tl.nF > 0)) ck.fail("tile %ld: fast_tiles membership", (long)ti);
         int homes = 0, khomes = 0;
-        for (int v = 0; v < 4; ++v) {
+        for (int v = 0; v < LSX_FGC_LISTS; ++v) {
             homes += (int)std::count(P.fast_cols[v].begin(), P.fast_cols[v].end(), (int)ti);
             khomes += (int)std::count(k.fast_cols[v].begin(), k.fast_cols[v].end(), (int)ti);
-            if (std::count(P.fast_cols[v].begin(), P.fast_cols[v].end(), (int)ti) && (v != lkclass(tl) || v > 2)) ck.fail("tile %ld: wrong column-mapped list %ld", (long)ti, v);
+            if (std::count(P.fast_cols[v].begin(), P.fast_cols[v].end(), (int)ti) && (tl.fast_simple < 2 || v != fgc_list(tl) || (v & 3) > 2)) ck.fail("tile %ld: wrong column-mapped list %ld", (long)ti, v);
         }
         homes += (int)std::count(P.fast_rest.begin(), P.fast_rest.end(), (int)ti);
         khomes += (int)std::count(k.fast_rest.begin(), k.fast_rest.end(), (int)ti);
