@@ -296,7 +296,7 @@ static __device__ __forceinline__ void fast_gamma_cols_rows(const FastParams& f,
         const int nq = q1 - q0;                               // <= LSX_FAST_NQ (lsx_create) -- unless BIG
         if constexpr (BIG) {
             if (nq > LSX_FAST_NQ) {
-                constexpr int NQ = LSX_FAST_NQ, NPL = NPC / 2, NWL = NPC;      // pairs and wavelengths of a lane: pairs h, h + 2, h + 4
+                constexpr int NQ = NLC == 0 ? LSX_FAST_NQ : (NLC == 1 ? 3 : 4), NPL = NPC / 2, NWL = NPC;      // continua per chunk (fewer where the lines' sums take registers too: what fits 256 registers without scratch); pairs and wavelengths of a lane: pairs h, h + 2, h + 4
                 const unsigned lk0 = fs[q0].lkbits;
                 auto operands = [&](int c0, int nqc, double (&ni)[NQ], double (&nj)[NQ], double (&nr)[NQ]) __attribute__((always_inline)) {
 #pragma unroll
@@ -310,13 +310,11 @@ static __device__ __forceinline__ void fast_gamma_cols_rows(const FastParams& f,
                     }
                 };
                 // ---- the atom's sums at the lane's wavelengths: U_a[j] / u, eta_a / u, -chi_a[j], chi of the continua on line u's lower level
-                double Us[NWL], Es[NWL], Cs[NWL], XC[NL1][NWL];
+                // (the continua's share of chi_a[i_line] enters the line's correction dB = sum_w t_w sum_q h_q alpha_q only: it is added up
+                // term by term here, not kept per wavelength -- six registers per line less; the plain instance sums over q first)
+                double Us[NWL], Es[NWL], Cs[NWL];
 #pragma unroll
-                for (int wi = 0; wi < NWL; ++wi) {
-                    Us[wi] = Es[wi] = Cs[wi] = 0.0;
-#pragma unroll
-                    for (int u = 0; u < NL1; ++u) XC[u][wi] = 0.0;
-                }
+                for (int wi = 0; wi < NWL; ++wi) Us[wi] = Es[wi] = Cs[wi] = 0.0;
                 for (int c0 = q0; c0 < q1; c0 += NQ) {
                     const int nqc = min(NQ, q1 - c0);
                     double ni[NQ], nj[NQ], nr[NQ];
@@ -325,10 +323,16 @@ static __device__ __forceinline__ void fast_gamma_cols_rows(const FastParams& f,
                     for (int i = 0; i < NPL; ++i) {
                         const int p = h + 2 * i;
                         const double2 E2 = *reinterpret_cast<const double2*>(srow + (size_t)2 * R * L + 2 * p);
+                        double2 L2[NL1];
+#pragma unroll
+                        for (int u = 0; u < NL1; ++u) L2[u] = LINKS ? *reinterpret_cast<const double2*>(srow + (size_t)(3 + u) * R * L + 2 * p) : zero2;
 #pragma unroll
                         for (int w = 0; w < 2; ++w) {
                             const int jw = 2 * p + w, wi = 2 * i + w;
                             const double E = w ? E2.y : E2.x;
+                            double tt[NL1];
+#pragma unroll
+                            for (int u = 0; u < NL1; ++u) tt[u] = (LINKS && f.epi_corr) ? sLW[u * L + jw] * (w ? L2[u].y : L2[u].x) : 0.0;
 #pragma unroll
                             for (int q = 0; q < NQ; ++q) {
                                 if (q < nqc) {
@@ -342,7 +346,7 @@ static __device__ __forceinline__ void fast_gamma_cols_rows(const FastParams& f,
                                         const unsigned lkq = fs[c0 + q].lkbits;             // (wave-uniform)
 #pragma unroll
                                         for (int u = 0; u < NL1; ++u)
-                                            if (lkq & (2u << (8 * u))) XC[u][wi] = fma(hq, alf, XC[u][wi]);
+                                            if ((lkq & (2u << (8 * u))) && (lk0 & (1u << (8 * u)))) dB[u] = fma(tt[u], hq * alf, dB[u]);
                                     }
                                 }
                             }
@@ -387,11 +391,7 @@ static __device__ __forceinline__ void fast_gamma_cols_rows(const FastParams& f,
                                 if (f.epi_corr && c0 == q0) {
 #pragma unroll
                                     for (int u = 0; u < NL1; ++u)
-                                        if (lk0 & (1u << (8 * u))) {
-                                            const double tt = sLW[u * L + jw] * (w ? L2[u].y : L2[u].x);
-                                            dA[u] = fma(tt, etaA, dA[u]);
-                                            dB[u] = fma(tt, XC[u][wi], dB[u]);
-                                        }
+                                        if (lk0 & (1u << (8 * u))) dA[u] = fma(sLW[u * L + jw] * (w ? L2[u].y : L2[u].x), etaA, dA[u]);
                                 }
                             }
                             const double sIe = (sI - etaA * sPsi) - le;

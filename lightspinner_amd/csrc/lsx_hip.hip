@@ -744,7 +744,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NLC =
 
 // the big-set instances (lsx_fast.h): workgroups of two waves
 template <int NLC>
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(NLC == 0 ? 2 : 1))) k_fast_gamma_cols_big(const FastParams f)
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(NLC == 2 ? 1 : 2))) k_fast_gamma_cols_big(const FastParams f)
 {
     extern __shared__ double sm[];
     fast_gamma_cols_rows<NLC, 6, 2, true>(f, f.fast_tiles[blockIdx.y], (long)blockIdx.x * 2 * LSX_FGC_ROWS, (long)f.ncol * f.Nspace, sm);
