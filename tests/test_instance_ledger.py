@@ -113,3 +113,20 @@ def test_shapes_without_an_instance_cannot_be_planned(host):
                 seen.add(k)
                 assert k[0] < 0 or k in lane, k
     assert len(seen) >= 12
+
+
+def test_which_epilogue_the_reference_problems_tiles_take(host):
+    """DevTile.fast_simple as the planner files the reference's problems (lsx_plan.cpp): 2 = the column-mapped fast-continuum epilogue's
+    plain instances (at most six continua per atom, twelve per tile), 3 = its big-set instances (round 5: carbon's and iron's fourteen,
+    MgII's ten bound-free continua onto one level), 1 = the row-mapped kernel.  BASELINE's CaII and Ca+H problems take the plain
+    instances only -- their path is untouched by the big-set instances; with all five atoms active 183 of 328 tiles take those."""
+    from collections import Counter
+    want = {'falc_ca.npz': {2}, 'falc_cah.npz': {2}, 'falc_c.npz': {2, 3}, 'falc_fe.npz': {2, 3}, 'falc_mg.npz': {1, 2, 3}, 'falc_all.npz': {1, 2, 3}}
+    for fx, kinds in want.items():
+        prob, base, raw = fixtures.load_problem_npz(golden(fx), phi_compact=False)
+        rc, msg, s, tiles = host.probe(prob, 0)
+        assert rc == 0, msg
+        c = Counter(int(t[7]) for t in tiles if t[3] > 0)        # tiles with fast continua
+        assert set(c) == kinds, (fx, c)
+        if fx == 'falc_all.npz':
+            assert c[3] == 183 and c[2] == 136 and c[1] == 9, c
