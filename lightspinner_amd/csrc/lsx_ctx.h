@@ -57,6 +57,7 @@ struct lsx_ctx : lsxd::LsxPlan {        // the plan (lsx_plan.h: dimensions, tab
     // device: column independent
     double *d_wavelength = nullptr, *d_zmu = nullptr, *d_wmuh = nullptr, *d_wl = nullptr, *d_alpha = nullptr,
            *d_u_la = nullptr, *d_fgtab = nullptr;
+    int* d_level_atom = nullptr;
     uint8_t* d_active = nullptr;
     DevTrans* d_trans = nullptr;
     DevTile* d_tiles = nullptr;

@@ -427,6 +427,55 @@ __global__ void k_gamma_finish(const FinishParams f)
     }
 }
 
+// The same epilogue for atoms of many levels (LaunchShapes.finish_w > 0, lsx_plan.cpp: a thread's whole Gamma no longer fits the LDS
+// of 128 threads -- carbon, iron: 15 levels, MgII: 11): a thread takes ONE COLUMN i of its atom's Gamma, the entries (l, i) of every
+// row l, one after the other in registers -- each summed from the entry's slab list (fin_ptr / fin_idx, what k_gamma_finish_small
+// walks: slot order, i.e. the order k_gamma_finish adds them in), stored, and added to the column sum that becomes the diagonal
+// (Gamma_ii = -sum_l Gamma_li with the diagonal's own place counted as zero: a column sum, complete inside one thread).  No LDS; one
+// workgroup row per level of the problem.  The same bits as k_gamma_finish and k_gamma_finish_small.
+__global__ void __launch_bounds__(128) k_gamma_finish_levels(const FinishParams f, const int* __restrict__ level_atom, const int* __restrict__ level_first)
+{
+    const int Ns = f.Nspace;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)f.ncol * Ns) return;
+    const int col = gid / Ns, k = gid % Ns;
+    const int lev = blockIdx.y;                              // global level index: column i of atom `atom`
+    const int atom = level_atom[lev], i = lev - level_first[atom];
+    const bool first = lev == 0;
+    if (f.clear_dp && first) {
+        if (k == 0) f.dPcol[col] = 0.0;
+        if (gid == 0) *f.singular = 0ull;
+    }
+    if (f.colmask && !f.colmask[col]) {
+        if (k == 0 && first) f.dJcol[col] = 0.0;
+        return;
+    }
+    const int Nl = f.Nlevel[atom], off2 = f.lev2_off[atom];
+    const double* P = f.Gpart + (size_t)col * f.nslot_total * 4 * Ns + k;
+    const double* Cm = f.C + ((size_t)col * f.NL2tot + off2) * Ns + k;
+    double* Gout = f.Gamma + ((size_t)col * f.NL2tot + off2) * Ns + k;
+    double s = 0.0;
+    for (int l = 0; l < Nl; ++l) {
+        if (l == i) { s += 0.0; continue; }
+        const int e = l * Nl + i;
+        double g = 0.0 + Cm[(size_t)e * Ns];                 // Gamma = C, :587-590
+        const int b = f.fin_ptr[off2 + e], n = f.fin_ptr[off2 + e + 1];
+#pragma unroll 4
+        for (int x = b; x < n; ++x) g += P[(size_t)f.fin_idx[x] * Ns];
+        Gout[(size_t)e * Ns] = g;
+        s += g;
+    }
+    Gout[(size_t)(i * Nl + i) * Ns] = -s;                    // Gamma_ii = -sum_{l != i} Gamma_li, :698-703
+    if (k == 0 && first) { // per-column dJ: max over the column's tiles, NaN propagating (rh_method.py:705-706)
+        double m = 0.0;
+        for (int t = 0; t < 2 * f.ntile; ++t) {
+            const double v = f.dJpart[(size_t)col * 2 * f.ntile + t];
+            m = (v != v || m != m) ? __builtin_nan("") : fmax(m, v);
+        }
+        f.dJcol[col] = m;
+    }
+}
+
 // The same epilogue for small batches (fewer than 32 columns: the fused sweep launch), where k_gamma_finish is one long chain
 // of dependent adds per thread and nothing else runs: one wavefront per (column, depth), lane = Gamma entry.  The slabs of an
 // entry are listed in slot order (fin_ptr / fin_idx, made with the context), i.e. each entry is summed in exactly the order
@@ -1210,7 +1259,7 @@ void lsx_destroy(lsx_ctx* c)
                     c->d_tiles, c->d_slots, c->d_tile_slots, c->d_fin_ptr, c->d_fin_idx, c->d_atom_ptr, c->d_atom_slots, c->d_Nlevel, c->d_lev2_off, c->d_height,
                     c->d_temperature, c->d_nStar, c->d_nTotal, c->d_n, c->d_C, c->d_Gamma, c->d_wphi, c->d_bgchi,
                     c->d_bgeta, c->d_sca, c->d_phi, c->d_E, c->d_corr, c->d_Psi3, c->d_J[0], c->d_J[1], c->d_I, c->d_Gpart, c->d_dJpart,
-                    c->d_res, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_fast_rest, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab, c->d_voigt_w, c->d_muz, c->d_wmu, c->d_optab, c->d_trans_row, c->d_fgtab,
+                    c->d_res, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_fast_rest, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab, c->d_voigt_w, c->d_muz, c->d_wmu, c->d_optab, c->d_trans_row, c->d_fgtab, c->d_level_atom,
                     c->d_sa_atoms, c->d_sa_lines, c->d_sa_colls, c->d_sa_spl, c->d_sa_levE, c->d_sa_levg, c->d_sa_levnD, c->d_sa_levdZ,
                     c->d_vBroad, c->d_aDamp};
     for (void* p : ptrs)
@@ -1349,6 +1398,12 @@ int lsx_create_with_options(const lsx_problem* d, int32_t ncol, int32_t device, 
         }
         if (idx.empty()) idx.push_back(0);
         TRY(upload(&c->d_fin_ptr, ptr, c->stream));
+        {   // k_gamma_finish_levels: [NLtot] the atom of every level, then [Natoms] each atom's first level
+            std::vector<int> lt;
+            for (int a = 0; a < c->Natoms; ++a) for (int l = 0; l < c->Nlevel[a]; ++l) lt.push_back(a);
+            for (int a = 0; a < c->Natoms; ++a) lt.push_back(c->lev_off[a]);
+            TRY(upload(&c->d_level_atom, lt, c->stream));
+        }
         TRY(upload(&c->d_fin_idx, idx, c->stream));
         // k_gamma_finish: the slots of each atom's transitions, in slot order
         std::vector<int> aptr((size_t)c->Natoms + 1, 0), aslots;
@@ -1830,7 +1885,10 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
     const long nthreads = (long)c->ncol * c->Nspace;
     if (c->ncol < 32 && !c->opt_finish_big)
         hipLaunchKernelGGL(k_gamma_finish_small, dim3((unsigned)nthreads), dim3(64), (size_t)c->NL2tot * sizeof(double), c->stream, f);
-    else
+    else if (S.finish_w > 0) {
+        hipLaunchKernelGGL(k_gamma_finish_levels, dim3((unsigned)((nthreads + 127) / 128), (unsigned)c->NLtot), dim3(128), 0, c->stream, f,
+                           (const int*)c->d_level_atom, (const int*)c->d_level_atom + c->NLtot);
+    } else
         hipLaunchKernelGGL(k_gamma_finish, dim3((unsigned)((nthreads + S.finish_nt - 1) / S.finish_nt), (unsigned)c->Natoms), dim3(S.finish_nt), S.finish_lds, c->stream, f);
     }   // (!gexec)
     if (capturing) {

@@ -521,8 +521,18 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
     size_t nl2max = 1;
     for (int a = 0; a < P.Natoms; ++a) nl2max = std::max(nl2max, (size_t)P.Nlevel[a] * P.Nlevel[a]);
     S.finish_nt = 128;
+    int nlmax = 1;
+    for (int a = 0; a < P.Natoms; ++a) nlmax = std::max(nlmax, (int)P.Nlevel[a]);
+    if (nl2max * 128 * sizeof(double) > 48 * 1024) {
+        // an atom of more than six levels (carbon, iron: 15; MgII: 11): a thread's whole Gamma no longer fits 128 threads' LDS -- at 32
+        // threads per workgroup and two workgroups per CU the kernel ran on two half-filled waves per CU.  k_gamma_finish_levels: a
+        // thread takes one COLUMN of the matrix entry by entry in registers (lsx_hip.hip), no LDS
+        S.finish_w = 1;
+        S.finish_lds = 0;
+    } else {
     while (S.finish_nt > 32 && nl2max * S.finish_nt * sizeof(double) > 48 * 1024) S.finish_nt >>= 1;
     S.finish_lds = nl2max * S.finish_nt * sizeof(double);
+    }
     if (S.finish_lds > 64 * 1024) return perr(err, LSX_EUNSUPPORTED, "lsx_create: the Gamma epilogue needs %zu B of LDS", S.finish_lds);
     for (int a = 0; a < P.Natoms; ++a) {       // k_stat_equil: atoms with more than 8 levels keep their system in LDS
         const int Nl = P.Nlevel[a];

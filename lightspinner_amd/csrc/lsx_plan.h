@@ -288,6 +288,7 @@ struct LaunchShapes {
     int rows_lp = 16, rows_nt = 256, rows_seg = 0; size_t rows_lds = 0;   // k_fast_gamma
     size_t cols_lds[LSX_FGC_LISTS] = {0, 0, 0, 0, 0, 0, 0};      // k_fast_gamma_cols<0, 1, 2>, [4..6]: k_fast_gamma_cols_big<0, 1, 2>
     int finish_nt = 128; size_t finish_lds = 0;                   // k_gamma_finish
+    int finish_w = 0;                                             // > 0: k_gamma_finish_levels, a thread per column of its atom's Gamma (atoms of many levels)
     size_t fused_lds = 0; int fused_ncell_lev = 1, fused_ncell_atom = 1;   // fused small-batch / parabolic launch
     bool fused_fast = false; size_t fused_fast_lds = 0;          // the fused launch runs pre-pass and Gamma epilogue of its fast tiles itself
 };

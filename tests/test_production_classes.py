@@ -167,7 +167,8 @@ def test_single_column_reaches_the_fused_kernel(hip_lib):
     e.close()
 
 
-@pytest.mark.parametrize('name,ncol', [('falc_ca.npz', 1), ('falc_cah.npz', 3)])
+# (falc_mg / falc_all: atoms of 11 and 15 levels -- the many-column epilogue is k_gamma_finish_split there, a thread per block of Gamma's columns)
+@pytest.mark.parametrize('name,ncol', [('falc_ca.npz', 1), ('falc_cah.npz', 3), ('falc_mg.npz', 2), ('falc_all.npz', 2)])
 def test_small_batch_gamma_epilogue_gives_the_bits_of_the_many_column_one(hip_lib, name, ncol):
     """fewer than 32 columns: the Gamma epilogue runs one wavefront per (column, depth) with one entry per lane
     (k_gamma_finish_small); it sums every entry in the order the many-column kernel does, so Gamma, the monitors and the
