@@ -523,10 +523,11 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
     S.finish_nt = 128;
     int nlmax = 1;
     for (int a = 0; a < P.Natoms; ++a) nlmax = std::max(nlmax, (int)P.Nlevel[a]);
-    if (nl2max * 128 * sizeof(double) > 48 * 1024) {
-        // an atom of more than six levels (carbon, iron: 15; MgII: 11): a thread's whole Gamma no longer fits 128 threads' LDS -- at 32
-        // threads per workgroup and two workgroups per CU the kernel ran on two half-filled waves per CU.  k_gamma_finish_levels: a
-        // thread takes one COLUMN of the matrix entry by entry in registers (lsx_hip.hip), no LDS
+    if (!opt.finish_lds || nl2max * 128 * sizeof(double) > 48 * 1024) {
+        // k_gamma_finish_levels (lsx_hip.hip): a thread per (column, depth, level) takes one COLUMN of its atom's Gamma entry by entry in
+        // registers, no LDS -- the default since the end of round 5.  k_gamma_finish (a thread's whole matrix in LDS, finish_lds=1) is 1 %
+        // slower on C4 (profiles/r05/ab_gamma_epilogue_thread_per_column.txt) and collapses for atoms of more than six levels: 15 levels
+        // are 1.8 kB per thread -- 32 threads per workgroup, two half-filled waves per CU (all five atoms active: 1.76 against 0.66 ms)
         S.finish_w = 1;
         S.finish_lds = 0;
     } else {
@@ -580,6 +581,7 @@ void options_from_env(CtxOptions* o)
     p.natural_tiles = (e = getenv("LSX_TILER")) && std::string(e) == "natural";
     p.no_topo = getenv("LSX_NO_TOPO") != nullptr;
     p.fast_rows = getenv("LSX_FAST_ROWS") != nullptr;
+    p.finish_lds = getenv("LSX_FINISH_LDS") != nullptr;
     p.order_by_cost = (e = getenv("LSX_ORDER")) && std::string(e) == "cost";
     p.occ_wg = (e = getenv("LSX_OCC_WG")) ? atoi(e) : 0;
     p.no_rs = getenv("LSX_NO_RS") != nullptr;
@@ -634,6 +636,7 @@ int options_apply(const char* list, CtxOptions* o, std::string* err)
         if (key == "linked") ok = flag(&p.no_linked, true);
         else if (key == "topo") ok = flag(&p.no_topo, true);
         else if (key == "fast_rows") ok = flag(&p.fast_rows, false);
+        else if (key == "finish_lds") ok = flag(&p.finish_lds, false);
         else if (key == "rs") ok = flag(&p.no_rs, true);
         else if (key == "fold") ok = flag(&p.no_fold, true);
         else if (key == "epi") ok = flag(&p.no_epi, true);
@@ -668,9 +671,9 @@ std::string options_string(const CtxOptions& o)
     const RunOptions& r = o.run;
     char b[512];
     snprintf(b, sizeof b,
-             "linked=%d;tiler=%s;topo=%d;fast_rows=%d;order=%s;occ_wg=%d;class_chunk=%d;rs=%d;fold=%d;epi=%d;phi_group=%d;rs_min_columns=%d;rs_max_npt=%d;"
+             "linked=%d;tiler=%s;topo=%d;fast_rows=%d;finish_lds=%d;order=%s;occ_wg=%d;class_chunk=%d;rs=%d;fold=%d;epi=%d;phi_group=%d;rs_min_columns=%d;rs_max_npt=%d;"
              "se_lds=%d;serial=%d;finish_big=%d;fused_epilogue=%d;graph=%d;fused_fast=%d;abl_fused_fast=%d",
-             !p.no_linked, p.natural_tiles ? "natural" : "dp", !p.no_topo, (int)p.fast_rows, p.order_by_cost ? "cost" : "plan", p.occ_wg, p.class_chunk,
+             !p.no_linked, p.natural_tiles ? "natural" : "dp", !p.no_topo, (int)p.fast_rows, (int)p.finish_lds, p.order_by_cost ? "cost" : "plan", p.occ_wg, p.class_chunk,
              !p.no_rs, !p.no_fold, !p.no_epi, !p.no_phi_group, p.rs_min_columns, p.rs_max_npt, (int)r.se_lds, (int)r.serial, (int)r.finish_big,
              (int)r.fused_epilogue, (int)r.graph, !r.no_fused_fast, r.abl_fast);
     return b;

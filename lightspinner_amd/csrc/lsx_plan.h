@@ -244,6 +244,7 @@ struct PlanOptions {           // diagnostic switches (lsx_create reads them fro
     bool natural_tiles = false; // LSX_TILER=natural: cut every L wavelengths
     bool no_topo = false;      // LSX_NO_TOPO
     bool fast_rows = false;    // LSX_FAST_ROWS: the row-mapped epilogue for every tile
+    bool finish_lds = false;   // finish_lds=1 / LSX_FINISH_LDS: the Gamma epilogue with a thread's whole matrix in LDS (k_gamma_finish) where that fits, instead of a thread per column (k_gamma_finish_levels) -- the same bits; measurement
     bool order_by_cost = false; // LSX_ORDER=cost
     int occ_wg = 0;            // LSX_OCC_WG: at most this many workgroups per CU (through the LDS request)
     int class_chunk = LSX_CLASS_CHUNK;   // class_chunk / LSX_CLASS_CHUNK: a tile class is cut into launch groups of at most this many tiles, each

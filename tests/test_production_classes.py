@@ -178,8 +178,10 @@ def test_small_batch_gamma_epilogue_gives_the_bits_of_the_many_column_one(hip_li
     prob, base, raw = fixtures.load_problem_npz(golden(name), phi_compact=False)
     blk, (aD, vB, vlos) = synth.perturbed_columns(prob, base, raw, ncol=ncol, seed=11, vlos_sigma=1.0e3)
     out = []
-    for big in (False, True):
-        e = Engine(prob, ncol, lib=hip_lib, options='finish_big=%d' % big)
+    # the small-batch kernel, the many-column one (a thread per column of Gamma, round 5) and the many-column one with a thread's whole
+    # matrix in LDS (finish_lds=1: the default before; atoms of more than six levels take the per-column kernel there too)
+    for opts in ('finish_big=0', 'finish_big=1', 'finish_big=1,finish_lds=1'):
+        e = Engine(prob, ncol, lib=hip_lib, options=opts)
         e.set_columns(0, blk)
         e.set_line_profiles(0, aD, vB, vlos)
         mon = []
@@ -190,9 +192,10 @@ def test_small_batch_gamma_epilogue_gives_the_bits_of_the_many_column_one(hip_li
         mon.append(e.stat_equil())                                  # twice on one Gamma
         out.append((e.get(_capi.LSX_GAMMA), e.get(_capi.LSX_N), e.get(_capi.LSX_DJ_COL), e.get(_capi.LSX_DPOPS_COL), mon))
         e.close()
-    for a, b in zip(out[0][:4], out[1][:4]):
-        assert np.array_equal(a, b)
-    assert out[0][4] == out[1][4]
+    for other in out[1:]:
+        for a, b in zip(out[0][:4], other[:4]):
+            assert np.array_equal(a, b)
+        assert out[0][4] == other[4]
     assert out[0][4][-1] == 0.0 < out[0][4][-2]
 
 
