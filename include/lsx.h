@@ -417,9 +417,10 @@ int32_t lsx_sweep_policy(const lsx_ctx* ctx);
  * a sharded job whose ranks differ in their environment would silently associate its sums differently per rank.  Now
  *   - lsx_create_with_options takes an explicit list "key=value,key=value" (NULL or "" = lsx_create).  Keys that change the
  *     association of a sum: linked=0|1 (continua of a line's atom outside the sweep), tiler=dp|natural, topo=0|1, fast_rows=0|1,
- *     rs=0|1 (ray-serial instances at all), rs_min_columns=N (LSX_SWEEP_AUTO's threshold), rs_max_npt=0..2; launch shape and
- *     measurement only (same bits, tested): order=plan|cost, occ_wg=N, phi_group=0|1, se_lds, serial, finish_big, fused_epilogue,
- *     graph, fused_fast (each 0|1), trace_classes.  Unknown keys / malformed values: LSX_EINVAL.  The LSX_* environment variables
+ *     rs=0|1 (ray-serial instances at all), rs_min_columns=N (LSX_SWEEP_AUTO's threshold), rs_max_npt=0..2,
+ *     fold=0|1 and epi=0|1 (the fast continua's opacities / rate integrands formed inside the ray-serial sweep); launch shape and
+ *     measurement only (same bits, tested): order=plan|cost, occ_wg=N, phi_group=0|1, se_lds, serial, finish_big, finish_lds (the Gamma
+ *     epilogue with a thread's matrix in LDS instead of a thread per column), fused_epilogue, graph, fused_fast (each 0|1), trace_classes.  Unknown keys / malformed values: LSX_EINVAL.  The LSX_* environment variables
  *     of rounds 1-4 remain as diagnostic DEFAULTS that an explicit entry overrides;
  *   - lsx_effective_options writes what the context ended up with, plus the rule, the sweep mapping the policy selects and the
  *     plan's class list, as one "key=value;..." string (LSX_EINVAL if `n` is too small: 1024 bytes are enough for any context);
