@@ -131,7 +131,9 @@ def run_response_function(prob: Problem, base: ColumnBlock, fixture: dict, ks, l
     from .problem import Engine
     e0 = Engine(prob, 1, device=device, lib=lib, stream=stream)
     e0.set_columns(0, base.slice(0, 1))
-    it0 = drivers.iterate_mali_columns(e0, log=log)
+    # (one column: its own stopping rule IS the global one -- the engine loop, which keeps the next formal solution enqueued while the
+    # host reads the monitors where the library says that pays, lsx_prefers_lookahead; the same iterations and bits)
+    it0 = [drivers.iterate_mali_engine(e0, log=log).n_iter]
     I_base, n_base = e0.get(_capi.LSX_I)[0], e0.get(_capi.LSX_N)[0]
     jobs = [(int(k), tag) for k in ks for tag in ('p', 'm')]
     if world > 1:
