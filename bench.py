@@ -310,7 +310,9 @@ def roofline_block(eng, lib, prob, ncol, workload, kernel_reps):
                            'Round 5 (profiles/r05_bound_evidence.md): a SECOND depth of prefetch was built and changes nothing (the kernel does not '
                            'wait for HBM at one depth), while ONE more stream per step (the Boltzmann factor of the folded fast continua) costs 8 % -- '
                            'what is scarce is vector issue and memory REQUESTS per wave at two waves per SIMD, not bytes; the per-depth operands now '
-                           'come through a ring in LDS (no depth limit) and the fast continua\'s opacity is formed in the lane (no pre-pass)',
+                           'come through a ring in LDS (no depth limit) and the fast continua\'s opacity is formed in the lane (no pre-pass). In REAL bytes '
+                           '(traffic_GBps: counter traffic over the live duration) the sweeps move 4.1-4.5 TB/s = 0.65-0.72 of the achievable rate; a wave\'s '
+                           'prologue is 8-13 % of its life and not on the critical path (shortened by a third: no change) -- r05_bound_evidence.md 6, 7',
                 fs_call=dict(ms=ms_total, ms_sweep_kernel=ms_sweep, ms_epilogue_kernels=info(4), alg_bytes=balg * ncol,
                              traffic=traffic_all, traffic_over_alg=(traffic_all / (balg * ncol)) if traffic_all else None,
                              traffic_note='HBM bytes of EVERY kernel of a formal solution (sweeps, fast-continuum kernels, operand-table build, '
