@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from conftest import golden, relerr
-from lightspinner_amd import fixtures, Engine, _capi, drivers, response
+from lightspinner_amd import fixtures, synth, Engine, _capi, drivers, response
 from lightspinner_amd.problem import ColumnBlock
 
 
@@ -77,6 +77,46 @@ def test_freeze_columns_oracle(oracle_lib):
 @pytest.mark.gpu
 def test_freeze_columns_gpu(hip_lib):
     _freeze_case(hip_lib)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['ray-per-lane', 'ray-serial'])
+def test_freeze_columns_of_a_many_level_atom_on_the_per_class_path_gpu(hip_lib, oracle_lib, mode):
+    """the column mask through the kernels a many-level atom takes at many columns (round 5: the big-set instances of the
+    column-mapped fast-continuum epilogue, the thread-per-column Gamma epilogue): MgII, 33 perturbed columns, every third one
+    frozen after two calls -- frozen columns keep J, Gamma and populations bit for bit and report dJ = dPops = 0, the others
+    go on like the oracle's"""
+    prob, base, raw = fixtures.load_problem_npz(golden('falc_mg.npz'), phi_compact=False)
+    ncol = 33
+    blk, (aD, vB, vlos) = synth.perturbed_columns(prob, base, raw, ncol=ncol, seed=77, vlos_sigma=1.5e3)
+    engs = []
+    for lib in (hip_lib, oracle_lib):
+        e = Engine(prob, ncol, lib=lib, **(dict(sweep_policy=mode) if lib is hip_lib else {}))
+        e.set_columns(0, blk)
+        e.set_line_profiles(0, aD, vB, vlos)
+        engs.append(e)
+    hip, ora = engs
+    oracle_lib.dll.lsx_oracle_set_threads(ora._h, 8)
+    for e in engs:
+        e.formal_sol_gamma(); e.formal_sol_gamma()
+    keep = {q: hip.get(q).copy() for q in (_capi.LSX_J, _capi.LSX_GAMMA, _capi.LSX_N)}
+    mask = np.array([c % 3 != 1 for c in range(ncol)], dtype=np.uint8)
+    frozen = np.flatnonzero(mask == 0)
+    for e in engs:
+        e.set_active_columns(mask)
+    for it in range(3):
+        dJ, dJo = hip.formal_sol_gamma(), ora.formal_sol_gamma()
+        dP, dPo = hip.stat_equil(), ora.stat_equil()
+        assert dJ == pytest.approx(dJo, rel=1e-6) and dP == pytest.approx(dPo, rel=1e-6)
+    for q, v in keep.items():
+        now = hip.get(q)
+        assert np.array_equal(now[frozen], v[frozen]) and not np.array_equal(now[0], v[0]), q
+    assert np.all(hip.get(_capi.LSX_DJ_COL)[frozen] == 0.0) and np.all(hip.get(_capi.LSX_DPOPS_COL)[frozen] == 0.0)
+    live = np.flatnonzero(mask)
+    assert relerr(hip.get(_capi.LSX_N)[live], ora.get(_capi.LSX_N)[live]) < 1e-7
+    assert relerr(hip.get(_capi.LSX_J)[live], ora.get(_capi.LSX_J)[live], floor=1e-300) < 1e-7
+    for e in engs:
+        e.close()
 
 
 def _all_depths_fixture():
