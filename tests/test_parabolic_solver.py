@@ -100,6 +100,38 @@ def test_parabolic_rule_on_production_shapes(hip_lib, oracle_lib, fixture, polic
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('policy', ['ray-per-lane', 'ray-serial'])
+def test_parabolic_rule_on_a_many_level_atom(hip_lib, oracle_lib, policy):
+    """MgII (11 levels; continua linked to one, two and three lines, ten bound-free continua onto one level) under the parabolic rule at
+    36 columns: the rule's sweeps in front of the kernels a many-level atom takes behind them since round 5 -- the big-set instances of
+    the column-mapped fast-continuum epilogue, the thread-per-column Gamma epilogue"""
+    import numpy as np
+    from conftest import golden, relerr, gamma_err
+    from lightspinner_amd import fixtures, synth, Engine, _capi
+    prob, base, raw = fixtures.load_problem_npz(golden('falc_mg.npz'), phi_compact=False)
+    blk, prof = synth.perturbed_columns(prob, base, raw, ncol=36, seed=4, vlos_sigma=2.0e3)
+    engs = []
+    for lib in (hip_lib, oracle_lib):
+        e = Engine(prob, 36, lib=lib, sweep_policy=policy)
+        synth.load_columns(e, blk, prof)
+        e.set_formal_solver('parabolic')
+        engs.append(e)
+    hip, ora = engs
+    oracle_lib.dll.lsx_oracle_set_threads(ora._h, 8)
+    for it in range(1, 6):
+        assert hip.formal_sol_gamma() == pytest.approx(ora.formal_sol_gamma(), rel=1e-7)
+        if it == 1:
+            assert relerr(hip.get(_capi.LSX_J), ora.get(_capi.LSX_J), floor=1e-300) < 3e-11 and relerr(hip.get(_capi.LSX_I), ora.get(_capi.LSX_I)) < 3e-11
+            off, diag = gamma_err(hip.get(_capi.LSX_GAMMA), ora.get(_capi.LSX_GAMMA), prob)
+            assert off < 3e-10 and diag < 3e-11, (off, diag)
+        if it > 3:
+            assert hip.stat_equil() == pytest.approx(ora.stat_equil(), rel=1e-6)
+    assert relerr(hip.get(_capi.LSX_N), ora.get(_capi.LSX_N)) < 1e-7
+    for e in engs:
+        e.close()
+
+
+@pytest.mark.gpu
 def test_parabolic_ray_serial_positions_and_frozen_columns(hip_lib):
     """the ray-serial instances of the rule share a wavefront between five columns: a column's bits do not depend on where it sits in
     the batch or on its neighbours (every original column appears several times at random positions of a ragged batch), and a frozen
