@@ -551,6 +551,32 @@ def main():
                                                 'container, numba absent (SURVEY.md 6); the reference cannot travel to the GPU box',
                           us_per_mali_iteration=t_c2 / max(h.n_iter, 1) * 1e6)
             e1.close()
+            # ... and what a user of the reference gets by changing one import (missing 1): the SAME loop, test.py:20-29,
+            # through lightspinner_amd.rh_method.Context on reference-shaped objects (tests/helpers.build_fakes: the golden fixture's
+            # atmosphere, spectrum, populations, background) -- two blocking calls per iteration, populations written back into the
+            # caller's array after every stat_equil, I read once after the loop (inside the timed region)
+            sys.path.insert(0, os.path.join(ROOT, 'tests'))
+            from helpers import build_fakes
+            from lightspinner_amd.rh_method import Context
+            dgold = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'falc_ca.npz')))
+            t_ctx, hc, n_ctx, I_ctx = [], None, None, None
+            for _ in range(3):
+                atmos, spect, eq, bg = build_fakes(dgold)
+                ctx = Context(atmos, spect, eq, bg, device=local_rank, stream=ts.cuda_stream, lib=lib)
+                t0 = time.perf_counter()
+                hc = drivers.iterate_mali(ctx)
+                I_ctx = np.array(ctx.I)
+                t_ctx.append(time.perf_counter() - t0)
+                n_ctx = np.array(eq['CA'].n)
+                ctx.close()
+            t_cx = min(t_ctx[1:])
+            single['context_dropin'] = dict(
+                n_iter=hc.n_iter, converged=hc.converged, seconds=t_cx, seconds_first_run=t_ctx[0], mali_iters_per_sec=hc.n_iter / t_cx,
+                us_per_mali_iteration=t_cx / max(hc.n_iter, 1) * 1e6, ratio_to_engine_loop=t_cx / t_c2,
+                max_dn_over_n_vs_ref=float(np.max(np.abs(n_ctx - nref) / np.abs(nref))),
+                max_dI_over_I_vs_ref=float(np.max(np.abs(I_ctx - r1['conv_I']) / np.abs(r1['conv_I']))),
+                readback='lazy (J, I, Gamma fetched when first looked at; n written back after every stat_equil)',
+                loop='drivers.iterate_mali(Context) = test.py:20-29: formal_sol_gamma_matrices(); if i > 3: stat_equil(); one blocking call each')
 
         result = dict(metric='depth_points_x_wavelengths_x_rays_per_sec', value=units / dt, unit='point-updates/s',
                       n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,

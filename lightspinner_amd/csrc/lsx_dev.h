@@ -265,6 +265,20 @@ static __device__ __forceinline__ double exp_tab64(double x, const lds_f64* tab)
     return ldexp(fma(th, m, tl) + th, ki >> 6);
 }
 
+// Boltzmann factor of a continuum's g_ij, exp(-hc / (k lambda T)) (rh_method.py:453): a per-wavelength constant times 1 / T through
+// the table exponential above.  The ray-serial sweep forms it in the lane (1 / T arrives with the depth's operand row, lsx_plan.h
+// LSX_RS_GEO) and k_build_E writes the SAME bits into the stream the other kernels read.  Against the reference's two divisions the
+// argument differs by at most 1.5 ulp, i.e. the factor by |x| 1.7e-16 relative -- and the factor only matters where |x| is small
+// (x e^-x <= 0.37): below 1e-16 of the opacity it enters.
+static __device__ __forceinline__ double boltzmann_lane_constant(double wavelength_nm)
+{
+    return -(6.6260755E-34 * 2.99792458E+08 / (1.380658E-23 * 1.0E-09)) / wavelength_nm;
+}
+static __device__ __forceinline__ double boltzmann_factor(double lane_constant, double rT, const lds_f64* tab)
+{
+    return exp_tab64(fmax(lane_constant * rT, -740.0), tab);
+}
+
 // min of two doubles as ONE instruction: fmin() is preceded by a canonicalising v_max_f64(x, x) (signalling NaNs); the
 // instruction itself already returns the other operand for any NaN, which is all the callers rely on
 static __device__ __forceinline__ double min_noquiet(double a, double b)

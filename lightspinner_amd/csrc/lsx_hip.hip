@@ -226,15 +226,20 @@ __global__ void k_voigt_wphi(const VoigtParams q, double* __restrict__ wphi, int
 // Boltzmann factor of the continuum g_ij (rh_method.py:453-454: g_ij = nStar_i / nStar_j * exp(-hc / (k lambda T))),
 // tile-major like the background streams: E_T[col][tile][k][j].  Depends on the temperature only: built at upload.
 __global__ void k_build_E(const double* __restrict__ temperature, const double* __restrict__ wavelength,
-                          double* __restrict__ out, const DevTile* __restrict__ tiles, int ntile, int L, int Ns)
+                          double* __restrict__ out, const DevTile* __restrict__ tiles, int ntile, int L, int Ns,
+                          const double* __restrict__ exp2_tab)
 {
+    // ONE Boltzmann factor in the library (round 6): the stream holds the bits the ray-serial sweep forms in the lane
+    // (lsx_dev.h, boltzmann_factor: (-hc / k lambda) * (1 / T) through the sweep's table exponential)
+    __shared__ double etab_s[LSX_EXP_TAB];
+    for (int e = threadIdx.x; e < LSX_EXP_TAB; e += blockDim.x) etab_s[e] = exp2_tab[e];
+    __syncthreads();
     const size_t col = blockIdx.y;
-    const double hc_k = kHC / (kKBoltzmann * kNM_TO_M);
     const int total = ntile * Ns * L;
     for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gridDim.x * blockDim.x) {
         const int j = o % L, k = (o / L) % Ns, t = o / (L * Ns);
         const int la = tiles[t].la0 + (j < tiles[t].nla ? j : tiles[t].nla - 1);
-        out[col * (size_t)total + o] = exp(-hc_k / wavelength[la] / temperature[col * Ns + k]);
+        out[col * (size_t)total + o] = boltzmann_factor(boltzmann_lane_constant(wavelength[la]), 1.0 / temperature[col * Ns + k], (const lds_f64*)etab_s);
     }
 }
 
@@ -260,7 +265,7 @@ struct OptabParams {
     const DevTrans* trans;
     const int* trans_row;
     const int *cont_li, *cont_lj;
-    const double *n, *wphi, *nsr, *height, *sca;
+    const double *n, *wphi, *nsr, *height, *sca, *temperature;
     double* optab;
     size_t gstride;
 };
@@ -295,19 +300,21 @@ __global__ void k_build_optab(const OptabParams p)
         }
     } else if (t < p.Ntrans + 2) {
         const int up = t - p.Ntrans;                              // 0: the down-going sweep's geometry, 1: the up-going one's
-        double* const blk = grp + ((size_t)p.Ntrans * (3 * NC) + (size_t)up * (2 * NC)) * NR;
+        constexpr int GEO = LSX_RS_GEO;
+        double* const blk = grp + ((size_t)p.Ntrans * (3 * NC) + (size_t)up * (GEO * NC)) * NR;
         for (int e = threadIdx.x; e < NR * NC; e += blockDim.x) {
             const int r = e / NC - PAD, c = e - (e / NC) * NC;
             const size_t col = (size_t)g * NC + (c < ncg ? c : ncg - 1);
             const double* z = p.height + col * Ns;
             double hz = 0.0;
             if (r >= 0 && r < Ns) hz = up ? (r + 1 < Ns ? 0.5 * fabs(z[r] - z[r + 1]) : 0.0) : (r > 0 ? 0.5 * fabs(z[r - 1] - z[r]) : 0.0);
-            blk[(size_t)e * 2 + 0] = hz;
-            blk[(size_t)e * 2 + 1] = (r >= 0 && r < Ns) ? p.sca[col * Ns + r] : 0.0;
+            blk[(size_t)e * GEO + 0] = hz;
+            blk[(size_t)e * GEO + 1] = (r >= 0 && r < Ns) ? p.sca[col * Ns + r] : 0.0;
+            if constexpr (GEO > 2) blk[(size_t)e * GEO + 2] = (r >= 0 && r < Ns) ? 1.0 / p.temperature[col * Ns + r] : 0.0;     // (lsx_dev.h, boltzmann_factor)
         }
     } else {
         const int q = t - p.Ntrans - 2;                           // continuum q: n_i, n_j nStar_i / nStar_j, nStar_i / nStar_j (the folded instances' operands)
-        double* const blk = grp + ((size_t)p.Ntrans * (3 * NC) + 2 * (2 * NC) + (size_t)q * (3 * NC)) * NR;
+        double* const blk = grp + ((size_t)p.Ntrans * (3 * NC) + 2 * (LSX_RS_GEO * NC) + (size_t)q * (3 * NC)) * NR;
         const int li = p.cont_li[q], lj = p.cont_lj[q];
         for (int e = threadIdx.x; e < NR * NC; e += blockDim.x) {
             const int r = e / NC - PAD, c = e - (e / NC) * NC;
@@ -1180,7 +1187,7 @@ int rebuild_derived(lsx_ctx* c, size_t cc, size_t nb)
     if (c->d_E) {
         dim3 grid((unsigned)((c->til_col + 255) / 256), (unsigned)nb);
         hipLaunchKernelGGL(k_build_E, grid, dim3(256), 0, c->stream, c->d_temperature + cc * Ns, c->d_wavelength,
-                           c->d_E + cc * c->til_col, c->d_tiles, (int)c->tiles.size(), c->L, Ns);
+                           c->d_E + cc * c->til_col, c->d_tiles, (int)c->tiles.size(), c->L, Ns, c->d_exp2_tab);
         HIPCHK(hipGetLastError());
     }
     if (c->d_nsr) {
@@ -1643,7 +1650,7 @@ static void launch_build_optab(lsx_ctx* c)
     op.Ns = c->Nspace; op.Ntrans = c->Ntrans; op.ncol = c->ncol; op.NLtot = c->NLtot; op.Nlines = c->Nlines; op.Ncont = c->Ncont;
     op.trans = c->d_trans; op.trans_row = c->d_trans_row; op.cont_li = c->d_cont_li; op.cont_lj = c->d_cont_lj;
     op.n = c->d_n; op.wphi = c->d_wphi; op.nsr = c->d_nsr; op.height = c->d_height;
-    op.sca = c->d_sca; op.optab = c->d_optab; op.gstride = lsx_optab_group_doubles(c->Ntrans, c->Nspace, c->Ncont);
+    op.sca = c->d_sca; op.temperature = c->d_temperature; op.optab = c->d_optab; op.gstride = lsx_optab_group_doubles(c->Ntrans, c->Nspace, c->Ncont);
     bool fold_any = false;
     for (auto& k : c->classes) fold_any = fold_any || k.fold;
     hipLaunchKernelGGL(k_build_optab, dim3((unsigned)((c->ncol + LSX_RS_COLS - 1) / LSX_RS_COLS), (unsigned)(c->Ntrans + 2 + (fold_any ? c->Ncont : 0))),

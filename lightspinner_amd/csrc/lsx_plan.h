@@ -174,7 +174,14 @@ inline bool lsx_rsp_instance_exists(int npt, int nl, bool lk, int topo)
 #define LSX_RS_RING_EPI 4               // ... of the EPI instances (their reduction rows need the LDS)
 #define LSX_RS_EPI_ROUND 12             // values per reduction round: 64 lanes / 5 columns
 #define LSX_RS_FOLD_ROW_MAX 128         // doubles of a folded row: two elements per lane
-constexpr int lsx_rs_row_doubles(int npt, int nF = 0) { return 3 * LSX_RS_COLS * npt + 2 * LSX_RS_COLS + 3 * LSX_RS_COLS * nF; }
+// doubles per column of a geometry row: the half length of the interval behind the ray, the scattering coefficient and (round 6)
+// 1 / T: the Boltzmann factor exp(-hc / k lambda T) of the continua (rh_method.py:453) is formed in the lane from it instead of being
+// read as a stream by both directions (LSX_ELANE=0: the stream, round 5's form)
+#ifndef LSX_ELANE
+#define LSX_ELANE 1
+#endif
+#define LSX_RS_GEO (LSX_ELANE ? 3 : 2)
+constexpr int lsx_rs_row_doubles(int npt, int nF = 0) { return 3 * LSX_RS_COLS * npt + LSX_RS_GEO * LSX_RS_COLS + 3 * LSX_RS_COLS * nF; }
 // the folded instances take the fast continua four at a time in straight-line code (the LDS reads of a chunk in flight together; a
 // continuum the tile does not have: zero cross-section against a zeroed pad of the row), so the rings' rows and the cross-section
 // table are laid out for the class's largest tile rounded up to a multiple of four
@@ -191,7 +198,7 @@ constexpr int lsx_rs_row_pitch(int npt, int nF = 0) { return (lsx_rs_row_doubles
 constexpr int lsx_optab_rows(int Ns) { return Ns + 2 * LSX_RS_RING; }
 constexpr size_t lsx_optab_group_doubles(int Ntrans, int Ns, int Ncont)
 {
-    return ((size_t)Ntrans * 3 * LSX_RS_COLS + 2 * 2 * LSX_RS_COLS + (size_t)Ncont * 3 * LSX_RS_COLS) * (size_t)lsx_optab_rows(Ns);
+    return ((size_t)Ntrans * 3 * LSX_RS_COLS + 2 * LSX_RS_GEO * LSX_RS_COLS + (size_t)Ncont * 3 * LSX_RS_COLS) * (size_t)lsx_optab_rows(Ns);
 }
 // (the parabolic instances park 16 depths in every class: they need the LDS for the lane-private cells below)
 constexpr int lsx_rs_park(int npt, bool par = false) { return (npt >= 2 || par) ? 16 : 64; }      // depths a row of parked Gamma totals holds (two slots: 16, for two workgroups more per CU)

@@ -50,6 +50,25 @@ __device__ __forceinline__ double& at(double* base, unsigned byte_off)
 {
     return *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + byte_off);
 }
+// cache-policy hints (round 6): a stream that is read exactly once per call (the line profiles) is requested non-temporally, so that
+// it does not push out of the L2 what the partner wave of the workgroup re-reads (background, J-dagger, the first visitor's halves);
+// slabs and sums that nobody re-reads inside the sweep are stored non-temporally
+__device__ __forceinline__ double ld_once(const double* base, unsigned byte_off)
+{
+#ifdef LSX_NT_PHI
+    return __builtin_nontemporal_load(reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off));
+#else
+    return at(base, byte_off);
+#endif
+}
+__device__ __forceinline__ void st_once(double* base, unsigned byte_off, double v)
+{
+#ifdef LSX_NT_ST
+    __builtin_nontemporal_store(v, reinterpret_cast<double*>(reinterpret_cast<char*>(base) + byte_off));
+#else
+    at(base, byte_off) = v;
+#endif
+}
 __device__ __forceinline__ double nanmax(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : fmax(a, b); }
 
 constexpr int NR = LSX_RS_RAYS;        // rays per wavelength (compile time: the ray loop is unrolled)
@@ -173,12 +192,12 @@ lsx_sweep_rs_kernel(const SweepParams p)
             w = e - u * (3 * NC); rowd = 3 * NC;
             blk = (size_t)slots[NPT > 0 ? (u < NPT ? u : 0) : 0].trans * NRT * (3 * NC);
         } else if (e < RL0) {
-            w = e - 3 * NC * NPT; rowd = 2 * NC;
-            blk = ((size_t)p.Ntrans * (3 * NC) + (size_t)dir * (2 * NC)) * NRT;
+            w = e - 3 * NC * NPT; rowd = LSX_RS_GEO * NC;
+            blk = ((size_t)p.Ntrans * (3 * NC) + (size_t)dir * (LSX_RS_GEO * NC)) * NRT;
         } else {
             const int q = (e - RL0) / (3 * NC);
             w = e - RL0 - q * (3 * NC); rowd = 3 * NC;
-            blk = ((size_t)p.Ntrans * (3 * NC) + 2 * (2 * NC) + (size_t)LSX_CONST(int32_t, p.trans_row)[slots[NPT + q].trans] * (3 * NC)) * NRT;
+            blk = ((size_t)p.Ntrans * (3 * NC) + 2 * (LSX_RS_GEO * NC) + (size_t)LSX_CONST(int32_t, p.trans_row)[slots[NPT + q].trans] * (3 * NC)) * NRT;
         }
         ob = (unsigned)((blk + (size_t)(LSX_RS_RING + kS) * rowd + w) * 8u);       // (the table's pad: LSX_RS_RING rows, whatever this instance's ring)
         os = dk * rowd * 8;
@@ -248,7 +267,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
 #ifdef LSX_CLOCK
     unsigned long long tk_s1; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk_s1)::"memory");
 #endif
-    const int lc3 = cc * 3, lcg = 3 * NC * NPT + cc * 2;   // the lane's column inside a row: slot values at lc3 + 15 u + t, geometry at lcg + {0, 1}
+    const int lc3 = cc * 3, lcg = 3 * NC * NPT + cc * LSX_RS_GEO;   // the lane's column inside a row: slot values at lc3 + 15 u + t, geometry at lcg + {0, 1 (, 2: 1 / T)}
     const int lcf = RL0 + cc * 3;                          // ... the fast continua's triples (n_i, n_j nsr, nsr) at lcf + 15 q + {0, 1, 2}
     constexpr int TU = 3 * NC;                             // doubles between two slots of a row
     // what the tile's fast continua add to opacity and emissivity at the depth of step v (rh_method.py:284-286, 453-455, 613-614):
@@ -313,6 +332,17 @@ lsx_sweep_rs_kernel(const SweepParams p)
     const bool compact = p.phi_compact != 0;
     const double wav = p.wavelength[la];
     const double u_la = p.u_la[la];
+    // the Boltzmann factor of the tile's continua at depth row v (rh_method.py:453), formed from the row's 1 / T (lsx_dev.h,
+    // boltzmann_factor; the stream E_T holds the same bits for the kernels that read it)
+    const double aE = boltzmann_lane_constant(wav);
+    auto E_of = [&](const int v, const double E_stream) __attribute__((always_inline)) {
+#if LSX_ELANE
+        if constexpr (HASC || FOLD) return boltzmann_factor(aE, ring_row(v)[lcg + 2], etab);
+        else return 0.0;
+#else
+        return E_stream;
+#endif
+    };
     // angle quadrature: wave-uniform
     // two-slot instances: the ten quadrature constants live in LDS behind the parked totals and are read where they are used
     // (broadcast reads with immediate offsets): twenty vector registers less in the instances that sit at the 256-register limit
@@ -396,13 +426,13 @@ lsx_sweep_rs_kernel(const SweepParams p)
 #ifdef LSX_ABL_FOLD_NOE
         if constexpr (HASC) o.E = at(Eb, kt);          // ablation build (wrong results): the folded instances do not read the Boltzmann stream
         else if constexpr (FOLD) o.E = 0.5;
-#else
+#elif !LSX_ELANE
         if constexpr (HASC || FOLD) o.E = at(Eb, kt);
 #endif
 #pragma unroll
         for (int u = 0; u < NL; ++u)
 #pragma unroll
-            for (int m = 0; m < NR; ++m) o.ph[u][m] = at(phi0, phi_o[u] + (unsigned)kk * phi_k[u] + (unsigned)m * phi_m[u]);
+            for (int m = 0; m < NR; ++m) o.ph[u][m] = ld_once(phi0, phi_o[u] + (unsigned)kk * phi_k[u] + (unsigned)m * phi_m[u]);
         if constexpr (CORR) {
             const unsigned kq = o_corr + (unsigned)(kk * LW) * 8u;
 #pragma unroll
@@ -422,13 +452,14 @@ lsx_sweep_rs_kernel(const SweepParams p)
     auto chi_of = [&](const Ops& o, int v, int m) __attribute__((always_inline)) {          // v: step index of the depth
         const lds_f64* tk = ring_row(v) + lc3;
         double c = o.bc;
-        if constexpr (FOLD) { double e_ = 0.0; fast_fold(v, o.E, u_la, c, e_); }
+        const double Ev = E_of(v, o.E);
+        if constexpr (FOLD) { double e_ = 0.0; fast_fold(v, Ev, u_la, c, e_); }
 #pragma unroll
         for (int u = 0; u < NPT; ++u) {
             if (u < NL) c = fma(tk[TU * u + 0], o.ph[u][m], c);
             else {
                 const bool a = (pact >> u) & 1u;
-                const double Vji = a ? (tk[TU * u + 2] * o.E) * alv[u] : 0.0;
+                const double Vji = a ? (tk[TU * u + 2] * Ev) * alv[u] : 0.0;
                 c += tk[TU * u + 0] * alv[u] - tk[TU * u + 1] * Vji;
             }
         }
@@ -486,7 +517,13 @@ lsx_sweep_rs_kernel(const SweepParams p)
                     for (int c = 0; c < ncg; ++c) {
                         if (p.colmask && LSX_CONST(uint8_t, p.colmask)[col0 + c] == 0) continue;      // a frozen column keeps its slabs
 #pragma unroll
-                        for (int q = 0; q < NV; ++q) gbase[((size_t)c * p.nslot_total * 4 + (size_t)q * 2) * Ns + kk] = park[(c * NV + q) * PE + lane];
+                        for (int q = 0; q < NV; ++q) {
+#ifdef LSX_NT_ST
+                            __builtin_nontemporal_store((double)park[(c * NV + q) * PE + lane], &gbase[((size_t)c * p.nslot_total * 4 + (size_t)q * 2) * Ns + kk]);
+#else
+                            gbase[((size_t)c * p.nslot_total * 4 + (size_t)q * 2) * Ns + kk] = park[(c * NV + q) * PE + lane];
+#endif
+                        }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -1000,7 +1037,8 @@ lsx_sweep_rs_kernel(const SweepParams p)
         const double hdz = ring_row(s)[lcg];                         // the interval behind this ray: row k (down) / k + 1 (up)
         double etaB = cur.be + ring_row(s)[lcg + 1] * cur.jd;
         double chiB = cur.bc;
-        fast_fold(s, cur.E, u_la, chiB, etaB);
+        const double Ek = E_of(s, cur.E);
+        fast_fold(s, Ek, u_la, chiB, etaB);
         double X[NS], Vjc[NS], Ujc[NS], chic[NS], njUc[NS], njc[NS], w3k[NS];   // lines: X = cB (n_i - g n_j), n_j Uc, wphi; continua: Vji, Uji, chi, n_j
 #pragma unroll
         for (int u = 0; u < NPT; ++u) {
@@ -1013,7 +1051,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
                 const bool a = (pact >> u) & 1u;
                 X[u] = njUc[u] = 0.0;
                 njc[u] = tk[TU * u + 1];
-                Vjc[u] = a ? (w3k[u] * cur.E) * alv[u] : 0.0;             // g_ij alpha, :284-285, :453
+                Vjc[u] = a ? (w3k[u] * Ek) * alv[u] : 0.0;                // g_ij alpha, :284-285, :453
                 Ujc[u] = u_la * Vjc[u];                                   // :286
                 chic[u] = tk[TU * u + 0] * alv[u] - njc[u] * Vjc[u];
                 chiB += chic[u];
@@ -1256,11 +1294,11 @@ lsx_sweep_rs_kernel(const SweepParams p)
         // stores retire in issue order, a wait for the next depth's operands waits for every store before them); the
         // Psibar of a frozen column is read by nobody (the fast-continuum kernels skip frozen columns)
         // (EPI: only the FIRST visitor of a depth stores them -- for the second visitor, which finishes the fast continua's rates itself)
-        if constexpr (!EPI || PH == 0) { if (LK || nF > 0) at(psibar, kt) = Pacc; }      // (a tile with linked continua has fast continua: no test at all in those instances)
+        if constexpr (!EPI || PH == 0) { if (LK || nF > 0) st_once(psibar, kt, Pacc); }      // (a tile with linked continua has fast continua: no test at all in those instances)
 #endif
         if constexpr (LK && (!EPI || PH == 0)) {       // (no lane mask either: shadow lanes repeat their lane's store, a frozen column's sums are read by nobody)
 #pragma unroll
-            for (int u = 0; u < NL; ++u) at(ppsum, (unsigned)(u * plane) * 8u + o_pp + (unsigned)(k * LW) * 8u) = PP[u];
+            for (int u = 0; u < NL; ++u) st_once(ppsum, (unsigned)(u * plane) * 8u + o_pp + (unsigned)(k * LW) * 8u, PP[u]);
         }
         if constexpr (NPT >= 1) {
             // lanes (c, j) -> element c * 12 + j of the value's row (= the lane number); idle lanes park zeros
@@ -1298,7 +1336,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
                     double PPt[NLK];
 #pragma unroll
                     for (int u = 0; u < NLK; ++u) PPt[u] = (LK && u < NL) ? PP[u] + xw2[((1 + NL) + 1 + u) * LSX_WAVE + lane] : 0.0;
-                    epi_fast(s, k, Jacc + xwg[LSX_WAVE + lane], Pacc + xw2[(1 + (LK ? NL : 0)) * LSX_WAVE + lane], PPt, cur.E, X, njUc, w3k);
+                    epi_fast(s, k, Jacc + xwg[LSX_WAVE + lane], Pacc + xw2[(1 + (LK ? NL : 0)) * LSX_WAVE + lane], PPt, Ek, X, njUc, w3k);
                 }
             }
         } else {
@@ -1307,12 +1345,12 @@ lsx_sweep_rs_kernel(const SweepParams p)
                 double PPt[NLK];
 #pragma unroll
                 for (int u = 0; u < NLK; ++u) PPt[u] = pph[u] + ((LK && u < NL) ? PP[u] : 0.0);
-                epi_fast(s, k, Jv, phalf + Pacc, PPt, cur.E, X, njUc, w3k);
+                epi_fast(s, k, Jv, phalf + Pacc, PPt, Ek, X, njUc, w3k);
             }
 #ifdef LSX_ABL_NOSTORE
             if (valid && Jv == 1.2345) at(Jnew, kt) = Jv;
 #else
-            at(Jnew, kt) = live_col ? Jv : cur.jd;
+            st_once(Jnew, kt, live_col ? Jv : cur.jd);       // (the total: read again by the NEXT call only)
 #endif
             if (act) dJ = nanmax(dJ, fabs(1.0 - cur.jd * rcp(Jv)));             // :705
         }

@@ -24,6 +24,14 @@ evaluated by the library,
 hot calls run on the GPU through the lsx C ABI; there is no CPU fallback (the HIP library must be
 built).
 
+Read-back (round 6).  The reference's `ctx.J`, `ctx.I` and `atom.Gamma` are live arrays that every call rewrites in
+place; its drivers (test.py:20-29, response_fn.py:11-21) read them once, after the loop.  Here they are fetched from the
+device when they are first LOOKED AT: until then a call costs the enqueue, the wait and one 16-byte monitor read-back.
+An array that has been handed out once is kept current after every call from then on (its holder may read it, or write it,
+at any time: edits are found by comparing with what was last synchronised, as before) -- `readback='eager'` asks for that
+from the start.  `atom.n` is the caller's own array (`eqPops[name].pops`, rh_method.py:412-416): stat_equil writes it
+in place after every call, always.
+
 Deliberate differences, all outside the numbers the drivers use:
   * `t.Rij` / `t.Rji` are not produced (the reference accumulates them without ever zeroing or
     reading them, rh_method.py:691-692); accessing them raises AttributeError.
@@ -162,7 +170,7 @@ class ComputationalAtom:
         Nlevel = len(atom.levels)
         self.Nlevel = Nlevel
         self.Ntrans = len(self.trans)
-        self.Gamma = np.zeros((Nlevel, Nlevel, atmos.Nspace))
+        self._Gamma = np.zeros((Nlevel, Nlevel, atmos.Nspace))
         self.nStar = self.pops.nStar
         if self.pops.pops is not None:                         # warm start, :412-416
             self.n = self.pops.pops
@@ -171,6 +179,14 @@ class ComputationalAtom:
             self.pops.pops = self.n
         self._context = None
         self._index = None
+
+    @property
+    def Gamma(self):
+        """[Nlevel][Nlevel][Nspace], rh_method.py:587-590, 698-703 (fetched when first looked at, kept current from then on)"""
+        ctx = self._context
+        if ctx is None:
+            return self._Gamma
+        return ctx._lazy_out('Gamma')[self._index]
 
     @property
     def vBroad(self):
@@ -187,7 +203,7 @@ class Context:
     """rh_method.py:490-745 on the GPU."""
 
     def __init__(self, atmos, spect, eqPops, background, device: int = 0, stream=None, lib=None, setup: str = 'auto',
-                 formal_solver: str = 'linear'):
+                 formal_solver: str = 'linear', readback: str = 'lazy'):
         self.atmos = atmos
         self.atmos.nondimensionalise()
         self.spect = spect
@@ -196,8 +212,15 @@ class Context:
         self.activeAtoms: List[ComputationalAtom] = [ComputationalAtom(a, atmos, spect, eqPops)
                                                      for a in spect.radSet.activeAtoms]
         Nspect, Nspace, Nrays = spect.wavelength.shape[0], atmos.Nspace, atmos.Nrays
-        self.J = np.zeros((Nspect, Nspace))
-        self.I = np.zeros((Nspect, Nrays))
+        if readback not in ('lazy', 'eager'):
+            raise ValueError("readback must be 'lazy' or 'eager'")
+        # the result arrays (one object each for the life of the context, rewritten in place like the reference's), whether the
+        # device holds something newer (`_stale`), and whether somebody outside holds them (`_handed`: kept current and checked for edits)
+        self._host = {'J': np.zeros((Nspect, Nspace)), 'I': np.zeros((Nspect, Nrays)),
+                      'Gamma': [a._Gamma for a in self.activeAtoms]}
+        self._stale = {'J': False, 'I': False, 'Gamma': False}
+        self._handed = {k: readback == 'eager' for k in self._host}
+        self._J_synced = None
         models = [a.atomicModel for a in self.activeAtoms]
         if setup == 'auto':
             setup = 'native' if models_carry_atomic_data(models, atmos) else 'methods'
@@ -237,8 +260,56 @@ class Context:
             in_table = lambda m, l: _contains(spect.transitions, l)
             self._engine.set_atomic_data(atomdata.from_models(models, line_filter=in_table))
         self._upload()
-        self._n_synced = self._cat_n()
-        self._J_synced = self.J.copy()
+        self._n_synced = [np.array(a.n, dtype=np.float64) for a in self.activeAtoms]
+        if self._handed['J']:
+            self._J_synced = self._host['J'].copy()
+
+    # -- the live result arrays ------------------------------------------------------------
+    def _fetch(self, what):
+        eng = self._engine
+        if what == 'J':
+            self._host['J'][...] = eng.get(_capi.LSX_J)[0]
+            if self._handed['J']:
+                self._J_synced = self._host['J'].copy()
+        elif what == 'I':
+            self._host['I'][...] = eng.get(_capi.LSX_I)[0]
+        else:
+            G = eng.get(_capi.LSX_GAMMA)
+            for a, arr in enumerate(self._host['Gamma']):
+                arr[...] = eng.gamma_of_atom(G, a)[0]
+        self._stale[what] = False
+
+    def _lazy_out(self, what):
+        """the array, current; from now on somebody outside may hold it"""
+        if self._stale[what]:
+            self._fetch(what)
+        if not self._handed[what]:
+            self._handed[what] = True
+            if what == 'J':
+                self._J_synced = self._host['J'].copy()
+        return self._host[what]
+
+    @property
+    def J(self):
+        """[Nspect][Nspace] mean intensity, rh_method.py:562, 640"""
+        return self._lazy_out('J')
+
+    @J.setter
+    def J(self, value):
+        self._lazy_out('J')[...] = value          # found by the next call's comparison and sent down
+
+    @property
+    def I(self):
+        """[Nspect][Nrays] emergent intensity, rh_method.py:563, 638"""
+        return self._lazy_out('I')
+
+    def _results_changed(self, names):
+        """a call has rewritten these on the device: refresh the ones somebody holds, mark the others"""
+        for k in names:
+            if self._handed[k]:
+                self._fetch(k)
+            else:
+                self._stale[k] = True
 
     # -- packing -------------------------------------------------------------------------
     def _cat_n(self):
@@ -305,30 +376,28 @@ class Context:
     def update_collisions(self):
         """re-derive everything that depends on the atmosphere alone (the reference recomputes the collisional rates
         on every formal solution, rh_method.py:589) and keep J"""
-        J = self.J.copy()
+        if self._stale['J']:
+            self._fetch('J')
+        J = self._host['J'].copy()
         self._upload()
         self._engine.set(_capi.LSX_J, J[None])
 
     def _push_host_edits(self):
-        # the reference's arrays are live numpy objects the caller may edit between calls
-        n = self._cat_n()
-        if not np.array_equal(n, self._n_synced):
-            self._engine.set(_capi.LSX_N, n[None])
-            self._n_synced = n
-        if not np.array_equal(self.J, self._J_synced):
-            self._engine.set(_capi.LSX_J, self.J[None])
+        # the reference's arrays are live numpy objects the caller may edit between calls.  The populations are the caller's own
+        # arrays (eqPops[...].pops): compared on every call (a few kB).  J can only have been edited if it has been handed out.
+        if any(not np.array_equal(a.n, s) for a, s in zip(self.activeAtoms, self._n_synced)):
+            self._engine.set(_capi.LSX_N, self._cat_n()[None])
+            self._n_synced = [np.array(a.n, dtype=np.float64) for a in self.activeAtoms]
+        if self._handed['J'] and not np.array_equal(self._host['J'], self._J_synced):
+            self._engine.set(_capi.LSX_J, self._host['J'][None])
+            self._J_synced = self._host['J'].copy()
 
     # -- the two verbs ---------------------------------------------------------------------
     def formal_sol_gamma_matrices(self) -> float:
         """rh_method.py:565-708 -> max relative change of J"""
         self._push_host_edits()
         dJ = self._engine.formal_sol_gamma()
-        self.J[...] = self._engine.get(_capi.LSX_J)[0]
-        self.I[...] = self._engine.get(_capi.LSX_I)[0]
-        self._J_synced = self.J.copy()
-        G = self._engine.get(_capi.LSX_GAMMA)
-        for a, atom in enumerate(self.activeAtoms):
-            atom.Gamma[...] = self._engine.gamma_of_atom(G, a)[0]
+        self._results_changed(('J', 'I', 'Gamma'))
         return dJ
 
     def stat_equil(self) -> float:
@@ -338,10 +407,10 @@ class Context:
         dPops = self._engine.stat_equil()
         n = self._engine.get(_capi.LSX_N)[0]
         off = 0
-        for atom in self.activeAtoms:
+        for a, atom in enumerate(self.activeAtoms):
             atom.n[...] = n[off:off + atom.Nlevel]
+            self._n_synced[a] = n[off:off + atom.Nlevel]
             off += atom.Nlevel
-        self._n_synced = n
         return dPops
 
     def close(self):

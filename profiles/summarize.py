@@ -65,6 +65,26 @@ def main():
                     allk[r['Counter_Name']][nm] += float(r['Counter_Value'])
                     if 'k_gamma_finish' in r['Kernel_Name']:
                         ncalls[r['Counter_Name']] += 1
+    # ---- ceiling model (round 6): per kernel of a call, what the bytes it really moves and the vector instructions it really issues
+    # allow at best -- t_min = max(counter bytes / ACHIEVABLE_BW, VALU instructions * 4 cycles / (1024 SIMDs * held clock)) -- against
+    # what it takes alone (the --pmc passes serialise the kernels of a call: End - Start of a dispatch in the lightest pass, FETCH_SIZE +
+    # GRBM_GUI_ACTIVE, is the kernel alone on the machine).  ACHIEVABLE_BW: the 6.29 TB/s MI355X_MICROARCH.md measures; held clock: what
+    # the chip holds under the fp64 sweeps (in-kernel s_memtime / s_memrealtime, profiles/r03_bound_evidence.md 7: 1.9 GHz C3, 2.1 C4).
+    valu_all = collections.defaultdict(float)
+    dur_all = collections.defaultdict(list)
+    nvalu_calls = 0
+    for d in sorted(glob.glob(tag + '_pmc*')):
+        for f in glob.glob(os.path.join(d, '*counter_collection.csv')):
+            for r in csv.DictReader(open(f)):
+                if not any(x in r['Kernel_Name'] for x in FS_KERNELS):
+                    continue
+                nm = short(r['Kernel_Name'])
+                if r['Counter_Name'] == 'SQ_INSTS_VALU':
+                    valu_all[nm] += float(r['Counter_Value'])
+                    if 'k_gamma_finish' in r['Kernel_Name']:
+                        nvalu_calls += 1
+                if r['Counter_Name'] == 'FETCH_SIZE' and d.endswith('pmc3'):
+                    dur_all[nm].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
     if allk.get('FETCH_SIZE') and allk.get('WRITE_SIZE') and ncalls['FETCH_SIZE'] and ncalls['WRITE_SIZE']:
         per_kernel = {}
         for nm in sorted(set(allk['FETCH_SIZE']) | set(allk['WRITE_SIZE'])):
@@ -74,6 +94,32 @@ def main():
         out['fs_calls_counted'] = dict(ncalls)
         if ncol:
             out['fs_call_hbm_bytes_per_call_per_column'] = out['fs_call_hbm_bytes_per_call'] / ncol
+        if nvalu_calls and dur_all:
+            wl = sys.argv[3] if len(sys.argv) > 3 else 'c3'
+            held = {'c3': 1.9e9, 'c4': 2.1e9}.get(wl, 2.0e9)
+            bw = 6.29e12
+            cm = {}
+            calls3 = max(len(dur_all.get(next((k for k in dur_all if 'k_gamma_finish' in k), ''), [])), 1)
+            for nm in sorted(per_kernel):
+                v = valu_all.get(nm, 0.0) / nvalu_calls
+                alone = sum(dur_all.get(nm, [])) / calls3 * 1e-9            # seconds per call (a kernel launched several times per call: summed)
+                tb, tv = per_kernel[nm] / bw, v * 4.0 / (1024.0 * held)
+                cm[nm] = dict(hbm_bytes=round(per_kernel[nm]), valu_insts=round(v), alone_ms=round(alone * 1e3, 4), t_bytes_ms=round(tb * 1e3, 4),
+                              t_valu_ms=round(tv * 1e3, 4), bound='hbm' if tb >= tv else 'valu',
+                              frac_of_ceiling=round(max(tb, tv) / alone, 4) if alone else None)
+            tb = sum(per_kernel.values()) / bw
+            tv = sum(valu_all.values()) / nvalu_calls * 4.0 / (1024.0 * held)
+            sw = [k for k in cm if 'lsx_sweep_' in k]
+            out['ceiling_model'] = dict(
+                achievable_bw_Bps=bw, held_clock_Hz=held, per_kernel=cm,
+                call=dict(hbm_bytes=round(sum(per_kernel.values())), valu_insts=round(sum(valu_all.values()) / nvalu_calls),
+                          t_bytes_ms=round(tb * 1e3, 4), t_valu_ms=round(tv * 1e3, 4), bound='hbm' if tb >= tv else 'valu',
+                          alone_sum_ms=round(sum(c['alone_ms'] for c in cm.values()), 4)),
+                sweeps=dict(hbm_bytes=round(sum(cm[k]['hbm_bytes'] for k in sw)), valu_insts=round(sum(cm[k]['valu_insts'] for k in sw)),
+                            t_bytes_ms=round(sum(cm[k]['hbm_bytes'] for k in sw) / bw * 1e3, 4),
+                            t_valu_ms=round(sum(cm[k]['valu_insts'] for k in sw) * 4.0 / (1024.0 * held) * 1e3, 4)),
+                note='t_min = max(t_bytes, t_valu); a kernel alone cannot be faster than its own t_min, a call cannot be faster than the call\'s '
+                     '(its kernels overlap: the call is work conserving); bench.py divides the call\'s t_min by the LIVE duration')
     if ctr:
         pc = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in ctr.items()}
         out['sweep_counters_per_launch'] = {k: {c: round(v, 1) for c, v in d.items()} for k, d in sorted(pc.items())}
@@ -134,6 +180,14 @@ def main():
         # sweep_binding_resource, the clock the chip actually holds is measured in the kernel: profiles/stamps.py)
         if 'fs_call_hbm_bytes_per_call_per_column' in out:
             fig['hbm_bytes_per_call_per_column_all_kernels'] = out['fs_call_hbm_bytes_per_call_per_column']
+        if 'ceiling_model' in out and ncol:
+            c = out['ceiling_model']
+            fig['valu_insts_per_call_per_column_all_kernels'] = c['call']['valu_insts'] / ncol
+            fig['held_clock_Hz'] = c['held_clock_Hz']
+            fig['achievable_bw_Bps'] = c['achievable_bw_Bps']
+            fig['ceiling_per_kernel'] = {k: dict(v, hbm_bytes_per_column=v['hbm_bytes'] / ncol, valu_insts_per_column=v['valu_insts'] / ncol)
+                                         for k, v in c['per_kernel'].items()}
+            fig['ceiling_profiled_columns'] = ncol
         if fig:
             out['figures'] = fig
     cal = glob.glob(tag + '_calib/*counter_collection.csv')

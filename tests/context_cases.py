@@ -53,6 +53,47 @@ def context_warm_start_and_host_edits(lib):
     assert dP > 0.1
 
 
+def context_lazy_readback_keeps_the_reference_semantics(lib):
+    """round 6: J, I and Gamma are fetched when they are first looked at (test.py:20-29 and response_fn.py:11-21 read them after
+    the loop) -- and from then on rewritten IN PLACE by every call, like the reference's live arrays (rh_method.py:562-563, 640, 638,
+    587-590), with edits of J honoured.  A driver that never looks pays no read-back; one that holds the arrays sees what the
+    reference would show it.  atom.n (the caller's own array, :412-416) is written back by every stat_equil either way."""
+    d = dict(np.load(golden('falc_ca.npz')))
+    atmos, spect, eq, bg = build_fakes(d)
+    ctx = Context(atmos, spect, eq, bg, lib=lib)
+    fetched = []
+    real_get = ctx._engine.get
+    ctx._engine.get = lambda what, *a, **k: (fetched.append(what), real_get(what, *a, **k))[1]
+    atom = ctx.activeAtoms[0]
+    for it in range(1, 4):
+        ctx.formal_sol_gamma_matrices()
+    assert fetched == []                                             # three formal solutions, nothing read back
+    assert relerr(ctx.J, d['fs3_J']) < 1e-12                         # first look: fetched now
+    assert len(fetched) == 1
+    Jheld, Iheld = ctx.J, ctx.I
+    assert Jheld is ctx.J and Iheld is ctx.I                         # one array object each for the life of the context
+    assert relerr(Iheld, d['fs3_I']) < 1e-12
+    G = atom.Gamma
+    assert gamma_err(G.reshape(-1, 82), d['fs3_Gamma_a0'].reshape(-1, 82), _ONE_ATOM_6)[0] < 1e-11
+    ctx.formal_sol_gamma_matrices()                                  # the held arrays follow, in place
+    assert relerr(Jheld, d['fs4_J']) < 1e-12 and relerr(Iheld, d['fs4_I']) < 1e-12
+    assert G is atom.Gamma and gamma_err(G.reshape(-1, 82), d['fs4_Gamma_a0'].reshape(-1, 82), _ONE_ATOM_6)[0] < 1e-11
+    n_before = atom.n
+    dP = ctx.stat_equil()
+    assert dP == pytest.approx(float(d['se4_dPops']), rel=1e-7)
+    assert atom.n is n_before and eq['CA'].n is atom.n and relerr(atom.n, d['se4_n_a0']) < 1e-7
+    Jheld[...] = d['conv_J']                                         # an edit through the held reference reaches the device
+    atom.n[...] = d['conv_n_a0']
+    assert ctx.formal_sol_gamma_matrices() < 2e-3
+    ctx._engine.get = real_get
+    # readback='eager' is round 5's behaviour from the first call on
+    atmos, spect, eq, bg = build_fakes(d)
+    ctx2 = Context(atmos, spect, eq, bg, lib=lib, readback='eager')
+    ctx2.formal_sol_gamma_matrices()
+    assert relerr(ctx2._host['J'], d['fs1_J']) < 1e-12 and not ctx2._stale['J']
+    ctx.close(); ctx2.close()
+
+
 def context_two_active_atoms_order_and_shapes(lib):
     d = dict(np.load(golden('falc_cah.npz')))
     atmos, spect, eq, bg = build_fakes(d)

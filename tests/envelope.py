@@ -81,3 +81,128 @@ def first_call_inside(oracle_lib, prob, block, I, J, solver='linear', base=1e-11
     runs = oracle_runs(oracle_lib, make, 1, what=(_capi.LSX_I, _capi.LSX_J))
     inside(J, runs, 0, _capi.LSX_J, base)
     return inside(I, runs, 0, _capi.LSX_I, base)
+
+
+# ---- round 6: the bars BEHIND a statistical equilibrium are computed too ----------------------------------
+# After stat_equil two faithful implementations differ by more than after a formal solution alone, for two reasons, and both can be
+# COMPUTED from the oracle instead of typed into the tests:
+#   (1) what they differed by before goes through the solve and the next formal solutions: the +-1-ulp-exp runs of `oracle_runs` go
+#       through the same calls, so their spread after any call is the envelope there.  Behind the solve it holds in the maximum
+#       norm, not entry by entry (the hook moves every exponential the same way; LU rounding does not follow that pattern):
+#       `spread(...)`, K_ENVELOPE x the largest relative spread of the quantity.
+#   (2) the LU itself.  rh_method.py:736-741 solves Gamma' n = b per depth; LAPACK's dgesv (the reference, through scipy), the oracle's
+#       and the HIP kernel's dgetf2-ordered elimination may round differently.  The populations' response to that is the system's
+#       componentwise condition number, cond(k) = max_i (|A^-1| |A| |n|)_i / |n_i| (Skeel; A = Gamma' with the eliminated row
+#       replaced by ones): u cond is what ONE rounding of the data does.  Measured on the reference's own atoms (the reference's golden
+#       populations against the oracle's, first statistical equilibrium): CaII 9.5e-11 = 0.38 u cond, MgII 1.2e-9 = 0.37 u cond,
+#       iron 1.07e-8 = 0.46 u cond (cond = 2.1e8), carbon 5.8e-14 (cond 1e4: the envelope term decides there).
+#   populations after a statistical equilibrium:   bar_n = K_ENVELOPE spread_n + K_LU u cond        (per atom; K_LU = 3)
+#   I, J of a formal solution behind one:          bar   = single-call bar + K_ENVELOPE spread + 2 delta_n
+#   Gamma behind one (both measures of gamma_err): bar   = single-call bar + K_ENVELOPE spread + 4 delta_n
+# with delta_n = the deviation of the two implementations' populations MEASURED after the preceding statistical equilibrium (asserted
+# below bar_n there): S = eta / chi moves by at most the two levels' relative changes, J and I are averages of S, the radiative
+# rates are linear in I and in ratios of populations.
+K_LU = 3.0
+U_ROUND = 2.0 ** -53
+
+
+def lu_condition(prob, Gamma, n_old, n_new):
+    """per atom: the largest componentwise condition number of the statistical-equilibrium systems of rh_method.py:725-741 over
+    columns and depths.  Gamma [ncol][NL2tot][Ns] as the solve saw it, n_old [ncol][NLtot][Ns] (decides the eliminated row: the first
+    maximum), n_new the solution."""
+    out = []
+    Gamma, n_old, n_new = (np.asarray(x, dtype=np.float64) for x in (Gamma, n_old, n_new))
+    off = 0
+    for a in range(prob.Natoms):
+        nl, o = prob.Nlevel[a], prob.lev2_off[a]
+        A = Gamma[:, o:o + nl * nl, :].reshape(Gamma.shape[0], nl, nl, prob.Nspace).transpose(0, 3, 1, 2).copy()     # [col][k][l][l']
+        no = n_old[:, off:off + nl, :].transpose(0, 2, 1)                                                        # [col][k][l]
+        x = np.abs(n_new[:, off:off + nl, :].transpose(0, 2, 1))
+        ie = np.argmax(no, axis=-1)                                                                              # first maximum
+        ci, ki = np.indices(ie.shape)
+        A[ci, ki, ie, :] = 1.0
+        with np.errstate(all='ignore'):
+            Ai = np.linalg.inv(A)
+            cw = np.einsum('ckij,ckj->cki', np.abs(Ai), np.einsum('ckij,ckj->cki', np.abs(A), x)) / x
+        cw = cw[np.isfinite(cw)]
+        out.append(float(cw.max()) if cw.size else 0.0)
+        off += nl
+    return out
+
+
+def spread(runs, call, what, measure):
+    """`measure(x(+1 ulp), x(-1 ulp))` of the snapshot `what` after `call` (a maximum-norm measure: conftest.relerr, gamma_err)"""
+    return measure(runs[1][call][what], runs[-1][call][what])
+
+
+class SequenceBars:
+    """Three oracle runs (exp as it is, +1 ulp, -1 ulp) through `ncalls` formal solutions with a statistical equilibrium behind
+    call index >= se_from, and the LU's conditioning at every one of those: the computed bars of the header above.
+    make_engine() -> a loaded oracle Engine."""
+
+    def __init__(self, oracle_lib, make_engine, prob, ncalls, se_from):
+        self.prob, self.se_from = prob, se_from
+        self.runs, self.cond = {}, {}
+        try:
+            for ulp in (0, 1, -1):
+                oracle_lib.dll.lsx_oracle_set_exp_ulp(int(ulp))
+                e = make_engine()
+                snaps = []
+                for it in range(ncalls):
+                    e.formal_sol_gamma()
+                    s = {w: e.get(w) for w in (_capi.LSX_I, _capi.LSX_J, _capi.LSX_GAMMA)}
+                    if se_from is not None and it >= se_from:
+                        n_old = e.get(_capi.LSX_N)
+                        e.stat_equil()
+                        s[_capi.LSX_N] = e.get(_capi.LSX_N)
+                        if ulp == 0:
+                            self.cond[it] = lu_condition(prob, s[_capi.LSX_GAMMA], n_old, s[_capi.LSX_N])
+                    snaps.append(s)
+                e.close()
+                self.runs[ulp] = snaps
+        finally:
+            oracle_lib.dll.lsx_oracle_set_exp_ulp(0)
+
+    def oracle(self, call, what):
+        return self.runs[0][call][what]
+
+    def _rel(self, a, b):
+        a, b = np.asarray(a), np.asarray(b)
+        return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
+
+    def n_bar(self, call):
+        """largest admissible relative deviation of the populations after the statistical equilibrium behind `call`, per atom"""
+        bars, off = [], 0
+        for a in range(self.prob.Natoms):
+            nl = self.prob.Nlevel[a]
+            sp = self._rel(self.runs[1][call][_capi.LSX_N][:, off:off + nl], self.runs[-1][call][_capi.LSX_N][:, off:off + nl])
+            bars.append(K_ENVELOPE * sp + K_LU * U_ROUND * self.cond[call][a])
+            off += nl
+        return bars
+
+    def n_dev(self, n, ref, call=None):
+        """measured relative deviation per atom"""
+        n, ref = np.asarray(n), np.asarray(ref)
+        out, off = [], 0
+        for a in range(self.prob.Natoms):
+            nl = self.prob.Nlevel[a]
+            out.append(self._rel(n[..., off:off + nl, :], ref[..., off:off + nl, :]))
+            off += nl
+        return out
+
+    def check_n(self, n, ref, call, who=''):
+        dev, bar = self.n_dev(n, ref), self.n_bar(call)
+        assert all(d <= b for d, b in zip(dev, bar)), ('populations after the statistical equilibrium behind call %d%s: deviation per atom %s '
+                                                       'above the computed bars %s (u cond = %s)' % (call + 1, who, dev, bar, [U_ROUND * c for c in self.cond[call]]))
+        return max(dev)
+
+    def field_bar(self, call, what, base, delta_n, floor=1e-300):
+        """I or J of formal solution `call` (relative, maximum norm); delta_n: the populations' measured deviation going in (0 before
+        the first statistical equilibrium)"""
+        a, b = self.runs[1][call][what], self.runs[-1][call][what]
+        sp = float(np.max(np.abs(a - b) / np.maximum(np.abs(self.runs[0][call][what]), floor)))
+        return base + K_ENVELOPE * sp + 2.0 * delta_n
+
+    def gamma_bar(self, call, base_off, base_diag, delta_n, gamma_err):
+        eo, ed = gamma_err(self.runs[1][call][_capi.LSX_GAMMA], self.runs[-1][call][_capi.LSX_GAMMA], self.prob)
+        return base_off + K_ENVELOPE * eo + 4.0 * delta_n, base_diag + K_ENVELOPE * ed + 4.0 * delta_n

@@ -19,6 +19,10 @@ def test_context_on_hip_warm_start_and_host_edits(hip_lib):
     context_cases.context_warm_start_and_host_edits(None)
 
 
+def test_context_on_hip_lazy_readback(hip_lib):
+    context_cases.context_lazy_readback_keeps_the_reference_semantics(None)
+
+
 def test_context_on_hip_two_active_atoms(hip_lib):
     context_cases.context_two_active_atoms_order_and_shapes(None)
 

@@ -61,6 +61,10 @@ def test_context_warm_start_and_host_edits(oracle_lib):
     context_cases.context_warm_start_and_host_edits(oracle_lib)
 
 
+def test_context_lazy_readback_keeps_the_reference_semantics(oracle_lib):
+    context_cases.context_lazy_readback_keeps_the_reference_semantics(oracle_lib)
+
+
 def test_context_two_active_atoms_order_and_shapes(oracle_lib):
     context_cases.context_two_active_atoms_order_and_shapes(oracle_lib)
 

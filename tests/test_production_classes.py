@@ -11,11 +11,14 @@ velocity (2 km/s), so the line profiles are ray dependent and are built by each 
 
 Tolerances: first formal-solution call J, I <= tol relative, off-diagonal Gamma <= 10 tol, diagonal <= tol of
 its column's largest entry; tol = 1e-12 (CaII), 3e-11 (Ca+H: DESIGN 2, the w2 cancellation next to the Taylor switch);
-after 8 MALI iterations (5 of them with stat_equil) populations <= 1e-8."""
+after 8 MALI iterations (5 of them with stat_equil) the populations, J and I against bars computed from the oracle on the same columns
+(tests/envelope.py, SequenceBars; round 5: a flat 1e-8 / 1e-7)."""
 import ctypes as C
 
 import numpy as np
 import pytest
+
+import envelope
 
 from conftest import golden, relerr, gamma_err
 from lightspinner_amd import fixtures, synth, Engine, _capi
@@ -40,20 +43,34 @@ def class_table(lib, eng):
     return table, fused
 
 
-def _run_pair(hip_lib, oracle_lib, name, ncol, seed, tol, expect_classes, ntol=1e-8, iters=8, **engine_kw):
+_BARS = {}      # (fixture, columns, seed, iterations) -> envelope.SequenceBars: the two mappings of a case share the oracle's three runs
+
+
+def _run_pair(hip_lib, oracle_lib, name, ncol, seed, tol, expect_classes, iters=8, **engine_kw):
     """engine_kw: what the HIP engine is made with (sweep_policy=, options=: include/lsx.h, lsx_set_sweep_policy /
-    lsx_create_with_options) -- explicit arguments, not the process environment"""
+    lsx_create_with_options) -- explicit arguments, not the process environment.
+    Bars: `tol` on the first call (identical inputs); behind the statistical equilibria they are computed from the oracle on the
+    same columns (tests/envelope.py, SequenceBars: +-1-ulp-exp spread through the same calls, the LU's componentwise conditioning,
+    the population deviation measured going into a formal solution) -- round 5 asserted a flat 1e-8 / 1e-7 here."""
     prob, base, raw = fixtures.load_problem_npz(golden(name), phi_compact=False)
     blk, (aD, vB, vlos) = synth.perturbed_columns(prob, base, raw, ncol=ncol, seed=seed, vlos_sigma=2.0e3)
     assert vlos is not None and np.any(vlos[1] != 0.0)
-    engs = []
-    for lib in (hip_lib, oracle_lib):
-        e = Engine(prob, ncol, lib=lib, **(engine_kw if lib is hip_lib else {}))
+
+    def make_oracle():
+        e = Engine(prob, ncol, lib=oracle_lib)
         e.set_columns(0, blk)
         e.set_line_profiles(0, aD, vB, vlos)
-        engs.append(e)
-    hip, ora = engs
-    oracle_lib.dll.lsx_oracle_set_threads(ora._h, 8)
+        oracle_lib.dll.lsx_oracle_set_threads(e._h, 16)
+        return e
+    key = (name, ncol, seed, iters)
+    if key not in _BARS:
+        _BARS[key] = envelope.SequenceBars(oracle_lib, make_oracle, prob, iters, 3)
+    bars = _BARS[key]
+    hip = Engine(prob, ncol, lib=hip_lib, **engine_kw)
+    hip.set_columns(0, blk)
+    hip.set_line_profiles(0, aD, vB, vlos)
+    ora = make_oracle()
+    engs = [hip, ora]
     # ---- first call: identical inputs on both sides
     dJ, dJo = hip.formal_sol_gamma(), ora.formal_sol_gamma()
     assert dJ == dJo == 1.0
@@ -64,15 +81,20 @@ def _run_pair(hip_lib, oracle_lib, name, ncol, seed, tol, expect_classes, ntol=1
     # per-column monitors agree column by column
     assert np.allclose(hip.get(_capi.LSX_DJ_COL), ora.get(_capi.LSX_DJ_COL), rtol=1e-9)
     # ---- `iters` (8) MALI iterations (test.py:20-29: the first three update J only)
+    dn = dn_in = 0.0
     for it in range(2, iters + 1):
         dJ, dJo = hip.formal_sol_gamma(), ora.formal_sol_gamma()
         assert dJ == pytest.approx(dJo, rel=1e-6)
         if it > 3:
             dP, dPo = hip.stat_equil(), ora.stat_equil()
             assert dP == pytest.approx(dPo, rel=1e-6)
-    assert relerr(hip.get(_capi.LSX_N), ora.get(_capi.LSX_N)) < ntol
-    assert relerr(hip.get(_capi.LSX_J), ora.get(_capi.LSX_J), floor=1e-300) < ntol
-    assert relerr(hip.get(_capi.LSX_I), ora.get(_capi.LSX_I)) < ntol
+            dn_in = dn                                          # what the populations differed by going into this iteration's formal solution
+            dn = bars.check_n(hip.get(_capi.LSX_N), ora.get(_capi.LSX_N), it - 1, ' (HIP vs oracle, iteration %d)' % it)
+    bJ, bI = bars.field_bar(iters - 1, _capi.LSX_J, tol, dn_in), bars.field_bar(iters - 1, _capi.LSX_I, tol, dn_in)
+    eJ, eI = relerr(hip.get(_capi.LSX_J), ora.get(_capi.LSX_J), floor=1e-300), relerr(hip.get(_capi.LSX_I), ora.get(_capi.LSX_I))
+    print('%s %s: after %d iterations n %.2e (bars per atom %s), J %.2e (bar %.1e), I %.2e (bar %.1e)'
+          % (name, engine_kw, iters, dn, ['%.1e' % b for b in bars.n_bar(iters - 1)], eJ, bJ, eI, bI))
+    assert eJ < bJ and eI < bI, (eJ, bJ, eI, bI)
     # ---- the production instantiations are what ran
     table, fused = class_table(hip_lib, hip)
     assert fused == 0, 'the fused small-batch kernel must not be what this test measures'
@@ -143,9 +165,9 @@ def test_multilevel_reference_atoms_per_class_path(hip_lib, oracle_lib, name, mo
     # statistical equilibria of five atoms each.
     iters = 7 if name == 'falc_all.npz' else 8
     if mode == 'unlinked':
-        table = _run_pair(hip_lib, oracle_lib, name, 33, 2468, 3e-11, unlinked, ntol=1e-7, iters=iters, options='linked=0')
+        table = _run_pair(hip_lib, oracle_lib, name, 33, 2468, 3e-11, unlinked, iters=iters, options='linked=0')
     else:
-        table = _run_pair(hip_lib, oracle_lib, name, 36, 2468, 3e-11, linked, ntol=1e-7, iters=iters, sweep_policy=mode)
+        table = _run_pair(hip_lib, oracle_lib, name, 36, 2468, 3e-11, linked, iters=iters, sweep_policy=mode)
         # the classes with at most two per-ray slots run the mapping that was asked for, the others one ray per lane -- and so does a
         # class with linked continua if one of its tiles needs the row-mapped epilogue (more than six continua of an atom at a
         # wavelength, as carbon's and magnesium's have: the ray-serial instances leave the linked corrections to the column-mapped one)
