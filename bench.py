@@ -279,55 +279,88 @@ def roofline_block(eng, lib, prob, ncol, workload, kernel_reps):
                         insts_per_launch=fig['valu_insts_per_call_per_column'] * ncol,
                         source='%s (instruction counts from a builder-run rocprofv3 --pmc pass of this command at source hash %s, per '
                                'column; divided by the LIVE duration)' % (src, fig.get('csrc_hash')))
-    return dict(bound='hbm', bound_means='the roofline the metric is DEFINED on (BASELINE.json north_star: fraction of the HBM roofline); what the '
-                                         'kernel actually waits for is in `limited_by` / `binding`',
-                binding='vector issue and memory-request latency at two waves per SIMD (neither HBM bytes nor the vector pipe is saturated: VALU busy 0.5-0.56 '
-                        'in the line classes, waves wait 24-37 % of their cycles; profiles/r05_pmc_summary.json)',
-                kernel='the sweep of one formal solution: lsx_sweep_rs_kernel<slots,lines,linked,topo> (ray-serial, five columns per '
-                                    'wavefront: every tile class with at most two per-ray slots in contexts of >= 160 columns) and '
-                                    'lsx_sweep_kernel<slots,lines,rays,sca,linked,topo> (one ray per lane: the other classes and smaller contexts), '
-                                    'one instance per tile class, launched side by side; duration = span',
-                achieved=ach, peak=HBM_PEAK_GBPS, unit='GB/s', frac=ach / HBM_PEAK_GBPS, frac_of_measured_peak=ach / HBM_MEASURED_GBPS,
-                measured_peak=HBM_MEASURED_GBPS, traffic=traffic,
-                # the same duration against the bytes the sweeps REALLY move past the L2 (counter figure, over-fetch and the second
-                # direction's re-reads included): how close the kernel is to the memory system in real, not algorithmic, bytes
-                traffic_GBps=(traffic / (ms_sweep * 1e-3) / 1e9) if traffic else None,
-                traffic_frac_of_peak=(traffic / (ms_sweep * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                traffic_frac_of_measured_peak=(traffic / (ms_sweep * 1e-3) / 1e9 / HBM_MEASURED_GBPS) if traffic else None,
+    # ---- ceiling model: what the bytes the call REALLY moves and the vector instructions it REALLY issues
+    # allow at best, t_min = max(counter bytes / 6.29 TB/s, VALU instructions x 4 cycles / (1024 SIMDs x held clock)), against the live
+    # durations -- per call, for the sweeps, and per kernel alone (the profile run's serialized durations).  `bound` is the larger term.
+    ceiling = None
+    bound = 'hbm'
+    if fig and not stale and traffic_all and fig.get('valu_insts_per_call_per_column_all_kernels'):
+        bw, held = fig.get('achievable_bw_Bps', HBM_MEASURED_GBPS * 1e9), fig.get('held_clock_Hz', HELD_CLOCK_HZ)
+        price = 4.0 / (N_SIMD * held)
+        tb_call, tv_call = traffic_all / bw * 1e3, fig['valu_insts_per_call_per_column_all_kernels'] * ncol * price * 1e3
+        tb_sw, tv_sw = traffic / bw * 1e3, fig['valu_insts_per_call_per_column'] * ncol * price * 1e3
+        bound = 'hbm' if tb_call >= tv_call else 'valu'
+        per_kernel = None
+        if fig.get('ceiling_per_kernel'):
+            per_kernel = {k: dict(t_bytes_ms=v['hbm_bytes_per_column'] * ncol / bw * 1e3, t_valu_ms=v['valu_insts_per_column'] * ncol * price * 1e3,
+                                  bound=v['bound'], alone_ms_profiled=v['alone_ms'], frac_of_ceiling_profiled=v['frac_of_ceiling'])
+                          for k, v in fig['ceiling_per_kernel'].items()}
+        ceiling = dict(achievable_bw_GBps=bw / 1e9, held_clock_GHz=held / 1e9,
+                       call=dict(t_bytes_ms=tb_call, t_valu_ms=tv_call, t_min_ms=max(tb_call, tv_call), bound=bound, measured_ms=ms_total,
+                                 frac_of_ceiling=max(tb_call, tv_call) / ms_total),
+                       sweeps=dict(t_bytes_ms=tb_sw, t_valu_ms=tv_sw, t_min_ms=max(tb_sw, tv_sw), bound='hbm' if tb_sw >= tv_sw else 'valu',
+                                   measured_ms=ms_sweep, frac_of_ceiling=max(tb_sw, tv_sw) / ms_sweep),
+                       per_kernel_alone=per_kernel,
+                       definition='t_min = max(HBM bytes from the counters / achievable bandwidth, wave64 VALU instructions x 4 cycles / (1024 SIMDs x '
+                                  'the clock the chip holds under the kernel)); frac_of_ceiling = t_min / measured (live HIP events for `call` and '
+                                  '`sweeps`; per_kernel_alone: each kernel alone on the machine in the builder\'s counter run at profiled_columns = %s, '
+                                  'profiles/summarize.py).  Bytes and instruction counts: %s at source hash %s, per column x columns; 6.29 TB/s and the '
+                                  'held clock: MI355X_MICROARCH.md / profiles/r03_bound_evidence.md 7.  A call whose bytes AND instructions overlapped '
+                                  'perfectly would take t_min: frac_of_ceiling says how far the kernels are from what the work they do allows, `frac` '
+                                  '(algorithmic bytes / 8 TB/s) how far the DESIGN is from the algorithm\'s bytes.'
+                                  % (fig.get('ceiling_profiled_columns'), src, fig.get('csrc_hash')))
+    ach_call = balg * ncol / (ms_total * 1e-3) / 1e9
+    return dict(bound=bound, bound_means='the larger term of the ceiling model (`ceiling`: counter bytes / 6.29 TB/s against VALU instructions / issue rate at the held clock); '
+                                         '"hbm" when the counters are stale (the roofline the metric is defined on, BASELINE.json north_star)',
+                binding='HBM bytes the call really moves (2.3-2.4 x the algorithmic bytes on C4, 1.5 x on C3) at ~0.7 of the achievable bandwidth, with vector issue '
+                        'close behind (t_valu = 0.7-0.75 t_bytes) at two waves per SIMD: `ceiling`',
+                kernel='one formal solution = every kernel of the call (SURVEY 8d: Ncol B_alg / t_FS): operand-table build, the sweep classes side by side '
+                       '(lsx_sweep_rs_kernel<slots,lines,linked,topo,...>, ray-serial, five columns per wavefront: every tile class with at most two per-ray '
+                       'slots in contexts of >= 160 columns; lsx_sweep_kernel<...>, one ray per lane: the other classes and smaller contexts), the '
+                       'fast-continuum epilogue behind each class, the Gamma epilogue.  The sweep classes alone: `sweep_*`',
+                # headline: the SURVEY 8d definition -- algorithmic bytes of the whole call over the whole call's duration
+                achieved=ach_call, peak=HBM_PEAK_GBPS, unit='GB/s', frac=ach_call / HBM_PEAK_GBPS, frac_of_measured_peak=ach_call / HBM_MEASURED_GBPS,
+                avg_launch_ms=ms_total, alg_bytes_per_launch=balg * ncol,
+                # ... and the dominant kernels alone (rounds 1-5's headline): the sweep's share of the algorithmic bytes over the sweep span
+                sweep_achieved=ach, sweep_frac=ach / HBM_PEAK_GBPS, sweep_frac_of_measured_peak=ach / HBM_MEASURED_GBPS, sweep_span_ms=ms_sweep,
+                sweep_alg_bytes_per_launch=bsweep * ncol,
+                measured_peak=HBM_MEASURED_GBPS, traffic=traffic_all, sweep_traffic=traffic,
+                # the same durations against the bytes REALLY moved past the L2 (counter figure, over-fetch and the second
+                # direction's re-reads included): how close the kernels are to the memory system in real, not algorithmic, bytes
+                traffic_GBps=(traffic_all / (ms_total * 1e-3) / 1e9) if traffic_all else None,
+                sweep_traffic_GBps=(traffic / (ms_sweep * 1e-3) / 1e9) if traffic else None,
+                traffic_frac_of_peak=(traffic_all / (ms_total * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic_all else None,
+                traffic_frac_of_measured_peak=(traffic_all / (ms_total * 1e-3) / 1e9 / HBM_MEASURED_GBPS) if traffic_all else None,
+                traffic_over_alg=(traffic_all / (balg * ncol)) if traffic_all else None,
                 traffic_stale=bool(stale) if fig else None,
                 traffic_source=('%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a builder run at source hash %s, (2*FETCH_SIZE + '
-                                'WRITE_SIZE)*1024 per call per column x columns; not measured in this run%s'
+                                'WRITE_SIZE)*1024 per call per column x columns, every kernel of the call (`sweep_traffic`: the sweep classes); not measured in this run%s'
                                 % (src, fig.get('csrc_hash'), '; STALE: the kernel sources have changed since, so the figure is withheld' if stale else ''))
                 if fig else None,
-                valu=valu, alg_bytes_per_launch=bsweep * ncol, avg_launch_ms=ms_sweep,
-                limited_by='not HBM: with its stream loads removed the ray-serial sweep is 10-15 % faster (no-load ablation). It holds 150-256 '
-                           'vector registers, i.e. two waves per SIMD; at that occupancy the vector pipe is about half busy (counter instruction '
-                           'mix x cycle costs / kernel cycles) and waves wait 40-48 % of their cycles: latency at two waves per SIMD. The '
-                           'one-ray-per-lane kernel it replaced sat on vector issue at the clock the chip holds under fp64 load (1.6-1.8 GHz) '
-                           '(profiles/r03_bound_evidence.md: in-kernel clock, stamps, occupancy sweep, ablations, class schedule). Round 4 '
-                           '(profiles/r04_bound_evidence.md): without its J / Psibar stores it is 7-10 % faster, with a fifth of the profile bytes '
-                           '15-18 %: memory queueing latency against one depth of prefetch; a third wave per SIMD does not fit the register file. '
-                           'Round 5 (profiles/r05_bound_evidence.md): a SECOND depth of prefetch was built and changes nothing (the kernel does not '
-                           'wait for HBM at one depth), while ONE more stream per step (the Boltzmann factor of the folded fast continua) costs 8 % -- '
-                           'what is scarce is vector issue and memory REQUESTS per wave at two waves per SIMD, not bytes; the per-depth operands now '
-                           'come through a ring in LDS (no depth limit) and the fast continua\'s opacity is formed in the lane (no pre-pass). In REAL bytes '
-                           '(traffic_GBps: counter traffic over the live duration) the sweeps move 4.1-4.5 TB/s = 0.65-0.72 of the achievable rate; a wave\'s '
-                           'prologue is 8-13 % of its life and not on the critical path (shortened by a third: no change) -- r05_bound_evidence.md 6, 7',
-                fs_call=dict(ms=ms_total, ms_sweep_kernel=ms_sweep, ms_epilogue_kernels=info(4), alg_bytes=balg * ncol,
+                ceiling=ceiling, valu=valu,
+                limited_by='real HBM bytes first, vector issue second (`ceiling`): a C4 call moves 2.3-2.4 x its algorithmic bytes -- both directions of a '
+                           'column read the ray-independent streams (they visit the depths in opposite order: the reuse distance is a workgroup\'s lifetime, '
+                           'far beyond the L2: cache-policy hints change FETCH_SIZE by 1-2 %, profiles/r06_bound_evidence.md), J leaves as a half and again '
+                           'as a total, the angle sums of Psi* leave per direction for the fast-continuum epilogue -- at 4.1-4.5 TB/s of the 6.29 achievable; '
+                           'the sweeps hold 150-256 vector registers (two waves per SIMD) and issue 0.7 of what the byte floor\'s time allows. History of what '
+                           'was tried and measured: profiles/r03..r06_bound_evidence.md',
+                fs_call=dict(ms=ms_total, ms_sweep_kernel=ms_sweep, ms_gamma_finish=info(4), ms_fast_epilogue_exposed=info(6),
+                             ms_note='ms_sweep_kernel: fork -> end of the last class\'s sweep; ms_fast_epilogue_exposed: from there to the join (the fast-continuum '
+                                     'epilogue of the class that finishes last, which nothing hides); ms_gamma_finish: the Gamma epilogue behind the join; ms: '
+                                     'everything, operand-table build included',
+                             alg_bytes=balg * ncol,
                              traffic=traffic_all, traffic_over_alg=(traffic_all / (balg * ncol)) if traffic_all else None,
                              traffic_note='HBM bytes of EVERY kernel of a formal solution (sweeps, fast-continuum kernels, operand-table build, '
                                           'Gamma epilogue) from the same counter passes as roofline.traffic (profiles/summarize.py: '
                                           'fs_call_hbm_bytes_per_call); null when those figures are stale',
-
-                             achieved_GBps=balg * ncol / (ms_total * 1e-3) / 1e9,
-                             frac=balg * ncol / (ms_total * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                             frac_of_measured_peak=balg * ncol / (ms_total * 1e-3) / 1e9 / HBM_MEASURED_GBPS),
+                             achieved_GBps=ach_call, frac=ach_call / HBM_PEAK_GBPS, frac_of_measured_peak=ach_call / HBM_MEASURED_GBPS),
                 point_updates_per_sec_kernel=prob.work_units_per_column() * ncol / (ms_sweep * 1e-3),
                 tiles_per_column=info(1), wavelengths_per_tile=info(3), lds_bytes_per_workgroup=info(2),
                 slab_bytes_per_column=info(5),
-                note='achieved / peak / frac = ALGORITHMIC bytes (SURVEY 8d) over the HIP-event duration of the sweep (events on the launch '
-                     'streams: before the first class launch -> after the last class joined back; profiles/README.md), against the HBM peak '
-                     'the metric is defined on.  `limited_by` says what the kernel actually runs against.')
+                note='achieved / peak / frac = ALGORITHMIC bytes of one formal solution (SURVEY 8d: Ncol B_alg) over the HIP-event duration of the whole '
+                     'call (events on the context\'s stream around the call: every kernel, the forked class streams joined back), against the 8 TB/s HBM '
+                     'peak the metric is defined on.  sweep_*: the sweep classes alone (their share of the bytes over fork -> last class end).  `ceiling` '
+                     'says what the kernels run against.')
 
 
 def timed_steps(eng, reducer, nsteps, warmup, barrier):
@@ -371,7 +404,7 @@ def measure_share(workload, ncol, local_rank, lib, torch, steps=40, warmup=3, ke
     return dict(workload='C4 share: %d FALC-perturbed Ca+H columns on one GPU (10 000 / 8), 82 depth x %d wavelengths x 5 rays x 2'
                          % (ncol, prob.Nspect),
                 columns=ncol, steps=steps, value=units / dt, unit='point-updates/s', ms_per_step=dt / steps * 1e3,
-                step_ms=stats_ms(per), last_dJ=dJ, last_dPops=dP, sweep_span_ms=roof['avg_launch_ms'], roofline=roof,
+                step_ms=stats_ms(per), last_dJ=dJ, last_dPops=dP, sweep_span_ms=roof['sweep_span_ms'], roofline=roof,
                 generate_s=t_gen, sweep_policy=policy)
 
 
@@ -499,7 +532,7 @@ def main():
     # one MALI iteration: both calls are enqueued, the monitors are read once -- what the reference's
     # `while dJ > 2e-3 or dPops > 1e-3` loop needs per iteration (test.py:23-29).  Over several ranks the monitors stay
     # on the device until RCCL has reduced them (parallel.MaxReducer.engine)
-    reducer = MaxReducer(device=dev, stream=ts) if world > 1 else None
+    reducer = MaxReducer(device=dev, stream=ts).attach(eng) if world > 1 else None      # (attach: the ranks compare their engines' options signatures here, all at once)
 
     def barrier():
         if world > 1:
@@ -617,18 +650,24 @@ def main():
         # short keys LAST, so that they survive a reader that keeps only the tail of the line: the headline workload and, at N = 1,
         # the north-star workload's per-GPU share (BASELINE.json: 10^4 Ca+H columns over 8 GPUs), each with its roofline fractions
         r = result['roofline']
-        result['summary'] = dict(workload=args.workload, ms_per_step=result['ms_per_step'], sweep_ms=r['avg_launch_ms'], sweep_frac=r['frac'],
-                                 fs_call_ms=r['fs_call']['ms'], fs_call_frac=r['fs_call']['frac'], frac_of_measured_peak=r['frac_of_measured_peak'])
+        cl = r.get('ceiling') or {}
+        result['summary'] = dict(workload=args.workload, ms_per_step=result['ms_per_step'], sweep_ms=r['sweep_span_ms'], sweep_frac=r['sweep_frac'],
+                                 fs_call_ms=r['fs_call']['ms'], fs_call_frac=r['frac'], frac_of_measured_peak=r['frac_of_measured_peak'],
+                                 traffic_over_alg=r['traffic_over_alg'], bound=r['bound'],
+                                 frac_of_ceiling=(cl.get('call') or {}).get('frac_of_ceiling'))
         c4 = result.get('c4_share')
         if c4:
             q = c4['roofline']
             result['c4_ms_per_step'] = c4['ms_per_step']
             result['c4_updates_per_s'] = c4['value']
             result['c4_fs_call_ms'] = q['fs_call']['ms']
-            result['c4_sweep_ms'] = q['avg_launch_ms']
-            result['c4_sweep_frac'] = q['frac']
-            result['c4_fs_call_frac'] = q['fs_call']['frac']
-        result['c3_sweep_frac' if args.workload == 'c3' else 'sweep_frac'] = r['frac']
+            result['c4_sweep_ms'] = q['sweep_span_ms']
+            result['c4_sweep_frac'] = q['sweep_frac']
+            result['c4_fs_call_frac'] = q['frac']
+            result['c4_traffic_over_alg'] = q['traffic_over_alg']
+            result['c4_frac_of_ceiling'] = ((q.get('ceiling') or {}).get('call') or {}).get('frac_of_ceiling')
+        result['c3_sweep_frac' if args.workload == 'c3' else 'sweep_frac'] = r['sweep_frac']
+        result['c3_fs_call_frac' if args.workload == 'c3' else 'fs_call_frac'] = r['frac']
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

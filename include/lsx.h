@@ -232,6 +232,10 @@ int lsx_stat_equil(lsx_ctx* ctx, double* dPops_max);
  * most recent calls (either pointer may be NULL). */
 int lsx_formal_sol_gamma_async(lsx_ctx* ctx);
 int lsx_stat_equil_async(lsx_ctx* ctx);
+/* lsx_sync returns when the monitors of the calls enqueued so far have been read back -- which implies that those calls have
+ * finished.  The HIP library may leave work of its own running behind that read-back (it rebuilds the ray-serial sweeps' operand
+ * table there after a stat_equil, while the host decides on the next iteration): every later call, lsx_get included, is ordered behind
+ * it on the context's stream. */
 int lsx_sync(lsx_ctx* ctx, double* dJ_max, double* dPops_max);
 
 /* ---- the MALI loop without a host round trip per iteration (test.py:20-29: `while dJ > 2e-3 or dPops > 1e-3`) ----------
@@ -260,6 +264,16 @@ int lsx_sync(lsx_ctx* ctx, double* dJ_max, double* dPops_max);
  *   have not been read back (`FS; SE; FS; lsx_sync`, `SE_async; lsx_formal_sol_gamma(&dJ)`) leaves them in place. */
 int lsx_sync_begin(lsx_ctx* ctx);
 int lsx_sync_end(lsx_ctx* ctx, double* dJ_max, double* dPops_max);
+/* lsx_sync_begin that also brings the POPULATIONS back (round 6): behind the monitors the read-back copies `n` of every column into a
+ * host buffer of the context; once lsx_sync_end has returned, lsx_fetch_populations copies it out ([ncol][NLtot][Nspace], the layout of
+ * lsx_get(LSX_N); nbytes must match) -- host memory to host memory, whatever has been enqueued behind the read-back.
+ * What it is for: Context.stat_equil() must leave the new populations in the CALLER's array (atom.n is eqPops[name].pops,
+ * rh_method.py:412-416, 736-741; read by response_fn.py:62) before it returns.  With lsx_get that copy would wait for everything
+ * enqueued so far -- including the next iteration's speculative formal solution; with this pair the drop-in Context enqueues that
+ * formal solution behind the read-back and the GPU goes from stat_equil into it while the host returns to the driver's loop
+ * (lightspinner_amd/rh_method.py).  lsx_fetch_populations without such a read-back collected: LSX_EINVAL. */
+int lsx_sync_begin_populations(lsx_ctx* ctx);
+int lsx_fetch_populations(lsx_ctx* ctx, double* dst, size_t nbytes);
 int lsx_formal_sol_gamma_speculative(lsx_ctx* ctx);
 int lsx_discard_formal_sol(lsx_ctx* ctx);
 /* 1 if enqueueing ahead pays for this context, else 0.  HIP library: 1 for contexts whose formal solution is one launch chain
@@ -420,12 +434,16 @@ int32_t lsx_sweep_policy(const lsx_ctx* ctx);
  *     rs=0|1 (ray-serial instances at all), rs_min_columns=N (LSX_SWEEP_AUTO's threshold), rs_max_npt=0..2,
  *     fold=0|1 and epi=0|1 (the fast continua's opacities / rate integrands formed inside the ray-serial sweep); launch shape and
  *     measurement only (same bits, tested): order=plan|cost, occ_wg=N, phi_group=0|1, se_lds, serial, finish_big, finish_lds (the Gamma
- *     epilogue with a thread's matrix in LDS instead of a thread per column), fused_epilogue, graph, fused_fast (each 0|1), trace_classes.  Unknown keys / malformed values: LSX_EINVAL.  The LSX_* environment variables
+ *     epilogue with a thread's matrix in LDS instead of a thread per column), fused_epilogue, graph, fused_fast (each 0|1), trace_classes,
+ *     class_chunk=N (cut a class into launch groups of N tiles: a measured alternative, same bits).  Unknown keys / malformed values: LSX_EINVAL.  The LSX_* environment variables
  *     of rounds 1-4 remain as diagnostic DEFAULTS that an explicit entry overrides;
  *   - lsx_effective_options writes what the context ended up with, plus the rule, the sweep mapping the policy selects and the
- *     plan's class list, as one "key=value;..." string (LSX_EINVAL if `n` is too small: 1024 bytes are enough for any context);
+ *     plan's class list, the ABI version and the library's build id (lsx_build_id), as one "key=value;..." string.  If `n` is too
+ *     small: LSX_EINVAL, and the message of lsx_last_error() names the bytes needed; 4096 bytes hold every context of the reference's
+ *     atoms (the class list grows with the plan: class_chunk can make it longer);
  *   - lsx_options_signature is a 64-bit hash of that string.  Contexts with equal signatures on equal problems give every column
- *     the same bits; a multi-process driver exchanges the signatures once and refuses to start on a mismatch
+ *     the same bits -- the string names the BUILD of the library too (two ranks that load different builds of liblsx_hip.so, e.g. through
+ *     LSX_HIP_LIBRARY, differ in it and are refused like ranks with different options); a multi-process driver exchanges the signatures once and refuses to start on a mismatch
  *     (lightspinner_amd/parallel.py, check_same_options).
  * The oracle accepts any well-formed list, ignores it and reports "backend=oracle-c". */
 int lsx_create_with_options(const lsx_problem* desc, int32_t ncol, int32_t device, void* stream, const char* options, lsx_ctx** out);
@@ -441,6 +459,9 @@ int lsx_time_formal_sol(lsx_ctx* ctx, int32_t warmup, int32_t reps, double* ms_t
 /* Introspection */
 const char* lsx_last_error(void);
 const char* lsx_backend_name(void);    /* "hip-gfx950" or "oracle-c"                   */
+/* 16 hex digits: hash of the sources this library was built from (csrc/Makefile; the oracle: "oracle-c").  Part of
+ * lsx_effective_options / lsx_options_signature. */
+const char* lsx_build_id(void);
 int32_t lsx_abi_version(void);
 /* Algorithmic bytes one FS call moves per column (SURVEY 8d formula) */
 double lsx_algorithmic_bytes_per_column(const lsx_ctx* ctx);

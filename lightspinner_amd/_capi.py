@@ -99,6 +99,7 @@ REQUIRED_SYMBOLS = (
     'lsx_sync_begin', 'lsx_sync_end', 'lsx_formal_sol_gamma_speculative', 'lsx_discard_formal_sol', 'lsx_prefers_lookahead',
     'lsx_set_sweep_policy', 'lsx_sweep_policy',
     'lsx_create_with_options', 'lsx_effective_options', 'lsx_options_signature',
+    'lsx_sync_begin_populations', 'lsx_fetch_populations', 'lsx_build_id',
 )
 
 
@@ -180,6 +181,9 @@ class LsxLibrary:
         d.lsx_monitors.argtypes = [C.c_void_p, C.c_void_p]
         d.lsx_sync_begin.argtypes = [C.c_void_p]
         d.lsx_sync_end.argtypes = [C.c_void_p, _dp, _dp]
+        d.lsx_sync_begin_populations.argtypes = [C.c_void_p]
+        d.lsx_fetch_populations.argtypes = [C.c_void_p, _dp, C.c_size_t]
+        d.lsx_build_id.restype = C.c_char_p
         d.lsx_formal_sol_gamma_speculative.argtypes = [C.c_void_p]
         d.lsx_discard_formal_sol.argtypes = [C.c_void_p]
         d.lsx_prefers_lookahead.argtypes = [C.c_void_p]

@@ -53,6 +53,7 @@ struct lsx_ctx : lsxd::LsxPlan {        // the plan (lsx_plan.h: dimensions, tab
     std::vector<SweepClass> classes;     // plan_classes, in launch order
     hipEvent_t ev_fork = nullptr;
     double ms_sweep = 0.0, ms_finish = 0.0;
+    double ms_epi_tail = 0.0;   // lsx_time_formal_sol: join - end of the last class's sweep (exposed fast-continuum epilogue)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     // device: column independent
     double *d_wavelength = nullptr, *d_zmu = nullptr, *d_wmuh = nullptr, *d_wl = nullptr, *d_alpha = nullptr,
@@ -106,6 +107,8 @@ struct lsx_ctx : lsxd::LsxPlan {        // the plan (lsx_plan.h: dimensions, tab
     double* d_stage = nullptr;
     size_t stage_doubles = 0;
     double* h_pinned = nullptr; // host mirror of d_res
+    double* h_n = nullptr;      // pinned host mirror of the populations (lsx_sync_begin_populations), made on first use
+    bool h_n_pending = false, h_n_valid = false;      // a read-back of n is in flight / has been collected by lsx_sync_end
     double last_dJ = 0.0, last_dP = 0.0;
     bool fs_pending = false, se_pending = false;
     hipEvent_t evA = nullptr, evB = nullptr;

@@ -1256,6 +1256,7 @@ extern "C" {
 const char* lsx_last_error(void) { return lsxd::g_err.c_str(); }
 const char* lsx_backend_name(void) { return "hip-gfx950"; }
 int32_t lsx_abi_version(void) { return LSX_ABI_VERSION; }
+// lsx_build_id(): build/lsx_build_id.cpp, written by the Makefile from a hash of the sources
 
 void lsx_destroy(lsx_ctx* c)
 {
@@ -1291,6 +1292,7 @@ void lsx_destroy(lsx_ctx* c)
     if (c->evA) (void)hipEventDestroy(c->evA);
     if (c->evB) (void)hipEventDestroy(c->evB);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->h_n) (void)hipHostFree(c->h_n);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1780,11 +1782,11 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
     // error is remembered and reported at the end (shapes, LDS sizes and grids were checked when the context was made).
     hipError_t lerr = hipSuccess;
     auto note = [&](hipError_t e) { if (e != hipSuccess && lerr == hipSuccess) lerr = e; };
-    if (timed) note(hipEventRecord(c->ev0, c->stream));
     if (rs_any && !c->optab_fresh) {
         launch_build_optab(c);
         c->optab_fresh = true;
     }
+    if (timed) note(hipEventRecord(c->ev0, c->stream));       // the sweep span starts behind the operand-table build (the whole-call figure, evA, in front of it)
     // small batches: one fused launch (n_class_tiles == ntile, identity tile list is not needed); the parabolic rule (N4) has one
     // generic instance for every tile and takes the same route at any size
     const bool parabolic = c->solver == LSX_SOLVER_PARABOLIC;
@@ -1983,6 +1985,12 @@ int lsx_stat_equil_async(lsx_ctx* c)
 {
     if (!c) return fail(LSX_EINVAL, "null ctx");
     c->spec_valid = false;            // the populations now build on the last formal solution
+    c->optab_fresh = false;           // the populations change (cleared FIRST: an early return below must not leave a stale table marked fresh)
+    for (int a = 0; a < c->Natoms; ++a) {       // nothing is launched unless every atom's system can be: the call does not fail partway
+        const size_t sm = (size_t)(c->Nlevel[a] * c->Nlevel[a] + 2 * c->Nlevel[a]) * 64 * sizeof(double);
+        if ((c->opt_se_lds || c->Nlevel[a] > 8) && sm > 160 * 1024)
+            return fail(LSX_EUNSUPPORTED, "stat_equil: Nlevel = %d needs %zu B of LDS", c->Nlevel[a], sm);
+    }
     HIPCHK(hipSetDevice(c->device));
     // dPcol and the singular flag behind it start at zero: the Gamma epilogue of the formal solution has done that, unless
     // this is a second stat_equil on the same Gamma
@@ -2053,18 +2061,41 @@ static unsigned long long digest_monitors(lsx_ctx* c, bool fs, bool se)
     return sing;
 }
 
-int lsx_sync_begin(lsx_ctx* c)
+static int sync_begin(lsx_ctx* c, bool with_n)
 {
     if (!c) return fail(LSX_EINVAL, "null ctx");
     if (c->mon_outstanding) return fail(LSX_EINVAL, "lsx_sync_begin: the previous read-back has not been collected (lsx_sync_end)");
     HIPCHK(hipSetDevice(c->device));
     if (!c->ev_mon) HIPCHK(hipEventCreateWithFlags(&c->ev_mon, hipEventDisableTiming));
+    c->h_n_valid = false;
+    c->h_n_pending = false;
+    const size_t n_bytes = (size_t)c->ncol * c->NLtot * c->Nspace * sizeof(double);
+    if (with_n && !c->h_n && hipHostMalloc(reinterpret_cast<void**>(&c->h_n), n_bytes, hipHostMallocDefault) != hipSuccess) {
+        c->h_n = nullptr;
+        return fail(LSX_EDEVICE, "lsx_sync_begin_populations: no pinned host memory for %zu bytes of populations", n_bytes);
+    }
     HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_res, (2 * (size_t)c->ncol + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (with_n) {
+        HIPCHK(hipMemcpyAsync(c->h_n, c->d_n, n_bytes, hipMemcpyDeviceToHost, c->stream));
+        c->h_n_pending = true;
+    }
     HIPCHK(hipEventRecord(c->ev_mon, c->stream));
     c->mon_spec = c->spec_valid;      // this read-back carries a speculative call's monitors: collect it before discarding that call
     c->mon_fs = c->fs_pending; c->mon_se = c->se_pending;
     c->fs_pending = c->se_pending = false;
     c->mon_outstanding = true;
+    return LSX_OK;
+}
+
+int lsx_sync_begin(lsx_ctx* c) { return sync_begin(c, false); }
+int lsx_sync_begin_populations(lsx_ctx* c) { return sync_begin(c, true); }
+
+int lsx_fetch_populations(lsx_ctx* c, double* dst, size_t nbytes)
+{
+    if (!c || !dst) return fail(LSX_EINVAL, "lsx_fetch_populations: null argument");
+    if (!c->h_n_valid) return fail(LSX_EINVAL, "lsx_fetch_populations: no collected read-back of the populations (lsx_sync_begin_populations, lsx_sync_end)");
+    if (nbytes != (size_t)c->ncol * c->NLtot * c->Nspace * sizeof(double)) return fail(LSX_EINVAL, "lsx_fetch_populations: nbytes does not match [ncol][NLtot][Nspace]");
+    memcpy(dst, c->h_n, nbytes);
     return LSX_OK;
 }
 
@@ -2077,6 +2108,7 @@ int lsx_sync_end(lsx_ctx* c, double* dJ, double* dP)
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventSynchronize(c->ev_mon));             // the read-back only: what was enqueued behind it keeps running
     c->mon_outstanding = false;
+    c->h_n_valid = c->h_n_pending; c->h_n_pending = false;
     const unsigned long long sing = digest_monitors(c, c->mon_fs, c->mon_se);
     if (dJ) *dJ = c->last_dJ;
     if (dP) *dP = c->last_dP;
@@ -2091,6 +2123,7 @@ int lsx_sync(lsx_ctx* c, double* dJ, double* dP)
     if (c->mon_outstanding) {                           // a read-back in flight: collect it first (its maxima are superseded below
         HIPCHK(hipEventSynchronize(c->ev_mon));         // if later calls are pending)
         c->mon_outstanding = false;
+        c->h_n_valid = c->h_n_pending; c->h_n_pending = false;
         sing = digest_monitors(c, c->mon_fs, c->mon_se);
     }
     if (c->fs_pending || c->se_pending) {
@@ -2407,6 +2440,8 @@ static std::string effective_options(const lsx_ctx* c)
     s += use_ray_serial(c) ? ";mapping=ray-serial" : ";mapping=ray-per-lane";
     if (c->solver == LSX_SOLVER_PARABOLIC) s += per_class_launches(c) ? ";parabolic=classes" : ";parabolic=generic";
     s += ";classes=" + plan_class_string(*c);
+    // which library this is: two ranks with different builds must not pass for alike (parallel.check_same_options)
+    s += ";abi=" + std::to_string(LSX_ABI_VERSION) + ";build=" + lsx_build_id();
     return s;
 }
 
@@ -2457,8 +2492,11 @@ int lsx_time_formal_sol(lsx_ctx* c, int32_t warmup, int32_t reps, double* ms_tot
     for (int i = 0; i < warmup; ++i)
         if ((rc = enqueue_fs(c, false))) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
-    double tot = 0.0, sw = 0.0, fin = 0.0;
+    double tot = 0.0, sw = 0.0, fin = 0.0, tail = 0.0;
     for (int i = 0; i < reps; ++i) {
+        // a MALI iteration rebuilds the ray-serial sweeps' operand table once (behind stat_equil's read-back, lsx_sync): the timed
+        // call pays for it too, so that the per-call figure covers every kernel an iteration runs for its formal solution
+        c->optab_fresh = false;
         HIPCHK(hipEventRecord(c->evA, c->stream));
         if ((rc = enqueue_fs(c, true))) return rc;
         HIPCHK(hipEventRecord(c->evB, c->stream));
@@ -2481,11 +2519,17 @@ int lsx_time_formal_sol(lsx_ctx* c, int32_t warmup, int32_t reps, double* ms_tot
             if (mx > 0.f) ms = mx;
         }
         sw += ms;
+        {   // fork -> join minus the sweep span: what the fast-continuum epilogue of the class that finishes last adds behind the sweeps
+            float fj = 0.f;
+            HIPCHK(hipEventElapsedTime(&fj, c->ev0, c->ev1));
+            tail += std::max(0.f, fj - ms);
+        }
         HIPCHK(hipEventElapsedTime(&ms, c->ev1, c->ev2));
         fin += ms;
     }
     c->ms_sweep = sw / reps;
     c->ms_finish = fin / reps;
+    c->ms_epi_tail = tail / reps;
     if (ms_total) *ms_total = tot / reps;
     if (ms_sweep) *ms_sweep = c->ms_sweep;
     return lsx_sync(c, nullptr, nullptr);
@@ -2493,8 +2537,9 @@ int lsx_time_formal_sol(lsx_ctx* c, int32_t warmup, int32_t reps, double* ms_tot
 
 // HIP-only introspection used by bench.py.  what: 0 = algorithmic bytes per column the sweep
 // kernel itself must move (B_alg without the C read / Gamma write of the epilogue), 1 = tiles per
-// column, 2 = LDS bytes per workgroup (the largest class of the mapping in use), 3 = wavelengths per tile, 4 = ms of the epilogue kernels in the
-// last lsx_time_formal_sol, 5 = slab bytes per column (extra, non-algorithmic traffic of the design)
+// column, 2 = LDS bytes per workgroup (the largest class of the mapping in use), 3 = wavelengths per tile, 4 = ms of the Gamma epilogue in the
+// last lsx_time_formal_sol, 5 = slab bytes per column (extra, non-algorithmic traffic of the design), 6 = ms between the end of the last
+// class's sweep and the join (the exposed part of the fast-continuum epilogue)
 double lsx_hip_info(const lsx_ctx* c, int32_t what)
 {
     if (!c) return 0.0;
@@ -2510,7 +2555,8 @@ double lsx_hip_info(const lsx_ctx* c, int32_t what)
         return (double)b;
     }
     case 3: return (double)c->L;
-    case 4: return c->ms_finish;
+    case 4: return c->ms_finish;      // the Gamma epilogue (k_gamma_finish*) of the last lsx_time_formal_sol
+    case 6: return c->ms_epi_tail;    // ... and what lay between the end of the last class's sweep and the join: fast-continuum epilogue kernels the sweeps did not hide
     case 5: return 8.0 * c->Nspace * 4.0 * (double)c->tile_slots.size();
     default: return 0.0;
     }

@@ -467,8 +467,8 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
                     if (P.tiles[t].fast_simple < 2) k.rs = false;
             // folded fast continua (lsx_plan.h): every tile's row fits two elements per lane, and the class needs no correction
             // streams from the pre-pass (the unfactored linked instance reads them)
-            // (not the two-line instances with a known relation and no linked continua: they sit at the register limit -- folded they
-            // spill; their classes keep the pre-pass)
+            // (round 5 left the two-line instances with a known relation and no linked continua out: at the register limit, folded they
+            // spilled.  With the Boltzmann factor formed in the lane they fit: lsx_plan.h, LSX_FOLD_TWOLINE)
             k.fold = k.rs && !opt.no_fold && k.has_fast && (!k.linked || k.lk_epi) && lsx_rs_fold_instance_exists(k.npt, k.linked, k.topo);
             k.fold_nF = 0;
             for (int t : k.tiles) {

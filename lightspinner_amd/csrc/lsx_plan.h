@@ -186,7 +186,12 @@ constexpr int lsx_rs_row_doubles(int npt, int nF = 0) { return 3 * LSX_RS_COLS *
 // continuum the tile does not have: zero cross-section against a zeroed pad of the row), so the rings' rows and the cross-section
 // table are laid out for the class's largest tile rounded up to a multiple of four
 // (nor of the unfactored two-line instance with linked continua: it reads the pre-pass's correction streams)
-constexpr bool lsx_rs_fold_instance_exists(int npt, bool lk, int topo) { return !(npt == 2 && !lk && topo != 0) && !(npt == 2 && lk && topo == 0); }
+// (round 6: with the Boltzmann factor formed in the lane -- one operand stream less -- the two-line instances with a known relation fit
+// the fold too: 255 registers, no scratch; LSX_FOLD_TWOLINE=0 restores round 5's list, in which they kept the pre-pass)
+#ifndef LSX_FOLD_TWOLINE
+#define LSX_FOLD_TWOLINE LSX_ELANE
+#endif
+constexpr bool lsx_rs_fold_instance_exists(int npt, bool lk, int topo) { return (LSX_FOLD_TWOLINE || !(npt == 2 && !lk && topo != 0)) && !(npt == 2 && lk && topo == 0); }
 constexpr int lsx_rs_fold_pad(int nF) { return (nF + 3) & ~3; }
 constexpr int lsx_rs_row_pitch(int npt, int nF = 0) { return (lsx_rs_row_doubles(npt, lsx_rs_fold_pad(nF)) + 1) & ~1; }
 // doubles per column group of the table: Ntrans blocks of (Nspace + 1) rows of 15, the geometry block of (Nspace + 1) rows of 10,

@@ -311,7 +311,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
     const double* __restrict__ Jdag = p.Jdag_T + tb0;
     double* __restrict__ Jnew = p.Jnew_T + tb0;
     double* __restrict__ psibar = p.Psi2_T + ((size_t)dir * p.ncol * ntile) * Ns * LW + tb0;
-    const double* __restrict__ Eb = p.E_T + tb0;
+    [[maybe_unused]] const double* __restrict__ Eb = p.E_T + tb0;      // (LSX_ELANE=0 and the ablation builds: the Boltzmann factor as a stream)
     // the line-profile store interleaves the columns of a group inside every block row (lsx_dev.h, phi_elem): with G = NC the five
     // columns of this wavefront are ONE group, and row x of a block is one contiguous run [c < NC][l < len] for the whole wavefront
     const int PG = p.phi_G;                                          // NC, or 1: the plain per-column store (LSX_PHI_GROUP=1)

@@ -75,10 +75,20 @@ class MaxReducer:
         self._host4 = None
         self._checked = set()           # engines whose options signature has been compared across the ranks (once each)
 
+    def attach(self, eng):
+        """Compare `eng`'s options signature across the ranks NOW -- a collective: call it at a point every rank reaches with its
+        engine of the job (after the engines are made, before the loop; bench.py, response.py).  The reducer's entry points fall back
+        to doing it at an engine's first exchange, which is only symmetric if every rank presents its engines in the same order."""
+        if self.active and hasattr(eng, 'options_signature'):
+            key = getattr(eng, 'serial', None)
+            if key is None or key not in self._checked:      # (a per-engine serial, not id(): the id of a collected engine can come back)
+                check_same_options(eng, self.group)
+                if key is not None:
+                    self._checked.add(key)
+        return self
+
     def _check(self, eng):
-        if self.active and id(eng) not in self._checked and hasattr(eng, 'options_signature'):
-            check_same_options(eng, self.group)
-            self._checked.add(id(eng))
+        self.attach(eng)
 
     def __call__(self, dJ: float, dPops: float):
         if not self.active:

@@ -8,6 +8,7 @@ feeds them through the lsx C ABI.
 `Engine`       -- owns one lsx_ctx (one device, one stream)
 """
 import ctypes as C
+import itertools
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -173,6 +174,7 @@ class ColumnBlock:
 
 class Engine:
     """One lsx_ctx.  `lib=None` binds the HIP backend (and raises if it is not built)."""
+    _serials = itertools.count(1)
 
     def __init__(self, problem: Problem, ncol: int, device: int = 0, stream: Optional[int] = None, lib=None,
                  policy_columns: Optional[int] = None, sweep_policy: str = 'auto', options=None):
@@ -182,6 +184,7 @@ class Engine:
         options: explicit plan / runtime switches, "key=value,..." or a dict (include/lsx.h, lsx_create_with_options); what the
         engine ended up with: effective_options() / options_signature()."""
         self.lib = lib if lib is not None else _capi.load_hip_library()
+        self.serial = next(Engine._serials)      # this process's n-th engine: what per-engine bookkeeping keys on (never re-used, unlike id())
         self.problem = problem
         self.ncol = int(ncol)
         self._h = C.c_void_p()
@@ -268,8 +271,11 @@ class Engine:
     def effective_options(self) -> str:
         """everything that decides how this engine associates its sums and launches its kernels: the options it was created with
         (environment defaults + explicit list), the rule, the sweep mapping the policy selects, the plan's class list"""
-        buf = C.create_string_buffer(4096)
-        self.lib.check(self.lib.dll.lsx_effective_options(self._h, buf, 4096))
+        for size in (4096, 1 << 16, 1 << 20):        # (the class list grows with the plan: include/lsx.h)
+            buf = C.create_string_buffer(size)
+            if self.lib.dll.lsx_effective_options(self._h, buf, size) == 0:
+                return buf.value.decode()
+        self.lib.check(self.lib.dll.lsx_effective_options(self._h, buf, size))
         return buf.value.decode()
 
     def options_signature(self) -> int:
@@ -314,9 +320,19 @@ class Engine:
         return a.value, b.value
 
     # ---- the loop without a host round trip per iteration (include/lsx.h; drivers.iterate_mali_engine) ----
-    def sync_begin(self):
-        """enqueue the read-back of the monitors of the calls enqueued so far"""
-        self.lib.check(self.lib.dll.lsx_sync_begin(self._h))
+    def sync_begin(self, populations=False):
+        """enqueue the read-back of the monitors of the calls enqueued so far (populations: and of n, for fetch_populations)"""
+        if populations:
+            self.lib.check(self.lib.dll.lsx_sync_begin_populations(self._h))
+        else:
+            self.lib.check(self.lib.dll.lsx_sync_begin(self._h))
+
+    def fetch_populations(self):
+        """the populations [ncol][NLtot][Nspace] as the last collected sync_begin(populations=True) read them back -- host to host:
+        it does not wait for what has been enqueued behind that read-back"""
+        out = np.empty((self.ncol,) + self._shape(_capi.LSX_N), dtype=np.float64)
+        self.lib.check(self.lib.dll.lsx_fetch_populations(self._h, _ptr(out), out.nbytes))
+        return out
 
     def sync_end(self):
         """-> (dJ, dPops) of that read-back; what was enqueued behind it keeps running"""

@@ -32,6 +32,14 @@ at any time: edits are found by comparing with what was last synchronised, as be
 from the start.  `atom.n` is the caller's own array (`eqPops[name].pops`, rh_method.py:412-416): stat_equil writes it
 in place after every call, always.
 
+Look-ahead (round 6).  test.py:20-29 calls the two verbs in turn; each returns a number the loop's condition needs, so each is a
+host round trip with the GPU idle behind it.  stat_equil() here enqueues the NEXT formal solution speculatively behind its own
+read-back (lsx_sync_begin_populations / lsx_formal_sol_gamma_speculative, include/lsx.h) before it returns: if the caller's next
+call is formal_sol_gamma_matrices() -- and it has not edited n or J in between -- that call only waits for it.  Anything else
+(another stat_equil, a look at J / I / Gamma, an edit, update_collisions) takes the speculative call back first
+(lsx_discard_formal_sol): every result is what the plain sequence gives, bit for bit (tests/context_cases.py).  `lookahead=False`
+switches it off.
+
 Deliberate differences, all outside the numbers the drivers use:
   * `t.Rij` / `t.Rji` are not produced (the reference accumulates them without ever zeroing or
     reading them, rh_method.py:691-692); accessing them raises AttributeError.
@@ -203,7 +211,7 @@ class Context:
     """rh_method.py:490-745 on the GPU."""
 
     def __init__(self, atmos, spect, eqPops, background, device: int = 0, stream=None, lib=None, setup: str = 'auto',
-                 formal_solver: str = 'linear', readback: str = 'lazy'):
+                 formal_solver: str = 'linear', readback: str = 'lazy', lookahead: Optional[bool] = None):
         self.atmos = atmos
         self.atmos.nondimensionalise()
         self.spect = spect
@@ -260,12 +268,22 @@ class Context:
             in_table = lambda m, l: _contains(spect.transitions, l)
             self._engine.set_atomic_data(atomdata.from_models(models, line_filter=in_table))
         self._upload()
+        # stat_equil enqueues the next formal solution ahead where the library says that pays (one launch chain on one stream)
+        self._lookahead = self._engine.prefers_lookahead() if lookahead is None else bool(lookahead)
+        self._spec = False               # a speculative formal solution is enqueued and has not been accepted or taken back
         self._n_synced = [np.array(a.n, dtype=np.float64) for a in self.activeAtoms]
         if self._handed['J']:
             self._J_synced = self._host['J'].copy()
 
     # -- the live result arrays ------------------------------------------------------------
+    def _cancel_lookahead(self):
+        """take the speculative formal solution back: the library's results are the last ACCEPTED call's again"""
+        if self._spec:
+            self._engine.discard_formal_sol()
+            self._spec = False
+
     def _fetch(self, what):
+        self._cancel_lookahead()
         eng = self._engine
         if what == 'J':
             self._host['J'][...] = eng.get(_capi.LSX_J)[0]
@@ -376,36 +394,68 @@ class Context:
     def update_collisions(self):
         """re-derive everything that depends on the atmosphere alone (the reference recomputes the collisional rates
         on every formal solution, rh_method.py:589) and keep J"""
+        self._cancel_lookahead()
         if self._stale['J']:
             self._fetch('J')
         J = self._host['J'].copy()
         self._upload()
         self._engine.set(_capi.LSX_J, J[None])
 
-    def _push_host_edits(self):
-        # the reference's arrays are live numpy objects the caller may edit between calls.  The populations are the caller's own
-        # arrays (eqPops[...].pops): compared on every call (a few kB).  J can only have been edited if it has been handed out.
-        if any(not np.array_equal(a.n, s) for a, s in zip(self.activeAtoms, self._n_synced)):
+    def _host_edits(self):
+        """the reference's arrays are live numpy objects the caller may edit between calls.  The populations are the caller's own
+        arrays (eqPops[...].pops): compared on every call (a few kB).  J can only have been edited if it has been handed out.
+        -> (n edited, J edited)"""
+        n_ed = any(not np.array_equal(a.n, s) for a, s in zip(self.activeAtoms, self._n_synced))
+        J_ed = self._handed['J'] and not self._stale['J'] and not np.array_equal(self._host['J'], self._J_synced)
+        return n_ed, J_ed
+
+    def _push_host_edits(self, edits=None):
+        n_ed, J_ed = self._host_edits() if edits is None else edits
+        if n_ed:
             self._engine.set(_capi.LSX_N, self._cat_n()[None])
             self._n_synced = [np.array(a.n, dtype=np.float64) for a in self.activeAtoms]
-        if self._handed['J'] and not np.array_equal(self._host['J'], self._J_synced):
+        if J_ed:
             self._engine.set(_capi.LSX_J, self._host['J'][None])
             self._J_synced = self._host['J'].copy()
 
     # -- the two verbs ---------------------------------------------------------------------
     def formal_sol_gamma_matrices(self) -> float:
         """rh_method.py:565-708 -> max relative change of J"""
-        self._push_host_edits()
-        dJ = self._engine.formal_sol_gamma()
+        edits = self._host_edits()
+        if self._spec and not any(edits):
+            # the formal solution stat_equil enqueued ahead IS this call: wait for it
+            self._spec = False
+            dJ = self._engine.sync()[0]
+        else:
+            self._cancel_lookahead()
+            self._push_host_edits(edits)
+            dJ = self._engine.formal_sol_gamma()
         self._results_changed(('J', 'I', 'Gamma'))
         return dJ
 
     def stat_equil(self) -> float:
         """rh_method.py:710-745 -> max relative population change; populations are written back IN
         PLACE into the arrays that alias eqPops[...].pops (rh_method.py:412-416, response_fn.py:62)"""
+        self._cancel_lookahead()                  # (a second stat_equil in a row works on the same Gamma, as in the reference)
         self._push_host_edits()
-        dPops = self._engine.stat_equil()
-        n = self._engine.get(_capi.LSX_N)[0]
+        eng = self._engine
+        if self._lookahead:
+            eng.stat_equil_async()
+            eng.sync_begin(populations=True)      # monitors + n, read back behind the solve ...
+            try:
+                eng.formal_sol_gamma_speculative()    # ... and the next iteration's formal solution behind the read-back
+                self._spec = True
+            except _capi.LsxError:
+                self._spec = False
+            try:
+                dPops = eng.sync_end()[1]
+            except _capi.LsxError:
+                self._cancel_lookahead()          # (a singular system, rh_method.py:739: nothing is built on it)
+                raise
+            n = eng.fetch_populations()[0]
+        else:
+            dPops = eng.stat_equil()
+            n = eng.get(_capi.LSX_N)[0]
         off = 0
         for a, atom in enumerate(self.activeAtoms):
             atom.n[...] = n[off:off + atom.Nlevel]
@@ -414,4 +464,5 @@ class Context:
         return dPops
 
     def close(self):
+        self._spec = False
         self._engine.close()

@@ -40,6 +40,7 @@ static int fail(int code, const char* msg)
 const char* lsx_last_error(void) { return g_err; }
 const char* lsx_backend_name(void) { return "oracle-c"; }
 int32_t lsx_abi_version(void) { return LSX_ABI_VERSION; }
+const char* lsx_build_id(void) { return "oracle-c"; }
 
 struct lsx_ctx {
     int Nspace, Nrays, Nspect, Natoms, Ntrans, ncol;
@@ -63,6 +64,8 @@ struct lsx_ctx {
     int spec_valid;
     double mon_dJ, mon_dP;    /* the maxima as they were at lsx_sync_begin */
     int mon_set, mon_spec;
+    double* mon_n;            /* the populations as they were at lsx_sync_begin_populations, or NULL */
+    int mon_n_pending, mon_n_valid;
     long* sing_col; /* per column: (depth << 8 | atom) of its first singular system in the last stat_equil, or -1 */
     /* set-up chain: deep copy of the atomic data (lsx_set_atomic_data) and what lsx_set_atmosphere derives */
     int have_atomic_data;
@@ -157,7 +160,7 @@ void lsx_destroy(lsx_ctx* c)
     free(c->bg_chi); free(c->bg_eta); free(c->bg_sca); free(c->phi); free(c->wphi);
     free(c->colmask);
     free(c->J); free(c->I); free(c->Gamma); free(c->Rij); free(c->Rji); free(c->dJcol); free(c->dPcol); free(c->sing_col);
-    free_atomic_data(c); free(c->vBroad); free(c->aDamp); free(c->spec_save);
+    free_atomic_data(c); free(c->vBroad); free(c->aDamp); free(c->spec_save); free(c->mon_n);
     free(c);
 }
 
@@ -1236,6 +1239,30 @@ int lsx_sync_begin(lsx_ctx* c)
     c->mon_dP = c->last_dP;
     c->mon_set = 1;
     c->mon_spec = c->spec_valid;      /* (as the HIP library: collect this read-back before discarding the call it reports) */
+    c->mon_n_pending = c->mon_n_valid = 0;
+    return LSX_OK;
+}
+
+/* include/lsx.h: the read-back that also brings the populations (the drop-in Context's stat_equil, rh_method.py:412-416, 736-741).
+ * Synchronous here: a snapshot. */
+int lsx_sync_begin_populations(lsx_ctx* c)
+{
+    int rc = lsx_sync_begin(c);
+    if (rc) return rc;
+    const size_t nb = (size_t)c->ncol * c->NLtot * c->Nspace * sizeof(double);
+    if (!c->mon_n) c->mon_n = (double*)malloc(nb);
+    if (!c->mon_n) return fail(LSX_EINVAL, "lsx_sync_begin_populations: out of memory");
+    memcpy(c->mon_n, c->n, nb);
+    c->mon_n_pending = 1;
+    return LSX_OK;
+}
+
+int lsx_fetch_populations(lsx_ctx* c, double* dst, size_t nbytes)
+{
+    if (!c || !dst) return fail(LSX_EINVAL, "lsx_fetch_populations: null argument");
+    if (!c->mon_n_valid) return fail(LSX_EINVAL, "lsx_fetch_populations: no collected read-back of the populations (lsx_sync_begin_populations, lsx_sync_end)");
+    if (nbytes != (size_t)c->ncol * c->NLtot * c->Nspace * sizeof(double)) return fail(LSX_EINVAL, "lsx_fetch_populations: nbytes does not match [ncol][NLtot][Nspace]");
+    memcpy(dst, c->mon_n, nbytes);
     return LSX_OK;
 }
 
@@ -1422,6 +1449,7 @@ int lsx_set_active_columns(lsx_ctx* c, const uint8_t* active)
 int lsx_sync(lsx_ctx* c, double* dJ, double* dP)
 {
     if (!c) return fail(LSX_EINVAL, "null ctx");
+    if (c->mon_set) { c->mon_n_valid = c->mon_n_pending; c->mon_n_pending = 0; }
     c->mon_set = 0;
     if (dJ) *dJ = c->last_dJ;
     if (dP) *dP = c->last_dP;
@@ -1433,6 +1461,7 @@ int lsx_sync_end(lsx_ctx* c, double* dJ, double* dP)
     if (!c) return fail(LSX_EINVAL, "null ctx");
     if (!c->mon_set) return lsx_sync(c, dJ, dP);
     c->mon_set = 0;
+    c->mon_n_valid = c->mon_n_pending; c->mon_n_pending = 0;
     if (dJ) *dJ = c->mon_dJ;
     if (dP) *dP = c->mon_dP;
     return LSX_OK;

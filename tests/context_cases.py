@@ -94,6 +94,48 @@ def context_lazy_readback_keeps_the_reference_semantics(lib):
     ctx.close(); ctx2.close()
 
 
+def context_lookahead_gives_the_plain_sequence_bit_for_bit(lib):
+    """round 6: stat_equil() enqueues the next formal solution ahead (lsx_sync_begin_populations / lsx_formal_sol_gamma_speculative);
+    a driver that does anything but call formal_sol_gamma_matrices() next gets the speculative call taken back.  The same script of
+    calls, looks and edits with and without look-ahead: every number identical."""
+    d = dict(np.load(golden('falc_ca.npz')))
+
+    def script(lookahead):
+        atmos, spect, eq, bg = build_fakes(d)
+        ctx = Context(atmos, spect, eq, bg, lib=lib, lookahead=lookahead)
+        atom = ctx.activeAtoms[0]
+        out = []
+        for it in range(1, 7):                                       # test.py:20-29
+            out.append(ctx.formal_sol_gamma_matrices())
+            if it > 3:
+                out.append(ctx.stat_equil())
+                assert ctx._spec == bool(lookahead)                  # the next formal solution is on its way
+                out.append(atom.n.copy())                            # written back already: rh_method.py:412-416
+        out.append(ctx.stat_equil())                                 # a second stat_equil in a row: the same Gamma (taken back first)
+        out.append(atom.n.copy())
+        out.append(ctx.I.copy()); out.append(ctx.J.copy()); out.append(atom.Gamma.copy())      # a look: the last ACCEPTED call's results
+        assert not ctx._spec
+        out.append(ctx.formal_sol_gamma_matrices())
+        out.append(ctx.stat_equil())
+        atom.n[...] = d['a0_nStar']                                  # an edit behind a stat_equil: the speculative call used the old n
+        out.append(ctx.formal_sol_gamma_matrices())
+        out.append(ctx.I.copy())
+        out.append(ctx.stat_equil())
+        ctx.J[...] = d['conv_J']                                     # ... and an edit of J
+        out.append(ctx.formal_sol_gamma_matrices())
+        out.append(ctx.J.copy())
+        out.append(ctx.stat_equil())
+        ctx.update_collisions()
+        out.append(ctx.formal_sol_gamma_matrices())
+        out.append(ctx.I.copy())
+        ctx.close()
+        return out
+    a, b = script(False), script(True)
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
 def context_two_active_atoms_order_and_shapes(lib):
     d = dict(np.load(golden('falc_cah.npz')))
     atmos, spect, eq, bg = build_fakes(d)

@@ -96,12 +96,21 @@ def first_call_inside(oracle_lib, prob, block, I, J, solver='linear', base=1e-11
 #       replaced by ones): u cond is what ONE rounding of the data does.  Measured on the reference's own atoms (the reference's golden
 #       populations against the oracle's, first statistical equilibrium): CaII 9.5e-11 = 0.38 u cond, MgII 1.2e-9 = 0.37 u cond,
 #       iron 1.07e-8 = 0.46 u cond (cond = 2.1e8), carbon 5.8e-14 (cond 1e4: the envelope term decides there).
-#   populations after a statistical equilibrium:   bar_n = K_ENVELOPE spread_n + K_LU u cond        (per atom; K_LU = 3)
-#   I, J of a formal solution behind one:          bar   = single-call bar + K_ENVELOPE spread + 2 delta_n
-#   Gamma behind one (both measures of gamma_err): bar   = single-call bar + K_ENVELOPE spread + 4 delta_n
-# with delta_n = the deviation of the two implementations' populations MEASURED after the preceding statistical equilibrium (asserted
-# below bar_n there): S = eta / chi moves by at most the two levels' relative changes, J and I are averages of S, the radiative
-# rates are linear in I and in ratios of populations.
+#   (3) what went in.  The Gamma a solve sees may differ by the single-call bar `tol` already, and -- behind an earlier statistical
+#       equilibrium -- by what the populations differed by then, delta_n: the new populations are ratios of rates (<= 2 x the rates'
+#       relative change), the rates are linear in I and in ratios of populations (<= 2 x).  In a problem with several active atoms the
+#       atoms talk to each other through the radiation field: carbon (cond 1e4) inherits what iron (cond 2e8) feeds into J.
+#       An intensity that is TRANSMITTED through tau optical depths answers a relative change of the opacity with tau times that
+#       change (I ~ e^-tau): deep in the Lyman continuum J is 1e-29 -- twenty orders below the surface value -- and moves by
+#       tau delta_n = 55 x 5e-11 (measured: 2.9e-9 at 30 nm, depth 41 of a Ca+H column, where the oracle's exp spread is 6e-15).
+#       tau is bounded by the attenuation itself: T = 1 + ln(max_k J / J) per (column, wavelength, depth).
+#   populations after a statistical equilibrium:   bar_n = K_ENVELOPE spread_n + K_LU u cond + 2 tol + 4 delta_n   (per atom; K_LU = 3)
+#   J of a formal solution behind one (entry by entry):  bar = tol + K_ENVELOPE spread + 2 delta_n T
+#   I (emergent: formed at tau ~ 1) behind one:          bar = tol + K_ENVELOPE spread + 2 delta_n
+#   Gamma behind one (both measures of gamma_err):       bar = single-call bar + K_ENVELOPE spread + 4 delta_n
+# with tol the single-call bar of the problem, spread the largest relative +-1-ulp spread of the quantity, delta_n = the deviation of
+# the two implementations' populations MEASURED after the preceding statistical equilibrium (asserted below bar_n there; the largest over
+# the atoms).
 K_LU = 3.0
 U_ROUND = 2.0 ** -53
 
@@ -140,8 +149,9 @@ class SequenceBars:
     call index >= se_from, and the LU's conditioning at every one of those: the computed bars of the header above.
     make_engine() -> a loaded oracle Engine."""
 
-    def __init__(self, oracle_lib, make_engine, prob, ncalls, se_from):
-        self.prob, self.se_from = prob, se_from
+    def __init__(self, oracle_lib, make_engine, prob, ncalls, se_from, tol=1e-12):
+        """tol: the single-call bar of this problem (1e-12: SURVEY 8d; 3e-11 where a ray crosses an interval next to w2's Taylor switch)"""
+        self.prob, self.se_from, self.tol = prob, se_from, tol
         self.runs, self.cond = {}, {}
         try:
             for ulp in (0, 1, -1):
@@ -170,13 +180,14 @@ class SequenceBars:
         a, b = np.asarray(a), np.asarray(b)
         return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
 
-    def n_bar(self, call):
-        """largest admissible relative deviation of the populations after the statistical equilibrium behind `call`, per atom"""
+    def n_bar(self, call, delta_n_prev=0.0):
+        """largest admissible relative deviation of the populations after the statistical equilibrium behind `call`, per atom;
+        delta_n_prev: what the populations (of any atom) differed by after the PREVIOUS statistical equilibrium (0: there was none)"""
         bars, off = [], 0
         for a in range(self.prob.Natoms):
             nl = self.prob.Nlevel[a]
             sp = self._rel(self.runs[1][call][_capi.LSX_N][:, off:off + nl], self.runs[-1][call][_capi.LSX_N][:, off:off + nl])
-            bars.append(K_ENVELOPE * sp + K_LU * U_ROUND * self.cond[call][a])
+            bars.append(K_ENVELOPE * sp + K_LU * U_ROUND * self.cond[call][a] + 2.0 * self.tol + 4.0 * delta_n_prev)
             off += nl
         return bars
 
@@ -190,19 +201,41 @@ class SequenceBars:
             off += nl
         return out
 
-    def check_n(self, n, ref, call, who=''):
-        dev, bar = self.n_dev(n, ref), self.n_bar(call)
+    def check_n(self, n, ref, call, who='', delta_n_prev=0.0):
+        dev, bar = self.n_dev(n, ref), self.n_bar(call, delta_n_prev)
         assert all(d <= b for d, b in zip(dev, bar)), ('populations after the statistical equilibrium behind call %d%s: deviation per atom %s '
                                                        'above the computed bars %s (u cond = %s)' % (call + 1, who, dev, bar, [U_ROUND * c for c in self.cond[call]]))
         return max(dev)
 
-    def field_bar(self, call, what, base, delta_n, floor=1e-300):
-        """I or J of formal solution `call` (relative, maximum norm); delta_n: the populations' measured deviation going in (0 before
-        the first statistical equilibrium)"""
+    def _spread(self, call, what, floor=1e-300):
         a, b = self.runs[1][call][what], self.runs[-1][call][what]
-        sp = float(np.max(np.abs(a - b) / np.maximum(np.abs(self.runs[0][call][what]), floor)))
-        return base + K_ENVELOPE * sp + 2.0 * delta_n
+        return float(np.max(np.abs(a - b) / np.maximum(np.abs(self.runs[0][call][what]), floor)))
 
-    def gamma_bar(self, call, base_off, base_diag, delta_n, gamma_err):
+    def I_bar(self, call, delta_n):
+        """emergent intensity of formal solution `call` (relative, maximum norm); delta_n: the populations' measured deviation going in
+        (0 before the first statistical equilibrium)"""
+        return self.tol + K_ENVELOPE * self._spread(call, _capi.LSX_I) + 2.0 * delta_n
+
+    def J_excess(self, J, ref, call, delta_n):
+        """mean intensity of formal solution `call`, entry by entry against tol + K spread + 2 delta_n T, T = 1 + ln(max_k J / J) the
+        optical depth the entry's radiation has been transmitted through at most.  -> (largest deviation / bar, largest relative
+        deviation, the bar where T = 1)"""
+        J, ref = np.asarray(J), np.asarray(ref)
+        J0 = np.abs(self.runs[0][call][_capi.LSX_J])
+        with np.errstate(divide='ignore', invalid='ignore'):
+            T = 1.0 + np.log(np.maximum(np.max(J0, axis=-1, keepdims=True) / np.maximum(J0, 1e-300), 1.0))
+            flat = self.tol + K_ENVELOPE * self._spread(call, _capi.LSX_J)
+            bar = flat + 2.0 * delta_n * T
+            rel = np.abs(J - ref) / np.maximum(np.abs(ref), 1e-300)
+            rel = np.where(np.abs(ref) > 0, rel, np.where(J == ref, 0.0, np.inf))
+        return float(np.max(rel / bar)), float(np.max(rel)), flat + 2.0 * delta_n
+
+    def check_J(self, J, ref, call, delta_n, who=''):
+        r, rel, flat = self.J_excess(J, ref, call, delta_n)
+        assert r <= 1.0, ('J of call %d%s: %.2f x the computed bar (largest relative deviation %.2e; bar where nothing is transmitted %.2e)'
+                          % (call + 1, who, r, rel, flat))
+        return rel
+
+    def gamma_bar(self, call, delta_n, gamma_err):
         eo, ed = gamma_err(self.runs[1][call][_capi.LSX_GAMMA], self.runs[-1][call][_capi.LSX_GAMMA], self.prob)
-        return base_off + K_ENVELOPE * eo + 4.0 * delta_n, base_diag + K_ENVELOPE * ed + 4.0 * delta_n
+        return 10.0 * self.tol + K_ENVELOPE * eo + 4.0 * delta_n, self.tol + K_ENVELOPE * ed + 4.0 * delta_n

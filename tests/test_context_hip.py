@@ -23,6 +23,10 @@ def test_context_on_hip_lazy_readback(hip_lib):
     context_cases.context_lazy_readback_keeps_the_reference_semantics(None)
 
 
+def test_context_on_hip_lookahead_gives_the_plain_sequence(hip_lib):
+    context_cases.context_lookahead_gives_the_plain_sequence_bit_for_bit(None)
+
+
 def test_context_on_hip_two_active_atoms(hip_lib):
     context_cases.context_two_active_atoms_order_and_shapes(None)
 

@@ -65,6 +65,10 @@ def test_context_lazy_readback_keeps_the_reference_semantics(oracle_lib):
     context_cases.context_lazy_readback_keeps_the_reference_semantics(oracle_lib)
 
 
+def test_context_lookahead_gives_the_plain_sequence_bit_for_bit(oracle_lib):
+    context_cases.context_lookahead_gives_the_plain_sequence_bit_for_bit(oracle_lib)
+
+
 def test_context_two_active_atoms_order_and_shapes(oracle_lib):
     context_cases.context_two_active_atoms_order_and_shapes(oracle_lib)
 

@@ -61,3 +61,7 @@ def test_the_reports_belong_to_the_sources():
             pytest.skip('not built here')
         src = os.path.join(CSRC, ('lsx_sweep_rs' if u.startswith('lsx_sweep_rs') else u) + '.hip')
         assert os.path.getmtime(log) >= os.path.getmtime(src) - 1.0, u
+        # ... and belongs to the object beside it: the compiler writes both in one run (a cached object with a deleted or older
+        # report would let the test above pass on nothing)
+        assert abs(os.path.getmtime(log) - os.path.getmtime(obj)) < 120.0, (u, 'the report is not from the compile that made the object: make clean && make')
+        assert 'Function Name' in open(log).read(), u

@@ -82,26 +82,28 @@ def test_first_calls_match_reference(oracle_lib, name, compact, tol):
         e = Engine(prob, 1, lib=oracle_lib)
         e.set_columns(0, block)
         return e
-    bars = envelope.SequenceBars(oracle_lib, make, prob, 5, 3)
+    bars = envelope.SequenceBars(oracle_lib, make, prob, 5, 3, tol)
     eng = make()
-    dn = 0.0
+    dn = dn_prev = 0.0
     for it in range(1, 6):
         dJ = eng.formal_sol_gamma()
         tag = 'fs%d' % it
         if tag + '_dJ' in d:
             assert dJ == pytest.approx(float(d[tag + '_dJ']), rel=1e-9)
-            bI, bJ = (tol, tol) if it < 5 else (bars.field_bar(it - 1, _capi.LSX_I, tol, dn), bars.field_bar(it - 1, _capi.LSX_J, tol, dn))
-            assert relerr(eng.get(_capi.LSX_I)[0], d[tag + '_I']) < bI
+            assert relerr(eng.get(_capi.LSX_I)[0], d[tag + '_I']) < (tol if it < 5 else bars.I_bar(it - 1, dn))
             if tag + '_J' in d:
-                assert relerr(eng.get(_capi.LSX_J)[0], d[tag + '_J']) < bJ
+                if it < 5:
+                    assert relerr(eng.get(_capi.LSX_J)[0], d[tag + '_J']) < tol
+                else:
+                    bars.check_J(eng.get(_capi.LSX_J), d[tag + '_J'][None], it - 1, dn, ' (oracle vs reference)')
             off, diag = gamma_err(eng.get(_capi.LSX_GAMMA)[0], fixtures.gamma_from_raw(d, tag, prob), prob)
-            bo, bd = (10 * tol, tol) if it < 5 else bars.gamma_bar(it - 1, 10 * tol, tol, dn, gamma_err)
+            bo, bd = (10 * tol, tol) if it < 5 else bars.gamma_bar(it - 1, dn, gamma_err)
             assert off < bo and diag < bd, (it, off, diag, bo, bd)
         if it > 3:
             dP = eng.stat_equil()
             if 'se%d_dPops' % it in d:
                 assert dP == pytest.approx(float(d['se%d_dPops' % it]), rel=1e-7)
-                dn = bars.check_n(eng.get(_capi.LSX_N), fixtures.pops_from_raw(d, 'se%d' % it, prob)[None], it - 1, ' (oracle vs reference)')
+                dn_prev, dn = dn, bars.check_n(eng.get(_capi.LSX_N), fixtures.pops_from_raw(d, 'se%d' % it, prob)[None], it - 1, ' (oracle vs reference)', dn)
     eng.close()
 
 
@@ -137,7 +139,7 @@ def test_multilevel_reference_atoms_match_reference(oracle_lib, name, compact):
         e = Engine(prob, 1, lib=oracle_lib)
         e.set_columns(0, block)
         return e
-    bars = envelope.SequenceBars(oracle_lib, make, prob, 4, 3)
+    bars = envelope.SequenceBars(oracle_lib, make, prob, 4, 3, tol)
     bars.check_n(eng.get(_capi.LSX_N), fixtures.pops_from_raw(d, 'se4', prob)[None], 3, ' (oracle vs reference)')
     eng.close()
 
@@ -172,7 +174,7 @@ def test_all_five_reference_atoms_active_match_reference(oracle_lib):
         e.set_columns(0, block)
         oracle_lib.dll.lsx_oracle_set_threads(e._h, 8)
         return e
-    bars = envelope.SequenceBars(oracle_lib, make, prob, 4, 3)
+    bars = envelope.SequenceBars(oracle_lib, make, prob, 4, 3, 2e-11)
     bars.check_n(eng.get(_capi.LSX_N), fixtures.pops_from_raw(d, 'se4', prob)[None], 3, ' (oracle vs reference)')
     eng.close()
 
