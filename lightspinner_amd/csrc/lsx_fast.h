@@ -49,6 +49,11 @@ struct FastParams {
     int epi_corr, Nlines;
     const double* fgtab;        // [tile][LSX_FGC_TAB(L)] the column-mapped epilogue's per-tile tables, ready made (lsx_create)
     const double* wphi;         // [col][Nlines][k]
+    // round 6: the column-mapped epilogue forms the Boltzmann factor exp(-hc / k lambda T) from the temperature and the tile's table
+    // (lsx_dev.h, boltzmann_factor: the bits E_T holds) instead of reading the stream: one stream of four less.  nullptr: read E_T
+    // (the fused small-batch launch: a single column is latency bound, not byte bound)
+    const double* temperature;  // [col][k]
+    const double* exp2_tab;     // the exponential's table (lsx_dev.h, exp_tab64)
 };
 
 // effective background of the tiles that have fast continua: bgx = bg + sum over the tile's fast continua; for the
@@ -194,14 +199,17 @@ static __device__ __forceinline__ void fast_gamma_cols_rows(const FastParams& f,
     double* sA = sm;                                          // [q][j]{alpha, wlambda}, 0 where the continuum is inactive
     double* sU = sA + (size_t)2 * MAXF * L;                    // [j] 2hc/lambda^3
     double* sLW = sU + L;                                      // [u < 2][j] the linked lines' wavelength weights (0 outside the line)
-    double* sS = sLW + 2 * L + (size_t)wv * NST * R * L;      // this wave's streams: [J | Psibar | E | PsiPhi_u][row][j]
+    double* sAE = sLW + 2 * L;                                 // [j] -hc / (k lambda): the Boltzmann factor's per-wavelength constant
+    double* sET = sAE + L;                                     // [LSX_EXP_TAB] the exponential's table
+    double* sS = sET + LSX_EXP_TAB + (size_t)wv * NST * R * L; // this wave's streams: [J | Psibar | E | PsiPhi_u][row][j]
     // The tile's tables -- cross-section and wavelength weight of every fast continuum (0 where it is not active), 2hc/lambda^3, the
     // linked lines' wavelength weights -- come ready made from lsx_create (f.fgtab, an image of this LDS area per tile): ONE coalesced
     // copy.  (Round 5.  Gathered here from the slot table, the activity table and the atoms' arrays they were a chain of four
     // dependent small loads at the head of every workgroup: profiles/r05/ablation_epilogue_kernel.txt.)
     {
         const double* tab = f.fgtab + (size_t)t * LSX_FGC_TAB(L);
-        const int nA = tl.nF * L, nB = 3 * L / 2;             // double2 pieces: [q][j]{alpha, wlambda} | u and the two lines' weights
+        const int nA = tl.nF * L, nB = 4 * L / 2;             // double2 pieces: [q][j]{alpha, wlambda} | u, the two lines' weights, the Boltzmann constants
+        if (f.temperature) for (int e = tid; e < LSX_EXP_TAB; e += NT) sET[e] = f.exp2_tab[e];
         for (int e = tid; e < nA + nB; e += NT) {       // (the image in memory is laid out for LSX_FGC_MAXF_BIG continua, the LDS area for MAXF)
             const int os = e < nA ? 2 * e : 2 * LSX_FGC_MAXF_BIG * L + 2 * (e - nA), od = e < nA ? 2 * e : 2 * MAXF * L + 2 * (e - nA);
             *reinterpret_cast<double2*>(sm + od) = *reinterpret_cast<const double2*>(tab + os);
@@ -228,16 +236,31 @@ static __device__ __forceinline__ void fast_gamma_cols_rows(const FastParams& f,
         }
         const bool kx = live && 2 * p < tl.nla, ky = live && 2 * p + 1 < tl.nla;
         const size_t o = ((size_t)((size_t)col * f.ntile + t) * Ns + k) * L + 2 * p;
+#ifdef LSX_NT_EPI     // (measured alternative, profiles/r06_bound_evidence.md 1: the epilogue's read-once streams non-temporally)
+        typedef double nt_d2 __attribute__((ext_vector_type(2)));
+        auto ldnt = [](const double* q) __attribute__((always_inline)) { const nt_d2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_d2*>(q)); return make_double2(v.x, v.y); };
+        const double2 vJ = ldnt(f.J_T + o);
+        const double2 a = ldnt(f.Psi2_T + o), b = ldnt(f.Psi2_T + dstride + o);
+#else
         const double2 vJ = *reinterpret_cast<const double2*>(f.J_T + o);
         const double2 a = *reinterpret_cast<const double2*>(f.Psi2_T + o), b = *reinterpret_cast<const double2*>(f.Psi2_T + dstride + o);
-        const double2 vE = *reinterpret_cast<const double2*>(f.E_T + o);
+#endif
+        double2 vE;
+        if (f.temperature) {       // (wave-uniform) exp(-hc / k lambda T) of the pair's two wavelengths: the bits k_build_E writes into E_T
+            const double rT = 1.0 / f.temperature[(size_t)col * Ns + k];
+            vE = make_double2(boltzmann_factor(sAE[2 * p], rT, (const lds_f64*)sET), boltzmann_factor(sAE[2 * p + 1], rT, (const lds_f64*)sET));
+        } else vE = *reinterpret_cast<const double2*>(f.E_T + o);
         double2 vL[NL1];
 #pragma unroll
         for (int u = 0; u < NL1; ++u) {
             vL[u] = zero2;
             if (LINKS && u < nLc) {
                 const double* pp = f.Psi3_T + (size_t)col * f.pp_col_stride + tl.pp_off + (size_t)u * plane + (size_t)k * L + 2 * p;
+#ifdef LSX_NT_EPI
+                const double2 x = ldnt(pp), y = ldnt(pp + pstride);
+#else
                 const double2 x = *reinterpret_cast<const double2*>(pp), y = *reinterpret_cast<const double2*>(pp + pstride);
+#endif
                 vL[u] = make_double2(x.x + y.x, x.y + y.y);
             }
         }

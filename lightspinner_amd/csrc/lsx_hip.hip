@@ -1450,6 +1450,8 @@ int lsx_create_with_options(const lsx_problem* d, int32_t ncol, int32_t device, 
                 }
             double* U = T + 2 * LSX_FGC_MAXF_BIG * L;
             for (int jj = 0; jj < L; ++jj) U[jj] = c->u_la[tl.la0 + std::min(jj, tl.nla - 1)];
+            for (int jj = 0; jj < L; ++jj)      // (lsx_dev.h, boltzmann_lane_constant: the same expression, the same bits as the sweep's lanes)
+                U[3 * L + jj] = -(6.6260755E-34 * 2.99792458E+08 / (1.380658E-23 * 1.0E-09)) / c->wave[tl.la0 + std::min(jj, tl.nla - 1)];
             const int nlc = tl.nK > 0 ? std::min(tl.nL, 2) : 0;
             for (int u = 0; u < nlc; ++u)
                 for (int jj = 0; jj < L; ++jj) {
@@ -1727,6 +1729,10 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
         ff.bgxchi_T = c->d_bgxchi; ff.bgxeta_T = c->d_bgxeta; ff.J_T = c->d_J[c->jcur ^ 1]; ff.Psi2_T = c->d_Psi2;
         ff.Gpart = c->d_Gpart; ff.colmask = c->d_colmask;
         ff.epi_corr = 0; ff.Nlines = c->Nlines; ff.wphi = c->d_wphi; ff.fgtab = c->d_fgtab;
+        // LSX_EPI_ELANE=1: the column-mapped epilogue forms the Boltzmann factor itself instead of reading the stream -- built and measured
+        // (profiles/r06_bound_evidence.md 4): 0.5 MB per column of C4 traffic less, the call 0.5 % SLOWER (the kernel is a chain of dependent
+        // phases, not a byte mover); off by default
+        ff.temperature = (LSX_ELANE && LSX_EPI_ELANE) ? c->d_temperature : nullptr; ff.exp2_tab = c->d_exp2_tab;
     }
     // launch shapes (rows per pass, staged depths, LDS bytes): fixed and checked when the plan was made (lsx_plan.cpp)
     const LaunchShapes& S = c->shapes;

@@ -347,7 +347,7 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
                 group_max = std::max(group_max, group);
             }
             const int lkn = tl.nK > 0 ? (int)lines.size() : 0;       // lines the linked continua feed
-            const size_t lds_cols = ((size_t)2 * LSX_FGC_MAXF * P.L + (size_t)3 * P.L + (size_t)4 * (3 + lkn) * LSX_FGC_ROWS * P.L) * sizeof(double);
+            const size_t lds_cols = fgc_lds_bytes(P.L, LSX_FGC_MAXF, 4, lkn);
             const bool cols = simple && group_max <= LSX_FAST_NQ && (int)fast.size() <= LSX_FGC_MAXF && P.L % 2 == 0 && lkn <= 2 && lds_cols <= 64 * 1024 && !opt.fast_rows;
             // 3: a simple set with MORE continua per atom (or per tile) than that -- carbon's and iron's fourteen, MgII's ten bound-free
             // continua onto one level -- takes the big-set instances of the same kernel (lsx_fast.h: the atom's sums first, then its

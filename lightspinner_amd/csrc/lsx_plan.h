@@ -22,7 +22,7 @@
 #define LSX_FGC_ROWS 32       // k_fast_gamma_cols: (column, depth) rows per wave
 #define LSX_FGC_MAXF_BIG 48   // ... of the instances for atoms with MORE than LSX_FAST_NQ continua at a wavelength (k_fast_gamma_cols_big: carbon, iron, MgII)
 #define LSX_FGC_LISTS 7       // tile lists of the column-mapped epilogue: [0..2] 0 / 1 / 2 lines fed by linked continua, [3] unused, [4..6] the same, big sets
-#define LSX_FGC_TAB(L) (2 * LSX_FGC_MAXF_BIG * (L) + 3 * (L))   // doubles of a tile's ready-made table (lsx_create): [q][j]{alpha, w} | [j] u | [2][j] line weights
+#define LSX_FGC_TAB(L) (2 * LSX_FGC_MAXF_BIG * (L) + 4 * (L))   // doubles of a tile's ready-made table (lsx_create): [q][j]{alpha, w} | [j] u | [2][j] line weights | [j] -hc / (k lambda) (round 6: the Boltzmann factor is formed from it)
 #define LSX_FGC_MAXF 12       // k_fast_gamma_cols: fast continua per tile (sizes its operand table)
 
 // ---- the compiled instances of lsx_sweep_kernel<NPT, NL, NR, SCAL, LK, TOPO> (per-ray slots, lines among them, linked
@@ -181,6 +181,9 @@ inline bool lsx_rsp_instance_exists(int npt, int nl, bool lk, int topo)
 #define LSX_ELANE 1
 #endif
 #define LSX_RS_GEO (LSX_ELANE ? 3 : 2)
+#ifndef LSX_EPI_ELANE
+#define LSX_EPI_ELANE 0      // the same in the column-mapped fast-continuum epilogue: a measured alternative (lsx_hip.hip, enqueue_fs)
+#endif
 constexpr int lsx_rs_row_doubles(int npt, int nF = 0) { return 3 * LSX_RS_COLS * npt + LSX_RS_GEO * LSX_RS_COLS + 3 * LSX_RS_COLS * nF; }
 // the folded instances take the fast continua four at a time in straight-line code (the LDS reads of a chunk in flight together; a
 // continuum the tile does not have: zero cross-section against a zeroed pad of the row), so the rings' rows and the cross-section
@@ -349,6 +352,7 @@ inline int lkclass(const DevTile& tl)
 inline int fgc_list(const DevTile& tl) { return lkclass(tl) + (tl.fast_simple == 3 ? 4 : 0); }
 inline int fgc_lines(int v) { return kLkLines[v & 3]; }
 // LDS of a workgroup of NW waves of the column-mapped epilogue: tables for MAXF continua, NW x (3 + lines) streams of LSX_FGC_ROWS rows
-inline size_t fgc_lds_bytes(int L, int maxf, int nw, int lines) { return ((size_t)2 * maxf * L + (size_t)3 * L + (size_t)nw * (3 + lines) * LSX_FGC_ROWS * L) * sizeof(double); }
+// (round 6: + the Boltzmann constants of the tile's wavelengths and the exponential's table: the kernel forms exp(-hc / k lambda T) itself)
+inline size_t fgc_lds_bytes(int L, int maxf, int nw, int lines) { return ((size_t)2 * maxf * L + (size_t)4 * L + LSX_EXP_TAB + (size_t)nw * (3 + lines) * LSX_FGC_ROWS * L) * sizeof(double); }
 
 } // namespace lsxd

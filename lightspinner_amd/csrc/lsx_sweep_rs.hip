@@ -50,12 +50,18 @@ __device__ __forceinline__ double& at(double* base, unsigned byte_off)
 {
     return *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + byte_off);
 }
-// cache-policy hints (round 6): a stream that is read exactly once per call (the line profiles) is requested non-temporally, so that
-// it does not push out of the L2 what the partner wave of the workgroup re-reads (background, J-dagger, the first visitor's halves);
-// slabs and sums that nobody re-reads inside the sweep are stored non-temporally
+// cache-policy hints (round 6; profiles/r06_bound_evidence.md 1).  The line profiles -- read exactly once per call, the largest stream --
+// are requested non-temporally (global_load ... nt): FETCH_SIZE does not move (the partner wave's re-reads are 100 us away, far beyond
+// any cache), but the profile bytes no longer wash through the CU's vector cache, where the 96-byte rows of the other streams share
+// their 128-byte lines from one depth to the next: C3 -4 % (three boxes: -3, -6, -4), C4 -0.7 %.  LSX_NT_PHI=0: plain loads.
+// Measured and NOT kept: the ray-independent streams non-temporally too (LSX_NT_BG: C3 +8 %, C4 +3.5 %: their lines ARE shared between
+// consecutive depths), non-temporal stores of the sums and slabs (LSX_NT_ST: C4 +8 %: partial lines past the L2's write combining)
+#ifndef LSX_NT_PHI
+#define LSX_NT_PHI 1
+#endif
 __device__ __forceinline__ double ld_once(const double* base, unsigned byte_off)
 {
-#ifdef LSX_NT_PHI
+#if LSX_NT_PHI
     return __builtin_nontemporal_load(reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off));
 #else
     return at(base, byte_off);
@@ -419,9 +425,15 @@ lsx_sweep_rs_kernel(const SweepParams p)
         kk = Ns / 2;
 #endif
         const unsigned kt = o_til + (unsigned)(kk * LW) * 8u;
+#ifdef LSX_NT_BG      // (measured alternative: the ray-independent streams non-temporally too)
+        o.jd = ld_once(Jdag, kt);
+        o.bc = ld_once(bgchi, kt);
+        o.be = ld_once(bgeta, kt);
+#else
         o.jd = at(Jdag, kt);
         o.bc = at(bgchi, kt);
         o.be = at(bgeta, kt);
+#endif
         o.E = 0.0;
 #ifdef LSX_ABL_FOLD_NOE
         if constexpr (HASC) o.E = at(Eb, kt);          // ablation build (wrong results): the folded instances do not read the Boltzmann stream

@@ -159,11 +159,14 @@ class SequenceBars:
                 e = make_engine()
                 snaps = []
                 for it in range(ncalls):
-                    e.formal_sol_gamma()
+                    dJ = e.formal_sol_gamma()
                     s = {w: e.get(w) for w in (_capi.LSX_I, _capi.LSX_J, _capi.LSX_GAMMA)}
+                    s['dJ'] = dJ
+                    if ulp == 0:
+                        s[_capi.LSX_DJ_COL] = e.get(_capi.LSX_DJ_COL)
                     if se_from is not None and it >= se_from:
                         n_old = e.get(_capi.LSX_N)
-                        e.stat_equil()
+                        s['dP'] = e.stat_equil()
                         s[_capi.LSX_N] = e.get(_capi.LSX_N)
                         if ulp == 0:
                             self.cond[it] = lu_condition(prob, s[_capi.LSX_GAMMA], n_old, s[_capi.LSX_N])
@@ -172,6 +175,14 @@ class SequenceBars:
                 self.runs[ulp] = snaps
         finally:
             oracle_lib.dll.lsx_oracle_set_exp_ulp(0)
+
+    def subset(self, ncol):
+        """the bars of the first `ncol` columns of the ensemble (columns are independent problems: the runs' snapshots are sliced; the
+        LU's condition number stays the larger set's maximum; the scalar monitors dJ / dP are maxima over ALL columns and are dropped)"""
+        import copy
+        b = copy.copy(self)
+        b.runs = {u: [{k: (v[:ncol] if isinstance(v, np.ndarray) else None) for k, v in s.items()} for s in snaps] for u, snaps in self.runs.items()}
+        return b
 
     def oracle(self, call, what):
         return self.runs[0][call][what]
