@@ -163,7 +163,8 @@ inline bool lsx_rsp_instance_exists(int npt, int nl, bool lk, int topo)
 // depth the table holds a third kind of block, [c][3] = n_i, n_j nStar_i / nStar_j, nStar_i / nStar_j, the row of a tile with nF fast
 // continua is 15 npt + 10 + 15 nF doubles (two elements per lane: at most 128), and per (wavelength, depth) the lane needs two fused
 // multiply-adds per continuum: chi += sum_q alpha_q n_i,q - E sum_q alpha_q (n_j nsr)_q, eta += (2hc/lambda^3) E sum_q alpha_q (n_j nsr)_q,
-// E = exp(-hc / k lambda T) the tile's Boltzmann stream.  No pre-pass launch, no effective-background streams for those classes.
+// E = exp(-hc / k lambda T): round 5 the tile's Boltzmann stream, round 6 formed in the lane from the row's 1 / T (LSX_ELANE below).
+// No pre-pass launch, no effective-background streams for those classes.
 // ... and their GAMMA INTEGRANDS (EPI instances; what k_fast_gamma_cols did, rh_method.py:652, 677-681 for a ray-independent
 // transition): the wave that visits a depth SECOND has the total mean intensity there; it also fetches the first visitor's half of
 // Psibar (and of sum_mu w Psi* phi per linked line), forms every fast continuum's two rate integrands and the linked lines'

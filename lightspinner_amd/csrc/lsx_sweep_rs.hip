@@ -108,7 +108,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
     lds_f64* const etab = (lds_f64*)lds_raw;                         // [64][2] exp table
     constexpr int NS = NPT > 0 ? NPT : 1;
     constexpr int NV = 2 * NS;                                       // Gamma integrands per lane and depth
-    constexpr bool HASC = NPT > NL;                                  // per-ray continua: they share the tile's E stream
+    constexpr bool HASC = NPT > NL;                                  // per-ray continua: they share the tile's Boltzmann factor (E_of)
     constexpr int NLK = (LK && NL > 0) ? NL : 1;
     constexpr int NCR = NPT == 1 ? 2 : 3;                            // a single slot never reads atom.chi[j_line]
     constexpr bool FACT = NPT >= 1 && NL == NPT && (NPT == 1 || TOPO != 0);    // factored Gamma integrands (step, pass C)
