@@ -326,6 +326,7 @@ int lsx_set_atomic_data(lsx_ctx* c, const lsx_atomic_data* d)
                 return fail(LSX_EINVAL, "lsx_set_atomic_data: inconsistent collision");
     }
     free_atomic_data(c);
+    if (c->Natoms < 1) return fail(LSX_EINVAL, "lsx_set_atomic_data: the context has no atoms");
     c->am = (lsx_atom_model*)calloc((size_t)c->Natoms, sizeof(lsx_atom_model));
     for (int a = 0; a < c->Natoms; ++a) {
         const lsx_atom_model* m = &d->atoms[a];
