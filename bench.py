@@ -312,8 +312,10 @@ def roofline_block(eng, lib, prob, ncol, workload, kernel_reps):
     ach_call = balg * ncol / (ms_total * 1e-3) / 1e9
     return dict(bound=bound, bound_means='the larger term of the ceiling model (`ceiling`: counter bytes / 6.29 TB/s against VALU instructions / issue rate at the held clock); '
                                          '"hbm" when the counters are stale (the roofline the metric is defined on, BASELINE.json north_star)',
-                binding='HBM bytes the call really moves (2.3-2.4 x the algorithmic bytes on C4, 1.5 x on C3) at ~0.7 of the achievable bandwidth, with vector issue '
-                        'close behind (t_valu = 0.7-0.75 t_bytes) at two waves per SIMD: `ceiling`',
+                binding='two floors, neither reached: the HBM bytes the call really moves (2.3 x the algorithmic bytes on C4, 1.5 x on C3; 0.73-0.75 of the measured '
+                        'call at 6.29 TB/s) and vector issue (0.51-0.57), overlapped as far as two waves per SIMD allow; what a wave waits for is the latency of its own '
+                        'requests and dependent instructions (ablation, profiles/r06_bound_evidence.md 5: both directions SHARING their ray-independent reads, -12 % of '
+                        'the sweeps\' bytes, buys 0.6 %)',
                 kernel='one formal solution = every kernel of the call (SURVEY 8d: Ncol B_alg / t_FS): operand-table build, the sweep classes side by side '
                        '(lsx_sweep_rs_kernel<slots,lines,linked,topo,...>, ray-serial, five columns per wavefront: every tile class with at most two per-ray '
                        'slots in contexts of >= 160 columns; lsx_sweep_kernel<...>, one ray per lane: the other classes and smaller contexts), the '
@@ -338,11 +340,12 @@ def roofline_block(eng, lib, prob, ncol, workload, kernel_reps):
                                 % (src, fig.get('csrc_hash'), '; STALE: the kernel sources have changed since, so the figure is withheld' if stale else ''))
                 if fig else None,
                 ceiling=ceiling, valu=valu,
-                limited_by='real HBM bytes first, vector issue second (`ceiling`): a C4 call moves 2.3-2.4 x its algorithmic bytes -- both directions of a '
+                limited_by='latency at two waves per SIMD between two floors (`ceiling`: bytes first, vector issue second). A C4 call moves 2.3 x its algorithmic bytes -- both directions of a '
                            'column read the ray-independent streams (they visit the depths in opposite order: the reuse distance is a workgroup\'s lifetime, '
                            'far beyond the L2: cache-policy hints change FETCH_SIZE by 1-2 %, profiles/r06_bound_evidence.md), J leaves as a half and again '
                            'as a total, the angle sums of Psi* leave per direction for the fast-continuum epilogue -- at 4.1-4.5 TB/s of the 6.29 achievable; '
-                           'the sweeps hold 150-256 vector registers (two waves per SIMD) and issue 0.7 of what the byte floor\'s time allows. History of what '
+                           'the sweeps hold 150-256 vector registers (two waves per SIMD) and issue 0.7 of what the byte floor\'s time allows; removing the second reads altogether '
+                           '(ablation) changes the call by 0.6 %: the bytes are a floor, not what the waves wait for. History of what '
                            'was tried and measured: profiles/r03..r06_bound_evidence.md',
                 fs_call=dict(ms=ms_total, ms_sweep_kernel=ms_sweep, ms_gamma_finish=info(4), ms_fast_epilogue_exposed=info(6),
                              ms_note='ms_sweep_kernel: fork -> end of the last class\'s sweep; ms_fast_epilogue_exposed: from there to the join (the fast-continuum '

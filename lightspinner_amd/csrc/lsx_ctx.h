@@ -72,7 +72,7 @@ struct lsx_ctx : lsxd::LsxPlan {        // the plan (lsx_plan.h: dimensions, tab
     bool opt_no_fused_fast = false;  // LSX_NO_FUSED_FAST=1: small batches launch the fast-continuum kernels around the fused sweep (tests)
     // device: per column
     double *d_height = nullptr, *d_temperature = nullptr, *d_nStar = nullptr, *d_nTotal = nullptr, *d_n = nullptr,
-           *d_C = nullptr, *d_Gamma = nullptr, *d_wphi = nullptr, *d_bgchi = nullptr, *d_bgeta = nullptr,
+           *d_C = nullptr, *d_Gamma = nullptr, *d_wphi = nullptr, *d_bgchi = nullptr, *d_bgeta = nullptr, *d_bgce = nullptr, *d_bgxce = nullptr,
            *d_sca = nullptr, *d_phi = nullptr, *d_E = nullptr, *d_corr = nullptr, *d_Psi3 = nullptr, *d_J[2] = {nullptr, nullptr}, *d_I = nullptr,
            *d_Gpart = nullptr, *d_dJpart = nullptr, *d_dJcol = nullptr, *d_dPcol = nullptr, *d_res = nullptr;
     unsigned long long* d_singular = nullptr;

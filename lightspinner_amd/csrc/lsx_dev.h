@@ -143,6 +143,9 @@ struct SweepParams {
     const double* wphi;         // [col][Nlines][k]
     const double* bgchi_T;
     const double* bgeta_T;
+    const double* bgce_T;       // [col][tile][k][j<L][2]: background opacity and emissivity as PAIRS (round 6: one 16-byte load per lane and depth
+                                // instead of two 8-byte ones in the ray-serial instances; LSX_BG_PAIRS), or nullptr
+    const double* bgxce_T;      // ... and the effective background (pre-pass output) of the ray-serial classes that keep the pre-pass
     const double* bgxchi_T;     // effective background of tiles with fast continua (k_fast_prepass)
     const double* bgxeta_T;
     double* Psi2_T;             // [dir][col][tile][k][j]  sum_mu w Psi* per direction (tiles with fast continua)

@@ -36,6 +36,8 @@ struct FastParams {
     const double* bgeta_T;
     double* bgxchi_T;
     double* bgxeta_T;
+    double* bgxce_T;            // the same as (chi, eta) pairs: what the pre-pass of a RAY-SERIAL class writes instead (pairs_out; lsx_dev.h)
+    int pairs_out;
     double* corr_T;             // [col]{tile: [line][EC, XCi, XCj][k][j]}
     int64_t corr_col_stride, pp_col_stride;
     const double* J_T;          // the NEW J (after the sweep), tile-major
@@ -143,8 +145,8 @@ static __device__ __forceinline__ void fast_prepass_tile(const FastParams& f, co
             }
         }
         const size_t o = tb + (size_t)k * f.L + j;
-        f.bgxchi_T[o] = chi;
-        f.bgxeta_T[o] = eta;
+        if (f.pairs_out) *reinterpret_cast<double2*>(f.bgxce_T + 2 * o) = make_double2(chi, eta);
+        else { f.bgxchi_T[o] = chi; f.bgxeta_T[o] = eta; }
         if (nLc > 0 && !f.epi_corr) {
             double* cr = f.corr_T + col * f.corr_col_stride + tl.corr_off + (size_t)k * f.L + j;
 #pragma unroll

@@ -243,6 +243,15 @@ __global__ void k_build_E(const double* __restrict__ temperature, const double* 
     }
 }
 
+// out[i] = (a[i], b[i]) as pairs (the background's opacity and emissivity for the folded ray-serial instances: lsx_dev.h, bgce_T)
+__global__ void k_interleave2(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        out[2 * i] = a[i];
+        out[2 * i + 1] = b[i];
+    }
+}
+
 // nStar_i / nStar_j of every continuum: out[col][cont][k]
 __global__ void k_build_nsr(const double* __restrict__ nStar, double* __restrict__ out, const int* __restrict__ li,
                             const int* __restrict__ lj, int Ncont, int Ns, int NLtot)
@@ -1265,7 +1274,7 @@ void lsx_destroy(lsx_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_wavelength, c->d_zmu, c->d_wmuh, c->d_wl, c->d_alpha, c->d_u_la, c->d_active, c->d_trans,
                     c->d_tiles, c->d_slots, c->d_tile_slots, c->d_fin_ptr, c->d_fin_idx, c->d_atom_ptr, c->d_atom_slots, c->d_Nlevel, c->d_lev2_off, c->d_height,
-                    c->d_temperature, c->d_nStar, c->d_nTotal, c->d_n, c->d_C, c->d_Gamma, c->d_wphi, c->d_bgchi,
+                    c->d_temperature, c->d_nStar, c->d_nTotal, c->d_n, c->d_C, c->d_Gamma, c->d_wphi, c->d_bgchi, c->d_bgce, c->d_bgxce,
                     c->d_bgeta, c->d_sca, c->d_phi, c->d_E, c->d_corr, c->d_Psi3, c->d_J[0], c->d_J[1], c->d_I, c->d_Gpart, c->d_dJpart,
                     c->d_res, c->d_stage, c->d_debug, c->d_colmask, c->d_bgxchi, c->d_bgxeta, c->d_Psi2, c->d_fast_tiles, c->d_fast_rest, c->d_nsr, c->d_cont_li, c->d_cont_lj, c->d_exp2_tab, c->d_voigt_w, c->d_muz, c->d_wmu, c->d_optab, c->d_trans_row, c->d_fgtab, c->d_level_atom,
                     c->d_sa_atoms, c->d_sa_lines, c->d_sa_colls, c->d_sa_spl, c->d_sa_levE, c->d_sa_levg, c->d_sa_levnD, c->d_sa_levdZ,
@@ -1503,6 +1512,7 @@ int lsx_create_with_options(const lsx_problem* d, int32_t ncol, int32_t device, 
     TRY(dmalloc(&c->d_wphi, nc * c->Nlines * Ns));
     TRY(dmalloc(&c->d_bgchi, nc * c->til_col));
     TRY(dmalloc(&c->d_bgeta, nc * c->til_col));
+    if (LSX_BG_PAIRS && c->rs_ok) TRY(dmalloc(&c->d_bgce, 2 * nc * c->til_col));      // the same two arrays as pairs, for the folded ray-serial instances
     TRY(dmalloc(&c->d_sca, nc * c->sca_col));
     // (whole column groups: the store interleaves the columns of a group, lsx_dev.h phi_elem)
     const size_t nc_phi = (nc + c->phi_group - 1) / c->phi_group * c->phi_group;
@@ -1539,6 +1549,7 @@ int lsx_create_with_options(const lsx_problem* d, int32_t ncol, int32_t device, 
         if (!c->fast_rest.empty()) TRY(upload(&c->d_fast_rest, c->fast_rest, c->stream));
         TRY(dmalloc(&c->d_bgxchi, nc * c->til_col));
         TRY(dmalloc(&c->d_bgxeta, nc * c->til_col));
+        if (c->d_bgce) TRY(dmalloc(&c->d_bgxce, 2 * nc * c->til_col));
         TRY(dmalloc(&c->d_Psi2, 2 * nc * c->til_col));
         (void)hipMemsetAsync(c->d_Psi2, 0, 2 * nc * c->til_col * 8, c->stream);
     }
@@ -1596,6 +1607,12 @@ int lsx_set_columns(lsx_ctx* c, int32_t col0, int32_t ncol, const lsx_columns* s
         TRY(launch_tiles_pack(c, c->d_stage, c->d_bgchi + cc * c->til_col, (int)nb, false));
         TRY(h2d(c->d_stage, s->bg_eta + b0 * Nspect * Ns, (size_t)Nspect * Ns, nb));
         TRY(launch_tiles_pack(c, c->d_stage, c->d_bgeta + cc * c->til_col, (int)nb, false));
+        if (c->d_bgce) {
+            const size_t n = nb * c->til_col;
+            hipLaunchKernelGGL(k_interleave2, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535)), dim3(256), 0, c->stream,
+                               c->d_bgchi + cc * c->til_col, c->d_bgeta + cc * c->til_col, c->d_bgce + 2 * cc * c->til_col, n);
+            HIPCHK(hipGetLastError());
+        }
         if (c->sca_per_lambda) {
             TRY(h2d(c->d_stage, s->bg_sca + b0 * Nspect * Ns, (size_t)Nspect * Ns, nb));
             TRY(launch_tiles_pack(c, c->d_stage, c->d_sca + cc * c->sca_col, (int)nb, false));
@@ -1713,7 +1730,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
     p.phi_G = c->phi_group;
     p.phi_col_stride = (int64_t)c->phi_col; p.corr_col_stride = (int64_t)c->corr_col; p.pp_col_stride = (int64_t)c->pp_col;
     p.height = c->d_height; p.temperature = c->d_temperature; p.n = c->d_n; p.wphi = c->d_wphi;
-    p.bgchi_T = c->d_bgchi; p.bgeta_T = c->d_bgeta; p.bgxchi_T = c->d_bgxchi; p.bgxeta_T = c->d_bgxeta; p.Psi2_T = c->d_Psi2; p.sca = c->d_sca; p.phi_T = c->d_phi; p.nsr = c->d_nsr; p.Ncont = c->Ncont; p.E_T = c->d_E; p.corr_T = c->d_corr; p.Psi3_T = c->d_Psi3;
+    p.bgchi_T = c->d_bgchi; p.bgeta_T = c->d_bgeta; p.bgce_T = c->d_bgce; p.bgxce_T = c->d_bgxce; p.bgxchi_T = c->d_bgxchi; p.bgxeta_T = c->d_bgxeta; p.Psi2_T = c->d_Psi2; p.sca = c->d_sca; p.phi_T = c->d_phi; p.nsr = c->d_nsr; p.Ncont = c->Ncont; p.E_T = c->d_E; p.corr_T = c->d_corr; p.Psi3_T = c->d_Psi3;
     p.Jdag_T = c->d_J[c->jcur]; p.Jnew_T = c->d_J[c->jcur ^ 1];
     p.Iout = c->d_I; p.Gpart = c->d_Gpart; p.dJpart = c->d_dJpart; p.debug = c->d_debug; p.colmask = c->d_colmask; p.exp2_tab = c->d_exp2_tab; p.static_max = c->static_max;
 
@@ -1726,7 +1743,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
         ff.active = c->d_active; ff.alpha = c->d_alpha; ff.wl = c->d_wl; ff.u_la = c->d_u_la; ff.wmuh = c->d_wmuh; ff.n = c->d_n;
         ff.nsr = c->d_nsr; ff.E_T = c->d_E; ff.corr_T = c->d_corr; ff.Psi3_T = c->d_Psi3; ff.corr_col_stride = (int64_t)c->corr_col; ff.pp_col_stride = (int64_t)c->pp_col; ff.Ncont = c->Ncont; ff.nF_max = c->nF_max; ff.generic = c->fast_generic ? 1 : 0;
         ff.bgchi_T = c->d_bgchi; ff.bgeta_T = c->d_bgeta;
-        ff.bgxchi_T = c->d_bgxchi; ff.bgxeta_T = c->d_bgxeta; ff.J_T = c->d_J[c->jcur ^ 1]; ff.Psi2_T = c->d_Psi2;
+        ff.bgxchi_T = c->d_bgxchi; ff.bgxeta_T = c->d_bgxeta; ff.bgxce_T = c->d_bgxce; ff.pairs_out = 0; ff.J_T = c->d_J[c->jcur ^ 1]; ff.Psi2_T = c->d_Psi2;
         ff.Gpart = c->d_Gpart; ff.colmask = c->d_colmask;
         ff.epi_corr = 0; ff.Nlines = c->Nlines; ff.wphi = c->d_wphi; ff.fgtab = c->d_fgtab;
         // LSX_EPI_ELANE=1: the column-mapped epilogue forms the Boltzmann factor itself instead of reading the stream -- built and measured
@@ -1737,9 +1754,10 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
     // launch shapes (rows per pass, staged depths, LDS bytes): fixed and checked when the plan was made (lsx_plan.cpp)
     const LaunchShapes& S = c->shapes;
     const int LP = S.rows_lp;
-    auto launch_prepass = [&](hipStream_t st, const int* d_list, size_t n, bool epi = false) {
+    auto launch_prepass = [&](hipStream_t st, const int* d_list, size_t n, bool epi = false, bool pairs = false) {
         FastParams fq = ff;
         fq.epi_corr = epi ? 1 : 0;
+        fq.pairs_out = (pairs && c->d_bgxce) ? 1 : 0;          // a ray-serial class reads its effective background as (chi, eta) pairs
         fq.fast_tiles = d_list; fq.n_fast_tiles = (int)n;
         fq.seg_depths = S.prepass_seg;
         dim3 grid((unsigned)n, (unsigned)c->ncol);
@@ -1856,7 +1874,7 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
             const bool fold = k.fold && k.rs && ray_serial;
             const bool epi_in_sweep = fold && k.epi;          // ... and their Gamma integrands: no epilogue launch
             p.fold = fold ? 1 : 0; p.fold_nF = k.fold_nF; p.epi = epi_in_sweep ? 1 : 0;
-            if (!k.fast_tiles.empty() && !fold) launch_prepass(st, k.d_fast_tiles, k.fast_tiles.size(), epi);
+            if (!k.fast_tiles.empty() && !fold) launch_prepass(st, k.d_fast_tiles, k.fast_tiles.size(), epi, rs_here);
             const long nblocks = (long)k.tiles.size() * c->ncol;
             p.class_tiles = k.d_tiles;
             p.n_class_tiles = (int)k.tiles.size();

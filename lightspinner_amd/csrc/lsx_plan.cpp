@@ -449,7 +449,8 @@ int plan_build(const lsx_problem* d, const PlanOptions& opt, LsxPlan* out, std::
 
     // ---- ray-serial sweep: five columns per wavefront, addressed as one base + 32-bit byte offsets
     {
-        const size_t big = std::max(std::max(P.til_col, P.phi_col), std::max(std::max(P.corr_col, P.pp_col), (size_t)std::max(P.NLtot, std::max(P.Nlines, P.Ncont)) * Ns));
+        // (LSX_BG_PAIRS: the background pairs are two tile-major arrays in one: 16 bytes per element)
+        const size_t big = std::max(std::max((LSX_BG_PAIRS ? 2 : 1) * P.til_col, P.phi_col), std::max(std::max(P.corr_col, P.pp_col), (size_t)std::max(P.NLtot, std::max(P.Nlines, P.Ncont)) * Ns));
         // (round 5: the per-depth operands come through a ring in LDS, lsx_plan.h -- no limit on the depth count any more; the table
         // that feeds it is addressed with 32-bit byte offsets inside a column group)
         P.rs_ok = !opt.no_rs && P.Nrays == LSX_RS_RAYS && !P.sca_per_lambda && (LSX_RS_COLS + 1) * big * 8 < 0xffffffffull &&

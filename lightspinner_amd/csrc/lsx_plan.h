@@ -182,6 +182,9 @@ inline bool lsx_rsp_instance_exists(int npt, int nl, bool lk, int topo)
 #define LSX_ELANE 1
 #endif
 #define LSX_RS_GEO (LSX_ELANE ? 3 : 2)
+#ifndef LSX_BG_PAIRS
+#define LSX_BG_PAIRS 1       // the ray-serial instances read background chi / eta as one 16-byte pair per lane and depth (lsx_dev.h, bgce_T / bgxce_T)
+#endif
 #ifndef LSX_EPI_ELANE
 #define LSX_EPI_ELANE 0      // the same in the column-mapped fast-continuum epilogue: a measured alternative (lsx_hip.hip, enqueue_fs)
 #endif

@@ -314,6 +314,10 @@ lsx_sweep_rs_kernel(const SweepParams p)
     const unsigned o_til = (unsigned)((size_t)cc * til_col * 8u) + (unsigned)j * 8u;           // + k * LW * 8
     const double* __restrict__ bgchi = ((nF > 0 && !FOLD) ? p.bgxchi_T : p.bgchi_T) + tb0;      // (FOLD: the plain background; see fast_fold)
     const double* __restrict__ bgeta = ((nF > 0 && !FOLD) ? p.bgxeta_T : p.bgeta_T) + tb0;
+    // ... read as (chi, eta) pairs, ONE 16-byte load per lane and depth (lsx_dev.h, bgce_T / bgxce_T; round 6: the same bytes in one
+    // request less per step: C4 -2 %, profiles/r06_bound_evidence.md 6 -- what a wave waits for is its requests, not their bytes)
+    constexpr bool BGP = LSX_BG_PAIRS != 0;
+    [[maybe_unused]] const double* __restrict__ bgce = BGP ? ((nF > 0 && !FOLD) ? p.bgxce_T : p.bgce_T) + 2 * tb0 : nullptr;
     const double* __restrict__ Jdag = p.Jdag_T + tb0;
     double* __restrict__ Jnew = p.Jnew_T + tb0;
     double* __restrict__ psibar = p.Psi2_T + ((size_t)dir * p.ncol * ntile) * Ns * LW + tb0;
@@ -384,6 +388,9 @@ lsx_sweep_rs_kernel(const SweepParams p)
         if (l >= 0 && l < slots[u].Nlam && p.active[slots[u].trans * Nspect + la] != 0) pact |= 1u << u;
     }
     unsigned phi_o[NS], phi_k[NS], phi_m[NS];       // lines: byte offset of (depth 0, ray 0), per depth, per ray
+#ifdef LSX_ABL_PHI_WIDE
+    unsigned phi_w[NS];
+#endif
     double wlam[NS], alv[NS], cB[NS], Vc[NS], Uc[NS];
 #pragma unroll
     for (int u = 0; u < NPT; ++u) {
@@ -401,6 +408,12 @@ lsx_sweep_rs_kernel(const SweepParams p)
         const long e0 = !line ? 0L : PG > 1 ? (a ? (long)PG * xl0 + (long)cphi * len + lb : (long)PG * p.phi_col_stride - 1)
                                             : (long)cphi * p.phi_col_stride + (a ? xl0 + lb : (long)p.phi_col_stride - 1);
         phi_o[u] = (unsigned)(e0 * 8);
+#ifdef LSX_ABL_PHI_WIDE
+        // ablation build (wrong results; profiles/r06_bound_evidence.md 6): the five rays' profile values of a lane as THREE loads (16 + 16 + 8
+        // bytes) at lane-contiguous 40-byte pieces of the same 2400-byte region the five 480-byte rows of (direction, depth) occupy --
+        // what a [column][wavelength][ray] order of the block rows would cost, before anybody changes the layout
+        phi_w[u] = (line && a && !compact && PG > 1) ? (unsigned)(((long)cphi * len + lb) * 32) : 0u;
+#endif
         phi_k[u] = (line && a) ? (unsigned)(PG * (compact ? 1 : NR) * len * 8) : 0u;
         phi_m[u] = (line && a && !compact) ? (unsigned)(PG * len * 8) : 0u;
         wlam[u] = (a && act) ? (4.0 * kPi) * p.wl[slots[u].wl_off + l] : 0.0;   // :451/:455, :665 without the angle weight
@@ -424,15 +437,27 @@ lsx_sweep_rs_kernel(const SweepParams p)
         // values pass through an opaque move so that nothing computed from them leaves the loop
         kk = Ns / 2;
 #endif
+#ifdef LSX_ABL_SHARED_READS
+        // ablation build (wrong results; profiles/r06_bound_evidence.md 5): the up-going wave reads the ray-independent streams at the depth
+        // its partner is reading at the same moment -- what a call would cost if both directions of a column could share those reads
+        const unsigned kt = o_til + (unsigned)((dir ? Ns - 1 - kk : kk) * LW) * 8u;
+#else
         const unsigned kt = o_til + (unsigned)(kk * LW) * 8u;
+#endif
 #ifdef LSX_NT_BG      // (measured alternative: the ray-independent streams non-temporally too)
         o.jd = ld_once(Jdag, kt);
         o.bc = ld_once(bgchi, kt);
         o.be = ld_once(bgeta, kt);
 #else
         o.jd = at(Jdag, kt);
-        o.bc = at(bgchi, kt);
-        o.be = at(bgeta, kt);
+        if constexpr (BGP) {
+            typedef double bg_pair __attribute__((ext_vector_type(2)));
+            const bg_pair v = *reinterpret_cast<const bg_pair*>(reinterpret_cast<const char*>(bgce) + 2u * kt);
+            o.bc = v.x; o.be = v.y;
+        } else {
+            o.bc = at(bgchi, kt);
+            o.be = at(bgeta, kt);
+        }
 #endif
         o.E = 0.0;
 #ifdef LSX_ABL_FOLD_NOE
@@ -441,10 +466,22 @@ lsx_sweep_rs_kernel(const SweepParams p)
 #elif !LSX_ELANE
         if constexpr (HASC || FOLD) o.E = at(Eb, kt);
 #endif
+#ifdef LSX_ABL_PHI_WIDE
+        static_assert(NR == 5, "ablation: five rays");
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            typedef double ph2 __attribute__((ext_vector_type(2)));
+            const char* q = reinterpret_cast<const char*>(phi0) + (phi_o[u] + (unsigned)kk * phi_k[u] + phi_w[u]);
+            const ph2 v0 = __builtin_nontemporal_load(reinterpret_cast<const ph2*>(q)), v1 = __builtin_nontemporal_load(reinterpret_cast<const ph2*>(q + 16));
+            o.ph[u][0] = v0.x; o.ph[u][1] = v0.y; o.ph[u][2] = v1.x; o.ph[u][3] = v1.y;
+            o.ph[u][4] = __builtin_nontemporal_load(reinterpret_cast<const double*>(q + 32));
+        }
+#else
 #pragma unroll
         for (int u = 0; u < NL; ++u)
 #pragma unroll
             for (int m = 0; m < NR; ++m) o.ph[u][m] = ld_once(phi0, phi_o[u] + (unsigned)kk * phi_k[u] + (unsigned)m * phi_m[u]);
+#endif
         if constexpr (CORR) {
             const unsigned kq = o_corr + (unsigned)(kk * LW) * 8u;
 #pragma unroll
