@@ -388,7 +388,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
         if (l >= 0 && l < slots[u].Nlam && p.active[slots[u].trans * Nspect + la] != 0) pact |= 1u << u;
     }
     unsigned phi_o[NS], phi_k[NS], phi_m[NS];       // lines: byte offset of (depth 0, ray 0), per depth, per ray
-#ifdef LSX_ABL_PHI_WIDE
+#if defined(LSX_ABL_PHI_WIDE) || defined(LSX_ABL_PHI_PAIRS)
     unsigned phi_w[NS];
 #endif
     double wlam[NS], alv[NS], cB[NS], Vc[NS], Uc[NS];
@@ -408,7 +408,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
         const long e0 = !line ? 0L : PG > 1 ? (a ? (long)PG * xl0 + (long)cphi * len + lb : (long)PG * p.phi_col_stride - 1)
                                             : (long)cphi * p.phi_col_stride + (a ? xl0 + lb : (long)p.phi_col_stride - 1);
         phi_o[u] = (unsigned)(e0 * 8);
-#ifdef LSX_ABL_PHI_WIDE
+#if defined(LSX_ABL_PHI_WIDE) || defined(LSX_ABL_PHI_PAIRS)
         // ablation build (wrong results; profiles/r06_bound_evidence.md 6): the five rays' profile values of a lane as THREE loads (16 + 16 + 8
         // bytes) at lane-contiguous 40-byte pieces of the same 2400-byte region the five 480-byte rows of (direction, depth) occupy --
         // what a [column][wavelength][ray] order of the block rows would cost, before anybody changes the layout
@@ -466,7 +466,22 @@ lsx_sweep_rs_kernel(const SweepParams p)
 #elif !LSX_ELANE
         if constexpr (HASC || FOLD) o.E = at(Eb, kt);
 #endif
-#ifdef LSX_ABL_PHI_WIDE
+#if defined(LSX_ABL_PHI_PAIRS)
+        // ablation build (wrong results; profiles/r06_bound_evidence.md 6): the rays' profile values as (ray 0, ray 1), (ray 2, ray 3) PAIRS and
+        // ray 4 -- two 16-byte loads and one 8-byte load whose lanes stay contiguous (960 / 960 / 480 bytes per wave) over the bytes rows
+        // 0-1, 2-3 and 4 occupy today: what a [ray pair][column][wavelength][2] order of the block rows would cost
+        static_assert(NR == 5, "ablation: five rays");
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            typedef double ph2 __attribute__((ext_vector_type(2)));
+            const unsigned o0 = phi_o[u] + (unsigned)kk * phi_k[u];
+            // + (c len + l) 8: the lane's piece doubles; a lane outside the line reads the group's last element: its pair ends there
+            const char* q = reinterpret_cast<const char*>(phi0) + o0 + phi_w[u] / 4u - (phi_m[u] ? 0u : 8u);
+            const ph2 v0 = __builtin_nontemporal_load(reinterpret_cast<const ph2*>(q)), v1 = __builtin_nontemporal_load(reinterpret_cast<const ph2*>(q + 2u * phi_m[u]));
+            o.ph[u][0] = v0.x; o.ph[u][1] = v0.y; o.ph[u][2] = v1.x; o.ph[u][3] = v1.y;
+            o.ph[u][4] = ld_once(phi0, o0 + 4u * phi_m[u]);
+        }
+#elif defined(LSX_ABL_PHI_WIDE)
         static_assert(NR == 5, "ablation: five rays");
 #pragma unroll
         for (int u = 0; u < NL; ++u) {
