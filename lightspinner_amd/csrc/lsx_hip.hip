@@ -281,16 +281,16 @@ struct OptabParams {
 __global__ void k_build_optab(const OptabParams p)
 {
     const int g = blockIdx.x, t = blockIdx.y, Ns = p.Ns;
-    constexpr int NC = LSX_RS_COLS, PAD = LSX_RS_RING;
+    constexpr int NC = LSX_RS_COLS, PAD = LSX_RS_RING, SEG = LSX_RS_SEG;      // block rows of SEG doubles: [column][3], the rest zero (never written: the table starts zeroed)
     const int NR = lsx_optab_rows(Ns);                           // rows per block: depth r is row r + PAD, zero rows around
     const int ncg = min(NC, p.ncol - g * NC);
     double* const grp = p.optab + (size_t)g * p.gstride;
     if (t < p.Ntrans) {
         const DevTrans tr = p.trans[t];
         const double Uc = tr.AB * (tr.gij * tr.cB);               // DevSlot.Uc (lsx_plan.cpp)
-        double* const blk = grp + (size_t)t * NR * (3 * NC);
+        double* const blk = grp + (size_t)t * NR * SEG;
         for (int e = threadIdx.x; e < NR * NC; e += blockDim.x) {
-            const int r = e / NC - PAD, c = e - (e / NC) * NC;
+            const int row = e / NC, r = row - PAD, c = e - row * NC;
             double v0 = 0.0, v1 = 0.0, v2 = 0.0;
             if (r >= 0 && r < Ns) {
                 const size_t col = (size_t)g * NC + (c < ncg ? c : ncg - 1);
@@ -305,28 +305,30 @@ __global__ void k_build_optab(const OptabParams p)
                     v2 = p.nsr[(col * p.Ncont + p.trans_row[t]) * Ns + r];
                 }
             }
-            blk[(size_t)e * 3 + 0] = v0; blk[(size_t)e * 3 + 1] = v1; blk[(size_t)e * 3 + 2] = v2;
+            double* const o = blk + (size_t)row * SEG + c * 3;
+            o[0] = v0; o[1] = v1; o[2] = v2;
         }
     } else if (t < p.Ntrans + 2) {
         const int up = t - p.Ntrans;                              // 0: the down-going sweep's geometry, 1: the up-going one's
         constexpr int GEO = LSX_RS_GEO;
-        double* const blk = grp + ((size_t)p.Ntrans * (3 * NC) + (size_t)up * (GEO * NC)) * NR;
+        double* const blk = grp + ((size_t)p.Ntrans + (size_t)up) * SEG * NR;
         for (int e = threadIdx.x; e < NR * NC; e += blockDim.x) {
-            const int r = e / NC - PAD, c = e - (e / NC) * NC;
+            const int row = e / NC, r = row - PAD, c = e - row * NC;
             const size_t col = (size_t)g * NC + (c < ncg ? c : ncg - 1);
             const double* z = p.height + col * Ns;
             double hz = 0.0;
             if (r >= 0 && r < Ns) hz = up ? (r + 1 < Ns ? 0.5 * fabs(z[r] - z[r + 1]) : 0.0) : (r > 0 ? 0.5 * fabs(z[r - 1] - z[r]) : 0.0);
-            blk[(size_t)e * GEO + 0] = hz;
-            blk[(size_t)e * GEO + 1] = (r >= 0 && r < Ns) ? p.sca[col * Ns + r] : 0.0;
-            if constexpr (GEO > 2) blk[(size_t)e * GEO + 2] = (r >= 0 && r < Ns) ? 1.0 / p.temperature[col * Ns + r] : 0.0;     // (lsx_dev.h, boltzmann_factor)
+            double* const o = blk + (size_t)row * SEG + c * GEO;
+            o[0] = hz;
+            o[1] = (r >= 0 && r < Ns) ? p.sca[col * Ns + r] : 0.0;
+            if constexpr (GEO > 2) o[2] = (r >= 0 && r < Ns) ? 1.0 / p.temperature[col * Ns + r] : 0.0;     // (lsx_dev.h, boltzmann_factor)
         }
     } else {
         const int q = t - p.Ntrans - 2;                           // continuum q: n_i, n_j nStar_i / nStar_j, nStar_i / nStar_j (the folded instances' operands)
-        double* const blk = grp + ((size_t)p.Ntrans * (3 * NC) + 2 * (LSX_RS_GEO * NC) + (size_t)q * (3 * NC)) * NR;
+        double* const blk = grp + ((size_t)p.Ntrans + 2 + (size_t)q) * SEG * NR;
         const int li = p.cont_li[q], lj = p.cont_lj[q];
         for (int e = threadIdx.x; e < NR * NC; e += blockDim.x) {
-            const int r = e / NC - PAD, c = e - (e / NC) * NC;
+            const int row = e / NC, r = row - PAD, c = e - row * NC;
             double v0 = 0.0, v1 = 0.0, v2 = 0.0;
             if (r >= 0 && r < Ns) {
                 const size_t col = (size_t)g * NC + (c < ncg ? c : ncg - 1);
@@ -334,7 +336,8 @@ __global__ void k_build_optab(const OptabParams p)
                 v0 = p.n[(col * p.NLtot + li) * Ns + r];
                 v1 = p.n[(col * p.NLtot + lj) * Ns + r] * v2;
             }
-            blk[(size_t)e * 3 + 0] = v0; blk[(size_t)e * 3 + 1] = v1; blk[(size_t)e * 3 + 2] = v2;
+            double* const o = blk + (size_t)row * SEG + c * 3;
+            o[0] = v0; o[1] = v1; o[2] = v2;
         }
     }
 }
@@ -1716,6 +1719,8 @@ static int enqueue_fs(lsx_ctx* c, bool timed, bool speculative = false)
         int rc = dmalloc(&c->d_optab, (size_t)((c->ncol + LSX_RS_COLS - 1) / LSX_RS_COLS) * lsx_optab_group_doubles(c->Ntrans, c->Nspace, c->Ncont));
         if (!rc) rc = upload(&c->d_trans_row, c->trans_row, c->stream);
         if (rc) return rc;
+        // (the pad element of every block row -- [column][3] in LSX_RS_SEG doubles -- is fetched with its neighbour and never written)
+        HIPCHK(hipMemsetAsync(c->d_optab, 0, (size_t)((c->ncol + LSX_RS_COLS - 1) / LSX_RS_COLS) * lsx_optab_group_doubles(c->Ntrans, c->Nspace, c->Ncont) * sizeof(double), c->stream));
         c->optab_fresh = false;
     }
     SweepParams p{};

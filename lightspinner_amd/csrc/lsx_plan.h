@@ -153,15 +153,16 @@ inline bool lsx_rsp_instance_exists(int npt, int nl, bool lk, int topo)
 // wave-uniform per column.  Rounds 3-4 staged the WHOLE column of the five columns of a wavefront in LDS when the workgroup started
 // ([5][Nspace + 1][3 npt + 2]: 17-27 kB at 82 depths, growing with Nspace, and the reason contexts of more than ~160 depths fell back
 // to the one-ray-per-lane kernel).  Now `k_build_optab` (lsx_hip.hip) writes those numbers once per formal solution into a table
-//     optab[group of 5 columns][transition t < Ntrans | geometry (down, up) | continuum (folded instances)][row][c < 5][3 | 2]
-// (50 kB per column for FALC Ca+H), and
-// each WAVE keeps a ring of LSX_RS_RING rows [slot u][c][3] + [c][2] of the depths around its own: every depth step the first
-// 15 npt + 10 lanes fetch one element each of the row LSX_RS_RING - 1 steps ahead (one coalesced load per segment, landing a step
-// later) and write it over the row that was consumed two steps ago.  LDS per workgroup no longer depends on Nspace.
+//     optab[group of 5 columns][transition t < Ntrans | geometry (down, up) | continuum (folded instances)][row][LSX_RS_SEG = 16: [c < 5][3], pad]
+// (53 kB per column for FALC Ca+H), and
+// each WAVE keeps a ring of LSX_RS_RING rows -- one 16-double segment per per-ray slot, the geometry (half interval, sigma, 1 / T), every
+// folded continuum -- of the depths around its own: every depth step lane e fetches the PAIR of elements (2 e, 2 e + 1) of the row
+// LSX_RS_RING - 1 steps ahead (one 16-byte load per lane, landing a step later) and writes it over the row that was consumed two steps
+// ago.  LDS per workgroup no longer depends on Nspace.  (Round 5: rows of 15 npt + 10 (+ 15 nF) doubles, one 8-byte load per element.)
 // FOLDED fast continua (round 5): a class whose tiles have fast continua can run instances that form the continua's opacity and
 // emissivity themselves (what k_fast_prepass added to the background, rh_method.py:284-286, 453-455, 613-614) -- per continuum q and
 // depth the table holds a third kind of block, [c][3] = n_i, n_j nStar_i / nStar_j, nStar_i / nStar_j, the row of a tile with nF fast
-// continua is 15 npt + 10 + 15 nF doubles (two elements per lane: at most 128), and per (wavelength, depth) the lane needs two fused
+// continua is 16 (npt + 1 + nF) doubles (two elements per lane: at most 128), and per (wavelength, depth) the lane needs two fused
 // multiply-adds per continuum: chi += sum_q alpha_q n_i,q - E sum_q alpha_q (n_j nsr)_q, eta += (2hc/lambda^3) E sum_q alpha_q (n_j nsr)_q,
 // E = exp(-hc / k lambda T): round 5 the tile's Boltzmann stream, round 6 formed in the lane from the row's 1 / T (LSX_ELANE below).
 // No pre-pass launch, no effective-background streams for those classes.
@@ -188,7 +189,13 @@ inline bool lsx_rsp_instance_exists(int npt, int nl, bool lk, int topo)
 #ifndef LSX_EPI_ELANE
 #define LSX_EPI_ELANE 0      // the same in the column-mapped fast-continuum epilogue: a measured alternative (lsx_hip.hip, enqueue_fs)
 #endif
-constexpr int lsx_rs_row_doubles(int npt, int nF = 0) { return 3 * LSX_RS_COLS * npt + LSX_RS_GEO * LSX_RS_COLS + 3 * LSX_RS_COLS * nF; }
+// A row is made of SEGMENTS -- one per per-ray slot, the geometry, one per folded continuum --, each [column][3] = 15 doubles padded to
+// LSX_RS_SEG = 16 (round 6): a lane then fetches TWO consecutive elements of the row with one 16-byte load (64 lanes: the 128 doubles a
+// folded row may have), where it used to fetch elements e and 64 + e with two loads -- one request per step less in every folded
+// instance (what a wave waits for is its requests: profiles/r06_bound_evidence.md 6).  The table's block rows have the same pitch.
+#define LSX_RS_SEG 16
+static_assert(3 * LSX_RS_COLS <= LSX_RS_SEG && LSX_RS_GEO * LSX_RS_COLS <= LSX_RS_SEG, "a segment holds [column][3]");
+constexpr int lsx_rs_row_doubles(int npt, int nF = 0) { return LSX_RS_SEG * (npt + 1 + nF); }
 // the folded instances take the fast continua four at a time in straight-line code (the LDS reads of a chunk in flight together; a
 // continuum the tile does not have: zero cross-section against a zeroed pad of the row), so the rings' rows and the cross-section
 // table are laid out for the class's largest tile rounded up to a multiple of four
@@ -210,7 +217,7 @@ constexpr int lsx_rs_row_pitch(int npt, int nF = 0) { return (lsx_rs_row_doubles
 constexpr int lsx_optab_rows(int Ns) { return Ns + 2 * LSX_RS_RING; }
 constexpr size_t lsx_optab_group_doubles(int Ntrans, int Ns, int Ncont)
 {
-    return ((size_t)Ntrans * 3 * LSX_RS_COLS + 2 * LSX_RS_GEO * LSX_RS_COLS + (size_t)Ncont * 3 * LSX_RS_COLS) * (size_t)lsx_optab_rows(Ns);
+    return ((size_t)Ntrans + 2 + (size_t)Ncont) * LSX_RS_SEG * (size_t)lsx_optab_rows(Ns);
 }
 // (the parabolic instances park 16 depths in every class: they need the LDS for the lane-private cells below)
 constexpr int lsx_rs_park(int npt, bool par = false) { return (npt >= 2 || par) ? 16 : 64; }      // depths a row of parked Gamma totals holds (two slots: 16, for two workgroups more per CU)

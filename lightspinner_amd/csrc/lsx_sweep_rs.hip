@@ -179,70 +179,59 @@ lsx_sweep_rs_kernel(const SweepParams p)
     const int dk = dir ? -1 : 1;
     // ---- the operand ring.  Step v of this wave (depth kS + dk v) is row RING + kS + dk v of the table's blocks (RING zero rows
     // in front of depth 0 and behind depth Nspace - 1: the ring runs ahead of the sweep and past its end without clamping).
-    // Lane e < RL owns element e of every row: it fetches that element of the row RING - 1 steps ahead and, a step later, writes it
-    // over the row that was consumed two steps ago (the steps read rows v - 1 and v only); its table offset moves by one row per step.
+    // A row is a run of SEGMENTS of LSX_RS_SEG = 16 doubles ([column][3] + one pad): per-ray slots, geometry, folded continua -- the
+    // pitch of the table's block rows too.  Lane e with 2 e < RL owns the PAIR of elements (2 e, 2 e + 1) of every row: it fetches the
+    // pair of the row RING - 1 steps ahead with ONE 16-byte load and, a step later, writes it over the row that was consumed two steps
+    // ago (the steps read rows v - 1 and v only); its table offset moves by one row per step.  (Round 5 fetched elements e and 64 + e
+    // with two loads in the folded instances: one request per step more.)
+    constexpr int SEG = LSX_RS_SEG;
+    typedef double ring_pair __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) ring_pair lds_pair2;
     lds_f64* const ring = utab + (size_t)dir * RING * RLP;
     const int RL = FOLD ? lsx_rs_row_doubles(NPT, nF) : RL0;        // this tile's row
+    static_assert(lsx_rs_row_doubles(2, 0) <= 2 * LSX_WAVE && LSX_RS_FOLD_ROW_MAX <= 2 * LSX_WAVE, "a lane fetches two elements of a row");
     if constexpr (FOLD) {       // the rows' pad behind the tile's own continua is read (against zero cross-sections): keep it finite
         for (int e = lane; e < RING * RLP; e += LSX_WAVE) ring[e] = 0.0;
     }
     const double* __restrict__ otab = p.optab + (size_t)grp * p.optab_group_stride;
     const int NRT = lsx_optab_rows(Ns);
-    // byte offset of element e of the row of step 0 inside the group's table, and bytes per step (signed: the up sweep walks backwards)
-    auto elem = [&](const int e0, unsigned& ob, int& os) __attribute__((always_inline)) {
-        const int e = e0 < RL ? e0 : RL - 1;
-        size_t blk;                                       // the block's first double
-        int w, rowd;                                      // element inside the block's row, doubles per row
-        if (e < 3 * NC * NPT) {
-            const int u = e / (3 * NC);
-            w = e - u * (3 * NC); rowd = 3 * NC;
-            blk = (size_t)slots[NPT > 0 ? (u < NPT ? u : 0) : 0].trans * NRT * (3 * NC);
-        } else if (e < RL0) {
-            w = e - 3 * NC * NPT; rowd = LSX_RS_GEO * NC;
-            blk = ((size_t)p.Ntrans * (3 * NC) + (size_t)dir * (LSX_RS_GEO * NC)) * NRT;
-        } else {
-            const int q = (e - RL0) / (3 * NC);
-            w = e - RL0 - q * (3 * NC); rowd = 3 * NC;
-            blk = ((size_t)p.Ntrans * (3 * NC) + 2 * (LSX_RS_GEO * NC) + (size_t)LSX_CONST(int32_t, p.trans_row)[slots[NPT + q].trans] * (3 * NC)) * NRT;
-        }
-        ob = (unsigned)((blk + (size_t)(LSX_RS_RING + kS) * rowd + w) * 8u);       // (the table's pad: LSX_RS_RING rows, whatever this instance's ring)
-        os = dk * rowd * 8;
-    };
-    unsigned o_e0, o_e1 = 0;                              // running offsets: the element of the row that is requested next
-    int o_s0, o_s1 = 0;
-    elem(lane, o_e0, o_s0);
-    if constexpr (FOLD) elem(LSX_WAVE + lane, o_e1, o_s1);
-    auto ring_row = [&](int v) __attribute__((always_inline)) { return ring + ((v + 1) & (RING - 1)) * RLP; };
-    o_e0 -= (unsigned)o_s0; o_e1 -= (unsigned)o_s1;       // row -1 first
-    {   // rows -1 .. RING - 3: all requests first, then the writes (one memory round trip, not RING - 1 of them one after the other)
-        double x0[RING - 1], x1[RING - 1];
-#pragma unroll
-        for (int i = 0; i < RING - 1; ++i) {
-            x0[i] = at(otab, o_e0);
-            x1[i] = FOLD ? at(otab, o_e1) : 0.0;
-            o_e0 += (unsigned)o_s0; o_e1 += (unsigned)o_s1;
-        }
-#pragma unroll
-        for (int i = 0; i < RING - 1; ++i) {
-            if (lane < RL) ring_row(i - 1)[lane] = x0[i];
-            if constexpr (FOLD) {
-                if (LSX_WAVE + lane < RL) ring_row(i - 1)[LSX_WAVE + lane] = x1[i];
-            }
-        }
+    // byte offset of the lane's pair in the row of step 0 inside the group's table; bytes per step (signed: the up sweep walks backwards)
+    const bool ring_lane = 2 * lane < RL;
+    unsigned o_e0;
+    {
+        const int e = ring_lane ? 2 * lane : RL - 2;       // (a lane beyond the row repeats its last pair and writes nothing)
+        const int sgm = e / SEG, w = e - sgm * SEG;
+        size_t blkrow;                                     // the segment's block, in block rows
+        if (sgm < NPT) blkrow = (size_t)slots[NPT > 0 ? sgm : 0].trans;
+        else if (sgm == NPT) blkrow = (size_t)p.Ntrans + (size_t)dir;
+        else blkrow = (size_t)p.Ntrans + 2 + (size_t)LSX_CONST(int32_t, p.trans_row)[slots[NPT + (FOLD ? sgm - NPT - 1 : 0)].trans];
+        o_e0 = (unsigned)(((blkrow * NRT + (size_t)(LSX_RS_RING + kS)) * SEG + w) * 8u);      // (the table's pad: LSX_RS_RING rows, whatever this instance's ring)
     }
-    double ring_pend0 = at(otab, o_e0), ring_pend1 = 0.0;                        // row RING - 2: written at step 0
-    if constexpr (FOLD) ring_pend1 = at(otab, o_e1);
-    // one row per step: the element fetched a step ago goes over row s - 2, the element of row s + RING - 1 is requested
-    auto ring_step = [&](const int s) __attribute__((always_inline)) {
-        lds_f64* const w = ring_row(s - 2);
-        if (lane < RL) w[lane] = ring_pend0;
-        o_e0 += (unsigned)o_s0;
-        ring_pend0 = at(otab, o_e0);
-        if constexpr (FOLD) {
-            if (LSX_WAVE + lane < RL) w[LSX_WAVE + lane] = ring_pend1;
-            o_e1 += (unsigned)o_s1;
-            ring_pend1 = at(otab, o_e1);
+    const int o_s0 = dk * SEG * 8;
+    auto ring_row = [&](int v) __attribute__((always_inline)) { return ring + ((v + 1) & (RING - 1)) * RLP; };
+    auto ring_load = [&](unsigned off) __attribute__((always_inline)) {
+        return *reinterpret_cast<const ring_pair*>(reinterpret_cast<const char*>(otab) + off);
+    };
+    auto ring_put = [&](int v, ring_pair x) __attribute__((always_inline)) {
+        if (ring_lane) *reinterpret_cast<lds_pair2*>(ring_row(v) + 2 * lane) = x;
+    };
+    o_e0 -= (unsigned)o_s0;                               // row -1 first
+    {   // rows -1 .. RING - 3: all requests first, then the writes (one memory round trip, not RING - 1 of them one after the other)
+        ring_pair x0[RING - 1];
+#pragma unroll
+        for (int i = 0; i < RING - 1; ++i) {
+            x0[i] = ring_load(o_e0);
+            o_e0 += (unsigned)o_s0;
         }
+#pragma unroll
+        for (int i = 0; i < RING - 1; ++i) ring_put(i - 1, x0[i]);
+    }
+    ring_pair ring_pend0 = ring_load(o_e0);                                       // row RING - 2: written at step 0
+    // one row per step: the pair fetched a step ago goes over row s - 2, the pair of row s + RING - 1 is requested
+    auto ring_step = [&](const int s) __attribute__((always_inline)) {
+        ring_put(s - 2, ring_pend0);
+        o_e0 += (unsigned)o_s0;
+        ring_pend0 = ring_load(o_e0);
     };
     if constexpr (FOLD) {
         // the fast continua's cross-sections for this lane's wavelength (0 where the continuum is not active there, and for the
@@ -273,9 +262,9 @@ lsx_sweep_rs_kernel(const SweepParams p)
 #ifdef LSX_CLOCK
     unsigned long long tk_s1; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk_s1)::"memory");
 #endif
-    const int lc3 = cc * 3, lcg = 3 * NC * NPT + cc * LSX_RS_GEO;   // the lane's column inside a row: slot values at lc3 + 15 u + t, geometry at lcg + {0, 1 (, 2: 1 / T)}
-    const int lcf = RL0 + cc * 3;                          // ... the fast continua's triples (n_i, n_j nsr, nsr) at lcf + 15 q + {0, 1, 2}
-    constexpr int TU = 3 * NC;                             // doubles between two slots of a row
+    const int lc3 = cc * 3, lcg = LSX_RS_SEG * NPT + cc * LSX_RS_GEO;   // the lane's column inside a row: slot values at lc3 + 16 u + t, geometry at lcg + {0, 1 (, 2: 1 / T)}
+    const int lcf = RL0 + cc * 3;                          // ... the fast continua's triples (n_i, n_j nsr, nsr) at lcf + 16 q + {0, 1, 2}
+    constexpr int TU = LSX_RS_SEG;                         // doubles between two segments of a row
     // what the tile's fast continua add to opacity and emissivity at the depth of step v (rh_method.py:284-286, 453-455, 613-614):
     // chi += sum_q alpha_q n_i,q - E sum_q alpha_q (n_j nsr)_q,  eta += u_la E sum_q alpha_q (n_j nsr)_q
     auto fast_fold = [&](const int v, const double E, const double ula, double& chi, double& eta) __attribute__((always_inline)) {
@@ -290,7 +279,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
             auto chunk = [&](const int q0) __attribute__((always_inline)) {
                 double a[CH], x[CH], y[CH];
 #pragma unroll
-                for (int i = 0; i < CH; ++i) { a[i] = al[(q0 + i) * LSX_WAVE]; x[i] = fr[3 * NC * (q0 + i) + 0]; y[i] = fr[3 * NC * (q0 + i) + 1]; }
+                for (int i = 0; i < CH; ++i) { a[i] = al[(q0 + i) * LSX_WAVE]; x[i] = fr[TU * (q0 + i) + 0]; y[i] = fr[TU * (q0 + i) + 1]; }
 #pragma unroll
                 for (int i = 0; i < CH; ++i) { SA = fma(a[i], x[i], SA); SB = fma(a[i], y[i], SB); }
             };
@@ -667,7 +656,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
 #pragma unroll
                     for (int u = 0; u < NLK; ++u) XCi[u] = 0.0;
                     for (int q = q0; q < q1; ++q) {                        // rh_method.py:284-286, 453-455, 613-614; atom.chi / atom.U / atom.eta of :616-627
-                        const double alf = al[q * LSX_WAVE], ni = fr[3 * NC * q + 0], br = fr[3 * NC * q + 1], nr = fr[3 * NC * q + 2];
+                        const double alf = al[q * LSX_WAVE], ni = fr[TU * q + 0], br = fr[TU * q + 1], nr = fr[TU * q + 2];
                         const double g = nr * E, ng = br * E, hq = ni - ng;
                         Usum = fma(g, alf, Usum);
                         Esum = fma(ng, alf, Esum);
@@ -695,7 +684,7 @@ lsx_sweep_rs_kernel(const SweepParams p)
                     const double T = fma(u_la, sW, sIe), UP = U_j * sPsi;
                     for (int q = q0; q < q1; ++q) {
                         const double alf = al[q * LSX_WAVE], wl_ = wq[q * LSX_WAVE];
-                        const double ni = fr[3 * NC * q + 0], br = fr[3 * NC * q + 1], nr = fr[3 * NC * q + 2];
+                        const double ni = fr[TU * q + 0], br = fr[TU * q + 1], nr = fr[TU * q + 2];
                         const double g = nr * E, hq = ni - br * E;
                         const double wa = alf * wl_;
                         double a1 = wa * fma(-hq, UP, g * T), a2 = wa * sIe;
