@@ -52,7 +52,8 @@ def test_figures_carry_the_ceiling_model():
             assert v['bound'] == ('hbm' if v['t_bytes_ms'] >= v['t_valu_ms'] else 'valu')
             # a kernel alone cannot beat what its own bytes and instructions allow (5 %: the two clocks and the counters' granularity)
             assert v['alone_ms'] > 0 and t_min <= 1.05 * v['alone_ms'], (workload, k, v)
-            assert abs(v['frac_of_ceiling'] - t_min / v['alone_ms']) < 2e-3
+            # (the file keeps four decimals of a millisecond: a 17 us kernel's ratio moves by 1e-4 / 0.017)
+            assert abs(v['frac_of_ceiling'] - t_min / v['alone_ms']) < max(2e-3, 2e-4 / v['alone_ms'])
         # the per-kernel bytes add up to the call's
         assert abs(sum(v['hbm_bytes_per_column'] for v in ck.values()) - f['hbm_bytes_per_call_per_column_all_kernels']) < 1e-6 * f['hbm_bytes_per_call_per_column_all_kernels']
 
