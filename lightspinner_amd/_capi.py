@@ -135,7 +135,8 @@ class LsxLibrary:
         self.dll = C.CDLL(path, mode=getattr(os, 'RTLD_LOCAL', 0) | getattr(os, 'RTLD_NOW', 2))
         missing = [s for s in REQUIRED_SYMBOLS if not hasattr(self.dll, s)]
         # (profiles/ab.sh compares library variants built from older sources on one box: LSX_AB_OLD_ABI=1 lets a variant without the
-        # round-5 option entries load; Engine then creates its contexts with plain lsx_create)
+        # entries of the round after it load (round 6: the populations' read-back and the build id); Engine then creates its contexts
+        # with plain lsx_create)
         self.old_abi = bool(missing) and os.environ.get('LSX_AB_OLD_ABI') == '1' and set(missing) <= set(REQUIRED_SYMBOLS[-3:])
         if missing and not self.old_abi:
             raise ImportError('%s does not export: %s' % (path, ', '.join(missing)))
@@ -181,9 +182,10 @@ class LsxLibrary:
         d.lsx_monitors.argtypes = [C.c_void_p, C.c_void_p]
         d.lsx_sync_begin.argtypes = [C.c_void_p]
         d.lsx_sync_end.argtypes = [C.c_void_p, _dp, _dp]
-        d.lsx_sync_begin_populations.argtypes = [C.c_void_p]
-        d.lsx_fetch_populations.argtypes = [C.c_void_p, _dp, C.c_size_t]
-        d.lsx_build_id.restype = C.c_char_p
+        if not self.old_abi:          # (round 6's entries; a round-5 library loaded for an A/B lacks exactly these three)
+            d.lsx_sync_begin_populations.argtypes = [C.c_void_p]
+            d.lsx_fetch_populations.argtypes = [C.c_void_p, _dp, C.c_size_t]
+            d.lsx_build_id.restype = C.c_char_p
         d.lsx_formal_sol_gamma_speculative.argtypes = [C.c_void_p]
         d.lsx_discard_formal_sol.argtypes = [C.c_void_p]
         d.lsx_prefers_lookahead.argtypes = [C.c_void_p]
