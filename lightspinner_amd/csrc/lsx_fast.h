@@ -201,17 +201,19 @@ static __device__ __forceinline__ void fast_gamma_cols_rows(const FastParams& f,
     double* sA = sm;                                          // [q][j]{alpha, wlambda}, 0 where the continuum is inactive
     double* sU = sA + (size_t)2 * MAXF * L;                    // [j] 2hc/lambda^3
     double* sLW = sU + L;                                      // [u < 2][j] the linked lines' wavelength weights (0 outside the line)
-    double* sAE = sLW + 2 * L;                                 // [j] -hc / (k lambda): the Boltzmann factor's per-wavelength constant
-    double* sET = sAE + L;                                     // [LSX_EXP_TAB] the exponential's table
-    double* sS = sET + LSX_EXP_TAB + (size_t)wv * NST * R * L; // this wave's streams: [J | Psibar | E | PsiPhi_u][row][j]
+    [[maybe_unused]] double* sAE = sLW + 2 * L;                // LSX_EPI_ELANE: [j] -hc / (k lambda), the Boltzmann factor's per-wavelength constant,
+    [[maybe_unused]] double* sET = sAE + L;                    // and [LSX_EXP_TAB] the exponential's table (lsx_plan.h, LSX_FGC_EXTRA)
+    double* sS = sLW + 2 * L + LSX_FGC_EXTRA(L) + (size_t)wv * NST * R * L;     // this wave's streams: [J | Psibar | E | PsiPhi_u][row][j]
     // The tile's tables -- cross-section and wavelength weight of every fast continuum (0 where it is not active), 2hc/lambda^3, the
     // linked lines' wavelength weights -- come ready made from lsx_create (f.fgtab, an image of this LDS area per tile): ONE coalesced
     // copy.  (Round 5.  Gathered here from the slot table, the activity table and the atoms' arrays they were a chain of four
     // dependent small loads at the head of every workgroup: profiles/r05/ablation_epilogue_kernel.txt.)
     {
         const double* tab = f.fgtab + (size_t)t * LSX_FGC_TAB(L);
-        const int nA = tl.nF * L, nB = 4 * L / 2;             // double2 pieces: [q][j]{alpha, wlambda} | u, the two lines' weights, the Boltzmann constants
+        const int nA = tl.nF * L, nB = (LSX_EPI_ELANE ? 4 : 3) * L / 2;      // double2 pieces: [q][j]{alpha, wlambda} | u, the two lines' weights (, the Boltzmann constants)
+#if LSX_EPI_ELANE
         if (f.temperature) for (int e = tid; e < LSX_EXP_TAB; e += NT) sET[e] = f.exp2_tab[e];
+#endif
         for (int e = tid; e < nA + nB; e += NT) {       // (the image in memory is laid out for LSX_FGC_MAXF_BIG continua, the LDS area for MAXF)
             const int os = e < nA ? 2 * e : 2 * LSX_FGC_MAXF_BIG * L + 2 * (e - nA), od = e < nA ? 2 * e : 2 * MAXF * L + 2 * (e - nA);
             *reinterpret_cast<double2*>(sm + od) = *reinterpret_cast<const double2*>(tab + os);
@@ -248,10 +250,13 @@ static __device__ __forceinline__ void fast_gamma_cols_rows(const FastParams& f,
         const double2 a = *reinterpret_cast<const double2*>(f.Psi2_T + o), b = *reinterpret_cast<const double2*>(f.Psi2_T + dstride + o);
 #endif
         double2 vE;
+#if LSX_EPI_ELANE
         if (f.temperature) {       // (wave-uniform) exp(-hc / k lambda T) of the pair's two wavelengths: the bits k_build_E writes into E_T
             const double rT = 1.0 / f.temperature[(size_t)col * Ns + k];
             vE = make_double2(boltzmann_factor(sAE[2 * p], rT, (const lds_f64*)sET), boltzmann_factor(sAE[2 * p + 1], rT, (const lds_f64*)sET));
-        } else vE = *reinterpret_cast<const double2*>(f.E_T + o);
+        } else
+#endif
+        vE = *reinterpret_cast<const double2*>(f.E_T + o);
         double2 vL[NL1];
 #pragma unroll
         for (int u = 0; u < NL1; ++u) {

@@ -363,7 +363,9 @@ inline int lkclass(const DevTile& tl)
 inline int fgc_list(const DevTile& tl) { return lkclass(tl) + (tl.fast_simple == 3 ? 4 : 0); }
 inline int fgc_lines(int v) { return kLkLines[v & 3]; }
 // LDS of a workgroup of NW waves of the column-mapped epilogue: tables for MAXF continua, NW x (3 + lines) streams of LSX_FGC_ROWS rows
-// (round 6: + the Boltzmann constants of the tile's wavelengths and the exponential's table: the kernel forms exp(-hc / k lambda T) itself)
-inline size_t fgc_lds_bytes(int L, int maxf, int nw, int lines) { return ((size_t)2 * maxf * L + (size_t)4 * L + LSX_EXP_TAB + (size_t)nw * (3 + lines) * LSX_FGC_ROWS * L) * sizeof(double); }
+// (LSX_EPI_ELANE = 1, a measured alternative: + the Boltzmann constants of the tile's wavelengths and the exponential's table -- the kernel
+// then forms exp(-hc / k lambda T) itself; LSX_FGC_EXTRA: those doubles)
+#define LSX_FGC_EXTRA(L) (LSX_EPI_ELANE ? (L) + LSX_EXP_TAB : 0)
+inline size_t fgc_lds_bytes(int L, int maxf, int nw, int lines) { return ((size_t)2 * maxf * L + (size_t)3 * L + LSX_FGC_EXTRA(L) + (size_t)nw * (3 + lines) * LSX_FGC_ROWS * L) * sizeof(double); }
 
 } // namespace lsxd
